@@ -1,0 +1,70 @@
+"""Pin the CPU oracle (oracle/render_oracle.py) against golden vectors captured from the
+reference implementation (tests/golden/make_fixtures.py).  CPU only."""
+import pytest
+import torch
+
+from oracle import render_oracle as O
+from tests import fixtures as FX
+
+STAGE_FIXTURES = ['render_stages_v2_dn32', 'render_stages_v2_dn64', 'render_stages_v4_dn32',
+                  'render_stages_v3_vis', 'render_stages_v2_randinit']
+
+# tolerances: the reference differs from itself by ~4e-7 (coarse) between thread counts
+TOL = dict(px=2e-3, depth_v=2e-5, ddiff=2e-6, vis=2e-5, hit=2e-5, ray_feats=2e-5, rgb=2e-5, img_feats=2e-5,
+           neuray=5e-5, base_x=5e-5, geo=5e-5, attn=5e-5, density_nr=5e-5, colors_nr=2e-5,
+           pixel_colors_nr=2e-5, hit_prob_nr=2e-5, render_depth=2e-4, que_dists=1e-6)
+
+
+@pytest.mark.parametrize('name', STAGE_FIXTURES)
+def test_stage_parity(name):
+    torch.set_num_threads(1)
+    frame, w, cfg, g = FX.load(name)
+    coords = frame['coords']
+    dn = cfg['depth_sample_num']
+    depth = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], coords.shape[0], dn)
+    assert torch.equal(depth, g['coarse']['depth'])
+    use_vis = cfg['dist_decoder_cfg']['use_vis']
+    for tag, dd, ag in [('coarse', 'dist_decoder', 'agg_net'), ('fine', 'fine_dist_decoder', 'fine_agg_net')]:
+        gold = g[tag]
+        out = O.render_pass(w, dd, ag, frame, coords, gold['depth'], {'use_vis': use_vis}, want_debug=True)
+        flat = {**out['dbg'], **{k: v for k, v in out.items() if k != 'dbg'}}
+        checked = 0
+        for k, tol in TOL.items():
+            if k in gold:
+                if k == 'px':
+                    # the seam makes x jump by W-1 for angles a hair either side of it; compare on the circle
+                    W = frame['imgs'].shape[-1]
+                    dx = (flat[k][..., 0] - gold[k][..., 0]).abs()
+                    dx = torch.minimum(dx, (W - 1) - dx)
+                    assert float(dx.max()) < tol and FX.max_abs(flat[k][..., 1], gold[k][..., 1]) < tol
+                else:
+                    err = FX.max_abs(flat[k], gold[k])
+                    assert err < tol * max(1.0, float(gold[k].abs().max())), (name, tag, k, err)
+                checked += 1
+        assert checked >= 10
+    # importance sampler, fed with the reference's own coarse outputs
+    fd = O.sample_fine_depth(g['coarse']['depth'], g['coarse']['hit_prob_nr'], frame['que_depth_range'], dn)
+    assert FX.max_abs(fd, g['fine']['depth']) < 1e-4 * 15.0
+
+
+def test_gather_explicit_matches_grid_sample():
+    frame, w, cfg, g = FX.load('render_stages_v2_dn32')
+    H, W = frame['imgs'].shape[-2:]
+    px = g['coarse']['px'].reshape(2, -1, 2)
+    for key in ['imgs', 'img_feats', 'ray_feats']:
+        a = O.gather_map(frame[key], px, H, W)
+        b = O.gather_map_explicit(frame[key], px, H, W)
+        assert FX.max_abs(a, b) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['render_frame_v2_dn32', 'render_frame_v2_c2fall'])
+def test_frame_parity_and_chunk_invariance(name):
+    torch.set_num_threads(1)
+    frame, w, cfg, g = FX.load(name)
+    out = O.render_frame(w, frame, cfg, ray_batch_num=512)
+    gold = g['out']
+    assert FX.max_abs(out['pixel_colors_nr'], gold['pixel_colors_nr']) < 2e-5
+    assert FX.psnr(out['pixel_colors_nr_fine'], gold['pixel_colors_nr_fine']) > 80.0
+    assert FX.max_abs(out['render_depth_fine'], gold['render_depth_fine']) < 5e-3
+    out2 = O.render_frame(w, frame, cfg, ray_batch_num=173)
+    assert FX.max_abs(out2['pixel_colors_nr_fine'], out['pixel_colors_nr_fine']) < 1e-4
