@@ -1,0 +1,155 @@
+/* panogrf_hip.h — C ABI of the MI355X (gfx950) PanoGRF inference hot path.
+ *
+ * Drop-in boundary for the reference's per-ray renderer and spherical cost volume
+ * (thucz/PanoGRF).  The reference is pure Python/PyTorch: there is no FFI in it to replace, so
+ * each entry point cites the Python function(s) whose work it takes over; INTEGRATION.md shows
+ * the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - plain C, no torch types: raw pointers + explicit sizes, float32, contiguous.
+ *  - every `*_dev` / unqualified data pointer is DEVICE memory owned by the caller; the library
+ *    never allocates, frees or synchronises.  `*_host` pointers are host memory.
+ *  - `stream` is a hipStream_t passed as void* (0 = null stream); all work is enqueued
+ *    asynchronously on it.
+ *  - return value: 0 = PGRF_OK, < 0 = error; pgrf_last_error() returns the message of the last
+ *    failing call on the calling thread.  Nothing is printed, nothing blocks.
+ */
+#ifndef PANOGRF_HIP_H
+#define PANOGRF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGRF_OK 0
+#define PGRF_ERR_ARG (-1)     /* invalid argument (null pointer, unsupported size, ...) */
+#define PGRF_ERR_LAUNCH (-2)  /* HIP reported an error when enqueuing */
+#define PGRF_ERR_UNSUPPORTED (-3)
+
+#define PGRF_FEAT_CH 32       /* channels of img_feats / ray_feats (network/ops.py ResUNetLight out_dim) */
+#define PGRF_MAX_VIEWS 4
+#define PGRF_MAX_DN 128
+
+const char* pgrf_last_error(void);
+/* library / kernel ABI version, bumped when struct layouts change */
+int pgrf_abi_version(void);
+
+/* ------------------------------------------------------------------ per-frame source maps -- */
+/* Source-view data of one frame, re-laid-out channel-last by pgrf_pack_map so that one bilinear
+ * tap of a 32-channel map is one 128-byte line (reference keeps NCHW: utils/imgs_info.py:105-156,
+ * network/renderer.py:639-642). */
+typedef struct PgrfFrame {
+  int rfn;                     /* source views, 1..PGRF_MAX_VIEWS */
+  int H, W;                    /* full ERP resolution of the source images (= cfg height,width) */
+  int hf, wf;                  /* img_feats resolution  (H/4, W/4 in the shipped config) */
+  int hr, wr;                  /* ray_feats resolution  (depth_height/4, depth_width/4) */
+  const float* imgs;           /* [rfn,H,W,4]   rgb + zero pad, values in [0,1] */
+  const float* img_feats;      /* [rfn,hf,wf,32] */
+  const float* ray_feats;      /* [rfn,hr,wr,32] */
+  const float* w2c;            /* [rfn,3,4] world->camera of every source view */
+  const float* ref_depth_range;/* [rfn,2] near,far of every source view */
+  float que_c2w[12];           /* [3,4] camera->world of the query view (host values) */
+  float que_depth_range[2];    /* near,far of the query view (host values) */
+} PgrfFrame;
+
+/* NCHW [n,C,h,w] -> NHWC [n,h,w,Cpad] (Cpad = 4 for C = 3, else C); replaces nothing in the
+ * reference (layout change only). */
+int pgrf_pack_map(const float* src_nchw, int n, int C, int h, int w, float* dst_nhwc, void* stream);
+
+/* ------------------------------------------------------------------ network weights -------- */
+/* Number of floats of one packed pass blob (coarse or fine). */
+int pgrf_blob_floats(void);
+/* Number of raw tensors pgrf_pack_weights expects and the state_dict suffix of entry i
+ * (e.g. "dist_decoder.mean_decoder.0.weight" with the pass prefix removed: see INTEGRATION.md). */
+int pgrf_raw_count(void);
+const char* pgrf_raw_name(int i);
+/* Pack one pass (dist decoder + aggregation net) from reference-layout HOST tensors
+ * (nn.Linear [out,in] + [out]) into the MFMA operand order; raw_host[i] follows pgrf_raw_name(i).
+ * Replaces: nothing computed — it is the load_state_dict-time transform
+ * (network/dist_decoder.py:53-97, network/aggregate_net.py:16-39, network/ibrnet.py:239-313). */
+int pgrf_pack_weights(const float* const* raw_host, int n_raw, int use_vis, int max_dn, float* blob_host);
+
+/* ------------------------------------------------------------------ sampling --------------- */
+/* Deterministic (eval) stratified depths, depth[rn,dn].  network/render_ops.py:292-339 sample_depth. */
+int pgrf_sample_coarse_depth(float min_depth, float max_depth, int use_disp, int rn, int dn, float* depth,
+                             void* stream);
+/* Inverse-CDF importance sampling + sort.  depth,hit_prob [rn,dn] -> out [rn, fdn] (or
+ * [rn, dn+fdn] sorted union when use_all != 0: cfg fine_depth_use_all).
+ * network/render_ops.py:413-473 sample_fine_depth + network/renderer.py:469-472. */
+int pgrf_sample_fine_depth(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
+                           int use_all, int rn, int dn, int fdn, float* out, void* stream);
+
+/* ------------------------------------------------------------------ one network pass ------- */
+typedef struct PgrfPassOut {   /* any pointer may be NULL = not wanted */
+  float* pixel_colors;         /* [rn,3]     'pixel_colors_nr' */
+  float* render_depth;         /* [rn]       'render_depth'    */
+  float* hit_prob;             /* [rn,dn]    'hit_prob_nr'     */
+  float* colors;               /* [rn,dn,3]  'colors_nr'       */
+  float* density;              /* [rn,dn]    'density_nr'      */
+} PgrfPassOut;
+
+typedef struct PgrfPassDebug { /* intermediate tensors for stage-level parity tests; NULL = skip */
+  float* px;                   /* [rfn,rn,dn,2] projected pixel coords */
+  float* depth_v;              /* [rfn,rn,dn]   distance to the source camera */
+  float* ddiff;                /* [rfn,rn,dn,4] */
+  float* vis;                  /* [rfn,rn,dn] */
+  float* hit;                  /* [rfn,rn,dn] */
+  float* ray_feats;            /* [rfn,rn,dn,32] */
+  float* rgb;                  /* [rfn,rn,dn,3] */
+  float* img_feats;            /* [rfn,rn,dn,32] */
+  float* neuray;               /* [rn,dn,rfn,32] prob_embed output */
+  float* base_x;               /* [rn,dn,rfn,32] base_fc output */
+  float* geo;                  /* [rn,dn,16] geometry_fc output */
+  float* attn;                 /* [rn,dn,16] ray_attention output */
+} PgrfPassDebug;
+
+/* One pass (coarse or fine) of the renderer over rn rays at the given per-ray sample depths:
+ * ERP ray generation, projection into the rfn source views, bilinear gathers, mixture-of-logistics
+ * visibility, IBRNet aggregation with per-ray attention, alpha compositing.
+ * coords [rn,2] (x,y) pixel of each ray in the query ERP (H x W = frame->H, frame->W);
+ * depth [rn,dn], dn in {32,64,128}.
+ * Replaces NeuralRayBaseRenderer.render_by_depth (network/renderer.py:223-304) and everything it
+ * calls: depth2inv_dists, depth2points_spherical, project_points_dict (network/render_ops.py:76-258),
+ * predict_proj_ray_prob (renderer.py:120-136), get_img_feats (:180-188), network_rendering (:210-219),
+ * DefaultAggregationNet.forward (network/aggregate_net.py:41-89), IBRNetWithNeuRay.forward
+ * (network/ibrnet.py:315-373), MixtureLogisticsDistDecoder.forward/compute_prob
+ * (network/dist_decoder.py:99-140). */
+int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords,
+                     const float* depth, int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg,
+                     void* stream);
+
+/* `render_c2f_all` (network/renderer.py:484-518): one composite over the sorted union of the
+ * coarse and fine samples.  Inputs [rn,dn_c]/[rn,dn_f]; outputs sized dn_c+dn_f. */
+int pgrf_merge_c2f(const float* depth_c, const float* colors_c, const float* density_c, int dn_c,
+                   const float* depth_f, const float* colors_f, const float* density_f, int dn_f, int rn,
+                   const PgrfPassOut* out, void* stream);
+
+/* ------------------------------------------------------------------ whole per-batch path --- */
+typedef struct PgrfRenderCfg {
+  float min_depth, max_depth;  /* cfg min_depth / max_depth */
+  int use_disp;                /* cfg use_disp */
+  int dn, fdn;                 /* depth_sample_num, fine_depth_sample_num */
+  int hierarchical;            /* use_hierarchical_sampling */
+  int fine_use_all;            /* fine_depth_use_all */
+  int c2f_all;                 /* render_c2f_all */
+  int use_vis_coarse, use_vis_fine;
+} PgrfRenderCfg;
+
+/* Bytes of scratch pgrf_render_rays needs for rn rays. */
+size_t pgrf_render_workspace_bytes(const PgrfRenderCfg* cfg, int rn);
+/* Coarse (+ importance-sampled fine) render of rn rays: NeuralRayBaseRenderer.render_impl
+ * (network/renderer.py:567-633, non-DINER branch).  `fine` outputs may be NULL when
+ * cfg->hierarchical == 0.  All rays of a frame can be passed at once: the result does not depend
+ * on ray batching (the reference's ray_batch_num loop, renderer.py:656-683, exists only to bound
+ * memory). */
+int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const float* blob_fine,
+                     const PgrfRenderCfg* cfg, const float* coords, int rn, const PgrfPassOut* coarse,
+                     const PgrfPassOut* fine, float* fine_depth_out, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANOGRF_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libpanogrf_hip.so (include/panogrf_hip.h).  Fails loudly when absent."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path():
+    return os.environ.get("PANOGRF_HIP_LIB", os.path.join(_HERE, "libpanogrf_hip.so"))
+
+
+class PgrfError(RuntimeError):
+    pass
+
+
+class PgrfFrame(C.Structure):
+    _fields_ = [("rfn", C.c_int), ("H", C.c_int), ("W", C.c_int), ("hf", C.c_int), ("wf", C.c_int),
+                ("hr", C.c_int), ("wr", C.c_int),
+                ("imgs", C.c_void_p), ("img_feats", C.c_void_p), ("ray_feats", C.c_void_p),
+                ("w2c", C.c_void_p), ("ref_depth_range", C.c_void_p),
+                ("que_c2w", C.c_float * 12), ("que_depth_range", C.c_float * 2)]
+
+
+class PgrfPassOut(C.Structure):
+    _fields_ = [("pixel_colors", C.c_void_p), ("render_depth", C.c_void_p), ("hit_prob", C.c_void_p),
+                ("colors", C.c_void_p), ("density", C.c_void_p)]
+
+
+class PgrfPassDebug(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("px", "depth_v", "ddiff", "vis", "hit", "ray_feats", "rgb", "img_feats",
+                                          "neuray", "base_x", "geo", "attn")]
+
+
+class PgrfRenderCfg(C.Structure):
+    _fields_ = [("min_depth", C.c_float), ("max_depth", C.c_float), ("use_disp", C.c_int), ("dn", C.c_int),
+                ("fdn", C.c_int), ("hierarchical", C.c_int), ("fine_use_all", C.c_int), ("c2f_all", C.c_int),
+                ("use_vis_coarse", C.c_int), ("use_vis_fine", C.c_int)]
+
+
+# every symbol include/panogrf_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "pgrf_last_error": (C.c_char_p, []),
+    "pgrf_abi_version": (C.c_int, []),
+    "pgrf_pack_map": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "pgrf_blob_floats": (C.c_int, []),
+    "pgrf_raw_count": (C.c_int, []),
+    "pgrf_raw_name": (C.c_char_p, [C.c_int]),
+    "pgrf_pack_weights": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P]),
+    "pgrf_sample_coarse_depth": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "pgrf_sample_fine_depth": (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "pgrf_render_pass": (C.c_int, [C.POINTER(PgrfFrame), _P, C.c_int, _P, _P, C.c_int, C.c_int,
+                                   C.POINTER(PgrfPassOut), C.POINTER(PgrfPassDebug), _P]),
+    "pgrf_merge_c2f": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.POINTER(PgrfPassOut), _P]),
+    "pgrf_render_workspace_bytes": (C.c_size_t, [C.POINTER(PgrfRenderCfg), C.c_int]),
+    "pgrf_render_rays": (C.c_int, [C.POINTER(PgrfFrame), _P, _P, C.POINTER(PgrfRenderCfg), _P, C.c_int,
+                                   C.POINTER(PgrfPassOut), C.POINTER(PgrfPassOut), _P, _P, C.c_size_t, _P]),
+}
+
+
+class _Lib:
+    """Lazy handle: loading is deferred to first use so that importing the package on a box
+    without the built library gives a clear error at the call site, not an ImportError maze."""
+
+    def __init__(self):
+        self._dll = None
+
+    def _load(self):
+        if self._dll is None:
+            path = library_path()
+            if not os.path.exists(path):
+                raise PgrfError(
+                    f"{path} not found: build it with `make -C panogrf_amd/csrc -j8` (or `python -c "
+                    f"'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+            dll = C.CDLL(path)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(dll, name)   # AttributeError if the .so lacks a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        return getattr(self._load(), name)
+
+    def check(self, rc):
+        if rc != 0:
+            raise PgrfError(f"libpanogrf_hip error {rc}: {self.pgrf_last_error().decode()}")
+
+
+lib = _Lib()

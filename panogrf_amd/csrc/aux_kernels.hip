@@ -1,0 +1,229 @@
+// Small HBM-bound kernels around the fused render pass: map re-layout, depth samplers, c2f merge.
+#include <hip/hip_runtime.h>
+
+#include "pgrf_internal.h"
+
+namespace pgrf {
+
+#define PGRF_CHECK_LAUNCH(what)                                                                       \
+  do {                                                                                                \
+    const hipError_t e__ = hipGetLastError();                                                         \
+    if (e__ != hipSuccess) return set_error(PGRF_ERR_LAUNCH, what " launch failed: %s", hipGetErrorString(e__)); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// NCHW -> NHWC(Cpad).  One thread per (pixel, 4-channel group); reads are coalesced along x for
+// each channel, writes are one float4 per thread.
+__global__ void pack_map_kernel(const float* __restrict__ src, int n, int C, int hw, int Cpad, float* __restrict__ dst) {
+  const int groups = Cpad / 4;
+  const size_t total = (size_t)n * hw * groups;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i % hw;
+    const size_t rest = i / hw;
+    const int gq = (int)(rest % groups);
+    const size_t img = rest / groups;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = gq * 4 + k;
+      v[k] = (c < C) ? src[(img * C + c) * hw + pix] : 0.f;
+    }
+    *reinterpret_cast<float4*>(dst + (img * hw + pix) * Cpad + gq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+int launch_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream) {
+  const int Cpad = (C + 3) / 4 * 4;
+  const size_t total = (size_t)n * h * w * (Cpad / 4);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_map_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, src, n, C, h * w, Cpad, dst);
+  PGRF_CHECK_LAUNCH("pack_map");
+  return PGRF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sample_depth, eval mode (network/render_ops.py:292-339): identical for every ray.
+__global__ void coarse_depth_kernel(float near, float far, int use_disp, int rn, int dn, float* __restrict__ depth) {
+  const size_t total = (size_t)rn * dn;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % dn);
+    float d;
+    if (use_disp) {
+      const float diff = 1.f / far - 1.f / near;
+      const float interval = diff / (float)(dn - 1);
+      const float tick = (k == 0) ? 0.f : (k == dn - 1 ? diff : interval * (float)k);
+      d = 1.f / (1.f / near + tick);
+    } else {
+      const float diff = far - near;
+      const float interval = diff / (float)(dn - 1);
+      const float tick = (k == 0) ? 0.f : (k == dn - 1 ? diff : interval * (float)k);
+      d = near + tick;
+    }
+    depth[i] = d;
+  }
+}
+
+int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, float* depth, void* stream) {
+  const size_t total = (size_t)rn * dn;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(coarse_depth_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, near, far, use_disp, rn, dn, depth);
+  PGRF_CHECK_LAUNCH("coarse_depth");
+  return PGRF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sample_fine_depth (render_ops.py:413-473) + sort (renderer.py:469-472).  One wave per ray,
+// 4 rays per workgroup; the cdf is accumulated serially in index order (like torch.cumsum on
+// the CPU path the golden vectors come from), searchsorted(right=True) is a count of cdf <= u.
+constexpr int kMaxS = 128;   // max dn, max fdn
+
+__global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict__ depth, const float* __restrict__ hit,
+                                                         float qnear, float qfar, int use_disp, int use_all, int rn,
+                                                         int dn, int fdn, float* __restrict__ out) {
+  __shared__ float s_pdf[4][kMaxS];
+  __shared__ float s_cdf[4][kMaxS + 1];
+  __shared__ float s_ctr[4][kMaxS + 1];
+  __shared__ float s_d[4][kMaxS];
+  __shared__ float s_val[4][2 * kMaxS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  const bool ok = ray < rn;
+  const int rayc = ok ? ray : rn - 1;
+  const float n_ = -1.f / qnear, f_ = -1.f / qfar;
+  float part = 0.f;
+  for (int i = lane; i < dn; i += 64) {
+    const float z = depth[(size_t)rayc * dn + i];
+    const float d = use_disp ? (-1.f / z - n_) / (f_ - n_) : z;
+    const float hp = hit[(size_t)rayc * dn + i] + 1e-5f;
+    s_d[wv][i] = d;
+    s_pdf[wv][i] = hp;
+    part += hp;
+    if (use_all) s_val[wv][i] = z;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+  __syncthreads();
+  for (int i = lane; i < dn; i += 64) s_pdf[wv][i] = s_pdf[wv][i] / part;
+  __syncthreads();
+  for (int k = lane; k <= dn; k += 64) {
+    float c = 0.f;
+    for (int j = 0; j < k; ++j) c += s_pdf[wv][j];      // cdf[k] = pdf[0] + ... + pdf[k-1], left to right
+    s_cdf[wv][k] = c;
+    float ctr;
+    if (k == 0) ctr = s_d[wv][0];
+    else if (k == dn) ctr = s_d[wv][dn - 1];
+    else ctr = (s_d[wv][k] + s_d[wv][k - 1]) / 2.f;
+    s_ctr[wv][k] = ctr;
+  }
+  __syncthreads();
+  const float interval = (float)(1.0 / (double)fdn);
+  const float half_iv = (float)(0.5 * (1.0 / (double)fdn));
+  const int base = use_all ? dn : 0;
+  for (int j = lane; j < fdn; j += 64) {
+    const float u = half_iv + (float)j * interval;
+    int inds = 0;
+    for (int k = 0; k <= dn; ++k) inds += (s_cdf[wv][k] <= u) ? 1 : 0;
+    const int below = max(inds - 1, 0), above = min(inds, dn);
+    const float c0 = s_cdf[wv][below], c1 = s_cdf[wv][above];
+    const float b0 = s_ctr[wv][below], b1 = s_ctr[wv][above];
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.f;
+    const float t = (u - c0) / denom;
+    float fd = b0 + t * (b1 - b0);
+    if (use_disp) {
+      fd = fd * (f_ - n_) + n_;
+      fd = -1.f / fd;
+    }
+    s_val[wv][base + j] = fd;
+  }
+  __syncthreads();
+  // stable rank sort of the (nearly sorted) values
+  const int total = base + fdn;
+  for (int j = lane; j < total; j += 64) {
+    const float v = s_val[wv][j];
+    int rank = 0;
+    for (int k = 0; k < total; ++k) {
+      const float o = s_val[wv][k];
+      rank += (o < v || (o == v && k < j)) ? 1 : 0;
+    }
+    if (ok) out[(size_t)ray * total + rank] = v;
+  }
+}
+
+int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
+                      int dn, int fdn, float* out, void* stream) {
+  const int blocks = (rn + 3) / 4;
+  hipLaunchKernelGGL(fine_depth_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, hit, qnear, qfar, use_disp,
+                     use_all, rn, dn, fdn, out);
+  PGRF_CHECK_LAUNCH("fine_depth");
+  return PGRF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// render_c2f_all (renderer.py:484-518): stable sort of the concatenated depths, gather colours and
+// densities, composite over the union.  One wave per ray.
+__global__ void __launch_bounds__(256) merge_c2f_kernel(const float* __restrict__ zc, const float* __restrict__ colc,
+                                                        const float* __restrict__ denc, int dnc, const float* __restrict__ zf,
+                                                        const float* __restrict__ colf, const float* __restrict__ denf,
+                                                        int dnf, int rn, PgrfPassOut o) {
+  __shared__ float s_z[4][2 * kMaxS];
+  __shared__ float s_sz[4][2 * kMaxS];
+  __shared__ float s_a[4][2 * kMaxS];
+  __shared__ float s_c[4][2 * kMaxS][3];
+  __shared__ float s_den[4][2 * kMaxS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  const bool ok = ray < rn;
+  const int rayc = ok ? ray : rn - 1;
+  const int total = dnc + dnf;
+  for (int i = lane; i < total; i += 64)
+    s_z[wv][i] = (i < dnc) ? zc[(size_t)rayc * dnc + i] : zf[(size_t)rayc * dnf + (i - dnc)];
+  __syncthreads();
+  for (int j = lane; j < total; j += 64) {
+    const float v = s_z[wv][j];
+    int rank = 0;
+    for (int k = 0; k < total; ++k) {
+      const float w = s_z[wv][k];
+      rank += (w < v || (w == v && k < j)) ? 1 : 0;
+    }
+    const float den = (j < dnc) ? denc[(size_t)rayc * dnc + j] : denf[(size_t)rayc * dnf + (j - dnc)];
+    const float* cp = (j < dnc) ? colc + ((size_t)rayc * dnc + j) * 3 : colf + ((size_t)rayc * dnf + (j - dnc)) * 3;
+    s_sz[wv][rank] = v;
+    s_den[wv][rank] = den;
+    s_a[wv][rank] = 1.f - __expf(-fmaxf(den, 0.f));
+    s_c[wv][rank][0] = cp[0]; s_c[wv][rank][1] = cp[1]; s_c[wv][rank][2] = cp[2];
+  }
+  __syncthreads();
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < total; i += 64) {
+    float T = 1.f;
+    for (int j = 0; j < i; ++j) T *= (1.f - s_a[wv][j] + 1e-10f);
+    const float hitp = s_a[wv][i] * T;
+    const size_t pt = (size_t)ray * total + i;
+    if (ok) {
+      if (o.hit_prob) o.hit_prob[pt] = hitp;
+      if (o.density) o.density[pt] = s_den[wv][i];
+      if (o.colors) { o.colors[pt * 3] = s_c[wv][i][0]; o.colors[pt * 3 + 1] = s_c[wv][i][1]; o.colors[pt * 3 + 2] = s_c[wv][i][2]; }
+    }
+    acc[0] += hitp * s_c[wv][i][0]; acc[1] += hitp * s_c[wv][i][1]; acc[2] += hitp * s_c[wv][i][2];
+    acc[3] += hitp * s_sz[wv][i];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+  if (ok && lane == 0) {
+    if (o.pixel_colors) { o.pixel_colors[(size_t)ray * 3] = acc[0]; o.pixel_colors[(size_t)ray * 3 + 1] = acc[1]; o.pixel_colors[(size_t)ray * 3 + 2] = acc[2]; }
+    if (o.render_depth) o.render_depth[ray] = acc[3];
+  }
+}
+
+int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
+                     const float* denf, int dnf, int rn, const PgrfPassOut& o, void* stream) {
+  const int blocks = (rn + 3) / 4;
+  hipLaunchKernelGGL(merge_c2f_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, zc, colc, denc, dnc, zf, colf, denf, dnf, rn, o);
+  PGRF_CHECK_LAUNCH("merge_c2f");
+  return PGRF_OK;
+}
+
+}  // namespace pgrf

@@ -1,0 +1,218 @@
+// extern "C" entry points of libpanogrf_hip.so (declared in include/panogrf_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "pgrf_internal.h"
+#include "pgrf_layout.h"
+#include "render_pass_args.h"
+
+namespace pgrf {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int launch_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream);
+int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, float* depth, void* stream);
+int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
+                      int dn, int fdn, float* out, void* stream);
+int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
+                     const float* denf, int dnf, int rn, const PgrfPassOut& o, void* stream);
+
+static const char* kRawNames[R_COUNT] = {
+    "dist_decoder.mean_decoder.0.weight", "dist_decoder.mean_decoder.0.bias", "dist_decoder.mean_decoder.2.weight",
+    "dist_decoder.mean_decoder.2.bias", "dist_decoder.mean_decoder.4.weight", "dist_decoder.mean_decoder.4.bias",
+    "dist_decoder.var_decoder.0.weight", "dist_decoder.var_decoder.0.bias", "dist_decoder.var_decoder.2.weight",
+    "dist_decoder.var_decoder.2.bias", "dist_decoder.var_decoder.4.weight", "dist_decoder.var_decoder.4.bias",
+    "dist_decoder.aw_decoder.0.weight", "dist_decoder.aw_decoder.0.bias", "dist_decoder.aw_decoder.2.weight",
+    "dist_decoder.aw_decoder.2.bias", "dist_decoder.aw_decoder.4.weight", "dist_decoder.aw_decoder.4.bias",
+    "dist_decoder.vis_decoder.0.weight", "dist_decoder.vis_decoder.0.bias", "dist_decoder.vis_decoder.2.weight",
+    "dist_decoder.vis_decoder.2.bias", "dist_decoder.vis_decoder.4.weight", "dist_decoder.vis_decoder.4.bias",
+    "agg_net.prob_embed.0.weight", "agg_net.prob_embed.0.bias", "agg_net.prob_embed.2.weight", "agg_net.prob_embed.2.bias",
+    "agg_net.agg_impl.ray_dir_fc.0.weight", "agg_net.agg_impl.ray_dir_fc.0.bias", "agg_net.agg_impl.ray_dir_fc.2.weight",
+    "agg_net.agg_impl.ray_dir_fc.2.bias",
+    "agg_net.agg_impl.base_fc.0.weight", "agg_net.agg_impl.base_fc.0.bias", "agg_net.agg_impl.base_fc.2.weight",
+    "agg_net.agg_impl.base_fc.2.bias",
+    "agg_net.agg_impl.vis_fc.0.weight", "agg_net.agg_impl.vis_fc.0.bias", "agg_net.agg_impl.vis_fc.2.weight",
+    "agg_net.agg_impl.vis_fc.2.bias",
+    "agg_net.agg_impl.vis_fc2.0.weight", "agg_net.agg_impl.vis_fc2.0.bias", "agg_net.agg_impl.vis_fc2.2.weight",
+    "agg_net.agg_impl.vis_fc2.2.bias",
+    "agg_net.agg_impl.geometry_fc.0.weight", "agg_net.agg_impl.geometry_fc.0.bias", "agg_net.agg_impl.geometry_fc.2.weight",
+    "agg_net.agg_impl.geometry_fc.2.bias",
+    "agg_net.agg_impl.ray_attention.w_qs.weight", "agg_net.agg_impl.ray_attention.w_ks.weight",
+    "agg_net.agg_impl.ray_attention.w_vs.weight", "agg_net.agg_impl.ray_attention.fc.weight",
+    "agg_net.agg_impl.ray_attention.layer_norm.weight", "agg_net.agg_impl.ray_attention.layer_norm.bias",
+    "agg_net.agg_impl.out_geometry_fc.0.weight", "agg_net.agg_impl.out_geometry_fc.0.bias",
+    "agg_net.agg_impl.out_geometry_fc.2.weight", "agg_net.agg_impl.out_geometry_fc.2.bias",
+    "agg_net.agg_impl.rgb_fc.0.weight", "agg_net.agg_impl.rgb_fc.0.bias", "agg_net.agg_impl.rgb_fc.2.weight",
+    "agg_net.agg_impl.rgb_fc.2.bias", "agg_net.agg_impl.rgb_fc.4.weight", "agg_net.agg_impl.rgb_fc.4.bias",
+    "agg_net.agg_impl.neuray_fc.0.weight", "agg_net.agg_impl.neuray_fc.0.bias", "agg_net.agg_impl.neuray_fc.2.weight",
+    "agg_net.agg_impl.neuray_fc.2.bias",
+};
+
+static int check_frame(const PgrfFrame* f, const char* who) {
+  if (!f) return set_error(PGRF_ERR_ARG, "%s: frame is null", who);
+  if (f->rfn < 1 || f->rfn > PGRF_MAX_VIEWS) return set_error(PGRF_ERR_ARG, "%s: rfn=%d not in [1,%d]", who, f->rfn, PGRF_MAX_VIEWS);
+  if (f->H < 2 || f->W < 2 || f->hf < 1 || f->wf < 1 || f->hr < 1 || f->wr < 1)
+    return set_error(PGRF_ERR_ARG, "%s: bad map sizes H=%d W=%d hf=%d wf=%d hr=%d wr=%d", who, f->H, f->W, f->hf, f->wf, f->hr, f->wr);
+  if (!f->imgs || !f->img_feats || !f->ray_feats || !f->w2c || !f->ref_depth_range)
+    return set_error(PGRF_ERR_ARG, "%s: frame has a null map/pose pointer", who);
+  if ((size_t)f->H * f->W >= (1u << 30)) return set_error(PGRF_ERR_ARG, "%s: frame too large", who);
+  return PGRF_OK;
+}
+
+static int do_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords, const float* depth,
+                          int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* stream) {
+  int rc = check_frame(frame, "pgrf_render_pass");
+  if (rc) return rc;
+  if (!blob || !coords || !depth || !out) return set_error(PGRF_ERR_ARG, "pgrf_render_pass: null blob/coords/depth/out");
+  if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_render_pass: rn=%d < 0", rn);
+  if (dn != 32 && dn != 64 && dn != 128)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass: dn=%d unsupported (32, 64 or 128 samples per ray)", dn);
+  if (rn == 0) return PGRF_OK;
+  PassArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.imgs = frame->imgs; a.img_feats = frame->img_feats; a.ray_feats = frame->ray_feats;
+  a.w2c = frame->w2c; a.ref_dr = frame->ref_depth_range;
+  std::memcpy(a.c2w, frame->que_c2w, sizeof(a.c2w));
+  a.que_near = frame->que_depth_range[0]; a.que_far = frame->que_depth_range[1];
+  a.H = frame->H; a.W = frame->W; a.hf = frame->hf; a.wf = frame->wf; a.hr = frame->hr; a.wr = frame->wr;
+  a.coords = coords; a.depth = depth; a.rn = rn; a.blob = blob; a.use_vis = use_vis ? 1 : 0;
+  a.out_pixel = out->pixel_colors; a.out_depth = out->render_depth; a.out_hit = out->hit_prob;
+  a.out_colors = out->colors; a.out_density = out->density;
+  if (dbg) a.dbg = *dbg;
+  return launch_render_pass(a, frame->rfn, dn, dbg != nullptr, stream);
+}
+
+}  // namespace pgrf
+
+using namespace pgrf;
+
+extern "C" {
+
+const char* pgrf_last_error(void) { return g_err; }
+int pgrf_abi_version(void) { return 1; }
+
+int pgrf_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream) {
+  if (!src || !dst) return set_error(PGRF_ERR_ARG, "pgrf_pack_map: null pointer");
+  if (n < 1 || C < 1 || h < 1 || w < 1) return set_error(PGRF_ERR_ARG, "pgrf_pack_map: bad shape [%d,%d,%d,%d]", n, C, h, w);
+  return launch_pack_map(src, n, C, h, w, dst, stream);
+}
+
+int pgrf_blob_floats(void) { return kBlobFloats; }
+int pgrf_raw_count(void) { return R_COUNT; }
+const char* pgrf_raw_name(int i) { return (i >= 0 && i < R_COUNT) ? kRawNames[i] : nullptr; }
+
+int pgrf_pack_weights(const float* const* raw_host, int n_raw, int use_vis, int max_dn, float* blob_host) {
+  return pack_weights_host(raw_host, n_raw, use_vis, max_dn, blob_host);
+}
+
+int pgrf_sample_coarse_depth(float min_depth, float max_depth, int use_disp, int rn, int dn, float* depth, void* stream) {
+  if (!depth) return set_error(PGRF_ERR_ARG, "pgrf_sample_coarse_depth: null output");
+  if (dn < 3 || rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_sample_coarse_depth: need dn > 2 (got %d), rn >= 0 (got %d)", dn, rn);
+  if (!(min_depth > 0.f) || !(max_depth > min_depth)) return set_error(PGRF_ERR_ARG, "pgrf_sample_coarse_depth: bad depth range");
+  if (rn == 0) return PGRF_OK;
+  return launch_coarse_depth(min_depth, max_depth, use_disp, rn, dn, depth, stream);
+}
+
+int pgrf_sample_fine_depth(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
+                           int use_all, int rn, int dn, int fdn, float* out, void* stream) {
+  if (!depth || !hit_prob || !out) return set_error(PGRF_ERR_ARG, "pgrf_sample_fine_depth: null pointer");
+  if (dn < 2 || dn > PGRF_MAX_DN || fdn < 1 || fdn > PGRF_MAX_DN)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_sample_fine_depth: dn=%d fdn=%d outside [2,%d]/[1,%d]", dn, fdn, PGRF_MAX_DN, PGRF_MAX_DN);
+  if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_sample_fine_depth: rn < 0");
+  if (rn == 0) return PGRF_OK;
+  return launch_fine_depth(depth, hit_prob, que_near, que_far, use_disp, use_all, rn, dn, fdn, out, stream);
+}
+
+int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords, const float* depth,
+                     int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* stream) {
+  return do_render_pass(frame, blob, use_vis, coords, depth, rn, dn, out, dbg, stream);
+}
+
+int pgrf_merge_c2f(const float* depth_c, const float* colors_c, const float* density_c, int dn_c, const float* depth_f,
+                   const float* colors_f, const float* density_f, int dn_f, int rn, const PgrfPassOut* out, void* stream) {
+  if (!depth_c || !colors_c || !density_c || !depth_f || !colors_f || !density_f || !out)
+    return set_error(PGRF_ERR_ARG, "pgrf_merge_c2f: null pointer");
+  if (dn_c < 1 || dn_f < 1 || dn_c > PGRF_MAX_DN || dn_f > PGRF_MAX_DN)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_merge_c2f: dn_c=%d dn_f=%d outside [1,%d]", dn_c, dn_f, PGRF_MAX_DN);
+  if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_merge_c2f: rn < 0");
+  if (rn == 0) return PGRF_OK;
+  return launch_merge_c2f(depth_c, colors_c, density_c, dn_c, depth_f, colors_f, density_f, dn_f, rn, *out, stream);
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t pgrf_render_workspace_bytes(const PgrfRenderCfg* cfg, int rn) {
+  if (!cfg || rn <= 0) return 0;
+  const size_t r = (size_t)rn;
+  const int fdn_eff = cfg->fine_use_all ? cfg->dn + cfg->fdn : cfg->fdn;
+  size_t b = 0;
+  b += align256(r * cfg->dn * 4);            // coarse depth
+  b += align256(r * cfg->dn * 4);            // coarse hit_prob (when the caller does not ask for it)
+  b += align256(r * fdn_eff * 4);            // fine depth
+  if (cfg->c2f_all) {
+    b += align256(r * cfg->dn * 12) + align256(r * cfg->dn * 4);        // coarse colors, density
+    b += align256(r * fdn_eff * 12) + align256(r * fdn_eff * 4);        // fine colors, density
+  }
+  return b;
+}
+
+int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const float* blob_fine, const PgrfRenderCfg* cfg,
+                     const float* coords, int rn, const PgrfPassOut* coarse, const PgrfPassOut* fine, float* fine_depth_out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+  if (!cfg || !coarse) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: null cfg/coarse");
+  if (cfg->hierarchical && (!fine || !blob_fine)) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: hierarchical render needs fine outputs and weights");
+  if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: rn < 0");
+  if (rn == 0) return PGRF_OK;
+  const size_t need = pgrf_render_workspace_bytes(cfg, rn);
+  if (!workspace || workspace_bytes < need)
+    return set_error(PGRF_ERR_ARG, "pgrf_render_rays: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+  const size_t r = (size_t)rn;
+  const int fdn_eff = cfg->fine_use_all ? cfg->dn + cfg->fdn : cfg->fdn;
+  char* ws = (char*)workspace;
+  float* depth_c = (float*)ws; ws += align256(r * cfg->dn * 4);
+  float* hit_c = (float*)ws; ws += align256(r * cfg->dn * 4);
+  float* depth_f = (float*)ws; ws += align256(r * fdn_eff * 4);
+  PgrfPassOut oc = *coarse;
+  if (!oc.hit_prob) oc.hit_prob = hit_c;
+  PgrfPassOut of;
+  std::memset(&of, 0, sizeof(of));
+  if (fine) of = *fine;
+  float *col_c = nullptr, *den_c = nullptr, *col_f = nullptr, *den_f = nullptr;
+  if (cfg->hierarchical && cfg->c2f_all) {
+    col_c = (float*)ws; ws += align256(r * cfg->dn * 12);
+    den_c = (float*)ws; ws += align256(r * cfg->dn * 4);
+    col_f = (float*)ws; ws += align256(r * fdn_eff * 12);
+    den_f = (float*)ws; ws += align256(r * fdn_eff * 4);
+    if (!oc.colors) oc.colors = col_c; else col_c = oc.colors;
+    if (!oc.density) oc.density = den_c; else den_c = oc.density;
+  }
+  int rc = pgrf_sample_coarse_depth(cfg->min_depth, cfg->max_depth, cfg->use_disp, rn, cfg->dn, depth_c, stream);
+  if (rc) return rc;
+  rc = do_render_pass(frame, blob_coarse, cfg->use_vis_coarse, coords, depth_c, rn, cfg->dn, &oc, nullptr, stream);
+  if (rc || !cfg->hierarchical) return rc;
+  float* fd = fine_depth_out ? fine_depth_out : depth_f;
+  rc = pgrf_sample_fine_depth(depth_c, oc.hit_prob, frame->que_depth_range[0], frame->que_depth_range[1], cfg->use_disp,
+                              cfg->fine_use_all, rn, cfg->dn, cfg->fdn, fd, stream);
+  if (rc) return rc;
+  if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, cfg->use_vis_fine, coords, fd, rn, fdn_eff, &of, nullptr, stream);
+  // fine pass into scratch, then one composite over the union (renderer.py:484-518)
+  PgrfPassOut tmp;
+  std::memset(&tmp, 0, sizeof(tmp));
+  tmp.colors = col_f; tmp.density = den_f;
+  rc = do_render_pass(frame, blob_fine, cfg->use_vis_fine, coords, fd, rn, fdn_eff, &tmp, nullptr, stream);
+  if (rc) return rc;
+  return pgrf_merge_c2f(depth_c, col_c, den_c, cfg->dn, fd, col_f, den_f, fdn_eff, rn, &of, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+// Host-side packing of one pass's per-ray network weights (reference state_dict layout) into
+// the MFMA-operand-ordered blob described in pgrf_layout.h.  Pure host code (no HIP calls).
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+#include "pgrf_internal.h"
+#include "pgrf_layout.h"
+
+namespace pgrf {
+
+namespace {
+
+// in_feat(step, half) -> column of W (or -1); out_row(mt, rho) -> row of W (or -1)
+using InMap = std::function<int(int, int)>;
+using OutMap = std::function<int(int, int)>;
+
+void pack_layer(float* blob, int id, const float* W, int in_dim, const float* bias, const InMap& in_feat,
+                const OutMap& out_row, int col_base = 0) {
+  const int ks = kKS[id], mt = kMT[id];
+  const int ks4 = (ks + 3) / 4;
+  float* A = blob + layer_a_off(id);
+  for (int m = 0; m < mt; ++m)
+    for (int s = 0; s < ks4 * 4; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        float v = 0.f;
+        if (s < ks && W) {
+          const int row = out_row(m, lane & 31);
+          const int col = in_feat(s, lane >> 5);
+          if (row >= 0 && col >= 0) v = W[(size_t)row * in_dim + col_base + col];
+        }
+        A[((size_t)(m * ks4 + s / 4) * 64 + lane) * 4 + (s & 3)] = v;
+      }
+  if (kHasBias[id]) {
+    float* B = blob + layer_b_off(id);
+    for (int m = 0; m < mt; ++m)
+      for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) {
+          const int row = out_row(m, rho(r, h));
+          B[m * 32 + h * 16 + r] = (row >= 0 && bias) ? bias[row] : 0.f;
+        }
+  }
+}
+
+// head block [half][R]: value = w[col(r, half)]
+void pack_head(float* dst, const float* w, int R, const std::function<int(int, int)>& col) {
+  for (int h = 0; h < 2; ++h)
+    for (int r = 0; r < R; ++r) {
+      const int c = col(r, h);
+      dst[h * R + r] = (c >= 0 && w) ? w[c] : 0.f;
+    }
+}
+
+int ident_in(int s, int h) { return rho(s, h); }                 // k-step s reads register s of a 32-feature tile
+int ident_out(int, int r) { return r; }                          // rows 0..31 -> outputs 0..31
+
+}  // namespace
+
+int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_dn, float* blob) {
+  if (!raw || !blob) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: null argument");
+  if (n_raw != R_COUNT) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: expected %d raw tensors, got %d", R_COUNT, n_raw);
+  if (max_dn < 1 || max_dn > kMaxDn) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: max_dn %d out of range [1,%d]", max_dn, kMaxDn);
+  for (int i = 0; i < R_COUNT; ++i) {
+    const bool is_vis = (i >= R_DD_VIS_0_W && i <= R_DD_VIS_4_B);
+    if (!raw[i] && !(is_vis && !use_vis)) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: raw tensor %d is null", i);
+  }
+  std::memset(blob, 0, sizeof(float) * kBlobFloats);
+
+  // ---- dist decoder -----------------------------------------------------------------
+  const int dec0[4] = {R_DD_MEAN_0_W, R_DD_VAR_0_W, R_DD_AW_0_W, R_DD_VIS_0_W};
+  {  // fused layer 0: tile m = MLP m
+    const int ks = kKS[L_DD1], ks4 = (ks + 3) / 4;
+    float* A = blob + layer_a_off(L_DD1);
+    float* B = blob + layer_b_off(L_DD1);
+    for (int m = 0; m < 4; ++m) {
+      const float* W = (m == 3 && !use_vis) ? nullptr : raw[dec0[m]];
+      const float* b = (m == 3 && !use_vis) ? nullptr : raw[dec0[m] + 1];
+      for (int s = 0; s < ks; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          A[((size_t)(m * ks4 + s / 4) * 64 + lane) * 4 + (s & 3)] = W ? W[(lane & 31) * 32 + rho(s, lane >> 5)] : 0.f;
+      for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) B[m * 32 + h * 16 + r] = b ? b[rho(r, h)] : 0.f;
+    }
+  }
+  for (int m = 0; m < 4; ++m) {
+    const bool off = (m == 3 && !use_vis);
+    pack_layer(blob, L_DD2_0 + m, off ? nullptr : raw[dec0[m] + 2], 32, off ? nullptr : raw[dec0[m] + 3], ident_in, ident_out);
+  }
+  {  // heads: mean0, mean1, var0, var1, aw, vis
+    const int head_src[6][2] = {{R_DD_MEAN_4_W, 0}, {R_DD_MEAN_4_W, 1}, {R_DD_VAR_4_W, 0}, {R_DD_VAR_4_W, 1}, {R_DD_AW_4_W, 0}, {R_DD_VIS_4_W, 0}};
+    for (int j = 0; j < 6; ++j) {
+      const bool off = (j == 5 && !use_vis);
+      const float* W = off ? nullptr : raw[head_src[j][0]];
+      const float* b = off ? nullptr : raw[head_src[j][0] + 1];
+      const int row = head_src[j][1];
+      pack_head(blob + OFF_DDH_W + j * 32, W ? W + row * 32 : nullptr, 16, [](int r, int h) { return rho(r, h); });
+      blob[OFF_DDH_B + j] = b ? b[row] : 0.f;
+    }
+  }
+  // ---- prob_embed -------------------------------------------------------------------
+  pack_layer(blob, L_PE1, raw[R_PE_0_W], 34, raw[R_PE_0_B],
+             [](int s, int h) { return s < 16 ? rho(s, h) : 32 + h; }, ident_out);
+  pack_layer(blob, L_PE2, raw[R_PE_2_W], 32, raw[R_PE_2_B], ident_in, ident_out);
+  // ---- neuray_fc --------------------------------------------------------------------
+  pack_layer(blob, L_NF1, raw[R_NF_0_W], 32, raw[R_NF_0_B], ident_in, [](int, int r) { return r < 8 ? r : -1; });
+  pack_head(blob + OFF_NFH_W, raw[R_NF_2_W], 4, [](int r, int h) { return rho(r, h); });
+  blob[OFF_NFH_B] = raw[R_NF_2_B][0];
+  // ---- ray_dir_fc -------------------------------------------------------------------
+  pack_layer(blob, L_RD1, raw[R_RD_0_W], 4, raw[R_RD_0_B], [](int s, int h) { return 2 * s + h; },
+             [](int, int r) { return r < 16 ? r : -1; });
+  // out feature order of the reference: [rgb(3), img_feats(32)]; tile0 = img part, tile1 rows 0..2 = rgb part
+  pack_layer(blob, L_RD2, raw[R_RD_2_W], 16, raw[R_RD_2_B], ident_in,
+             [](int m, int r) { return m == 0 ? 3 + r : (r < 3 ? r : -1); });
+  // ---- base_fc ----------------------------------------------------------------------
+  // columns of base_fc.0: [mean0(35) var0(35) mean1(35) var1(35) | rgb_feat(35) neuray(32)]
+  pack_layer(blob, L_BG, raw[R_BASE_0_W], 207, raw[R_BASE_0_B],
+             [](int s, int h) {
+               const int stat = s / 19, j = s % 19;
+               if (j < 16) return 35 * stat + 3 + rho(j, h);
+               return h == 0 ? 35 * stat + (j - 16) : -1;
+             },
+             [](int m, int r) { return 32 * m + r; });
+  pack_layer(blob, L_BV, raw[R_BASE_0_W], 207, nullptr,
+             [](int s, int h) {
+               if (s < 16) return 140 + 3 + rho(s, h);
+               if (s < 19) return h == 0 ? 140 + (s - 16) : -1;
+               return 175 + rho(s - 19, h);
+             },
+             [](int m, int r) { return 32 * m + r; });
+  pack_layer(blob, L_B2, raw[R_BASE_2_W], 64, raw[R_BASE_2_B],
+             [](int s, int h) { return s < 16 ? rho(s, h) : 32 + rho(s - 16, h); }, ident_out);
+  // ---- vis_fc / vis_fc2 -------------------------------------------------------------
+  pack_layer(blob, L_VF1, raw[R_VF_0_W], 32, raw[R_VF_0_B], ident_in, ident_out);
+  pack_layer(blob, L_VF2, raw[R_VF_2_W], 32, raw[R_VF_2_B], ident_in, ident_out);   // rows 0..31 = x_res
+  pack_head(blob + OFF_VFH_W, raw[R_VF_2_W] + 32 * 32, 16, [](int r, int h) { return rho(r, h); });
+  blob[OFF_VFH_B] = raw[R_VF_2_B][32];
+  pack_layer(blob, L_V21, raw[R_V2_0_W], 32, raw[R_V2_0_B], ident_in, ident_out);
+  pack_head(blob + OFF_V2H_W, raw[R_V2_2_W], 16, [](int r, int h) { return rho(r, h); });
+  blob[OFF_V2H_B] = raw[R_V2_2_B][0];
+  // ---- geometry_fc ------------------------------------------------------------------
+  pack_layer(blob, L_G1, raw[R_GEO_0_W], 65, raw[R_GEO_0_B],
+             [](int s, int h) {
+               if (s < 16) return rho(s, h);
+               if (s < 32) return 32 + rho(s - 16, h);
+               return h == 0 ? 64 : -1;
+             },
+             [](int m, int r) { return 32 * m + r; });
+  pack_layer(blob, L_G2, raw[R_GEO_2_W], 64, raw[R_GEO_2_B],
+             [](int s, int h) { return s < 16 ? rho(s, h) : 32 + rho(s - 16, h); },
+             [](int, int r) { return r < 16 ? r : -1; });
+  // ---- ray attention ----------------------------------------------------------------
+  {  // q|k in tile 0, v in tile 1 — three source matrices, so fill by hand
+    const int ks = kKS[L_QKV], ks4 = (ks + 3) / 4;
+    float* A = blob + layer_a_off(L_QKV);
+    for (int m = 0; m < 2; ++m)
+      for (int s = 0; s < ks; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int r = lane & 31, col = rho(s, lane >> 5);
+          float v = 0.f;
+          if (m == 0) v = (r < 16) ? raw[R_ATT_Q_W][attn_feat(r) * 16 + col] : raw[R_ATT_K_W][attn_feat(r - 16) * 16 + col];
+          else if (r < 16) v = raw[R_ATT_V_W][attn_feat(r) * 16 + col];
+          A[((size_t)(m * ks4 + s / 4) * 64 + lane) * 4 + (s & 3)] = v;
+        }
+  }
+  pack_layer(blob, L_FC, raw[R_ATT_FC_W], 16, nullptr,
+             [](int s, int h) { return 4 * (s >> 1) + 2 * (s & 1) + h; }, [](int, int r) { return r < 16 ? r : -1; });
+  pack_head(blob + OFF_LN_G, raw[R_ATT_LN_W], 8, [](int r, int h) { return rho(r, h); });
+  pack_head(blob + OFF_LN_B, raw[R_ATT_LN_B], 8, [](int r, int h) { return rho(r, h); });
+  // ---- out_geometry_fc --------------------------------------------------------------
+  pack_layer(blob, L_OG1, raw[R_OG_0_W], 16, raw[R_OG_0_B], ident_in, [](int, int r) { return r < 16 ? r : -1; });
+  pack_head(blob + OFF_OGH_W, raw[R_OG_2_W], 8, [](int r, int h) { return rho(r, h); });
+  blob[OFF_OGH_B] = raw[R_OG_2_B][0];
+  // ---- rgb_fc -----------------------------------------------------------------------
+  // columns of rgb_fc.0: [x(32), vis(1), ray_diff(4)]
+  pack_layer(blob, L_RGB1, raw[R_RGB_0_W], 37, raw[R_RGB_0_B],
+             [](int s, int h) {
+               if (s < 16) return rho(s, h);
+               const int c = 32 + 2 * (s - 16) + h;
+               return c < 37 ? c : -1;
+             },
+             [](int, int r) { return r < 16 ? r : -1; });
+  pack_layer(blob, L_RGB2, raw[R_RGB_2_W], 16, raw[R_RGB_2_B], ident_in, [](int, int r) { return r < 8 ? r : -1; });
+  pack_head(blob + OFF_RGBH_W, raw[R_RGB_4_W], 4, [](int r, int h) { return rho(r, h); });
+  blob[OFF_RGBH_B] = raw[R_RGB_4_B][0];
+  // ---- positional encoding (ibrnet.py:305-313: float64 table cast to float32) -------
+  for (int p = 0; p < max_dn; ++p)
+    for (int h = 0; h < 2; ++h)
+      for (int r = 0; r < 8; ++r) {
+        const int j = rho(r, h);
+        const double ang = (double)p / std::pow(10000.0, 2.0 * (j / 2) / 16.0);
+        blob[OFF_POS + p * 16 + h * 8 + r] = (float)((j & 1) ? std::cos(ang) : std::sin(ang));
+      }
+  return PGRF_OK;
+}
+
+}  // namespace pgrf

@@ -1,0 +1,128 @@
+// Packed-weight layout of one network pass (coarse or fine) of the per-ray renderer.
+// Shared by the host packer (pack_weights.cpp) and the HIP kernel (render_pass.h).
+//
+// Every Linear layer y = W x + b of the per-point MLPs is evaluated TRANSPOSED on the
+// f32 matrix cores:  Y^T[32 out-rows x 32 points] += W-tile[32 x 2] * X^T[2 x 32 points]
+// with v_mfma_f32_32x32x2_f32.  A wave owns 32 sample points; lane l holds point (l & 31)
+// and, in accumulator register r, output row  rho(r, l>>5) = (r&3) + 8*(r>>2) + 4*(l>>5).
+// Because the B operand of step s wants "feature k=0 in lanes 0-31, feature k=1 in lanes
+// 32-63", accumulator register r of one layer IS the B operand of k-step r of the next
+// layer: activations never leave registers.  The price is paid once, on the host: the
+// A operands (weights) are stored pre-permuted in exactly the order the lanes consume them:
+//
+//   A block of a layer:  [mt][ks4][lane 0..63][4]   float   (one dwordx4 per lane = 4 k-steps)
+//        value(mt, s, lane) = W[out_row(mt, lane & 31)][in_feat(s, lane >> 5)]   (0 if unmapped)
+//   bias block:          [mt][half][16]             float   value = b[out_row(mt, rho(r, half))]
+//
+// The tiny heads (N <= 2 outputs) run on the VALU from "head" blocks  [out][half][R] .
+#pragma once
+
+namespace pgrf {
+
+constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct LayerDesc {
+  int ks;      // k-steps (each consumes 2 input features)
+  int mt;      // 32-row output tiles
+  int a_off;   // float offset of the A block inside the blob
+  int b_off;   // float offset of the bias block (-1: none)
+};
+
+constexpr int a_size(int ks, int mt) { return mt * ((ks + 3) / 4) * 256; }
+constexpr int b_size(int mt) { return mt * 32; }
+
+// ---- layer ids ------------------------------------------------------------------------
+enum LayerId {
+  L_DD1 = 0,                       // dist decoder layer 0 of the 4 MLPs (mean,var,aw,vis), fused: 32 -> 4x32
+  L_DD2_0, L_DD2_1, L_DD2_2, L_DD2_3,  // dist decoder layer 2 of each MLP: 32 -> 32
+  L_PE1,                           // prob_embed.0  34 -> 32
+  L_PE2,                           // prob_embed.2  32 -> 32
+  L_NF1,                           // neuray_fc.0   32 -> 8
+  L_RD1,                           // ray_dir_fc.0   4 -> 16
+  L_RD2,                           // ray_dir_fc.2  16 -> 35   (tile0: img-feat part, tile1: rgb part)
+  L_BG,                            // base_fc.0, view-shared 140 columns  -> 64
+  L_BV,                            // base_fc.0, per-view 67 columns      -> 64 (accumulates onto L_BG)
+  L_B2,                            // base_fc.2     64 -> 32
+  L_VF1,                           // vis_fc.0      32 -> 32
+  L_VF2,                           // vis_fc.2      32 -> 32 (+ row 32 as a head)
+  L_V21,                           // vis_fc2.0     32 -> 32
+  L_G1,                            // geometry_fc.0 65 -> 64
+  L_G2,                            // geometry_fc.2 64 -> 16
+  L_QKV,                           // w_qs|w_ks (tile0), w_vs (tile1)  16 -> 48
+  L_FC,                            // ray_attention.fc 16 -> 16
+  L_OG1,                           // out_geometry_fc.0 16 -> 16
+  L_RGB1,                          // rgb_fc.0      37 -> 16
+  L_RGB2,                          // rgb_fc.2      16 -> 8
+  L_COUNT
+};
+
+constexpr int kKS[L_COUNT] = {16, 16, 16, 16, 16, 17, 16, 16, 2, 8, 76, 35, 32, 16, 16, 16, 33, 32, 8, 8, 8, 19, 8};
+constexpr int kMT[L_COUNT] = {4, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 2, 1, 2, 1, 1, 1, 1};
+constexpr bool kHasBias[L_COUNT] = {true, true, true, true, true, true, true, true, true, true, true, false, true,
+                                    true, true, true, true, true, false, false, true, true, true};
+
+constexpr int layer_a_off(int id) {
+  int off = 0;
+  for (int i = 0; i < id; ++i) off += a_size(kKS[i], kMT[i]) + (kHasBias[i] ? b_size(kMT[i]) : 0);
+  return off;
+}
+constexpr int layer_b_off(int id) { return kHasBias[id] ? layer_a_off(id) + a_size(kKS[id], kMT[id]) : -1; }
+constexpr int kLayersEnd = layer_a_off(L_COUNT);
+
+// ---- VALU head / misc region (float offsets) -------------------------------------------
+// dist-decoder heads: 6 outputs (mean0, mean1, var0, var1, aw, vis) x [half][16], then 6 biases (+2 pad)
+constexpr int OFF_DDH_W = kLayersEnd;
+constexpr int OFF_DDH_B = OFF_DDH_W + 6 * 32;
+// neuray_fc.2 head: [half][4] + bias (+3 pad)
+constexpr int OFF_NFH_W = OFF_DDH_B + 8;
+constexpr int OFF_NFH_B = OFF_NFH_W + 8;
+// vis_fc.2 row 32: [half][16] + bias
+constexpr int OFF_VFH_W = OFF_NFH_B + 4;
+constexpr int OFF_VFH_B = OFF_VFH_W + 32;
+// vis_fc2.2: [half][16] + bias
+constexpr int OFF_V2H_W = OFF_VFH_B + 4;
+constexpr int OFF_V2H_B = OFF_V2H_W + 32;
+// out_geometry_fc.2: [half][8] + bias
+constexpr int OFF_OGH_W = OFF_V2H_B + 4;
+constexpr int OFF_OGH_B = OFF_OGH_W + 16;
+// rgb_fc.4: [half][4] + bias
+constexpr int OFF_RGBH_W = OFF_OGH_B + 4;
+constexpr int OFF_RGBH_B = OFF_RGBH_W + 8;
+// LayerNorm gamma, beta: [half][8] each
+constexpr int OFF_LN_G = OFF_RGBH_B + 4;
+constexpr int OFF_LN_B = OFF_LN_G + 16;
+// positional encoding [PGRF_MAX_DN][half][8]
+constexpr int kMaxDn = 128;
+constexpr int OFF_POS = OFF_LN_B + 16;
+constexpr int kBlobFloats = OFF_POS + kMaxDn * 16;
+
+// attention feature permutation: accumulator row rho (< 16) of the q / k / v projections holds
+// head-feature  attn_feat(rho)  so that register 2*head+s carries dims (2s, 2s+1) in the two lane halves.
+constexpr int attn_feat(int rho_) {
+  int h = (rho_ >> 2) & 1;
+  int r = (rho_ & 3) + 4 * (rho_ >> 3);
+  return 4 * (r >> 1) + 2 * (r & 1) + h;
+}
+
+// ---- raw (reference-layout) weight table handed to pgrf_pack_weights --------------------
+// Order of the `const float*` array; every Linear is [out,in] row-major + [out] bias, exactly as in
+// the reference state_dict.  vis_decoder entries may be NULL (use_vis=false).
+enum RawId {
+  R_DD_MEAN_0_W = 0, R_DD_MEAN_0_B, R_DD_MEAN_2_W, R_DD_MEAN_2_B, R_DD_MEAN_4_W, R_DD_MEAN_4_B,
+  R_DD_VAR_0_W, R_DD_VAR_0_B, R_DD_VAR_2_W, R_DD_VAR_2_B, R_DD_VAR_4_W, R_DD_VAR_4_B,
+  R_DD_AW_0_W, R_DD_AW_0_B, R_DD_AW_2_W, R_DD_AW_2_B, R_DD_AW_4_W, R_DD_AW_4_B,
+  R_DD_VIS_0_W, R_DD_VIS_0_B, R_DD_VIS_2_W, R_DD_VIS_2_B, R_DD_VIS_4_W, R_DD_VIS_4_B,
+  R_PE_0_W, R_PE_0_B, R_PE_2_W, R_PE_2_B,
+  R_RD_0_W, R_RD_0_B, R_RD_2_W, R_RD_2_B,
+  R_BASE_0_W, R_BASE_0_B, R_BASE_2_W, R_BASE_2_B,
+  R_VF_0_W, R_VF_0_B, R_VF_2_W, R_VF_2_B,
+  R_V2_0_W, R_V2_0_B, R_V2_2_W, R_V2_2_B,
+  R_GEO_0_W, R_GEO_0_B, R_GEO_2_W, R_GEO_2_B,
+  R_ATT_Q_W, R_ATT_K_W, R_ATT_V_W, R_ATT_FC_W, R_ATT_LN_W, R_ATT_LN_B,
+  R_OG_0_W, R_OG_0_B, R_OG_2_W, R_OG_2_B,
+  R_RGB_0_W, R_RGB_0_B, R_RGB_2_W, R_RGB_2_B, R_RGB_4_W, R_RGB_4_B,
+  R_NF_0_W, R_NF_0_B, R_NF_2_W, R_NF_2_B,
+  R_COUNT
+};
+
+}  // namespace pgrf

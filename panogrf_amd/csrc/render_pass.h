@@ -1,0 +1,765 @@
+// Fused per-ray renderer pass for gfx950 (CDNA4).  One launch does, for every ray of the batch:
+// ERP ray generation -> projection into the V source views -> bilinear gathers (NHWC maps) ->
+// mixture-of-logistics visibility decoder -> IBRNet-with-NeuRay aggregation (all Linear layers on
+// v_mfma_f32_32x32x2_f32, transposed so activations stay in registers: see pgrf_layout.h) ->
+// 4-head attention over the samples of the ray (QK^T on MFMA, K/V staged in LDS) -> density,
+// colour blending -> alpha compositing (wave scan through LDS).
+//
+// Work decomposition: workgroup = 4 waves = 128 sample points = 128/DN rays.  A wave owns 32
+// consecutive samples of one ray for ALL source views; lane l holds point (l & 31); lanes l and
+// l+32 hold the two halves of each 32-feature activation tile (accumulator layout of the 32x32
+// MFMA).  Per-point scalars are computed redundantly by both halves.
+//
+// Reference semantics (file:line into /root/reference) are cited at each stage.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pgrf_internal.h"
+#include "pgrf_layout.h"
+#include "render_pass_args.h"
+
+namespace pgrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+#define PGRF_PI_F 3.14159265358979323846f
+#define PGRF_HALF_PI_F 1.57079632679489661923f
+#define PGRF_TWO_PI_F 6.28318530717958647692f
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
+__device__ __forceinline__ float sigmoid1(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+
+__device__ __forceinline__ void elu16(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = elu1(a[r]);
+}
+
+// One Linear layer on the matrix cores for NT point tiles sharing the A operand.
+//   acc[t][m] (+)= A(m) * b[t]   with b[t][s] = B operand of k-step s (see pgrf_layout.h)
+template <int KS, int MT, int NT, bool INIT_BIAS>
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const float* __restrict__ B, int lane,
+                                           const float (&b)[NT][KS], f32x16 (&acc)[NT][MT]) {
+  constexpr int KS4 = (KS + 3) / 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (INIT_BIAS) {
+      const float4* bp = reinterpret_cast<const float4*>(B + m * 32 + (lane >> 5) * 16);
+      const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+      f32x16 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][m] = bv;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < KS4; ++s4) {
+      const float4 a = reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (s4 * 4 + j < KS) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[t][s4 * 4 + j], acc[t][m], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// VALU head: out = sum_r w[half][r] * x[r], summed over both lane halves (bias added by caller).
+template <int R>
+__device__ __forceinline__ float head_dot(const float* __restrict__ w, int half, const f32x16& x) {
+  const float* wp = w + half * R;
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s = fmaf(wp[r], x[r], s);
+  return s + xhalf(s);
+}
+
+struct Bilin {
+  int o00, o01, o10, o11;   // pixel offsets (pixels, not floats) of the 4 taps inside one view's map
+  float wnw, wne, wsw, wse;
+};
+
+// grid_sample(bilinear, padding_mode=border) tap setup for a point given in FULL-image pixels.
+// network/render_ops.py:126-143, network/ops.py:32-52 (x/(W-1)*2-1 with the full-image W,H).
+__device__ __forceinline__ Bilin bilin_setup(float px, float py, int H, int W, int fh, int fw, bool align) {
+  const float xn = px / (float)(W - 1) * 2.f - 1.f;
+  const float yn = py / (float)(H - 1) * 2.f - 1.f;
+  float ix, iy;
+  if (align) {
+    ix = (xn + 1.f) / 2.f * (float)(fw - 1);
+    iy = (yn + 1.f) / 2.f * (float)(fh - 1);
+  } else {
+    ix = ((xn + 1.f) * (float)fw - 1.f) / 2.f;
+    iy = ((yn + 1.f) * (float)fh - 1.f) / 2.f;
+  }
+  ix = fminf(fmaxf(ix, 0.f), (float)(fw - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(fh - 1));
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const float fx1 = fx0 + 1.f, fy1 = fy0 + 1.f;
+  Bilin b;
+  b.wnw = (fx1 - ix) * (fy1 - iy);
+  b.wne = (ix - fx0) * (fy1 - iy);
+  b.wsw = (fx1 - ix) * (iy - fy0);
+  b.wse = (ix - fx0) * (iy - fy0);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const int x1 = min(x0 + 1, fw - 1), y1 = min(y0 + 1, fh - 1);   // out-of-range taps carry weight 0
+  b.o00 = y0 * fw + x0;
+  b.o01 = y0 * fw + x1;
+  b.o10 = y1 * fw + x0;
+  b.o11 = y1 * fw + x1;
+  return b;
+}
+
+// Gather one 32-channel NHWC map into the accumulator layout: register 4q+i of half h = channel 8q+4h+i.
+__device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const Bilin& b, int half) {
+  f32x16 out;
+  const float* base = map + half * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 a = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * 32 + q * 8);
+    const float4 c = *reinterpret_cast<const float4*>(base + (size_t)b.o01 * 32 + q * 8);
+    const float4 d = *reinterpret_cast<const float4*>(base + (size_t)b.o10 * 32 + q * 8);
+    const float4 e = *reinterpret_cast<const float4*>(base + (size_t)b.o11 * 32 + q * 8);
+    out[4 * q + 0] = a.x * b.wnw + c.x * b.wne + d.x * b.wsw + e.x * b.wse;
+    out[4 * q + 1] = a.y * b.wnw + c.y * b.wne + d.y * b.wsw + e.y * b.wse;
+    out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
+    out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
+  }
+  return out;
+}
+
+__device__ __forceinline__ void dump_tile32(float* dst, const f32x16& x, int half) {   // dst -> 32 floats of this point
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[rho(r, half)] = x[r];
+}
+__device__ __forceinline__ void dump_tile16(float* dst, const f32x16& x, int half) {   // regs 0..7 hold 16 features
+#pragma unroll
+  for (int r = 0; r < 8; ++r) dst[rho(r, half)] = x[r];
+}
+
+struct ViewState {
+  f32x16 fa;      // rgb_feat tile A (img-feat part, + dir feat); later: x (base_fc output, 32)
+  float fb[3];    // rgb_feat tile B (rgb part + dir feat), meaningful in lanes 0..31
+  f32x16 nf;      // prob_embed output ("neuray feat")
+  float dd[4];    // [prj_dir - que_dir, <prj_dir,que_dir>]
+  float rgb[3];   // gathered source colour (blended at the end)
+  float w0;       // sigmoid(neuray_fc) * w
+  float v2;       // vis_fc2 output
+};
+
+struct PointGeom {
+  float p[3];       // world position
+  float qdir[3];    // -d/|d|
+  float near_hw, far_hw;   // half widths of the sample's interval in normalised inverse depth
+};
+
+// ---------------------------------------------------------------------------------------------
+// Stage A for NT views starting at V0: projection, gathers, dist decoder, prob_embed, neuray_fc,
+// ray_dir_fc.  Fills vs[V0..V0+NT).
+template <int V, int V0, int NT, bool DBG>
+__device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& g, ViewState (&vs)[V], int lane,
+                                            size_t pt /* ray*DN+sample */, size_t npts, bool store_ok) {
+  const int half = lane >> 5;
+  const float* __restrict__ W = p.blob;
+  f32x16 rf[NT];
+  float vis_s[NT], hit_s[NT];
+  float dv[NT];
+  Bilin bimg[NT], bfeat[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int v = V0 + t;
+    const float* M = p.w2c + v * 12;
+    // world -> source camera  (render_ops.py:158-191)
+    const float cx = M[0] * g.p[0] + M[1] * g.p[1] + M[2] * g.p[2] + M[3];
+    const float cy = M[4] * g.p[0] + M[5] * g.p[1] + M[6] * g.p[2] + M[7];
+    const float cz = M[8] * g.p[0] + M[9] * g.p[1] + M[10] * g.p[2] + M[11];
+    const float r = sqrtf(cx * cx + cy * cy + cz * cz);
+    // m3d cartesian -> sphere -> ERP pixel (spt_utils.py:134-138, :176-179)
+    float th = atan2f(cz, cx) + PGRF_HALF_PI_F;
+    if (th < 0.f) th += PGRF_TWO_PI_F;                      // python-style remainder, |th| < 2pi
+    const float ph = acosf(cy / (r + 1e-5f));
+    const float px = th / PGRF_TWO_PI_F * (float)(p.W - 1);
+    const float py = ph / PGRF_PI_F * (float)(p.H - 1);
+    dv[t] = r;
+    // direction towards the source camera centre  (render_ops.py:195-209): c = -R^T t
+    const float ccx = -(M[0] * M[3] + M[4] * M[7] + M[8] * M[11]);
+    const float ccy = -(M[1] * M[3] + M[5] * M[7] + M[9] * M[11]);
+    const float ccz = -(M[2] * M[3] + M[6] * M[7] + M[10] * M[11]);
+    float dx = g.p[0] - ccx, dy = g.p[1] - ccy, dz = g.p[2] - ccz;
+    const float dn_ = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-5f);
+    dx = -dx / dn_; dy = -dy / dn_; dz = -dz / dn_;
+    vs[v].dd[0] = dx - g.qdir[0];
+    vs[v].dd[1] = dy - g.qdir[1];
+    vs[v].dd[2] = dz - g.qdir[2];
+    vs[v].dd[3] = dx * g.qdir[0] + dy * g.qdir[1] + dz * g.qdir[2];   // aggregate_net.py:8-14
+    // bilinear gathers (render_ops.py:243-245, renderer.py:180-188)
+    const Bilin brf = bilin_setup(px, py, p.H, p.W, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
+    bfeat[t] = bilin_setup(px, py, p.H, p.W, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
+    bimg[t] = bilin_setup(px, py, p.H, p.W, p.H, p.W, true);
+    rf[t] = gather32(p.ray_feats + (size_t)v * p.hr * p.wr * 32, brf, half);
+    if (DBG && store_ok) {
+      const size_t o = (size_t)v * npts + pt;
+      if (p.dbg.px && half == 0) { p.dbg.px[o * 2] = px; p.dbg.px[o * 2 + 1] = py; }
+      if (p.dbg.depth_v && half == 0) p.dbg.depth_v[o] = r;
+      if (p.dbg.ddiff && half == 0) for (int c = 0; c < 4; ++c) p.dbg.ddiff[o * 4 + c] = vs[v].dd[c];
+      if (p.dbg.ray_feats) dump_tile32(p.dbg.ray_feats + o * 32, rf[t], half);
+    }
+  }
+
+  // ---- mixture-of-logistics decoder: 3 (4) MLPs 32 -> 32 -> 32 -> head  (dist_decoder.py:53-107)
+  float bin[NT][16];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) bin[t][s] = rf[t][s];
+  float head[NT][6];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) head[t][5] = 1.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    if (m == 3 && !p.use_vis) break;
+    f32x16 a1[NT][1], a2[NT][1];
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD1) + m * 4 * 256, W + layer_b_off(L_DD1) + m * 32, lane, bin, a1);
+    float b2[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[t][0][s]);
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      elu16(a2[t][0]);
+      if (m == 0) {
+        head[t][0] = softplus1(head_dot<16>(W + OFF_DDH_W + 0 * 32, half, a2[t][0]) + W[OFF_DDH_B + 0]);
+        head[t][1] = softplus1(head_dot<16>(W + OFF_DDH_W + 1 * 32, half, a2[t][0]) + W[OFF_DDH_B + 1]);
+      } else if (m == 1) {   // softplus + AddBias(0.05)  (dist_decoder.py:73-81)
+        head[t][2] = softplus1(head_dot<16>(W + OFF_DDH_W + 2 * 32, half, a2[t][0]) + W[OFF_DDH_B + 2]) + 0.05f;
+        head[t][3] = softplus1(head_dot<16>(W + OFF_DDH_W + 3 * 32, half, a2[t][0]) + W[OFF_DDH_B + 3]) + 0.05f;
+      } else if (m == 2) {
+        head[t][4] = sigmoid1(head_dot<16>(W + OFF_DDH_W + 4 * 32, half, a2[t][0]) + W[OFF_DDH_B + 4]);
+      } else {
+        head[t][5] = sigmoid1(head_dot<16>(W + OFF_DDH_W + 5 * 32, half, a2[t][0]) + W[OFF_DDH_B + 5]);
+      }
+    }
+  }
+  // ---- compute_prob (dist_decoder.py:6-51 is_ref branch, :109-140)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int v = V0 + t;
+    const float rn_ = -1.f / p.ref_dr[2 * v], rf_ = -1.f / p.ref_dr[2 * v + 1];
+    const float z = (-1.f / fmaxf(dv[t], 1e-5f) - rn_) / (rf_ - rn_);
+    const float nearp = z - g.near_hw, farp = z + g.far_hw;
+    const float aw = head[t][4];
+    float visib = 0.f, hitp = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float mean = head[t][k], var = head[t][2 + k];
+      float c0 = 0.5f + 0.5f * tanhf((nearp - mean) * var);
+      float c1 = 0.5f + 0.5f * tanhf((farp - mean) * var);
+      if (p.use_vis) { c0 *= head[t][5]; c1 *= head[t][5]; }
+      const float mix = (k == 0) ? aw : 1.f - aw;
+      visib += (1.f - c0) * mix;
+      hitp += (c1 - c0) * mix;
+    }
+    vis_s[t] = visib;
+    hit_s[t] = hitp;
+    if (DBG && store_ok && half == 0) {
+      const size_t o = (size_t)v * npts + pt;
+      if (p.dbg.vis) p.dbg.vis[o] = visib;
+      if (p.dbg.hit) p.dbg.hit[o] = hitp;
+    }
+  }
+  // ---- prob_embed: [ray_feats(32), 2(hit-.5), 2(vis-.5)] -> 32 relu -> 32  (aggregate_net.py:53-61)
+  {
+    float b17[NT][17];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b17[t][s] = rf[t][s];
+      b17[t][16] = half ? (vis_s[t] - 0.5f) * 2.f : (hit_s[t] - 0.5f) * 2.f;
+    }
+    f32x16 a1[NT][1], a2[NT][1];
+    mfma_layer<17, 1, NT, true>(W + layer_a_off(L_PE1), W + layer_b_off(L_PE1), lane, b17, a1);
+    float b2[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b2[t][s] = fmaxf(a1[t][0][s], 0.f);
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_PE2), W + layer_b_off(L_PE2), lane, b2, a2);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) vs[V0 + t].nf = a2[t][0];
+  }
+  // ---- neuray_fc 32 -> 8 elu -> 1, weight0 = sigmoid(.) * w   (ibrnet.py:337-338)
+  {
+    float b16[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b16[t][s] = vs[V0 + t].nf[s];
+    f32x16 a1[NT][1];
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_NF1), W + layer_b_off(L_NF1), lane, b16, a1);
+    const float wgt = 1.f / ((float)V + 1e-8f);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 h = a1[t][0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = elu1(h[r]);
+      const float y = head_dot<4>(W + OFF_NFH_W, half, h) + W[OFF_NFH_B];
+      vs[V0 + t].w0 = sigmoid1(y) * wgt;
+      if (DBG && store_ok && p.dbg.neuray)
+        dump_tile32(p.dbg.neuray + (pt * V + (V0 + t)) * 32, vs[V0 + t].nf, half);
+    }
+  }
+  // ---- ray_dir_fc 4 -> 16 elu -> 35 elu; rgb_feat = [rgb, img_feats] + dir_feat  (ibrnet.py:325-327)
+  {
+    float b2[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      b2[t][0] = half ? vs[V0 + t].dd[1] : vs[V0 + t].dd[0];
+      b2[t][1] = half ? vs[V0 + t].dd[3] : vs[V0 + t].dd[2];
+    }
+    f32x16 a1[NT][1], a2[NT][2];
+    mfma_layer<2, 1, NT, true>(W + layer_a_off(L_RD1), W + layer_b_off(L_RD1), lane, b2, a1);
+    float b8[NT][8];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
+    mfma_layer<8, 2, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int v = V0 + t;
+      const f32x16 imf = gather32(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
+      const float* ib = p.imgs + (size_t)v * p.H * p.W * 4;
+      const float4 c00 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o00 * 4);
+      const float4 c01 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o01 * 4);
+      const float4 c10 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o10 * 4);
+      const float4 c11 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o11 * 4);
+      vs[v].rgb[0] = c00.x * bimg[t].wnw + c01.x * bimg[t].wne + c10.x * bimg[t].wsw + c11.x * bimg[t].wse;
+      vs[v].rgb[1] = c00.y * bimg[t].wnw + c01.y * bimg[t].wne + c10.y * bimg[t].wsw + c11.y * bimg[t].wse;
+      vs[v].rgb[2] = c00.z * bimg[t].wnw + c01.z * bimg[t].wne + c10.z * bimg[t].wsw + c11.z * bimg[t].wse;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vs[v].fa[r] = imf[r] + elu1(a2[t][0][r]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vs[v].fb[c] = vs[v].rgb[c] + elu1(a2[t][1][c]);
+      if (DBG && store_ok) {
+        const size_t o = (size_t)v * npts + pt;
+        if (p.dbg.img_feats) dump_tile32(p.dbg.img_feats + o * 32, imf, half);
+        if (p.dbg.rgb && half == 0) for (int c = 0; c < 3; ++c) p.dbg.rgb[o * 3 + c] = vs[v].rgb[c];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage C for NT views: base_fc (per-view part, onto the shared partial G), vis_fc, vis_fc2.
+template <int V, int V0, int NT, bool DBG>
+__device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2], ViewState (&vs)[V], int lane,
+                                          size_t pt, bool store_ok) {
+  const int half = lane >> 5;
+  const float* __restrict__ W = p.blob;
+  const float wgt = 1.f / ((float)V + 1e-8f);
+  f32x16 h[NT][2];
+  {
+    float b35[NT][35];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int v = V0 + t;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b35[t][s] = vs[v].fa[s];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) b35[t][16 + c] = vs[v].fb[c];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b35[t][19 + s] = vs[v].nf[s];
+      h[t][0] = G[0];
+      h[t][1] = G[1];
+    }
+    mfma_layer<35, 2, NT, false>(W + layer_a_off(L_BV), nullptr, lane, b35, h);
+  }
+  f32x16 x[NT][1];
+  {
+    float b32[NT][32];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        b32[t][s] = elu1(h[t][0][s]);
+        b32[t][16 + s] = elu1(h[t][1][s]);
+      }
+    mfma_layer<32, 1, NT, true>(W + layer_a_off(L_B2), W + layer_b_off(L_B2), lane, b32, x);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      elu16(x[t][0]);
+      if (DBG && store_ok && p.dbg.base_x) dump_tile32(p.dbg.base_x + (pt * V + (V0 + t)) * 32, x[t][0], half);
+    }
+  }
+  // vis_fc(x * weight): 32 -> 32 elu -> 33 elu; x += x_res; vis = sigmoid(.)   (ibrnet.py:347-350)
+  float vis1[NT];
+  {
+    float b16[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b16[t][s] = x[t][0][s] * wgt;
+    f32x16 a1[NT][1], a2[NT][1];
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF1), W + layer_b_off(L_VF1), lane, b16, a1);
+    float c16[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      elu16(a1[t][0]);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) c16[t][s] = a1[t][0][s];
+    }
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF2), W + layer_b_off(L_VF2), lane, c16, a2);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float raw = head_dot<16>(W + OFF_VFH_W, half, a1[t][0]) + W[OFF_VFH_B];
+      vis1[t] = sigmoid1(elu1(raw));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[t][0][r] += elu1(a2[t][0][r]);
+    }
+  }
+  // vis_fc2(x * vis): 32 -> 32 elu -> 1 sigmoid   (ibrnet.py:351)
+  {
+    float b16[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) b16[t][s] = x[t][0][s] * vis1[t];
+    f32x16 a1[NT][1];
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_V21), W + layer_b_off(L_V21), lane, b16, a1);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      elu16(a1[t][0]);
+      vs[V0 + t].v2 = sigmoid1(head_dot<16>(W + OFF_V2H_W, half, a1[t][0]) + W[OFF_V2H_B]);
+      vs[V0 + t].fa = x[t][0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage E for NT views: rgb_fc on [x, vis, ray_diff] -> blending logit   (ibrnet.py:365-366)
+template <int V, int V0, int NT>
+__device__ __forceinline__ void stage_rgb(const PassArgs& p, const ViewState (&vs)[V], int lane, float (&logit)[V]) {
+  const int half = lane >> 5;
+  const float* __restrict__ W = p.blob;
+  float b19[NT][19];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int v = V0 + t;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) b19[t][s] = vs[v].fa[s];
+    b19[t][16] = half ? vs[v].dd[0] : vs[v].v2;
+    b19[t][17] = half ? vs[v].dd[2] : vs[v].dd[1];
+    b19[t][18] = half ? 0.f : vs[v].dd[3];
+  }
+  f32x16 a1[NT][1], a2[NT][1];
+  mfma_layer<19, 1, NT, true>(W + layer_a_off(L_RGB1), W + layer_b_off(L_RGB1), lane, b19, a1);
+  float b8[NT][8];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
+  mfma_layer<8, 1, NT, true>(W + layer_a_off(L_RGB2), W + layer_b_off(L_RGB2), lane, b8, a2);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f32x16 hh = a2[t][0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hh[r] = elu1(hh[r]);
+    logit[V0 + t] = head_dot<4>(W + OFF_RGBH_W, half, hh) + W[OFF_RGBH_B];
+  }
+}
+
+constexpr int kKStride = 17;   // K rows in LDS: odd stride -> conflict-free column reads (A operand)
+constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast float4 reads
+
+template <int KT, int V, bool DBG>
+__global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(const PassArgs p) {
+  constexpr int DN = 32 * KT;
+  constexpr int RPW = 4 / KT;          // rays per workgroup
+  __shared__ __attribute__((aligned(16))) float lds_v[128 * kVStride];
+  __shared__ float lds_k[128 * kKStride];
+  __shared__ float lds_alpha[128];
+  __shared__ float lds_red[4][4];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int half = lane >> 5;
+  const int pl = lane & 31;
+  const int ray_local = wave / KT;
+  const int kt = wave % KT;
+  const int ray_raw = blockIdx.x * RPW + ray_local;
+  const bool ray_ok = ray_raw < p.rn;
+  const int ray = ray_ok ? ray_raw : p.rn - 1;
+  const int si = kt * 32 + pl;                       // sample index on the ray
+  const int pt_local = ray_local * DN + si;          // 0..127
+  const size_t pt = (size_t)ray * DN + si;
+  const size_t npts = (size_t)p.rn * DN;
+  const float* __restrict__ W = p.blob;
+
+  // ---- ray generation (ray_utils.py:4-16,53-71; spt_utils.py:45-58,106-111; render_ops.py:76-106)
+  PointGeom g;
+  float tdepth;
+  {
+    const int ix = (int)p.coords[2 * ray], iy = (int)p.coords[2 * ray + 1];
+    const float theta = (float)ix / (float)(p.W - 1) * 2.f * PGRF_PI_F - PGRF_HALF_PI_F;
+    const float phi = (float)iy / (float)(p.H - 1) * PGRF_PI_F;
+    const float sp = sinf(phi);
+    float dx = sp * cosf(theta), dy = cosf(phi), dz = sp * sinf(theta);
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx /= nrm; dy /= nrm; dz /= nrm;
+    const float wx = p.c2w[0] * dx + p.c2w[1] * dy + p.c2w[2] * dz;
+    const float wy = p.c2w[4] * dx + p.c2w[5] * dy + p.c2w[6] * dz;
+    const float wz = p.c2w[8] * dx + p.c2w[9] * dy + p.c2w[10] * dz;
+    const float* drow = p.depth + (size_t)ray * DN;
+    tdepth = drow[si];
+    g.p[0] = p.c2w[3] + wx * tdepth;
+    g.p[1] = p.c2w[7] + wy * tdepth;
+    g.p[2] = p.c2w[11] + wz * tdepth;
+    const float wn = sqrtf(wx * wx + wy * wy + wz * wz);
+    g.qdir[0] = -wx / wn; g.qdir[1] = -wy / wn; g.qdir[2] = -wz / wn;
+    // interval half-widths in normalised inverse depth (render_ops.py:110-122, dist_decoder.py:34-38)
+    const float qn = -1.f / p.que_near, qf = -1.f / p.que_far;
+    const float d_c = (-1.f / tdepth - qn) / (qf - qn);
+    const float d_p = (-1.f / drow[max(si - 1, 0)] - qn) / (qf - qn);
+    const float d_n = (-1.f / drow[min(si + 1, DN - 1)] - qn) / (qf - qn);
+    const float dist_c = (si == DN - 1) ? 1e6f : d_n - d_c;          // que_dists[i]
+    const float dist_p = (si == 0) ? dist_c : d_c - d_p;             // que_dists[i-1], first repeated
+    g.near_hw = dist_p / 2.f;
+    g.far_hw = dist_c / 2.f;
+  }
+
+  ViewState vs[V];
+  const bool store_ok = ray_ok;
+
+  // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
+  stage_front<V, 0, (V >= 2 ? 2 : 1), DBG>(p, g, vs, lane, pt, npts, store_ok);
+  if constexpr (V > 2) stage_front<V, 2, V - 2, DBG>(p, g, vs, lane, pt, npts, store_ok);
+
+  // ---- stage B: view statistics (ibrnet.py:112-116,339-342) and the view-shared part of base_fc.0
+  f32x16 G[1][2];
+  {
+    const float wgt = 1.f / ((float)V + 1e-8f);
+    float b76[1][76];
+#pragma unroll
+    for (int j = 0; j < 19; ++j) {
+      float xv[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) xv[v] = (j < 16) ? vs[v].fa[j < 16 ? j : 0] : vs[v].fb[j >= 16 ? j - 16 : 0];
+      float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { m0 += xv[v] * vs[v].w0; m1 += xv[v] * wgt; }
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float d0 = xv[v] - m0, d1 = xv[v] - m1;
+        v0 += vs[v].w0 * (d0 * d0);
+        v1 += wgt * (d1 * d1);
+      }
+      b76[0][j] = m0; b76[0][19 + j] = v0; b76[0][38 + j] = m1; b76[0][57 + j] = v1;
+    }
+    mfma_layer<76, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b76, G);
+  }
+
+  // ---- stage C: per-view base_fc / vis_fc / vis_fc2
+  stage_mid<V, 0, (V >= 2 ? 2 : 1), DBG>(p, G[0], vs, lane, pt, store_ok);
+  if constexpr (V > 2) stage_mid<V, 2, V - 2, DBG>(p, G[0], vs, lane, pt, store_ok);
+
+  // ---- stage D: pooled geometry feature -> geometry_fc -> ray attention -> density
+  float sigma;
+  {
+    float vsum = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) vsum += vs[v].v2;
+    float w2[V];
+    float wmean = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) { w2[v] = vs[v].v2 / (vsum + 1e-8f); wmean += w2[v]; }
+    wmean = wmean / (float)V;
+    float b33[1][33];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float m = 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) m += vs[v].fa[r] * w2[v];
+      float var = 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { const float d = vs[v].fa[r] - m; var += w2[v] * (d * d); }
+      b33[0][r] = m;
+      b33[0][16 + r] = var;
+    }
+    b33[0][32] = wmean;
+    f32x16 g1[1][2];
+    mfma_layer<33, 2, 1, true>(W + layer_a_off(L_G1), W + layer_b_off(L_G1), lane, b33, g1);
+    float b32[1][32];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { b32[0][s] = elu1(g1[0][0][s]); b32[0][16 + s] = elu1(g1[0][1][s]); }
+    f32x16 g2[1][1];
+    mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2);
+    float gp[1][8];     // geometry feature + positional encoding (ibrnet.py:356-358)
+    {
+      const float4* pp = reinterpret_cast<const float4*>(W + OFF_POS + si * 16 + half * 8);
+      const float4 p0 = pp[0], p1 = pp[1];
+      const float pe[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float ge = elu1(g2[0][0][r]);
+        g2[0][0][r] = ge;
+        gp[0][r] = ge + pe[r];
+      }
+      if (DBG && store_ok && p.dbg.geo) dump_tile16(p.dbg.geo + pt * 16, g2[0][0], half);
+    }
+    // q|k and v projections (ibrnet.py:80-82); rows permuted so register 2*head+s carries dims (2s,2s+1)
+    f32x16 qkv[1][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { qkv[0][0][r] = 0.f; qkv[0][1][r] = 0.f; }   // no bias on w_qs/w_ks/w_vs
+    mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
+      lds_v[pt_local * kVStride + 2 * r + half] = qkv[0][1][r];
+    }
+    __syncthreads();
+    float oatt[16];
+    const int key_base = ray_local * DN;
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+      f32x16 S[KT];
+#pragma unroll
+      for (int k2 = 0; k2 < KT; ++k2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[k2][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const float a = lds_k[(key_base + k2 * 32 + pl) * kKStride + hd * 4 + 2 * s + half];
+          const float q = qkv[0][0][2 * hd + s] * 0.5f;          // q / temperature, temperature = sqrt(d_k) = 2
+          S[k2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, q, S[k2], 0, 0, 0);
+        }
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int k2 = 0; k2 < KT; ++k2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[k2][r]);
+      mx = fmaxf(mx, xhalf(mx));
+      float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < KT; ++k2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pe = __expf(S[k2][r] - mx);
+          const float4 vv = *reinterpret_cast<const float4*>(&lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4]);
+          l += pe;
+          o0 = fmaf(pe, vv.x, o0); o1 = fmaf(pe, vv.y, o1); o2 = fmaf(pe, vv.z, o2); o3 = fmaf(pe, vv.w, o3);
+        }
+      l += xhalf(l);
+      o0 += xhalf(o0); o1 += xhalf(o1); o2 += xhalf(o2); o3 += xhalf(o3);
+      oatt[hd * 4 + 0] = o0 / l; oatt[hd * 4 + 1] = o1 / l; oatt[hd * 4 + 2] = o2 / l; oatt[hd * 4 + 3] = o3 / l;
+    }
+    // fc + residual + LayerNorm(eps 1e-6)  (ibrnet.py:95-102)
+    float bo[1][8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bo[0][s] = half ? oatt[4 * (s >> 1) + 2 * (s & 1) + 1] : oatt[4 * (s >> 1) + 2 * (s & 1)];
+    f32x16 fo[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fo[0][0][r] = (r < 8) ? gp[0][r < 8 ? r : 0] : 0.f;     // residual as the initial accumulator
+    mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo);
+    float ln[1][8];
+    {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += fo[0][0][r];
+      sum += xhalf(sum);
+      const float mean = sum / 16.f;
+      float sq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const float d = fo[0][0][r] - mean; sq += d * d; }
+      sq += xhalf(sq);
+      const float rstd = 1.f / sqrtf(sq / 16.f + 1e-6f);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        ln[0][r] = (fo[0][0][r] - mean) * rstd * W[OFF_LN_G + half * 8 + r] + W[OFF_LN_B + half * 8 + r];
+      if (DBG && store_ok && p.dbg.attn) {
+        f32x16 tmp;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) tmp[r] = ln[0][r];
+        dump_tile16(p.dbg.attn + pt * 16, tmp, half);
+      }
+    }
+    // out_geometry_fc 16 -> 16 elu -> 1 relu  (ibrnet.py:361)
+    f32x16 og[1][1];
+    mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) og[0][0][r] = elu1(og[0][0][r]);
+    sigma = fmaxf(head_dot<8>(W + OFF_OGH_W, half, og[0][0]) + W[OFF_OGH_B], 0.f);
+  }
+
+  // ---- stage E: colour blending over views (ibrnet.py:364-370)
+  float col[3];
+  {
+    float logit[V];
+    stage_rgb<V, 0, (V >= 2 ? 2 : 1)>(p, vs, lane, logit);
+    if constexpr (V > 2) stage_rgb<V, 2, V - 2>(p, vs, lane, logit);
+    float mx = logit[0];
+#pragma unroll
+    for (int v = 1; v < V; ++v) mx = fmaxf(mx, logit[v]);
+    float e[V], es = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) { e[v] = __expf(logit[v] - mx); es += e[v]; }
+    col[0] = col[1] = col[2] = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const float bw = e[v] / es;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[c] += vs[v].rgb[c] * bw;
+    }
+  }
+
+  // ---- stage F: alpha compositing along the ray (renderer.py:216-218,291-304; render_ops.py:145-153)
+  const float alpha = 1.f - __expf(-fmaxf(sigma, 0.f));
+  if (half == 0) lds_alpha[pt_local] = alpha;
+  __syncthreads();
+  float T = 1.f;
+  for (int j = 0; j < DN; ++j) {
+    const float a = lds_alpha[ray_local * DN + j];
+    if (j < si) T *= (1.f - a + 1e-10f);
+  }
+  const float hit = alpha * T;
+  if (store_ok && half == 0) {
+    if (p.out_hit) p.out_hit[pt] = hit;
+    if (p.out_density) p.out_density[pt] = sigma;
+    if (p.out_colors) { p.out_colors[pt * 3] = col[0]; p.out_colors[pt * 3 + 1] = col[1]; p.out_colors[pt * 3 + 2] = col[2]; }
+  }
+  float acc4[4] = {hit * col[0], hit * col[1], hit * col[2], hit * tdepth};
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc4[c] += __shfl_xor(acc4[c], off, 64);
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds_red[wave][c] = acc4[c];
+  __syncthreads();
+  if (kt == 0 && lane < 4 && store_ok) {
+    float s = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < KT; ++k2) s += lds_red[wave + k2][lane];
+    if (lane < 3) { if (p.out_pixel) p.out_pixel[(size_t)ray * 3 + lane] = s; }
+    else if (p.out_depth) p.out_depth[ray] = s;
+  }
+}
+
+template <int KT, int V, bool DBG>
+int launch_instance(const PassArgs& a, void* stream) {
+  constexpr int RPW = 4 / KT;
+  const int blocks = (a.rn + RPW - 1) / RPW;
+  hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(PGRF_ERR_LAUNCH, "render_pass launch failed: %s", hipGetErrorString(e));
+  return PGRF_OK;
+}
+
+}  // namespace pgrf

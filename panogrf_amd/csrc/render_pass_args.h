@@ -1,0 +1,33 @@
+// Kernel argument block of the fused render pass (by-value kernarg).
+#pragma once
+#include "pgrf_internal.h"
+
+namespace pgrf {
+
+struct PassArgs {
+  // frame
+  const float* imgs;        // [V,H,W,4]
+  const float* img_feats;   // [V,hf,wf,32]
+  const float* ray_feats;   // [V,hr,wr,32]
+  const float* w2c;         // [V,12]
+  const float* ref_dr;      // [V,2]
+  float c2w[12];
+  float que_near, que_far;
+  int H, W, hf, wf, hr, wr;
+  // rays
+  const float* coords;      // [rn,2]
+  const float* depth;       // [rn,dn]
+  int rn;
+  // network
+  const float* blob;
+  int use_vis;
+  // outputs (nullable)
+  float* out_pixel;
+  float* out_depth;
+  float* out_hit;
+  float* out_colors;
+  float* out_density;
+  PgrfPassDebug dbg;
+};
+
+}  // namespace pgrf

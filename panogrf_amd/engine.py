@@ -1,0 +1,226 @@
+"""Host-side driver of the HIP per-ray renderer: owns no math, only buffers and calls.
+
+torch is used for device memory and streams only; every tensor handed to the library is a
+caller-owned, contiguous float32 CUDA(HIP) tensor passed as a raw pointer.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, PgrfError, PgrfFrame, PgrfPassOut, PgrfPassDebug, PgrfRenderCfg
+
+FEAT_CH = 32
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise PgrfError("panogrf_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t, device=None):
+    t = t.detach()
+    if device is not None:
+        t = t.to(device)
+    return t.to(torch.float32).contiguous()
+
+
+def raw_names():
+    return [lib.pgrf_raw_name(i).decode() for i in range(lib.pgrf_raw_count())]
+
+
+def pack_pass_weights(state_dict, dd_prefix, agg_prefix, use_vis, max_dn=128):
+    """Pack one pass (dist decoder `dd_prefix`, aggregation net `agg_prefix`) of a reference
+    state_dict into the MFMA-ordered blob (host tensor).  Key names: SURVEY.md Appendix A."""
+    names = raw_names()
+    keep = []          # keep the contiguous host copies alive during the call
+    arr = (C.c_void_p * len(names))()
+    for i, n in enumerate(names):
+        if n.startswith('dist_decoder.'):
+            key = dd_prefix + n[len('dist_decoder'):]
+        else:
+            key = agg_prefix + n[len('agg_net'):]
+        if key not in state_dict:
+            if '.vis_decoder.' in key and not use_vis:
+                arr[i] = None
+                continue
+            raise PgrfError(f"state_dict lacks '{key}'")
+        t = state_dict[key].detach().to('cpu', torch.float32).contiguous()
+        keep.append(t)
+        arr[i] = t.data_ptr()
+    blob = torch.empty(lib.pgrf_blob_floats(), dtype=torch.float32)
+    lib.check(lib.pgrf_pack_weights(arr, len(names), int(bool(use_vis)), int(max_dn), C.c_void_p(blob.data_ptr())))
+    return blob
+
+
+def pack_map(t):
+    """[n,C,h,w] CUDA tensor -> channel-last [n,h,w,Cpad] (Cpad=4 for rgb)."""
+    _require_gpu()
+    t = _f32c(t)
+    n, c, h, w = t.shape
+    cpad = (c + 3) // 4 * 4
+    out = torch.empty(n, h, w, cpad, dtype=torch.float32, device=t.device)
+    lib.check(lib.pgrf_pack_map(_ptr(t), n, c, h, w, _ptr(out), _stream()))
+    return out
+
+
+class Frame:
+    """Source-view data of one frame in the layout the kernels read (PgrfFrame)."""
+
+    def __init__(self, imgs, img_feats, ray_feats, w2c, ref_depth_range, que_c2w, que_depth_range, device='cuda'):
+        _require_gpu()
+        dev = torch.device(device)
+        imgs, img_feats, ray_feats = _f32c(imgs, dev), _f32c(img_feats, dev), _f32c(ray_feats, dev)
+        if img_feats.shape[1] != FEAT_CH or ray_feats.shape[1] != FEAT_CH or imgs.shape[1] != 3:
+            raise PgrfError(f"expected imgs [rfn,3,H,W], img_feats/ray_feats [rfn,{FEAT_CH},h,w]")
+        self.rfn, _, self.H, self.W = imgs.shape
+        self.imgs = pack_map(imgs)
+        self.img_feats = pack_map(img_feats)
+        self.ray_feats = pack_map(ray_feats)
+        self.w2c = _f32c(w2c, dev).reshape(self.rfn, 12)
+        self.ref_dr = _f32c(ref_depth_range, dev).reshape(self.rfn, 2)
+        self.que_c2w = [float(x) for x in _f32c(que_c2w, 'cpu').reshape(-1)[:12]]
+        self.que_dr = [float(x) for x in _f32c(que_depth_range, 'cpu').reshape(-1)[:2]]
+        self.device = dev
+
+    def c_struct(self):
+        f = PgrfFrame()
+        f.rfn, f.H, f.W = self.rfn, self.H, self.W
+        f.hf, f.wf = self.img_feats.shape[1:3]
+        f.hr, f.wr = self.ray_feats.shape[1:3]
+        f.imgs, f.img_feats, f.ray_feats = self.imgs.data_ptr(), self.img_feats.data_ptr(), self.ray_feats.data_ptr()
+        f.w2c, f.ref_depth_range = self.w2c.data_ptr(), self.ref_dr.data_ptr()
+        f.que_c2w = (C.c_float * 12)(*self.que_c2w)
+        f.que_depth_range = (C.c_float * 2)(*self.que_dr)
+        return f
+
+
+_DEBUG_SHAPES = {
+    'px': lambda v, r, d: (v, r, d, 2), 'depth_v': lambda v, r, d: (v, r, d), 'ddiff': lambda v, r, d: (v, r, d, 4),
+    'vis': lambda v, r, d: (v, r, d), 'hit': lambda v, r, d: (v, r, d), 'ray_feats': lambda v, r, d: (v, r, d, 32),
+    'rgb': lambda v, r, d: (v, r, d, 3), 'img_feats': lambda v, r, d: (v, r, d, 32),
+    'neuray': lambda v, r, d: (r, d, v, 32), 'base_x': lambda v, r, d: (r, d, v, 32),
+    'geo': lambda v, r, d: (r, d, 16), 'attn': lambda v, r, d: (r, d, 16),
+}
+
+
+def sample_coarse_depth(min_depth, max_depth, rn, dn, use_disp=True, device='cuda'):
+    _require_gpu()
+    out = torch.empty(rn, dn, dtype=torch.float32, device=device)
+    lib.check(lib.pgrf_sample_coarse_depth(float(min_depth), float(max_depth), int(use_disp), rn, dn, _ptr(out), _stream()))
+    return out
+
+
+def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True, use_all=False):
+    _require_gpu()
+    depth, hit_prob = _f32c(depth), _f32c(hit_prob)
+    rn, dn = depth.shape
+    out = torch.empty(rn, (dn + fdn) if use_all else fdn, dtype=torch.float32, device=depth.device)
+    lib.check(lib.pgrf_sample_fine_depth(_ptr(depth), _ptr(hit_prob), float(que_depth_range[0]), float(que_depth_range[1]),
+                                         int(use_disp), int(use_all), rn, dn, fdn, _ptr(out), _stream()))
+    return out
+
+
+def _alloc_out(rn, dn, dev):
+    t = dict(pixel_colors_nr=torch.empty(rn, 3, device=dev), render_depth=torch.empty(rn, device=dev),
+             hit_prob_nr=torch.empty(rn, dn, device=dev), colors_nr=torch.empty(rn, dn, 3, device=dev),
+             density_nr=torch.empty(rn, dn, device=dev))
+    o = PgrfPassOut(t['pixel_colors_nr'].data_ptr(), t['render_depth'].data_ptr(), t['hit_prob_nr'].data_ptr(),
+                    t['colors_nr'].data_ptr(), t['density_nr'].data_ptr())
+    return t, o
+
+
+def render_pass(frame, blob_dev, use_vis, coords, depth, debug=False):
+    """One network pass; returns dict of [rn,...] CUDA tensors (reference key names without the
+    leading qn axis).  `debug=True` also returns the intermediate tensors under 'dbg'."""
+    _require_gpu()
+    coords, depth = _f32c(coords, frame.device), _f32c(depth, frame.device)
+    rn, dn = depth.shape
+    t, o = _alloc_out(rn, dn, frame.device)
+    dbg_t, dbg_s = None, None
+    if debug:
+        dbg_t = {k: torch.zeros(*f(frame.rfn, rn, dn), device=frame.device) for k, f in _DEBUG_SHAPES.items()}
+        dbg_s = PgrfPassDebug(*[dbg_t[n].data_ptr() for n, _ in PgrfPassDebug._fields_])
+    fs = frame.c_struct()
+    lib.check(lib.pgrf_render_pass(C.byref(fs), _ptr(blob_dev), int(bool(use_vis)), _ptr(coords), _ptr(depth), rn, dn,
+                                   C.byref(o), C.byref(dbg_s) if debug else None, _stream()))
+    if debug:
+        t['dbg'] = dbg_t
+    return t
+
+
+def make_cfg(cfg):
+    """reference cfg dict -> PgrfRenderCfg (keys: renderer.py:36-64)."""
+    c = PgrfRenderCfg()
+    c.min_depth, c.max_depth = float(cfg['min_depth']), float(cfg['max_depth'])
+    c.use_disp = int(cfg.get('use_disp', True))
+    c.dn = int(cfg.get('depth_sample_num', 64))
+    c.fdn = int(cfg.get('fine_depth_sample_num', 64))
+    c.hierarchical = int(cfg.get('use_hierarchical_sampling', False))
+    c.fine_use_all = int(cfg.get('fine_depth_use_all', False))
+    c.c2f_all = int(cfg.get('render_c2f_all', False))
+    c.use_vis_coarse = int(cfg.get('dist_decoder_cfg', {}).get('use_vis', True))
+    c.use_vis_fine = int(cfg.get('fine_dist_decoder_cfg', {}).get('use_vis', True))
+    return c
+
+
+class RayRenderer:
+    """Coarse(+fine) render of arbitrary ray sets against one Frame: the HIP counterpart of
+    NeuralRayBaseRenderer.render_impl (network/renderer.py:567-633)."""
+
+    def __init__(self, cfg, state_dict, device='cuda'):
+        _require_gpu()
+        self.cfg = dict(cfg)
+        self.ccfg = make_cfg(cfg)
+        dn_max = max(self.ccfg.dn, self.ccfg.fdn, self.ccfg.dn + self.ccfg.fdn if self.ccfg.fine_use_all else 0)
+        if dn_max > 128:
+            raise PgrfError("at most 128 samples per pass are supported")
+        self.blob_c = pack_pass_weights(state_dict, 'dist_decoder', 'agg_net', self.ccfg.use_vis_coarse).to(device)
+        self.blob_f = None
+        if self.ccfg.hierarchical:
+            if cfg.get('one_mlp', False):
+                self.blob_f = self.blob_c
+                self.ccfg.use_vis_fine = self.ccfg.use_vis_coarse
+            else:
+                self.blob_f = pack_pass_weights(state_dict, 'fine_dist_decoder', 'fine_agg_net',
+                                                self.ccfg.use_vis_fine).to(device)
+        self.device = torch.device(device)
+        self._ws = None
+
+    def _workspace(self, rn):
+        need = lib.pgrf_render_workspace_bytes(C.byref(self.ccfg), rn)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    def render_rays(self, frame, coords, want=('pixel', 'depth', 'density', 'colors')):
+        """coords [rn,2] -> dict with the reference's key names (no qn axis).  hit_prob_* are
+        dropped like the reference does in eval (renderer.py:675)."""
+        coords = _f32c(coords, self.device)
+        rn = coords.shape[0]
+        c = self.ccfg
+        fdn_eff = c.dn + c.fdn if c.fine_use_all else c.fdn
+        dn_f_out = c.dn + fdn_eff if c.c2f_all else fdn_eff
+        tc, oc = _alloc_out(rn, c.dn, self.device)
+        out = dict(tc)
+        of = None
+        fd = None
+        if c.hierarchical:
+            tf, of = _alloc_out(rn, dn_f_out, self.device)
+            fd = torch.empty(rn, fdn_eff, device=self.device)
+            for k, v in tf.items():
+                out[k + '_fine'] = v
+            out['depth_fine'] = fd
+        ws, nbytes = self._workspace(rn)
+        fs = frame.c_struct()
+        lib.check(lib.pgrf_render_rays(C.byref(fs), _ptr(self.blob_c), _ptr(self.blob_f), C.byref(c), _ptr(coords), rn,
+                                       C.byref(oc), C.byref(of) if of is not None else None, _ptr(fd), _ptr(ws),
+                                       C.c_size_t(nbytes), _stream()))
+        return out
