@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Throughput of the HIP per-ray renderer on synthetic panoramas (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W            (N=1: plain python; N>1: torchrun, one rank per GPU)
+
+A step = one whole query panorama (H*W rays) rendered against `views` source panoramas already
+resident in HBM: NCHW->NHWC re-layout of the source maps, depth sampling, the fused render pass
+(and the importance sampler + fine pass with --fine).  With N>1 the panorama is sharded by row tile
+across ranks and reassembled with one all-gather (RCCL), i.e. strong scaling of one frame.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic workload: data only, no reference code involved
+def _smooth_pano(g, C, H, W):
+    th = torch.linspace(0, 2 * math.pi, W).view(1, 1, W)
+    ph = torch.linspace(0, math.pi, H).view(1, H, 1)
+    out = torch.zeros(C, H, W)
+    for _ in range(8):
+        a = torch.randint(1, 5, (C, 1, 1), generator=g).float()
+        b = torch.randint(1, 4, (C, 1, 1), generator=g).float()
+        p = torch.rand(C, 1, 1, generator=g) * 2 * math.pi
+        q = torch.rand(C, 1, 1, generator=g) * 2 * math.pi
+        out = out + torch.sin(a * th + p) * torch.cos(b * ph + q)
+    return (out - out.amin()) / (out.amax() - out.amin())
+
+
+_LINEARS = {   # name -> (out, in, kaiming_normal?)   shapes: SURVEY.md Appendix A
+    'prob_embed.0': (32, 34, False), 'prob_embed.2': (32, 32, False),
+    'agg_impl.ray_dir_fc.0': (16, 4, False), 'agg_impl.ray_dir_fc.2': (35, 16, False),
+    'agg_impl.base_fc.0': (64, 207, True), 'agg_impl.base_fc.2': (32, 64, True),
+    'agg_impl.vis_fc.0': (32, 32, True), 'agg_impl.vis_fc.2': (33, 32, True),
+    'agg_impl.vis_fc2.0': (32, 32, True), 'agg_impl.vis_fc2.2': (1, 32, True),
+    'agg_impl.geometry_fc.0': (64, 65, True), 'agg_impl.geometry_fc.2': (16, 64, True),
+    'agg_impl.out_geometry_fc.0': (16, 16, False), 'agg_impl.out_geometry_fc.2': (1, 16, False),
+    'agg_impl.rgb_fc.0': (16, 37, True), 'agg_impl.rgb_fc.2': (8, 16, True), 'agg_impl.rgb_fc.4': (1, 8, True),
+    'agg_impl.neuray_fc.0': (8, 32, True), 'agg_impl.neuray_fc.2': (1, 8, True),
+}
+
+
+def synthetic_weights(seed, use_vis=False):
+    """Random-init per-ray networks with the reference's key names/shapes and PyTorch's default init
+    statistics, plus a seeded density boost so the rendered image is not black."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def lin(key, o, i, kaiming):
+        if kaiming:
+            sd[key + '.weight'] = torch.randn(o, i, generator=g) * math.sqrt(2.0 / i)
+            sd[key + '.bias'] = torch.zeros(o)
+        else:
+            b = 1.0 / math.sqrt(i)
+            sd[key + '.weight'] = (torch.rand(o, i, generator=g) * 2 - 1) * b
+            sd[key + '.bias'] = (torch.rand(o, generator=g) * 2 - 1) * b
+
+    for agg, dd in [('agg_net', 'dist_decoder'), ('fine_agg_net', 'fine_dist_decoder')]:
+        for name, (o, i, k) in _LINEARS.items():
+            lin(f'{agg}.{name}', o, i, k)
+        for nm in ['w_qs', 'w_ks', 'w_vs', 'fc']:
+            sd[f'{agg}.agg_impl.ray_attention.{nm}.weight'] = (torch.rand(16, 16, generator=g) * 2 - 1) * 0.25
+        sd[f'{agg}.agg_impl.ray_attention.layer_norm.weight'] = torch.ones(16)
+        sd[f'{agg}.agg_impl.ray_attention.layer_norm.bias'] = torch.zeros(16)
+        for dec, outs in [('mean_decoder', 2), ('var_decoder', 2), ('aw_decoder', 1)] + ([('vis_decoder', 1)] if use_vis else []):
+            lin(f'{dd}.{dec}.0', 32, 32, False)
+            lin(f'{dd}.{dec}.2', 32, 32, False)
+            lin(f'{dd}.{dec}.4', outs, 32, False)
+        # density boost
+        sd[f'{agg}.agg_impl.out_geometry_fc.2.bias'] += 0.6
+        sd[f'{agg}.agg_impl.out_geometry_fc.2.weight'] *= 3.0
+        sd[f'{agg}.agg_impl.out_geometry_fc.0.weight'] *= 2.0
+        sd[f'{dd}.var_decoder.4.bias'] += 2.0
+    return sd
+
+
+def synthetic_case(H, W, rfn, dn, seed=0, fine=False, use_vis=False):
+    g = torch.Generator().manual_seed(1234 + seed)
+    imgs = torch.stack([_smooth_pano(g, 3, H, W) for _ in range(rfn)])
+    img_feats = torch.randn(rfn, 32, H // 4, W // 4, generator=g)
+    ray_feats = torch.randn(rfn, 32, H // 8, W // 8, generator=g)
+    w2c = torch.zeros(rfn, 3, 4)
+    for v in range(rfn):
+        a = 2 * math.pi * v / rfn
+        yaw = math.radians(5.0) * (1 if v % 2 else -1)
+        c, s = math.cos(yaw), math.sin(yaw)
+        w2c[v, :, :3] = torch.tensor([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+        w2c[v, :, 3] = torch.tensor([0.5 * math.cos(a), 0.0, 0.5 * math.sin(a)])   # 1.0 m baseline (cfg gen_hr_1.0)
+    frame = dict(imgs=imgs, img_feats=img_feats, ray_feats=ray_feats, w2c=w2c,
+                 ref_depth_range=torch.tensor([[0.5, 15.0]] * rfn),
+                 que_c2w=torch.tensor([[1.0, 0, 0, 0.02], [0, 1.0, 0, 0.01], [0, 0, 1.0, -0.03]]),
+                 que_depth_range=torch.tensor([0.5, 15.0]))
+    cfg = dict(min_depth=0.5, max_depth=15.0, use_disp=True, depth_sample_num=dn, fine_depth_sample_num=dn,
+               use_hierarchical_sampling=bool(fine), dist_decoder_cfg={'use_vis': use_vis},
+               fine_dist_decoder_cfg={'use_vis': use_vis}, height=H, width=W)
+    return dict(frame=frame, cfg=cfg, weights=synthetic_weights(seed, use_vis))
+
+
+def flop_per_ray(rfn, dn, passes):
+    """Algorithmic matmul FLOP per ray (equals FlopCounterMode on the reference)."""
+    return passes * dn * 2 * (rfn * 28464 + 6480 + 32 * dn)
+
+
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(case, budget_s=15.0):
+    """The CPU oracle (a port of the reference algorithm) timed on a bounded sample of the workload."""
+    from oracle import render_oracle as O
+    H, W = case['frame']['imgs'].shape[-2:]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(7)
+
+    def run(n):
+        idx = torch.randperm(H * W, generator=g)[:n]
+        coords = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = O.render_rays(case['weights'], case['frame'], coords, case['cfg'])
+        return time.perf_counter() - t0, coords, out
+
+    t_probe, _, _ = run(256)
+    n = int(max(256, min(16384, 256 * budget_s / max(t_probe, 1e-3))))
+    n = n // 256 * 256
+    dt, coords, out = run(n)
+    return dict(value=n / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} random rays of the same frame through oracle.render_oracle.render_rays '
+                       f'({dt:.1f} s, torch CPU fp32)'), coords, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--height', type=int, default=512)
+    ap.add_argument('--width', type=int, default=1024)
+    ap.add_argument('--views', type=int, default=2)
+    ap.add_argument('--samples', type=int, default=64)
+    ap.add_argument('--fine', action='store_true', help='coarse + importance-sampled fine pass (BASELINE config 4)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU: the HIP renderer has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from panogrf_amd import engine as E
+    from panogrf_amd import dist as D
+
+    H, W, V, dn = args.height, args.width, args.views, args.samples
+    case = synthetic_case(H, W, V, dn, seed=0, fine=args.fine)
+    fr_in = {k: v.to(dev) for k, v in case['frame'].items()}
+    rr = E.RayRenderer(case['cfg'], case['weights'], device=dev)
+    coords = D.tile_coords(rank, world, H, W, device=dev)
+    rn = coords.shape[0]
+    passes = 2 if args.fine else 1
+
+    kern_ms = []
+
+    def step(timed):
+        # per-frame: channel-last re-layout of the source maps (inputs stay NCHW in HBM like the reference's)
+        fr = E.Frame(fr_in['imgs'], fr_in['img_feats'], fr_in['ray_feats'], fr_in['w2c'], fr_in['ref_depth_range'],
+                     case['frame']['que_c2w'], case['frame']['que_depth_range'], device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = rr.render_rays(fr, coords)
+        e1.record()
+        key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'
+        img = D.allgather_rows(out[key], H, W)
+        if timed:
+            kern_ms.append((e0, e1))
+        return img, out
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img, out = step(True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    rays_per_s = H * W * args.steps / dt
+
+    # dominant kernel = render_pass_kernel; events bracket render_rays on the launch stream
+    # (coarse depth fill + render pass [+ sampler + fine pass]); its share is > 99.9 % render pass.
+    k_ms = sum(a.elapsed_time(b) for a, b in kern_ms) / max(len(kern_ms), 1)
+    launches = passes
+    flops_launch = flop_per_ray(V, dn, 1) * rn
+    achieved = flops_launch / (k_ms / launches * 1e-3) / 1e12 if k_ms > 0 else 0.0
+
+    res = {
+        'metric': 'rendered rays/sec (512x1024 ERP, 64 samples)', 'value': rays_per_s, 'unit': 'rays/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{H}x{W} ERP query, {V} source views, {dn} samples/ray'
+                               + (' coarse + ' + str(dn) + ' fine' if args.fine else ', single pass')
+                               + ' (BASELINE configs[1])' * (not args.fine and (H, W, V, dn) == (512, 1024, 2, 64)),
+                   'rays_per_step': H * W, 'ray_tiles': world, 'parallelism': f'ray-tile x{world} + all-gather'},
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                     'kernel': 'render_pass_kernel', 'kernel_ms': k_ms / launches,
+                     'flop_per_ray': flop_per_ray(V, dn, 1), 'rays_per_launch': rn},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, ccoords, cout = cpu_baseline(case)
+        res['cpu_baseline'] = base
+        # PSNR of the HIP image against the oracle on the sampled rays
+        idx = (ccoords[:, 1].long() * W + ccoords[:, 0].long()).to(dev)
+        key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'
+        mse = float(((img[idx].cpu().double() - cout[key].double()) ** 2).mean())
+        res['psnr_vs_oracle_db'] = 10 * math.log10(1.0 / max(mse, 1e-20))
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

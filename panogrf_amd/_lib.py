@@ -2,6 +2,11 @@
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64.so.7; importing it FIRST makes libpanogrf_hip.so bind to that one
+# runtime.  Loaded the other way round the process ends up with two HIP runtimes and launches from
+# this library fail with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 

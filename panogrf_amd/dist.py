@@ -1,0 +1,47 @@
+"""Ray-tile sharding of one panorama across the GPUs of a node.
+
+Every ray is independent given the per-frame source maps, so rank g renders the contiguous row
+tile [g*H/G, (g+1)*H/G) with NO data-path collective; one all-gather (RCCL over xGMI when the
+backend is "nccl") reassembles the final image.  The reference has no multi-GPU inference at all
+(train/trainer.py:232-234): this is new, not a translation.
+"""
+import torch
+import torch.distributed as dist
+
+
+def tile_rows(rank, world, H):
+    """Row range [r0, r1) of rank `rank`: equal contiguous tiles, remainder rows to the first ranks."""
+    base, rem = divmod(H, world)
+    r0 = rank * base + min(rank, rem)
+    return r0, r0 + base + (1 if rank < rem else 0)
+
+
+def tile_coords(rank, world, H, W, device='cpu'):
+    """(x,y) pixel coords [rows*W,2] of this rank's tile, row-major like utils/imgs_info.py:158-181."""
+    r0, r1 = tile_rows(rank, world, H)
+    ys, xs = torch.meshgrid(torch.arange(r0, r1, dtype=torch.float32, device=device),
+                            torch.arange(W, dtype=torch.float32, device=device), indexing='ij')
+    return torch.stack([xs, ys], -1).reshape(-1, 2)
+
+
+def allgather_rows(shard, H, W, group=None):
+    """shard [rows_g*W, C] of every rank -> full [H*W, C] on every rank.  Equal tiles use one
+    all_gather_into_tensor (a single ncclAllGather); ragged tiles fall back to padded gather."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return shard
+    C = shard.shape[1]
+    if H % world == 0:
+        full = torch.empty(H * W, C, dtype=shard.dtype, device=shard.device)
+        dist.all_gather_into_tensor(full, shard.contiguous(), group=group)
+        return full
+    rows_max = -(-H // world)
+    pad = torch.zeros(rows_max * W, C, dtype=shard.dtype, device=shard.device)
+    pad[:shard.shape[0]] = shard
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = []
+    for g in range(world):
+        r0, r1 = tile_rows(g, world, H)
+        out.append(parts[g][:(r1 - r0) * W])
+    return torch.cat(out, 0)
