@@ -149,6 +149,33 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
                      const PgrfPassOut* fine, float* fine_depth_out, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+
+/* ------------------------------------------------------------------ spherical cost volume -- */
+/* Depth hypotheses of the mono-guided 360-degree MVS: n_guided planes clamp(ref_mu + offs[k]) plus
+ * n_uniform shared planes, sorted per pixel.  ref_mu [B,hw] -> depth_volume [B,n_guided+n_uniform,hw].
+ * guided_offsets_host[k] = k_list[k]*fixed_sigma (host array, <= 16); uniform_centres is a DEVICE
+ * array (ascending, e.g. torch.linspace(min,max,59)).
+ * Replaces network/omni_mvsnet/pipeline3_model.py:723-733 + :774-815 (concat + torch.sort). */
+int pgrf_depth_hypotheses(const float* ref_mu, int B, int hw, const float* guided_offsets_host, int n_guided,
+                          float min_depth, float max_depth, const float* uniform_centres, int n_uniform,
+                          float* depth_volume, void* stream);
+
+#define PGRF_COST_ABS_DIFF 0
+#define PGRF_COST_DOT 1
+#define PGRF_COST_NONE 2
+/* Spherical-homography warp of the source-view features onto every depth hypothesis of the
+ * reference view + cost.  feats [B,S,h,w,C] channel-last, depth_volume [B,D,h,w], rots [B,S,3,3],
+ * trans [B,S,3] (world->camera), out [B,D,h,w,C].  out = sum over the n_src listed source views of
+ * cost(warp(view), feats[:,ref_idx]) / src_div.
+ *   2-view  (models/spherical_cost_volume.py:231-341 calculate_cost_volume_erp):
+ *           S=2, ref_idx=1, src_idx={0}, src_div=1
+ *   multi-view (models/spherical_cost_volume_mv.py:219-347 calculate_cost_volume_erp_multiview):
+ *           ref_idx=curr_idx, src_idx = {v in 0..S-2, v != curr_idx}, src_div = S-2
+ * Both call get_cv_per_depth (:135-230) D times; helpers/my_torch_helpers.py:34-38,62-96. */
+int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const float* rots, const float* trans, int B,
+                         int S, int h, int w, int C, int D, int ref_idx, const int* src_idx_host, int n_src,
+                         float src_div, int cost_type, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

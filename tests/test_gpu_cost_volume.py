@@ -1,0 +1,70 @@
+"""HIP spherical cost volume / hypothesis generation vs golden vectors from the reference. -m gpu"""
+import pytest
+import torch
+
+from tests import cv_fixtures as CF
+from tests.fixtures import max_abs
+
+pytestmark = pytest.mark.gpu
+ARGS = dict(dataset_name='m3d', contain_dnet=True, mono_uncertainty=False)
+
+
+def test_depth_hypotheses_bit_exact():
+    from panogrf_amd import cost_volume as CV
+    fx = CF.load()['hyp']
+    k = CV.depth_sampling(5, 3)
+    out = CV.build_depth_volume(fx['ref_mu'].cuda(), k, 0.5, 0.1, 10, 64)
+    assert torch.equal(out.cpu(), fx['out'])          # clamp/sort/merge: no arithmetic beyond one add
+
+
+def test_cost_volume_two_view():
+    from panogrf_amd import cost_volume as CV
+    fx = CF.load()['cv2']
+    out = CV.calculate_cost_volume_erp(ARGS, fx['feats'].cuda(), None, fx['trans'].cuda(), fx['rots'].cuda(),
+                                       depth_volume=fx['depth_volume'].cuda())
+    assert out.shape == fx['out'].shape
+    assert max_abs(out.cpu(), fx["out"]) < 2e-4   # white-noise features: |dfeat| ~ 2 x |du| (px), |du| <= 5e-5
+    outd = CV.calculate_cost_volume_erp(ARGS, fx['feats'].cuda(), None, fx['trans'].cuda(), fx['rots'].cuda(),
+                                        depth_volume=fx['depth_volume'][:, :4].contiguous().cuda(), cost_type='dot')
+    assert max_abs(outd.cpu(), fx['out_dot']) < 2e-4
+
+
+def test_cost_volume_multiview():
+    from panogrf_amd import cost_volume as CV
+    fx = CF.load()['cvm']
+    out = CV.calculate_cost_volume_erp_multiview(ARGS, fx['feats'].cuda(), None, fx['trans'].cuda(), fx['rots'].cuda(),
+                                                 depth_volume=fx['depth_volume'].cuda(), curr_idx=0)
+    assert max_abs(out.cpu(), fx["out"]) < 2e-4   # white-noise features: |dfeat| ~ 2 x |du| (px), |du| <= 5e-5
+    out1 = CV.calculate_cost_volume_erp_multiview(ARGS, fx['feats'].cuda(), None, fx['trans'].cuda(), fx['rots'].cuda(),
+                                                  depth_volume=fx['depth_volume'][:, :2].contiguous().cuda(), curr_idx=1)
+    assert max_abs(out1.cpu(), fx['out_idx1']) < 2e-4
+
+
+def test_cost_volume_full_size_vs_oracle_planes():
+    """BASELINE config 3 size (D=64, C=32, 128x256): identity-pose property on the whole volume +
+    oracle parity on a few planes."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_volume as CV
+    g = torch.Generator().manual_seed(7)
+    B, h, w, Cc, D = 1, 128, 256, 32, 64
+    feats = torch.randn(B, 2, h, w, Cc, generator=g)
+    ref_mu = 1.0 + 7.0 * torch.rand(B, 1, h, w, generator=g)
+    dv = CV.build_depth_volume(ref_mu.cuda(), CV.depth_sampling(5, 3), 0.5, 0.1, 10, 64)
+    assert bool((dv[:, 1:] >= dv[:, :-1]).all())
+    eye = torch.eye(3).view(1, 1, 3, 3).repeat(B, 2, 1, 1)
+    trans = torch.tensor([[[0.5, 0.0, 0.0], [-0.5, 0.0, 0.0]]])
+    # size-independent property: the warp (cost_type 'none') is linear in the source features
+    f2 = torch.randn(B, 2, h, w, Cc, generator=g)
+    wa = CV.calculate_cost_volume_erp(ARGS, feats.cuda(), None, trans.cuda(), eye.cuda(), depth_volume=dv, cost_type='none')
+    wb = CV.calculate_cost_volume_erp(ARGS, f2.cuda(), None, trans.cuda(), eye.cuda(), depth_volume=dv, cost_type='none')
+    wab = CV.calculate_cost_volume_erp(ARGS, (2.0 * feats - 0.5 * f2).cuda(), None, trans.cuda(), eye.cuda(),
+                                       depth_volume=dv, cost_type='none')
+    assert float((wab - (2.0 * wa - 0.5 * wb)).abs().max()) < 2e-5
+    del wa, wb, wab
+    cv = CV.calculate_cost_volume_erp(ARGS, feats.cuda(), None, trans.cuda(), eye.cuda(), depth_volume=dv)
+    assert cv.shape == (B, D, h, w, Cc) and not torch.isnan(cv).any()
+    sel = [0, 31, 63]
+    ref = O.cost_volume_erp(feats, dv[:, sel].cpu(), eye, trans)
+    err = (cv[:, sel].cpu() - ref).abs()
+    # warp coordinates carry ~1e-4 px of float32 noise at w=256; features are white noise (gradient ~2/px)
+    assert float(err.max()) < 5e-3 and float(err.mean()) < 2e-5
