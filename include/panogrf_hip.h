@@ -176,6 +176,28 @@ int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const fl
                          int S, int h, int w, int C, int D, int ref_idx, const int* src_idx_host, int n_src,
                          float src_div, int cost_type, float* out, void* stream);
 
+
+/* ------------------------------------------------------------------ 3-D cost regularisation -- */
+/* Activations are channel-last [B,D,H,W,Cs]; (cs, coff) = channel stride of the buffer and first channel of
+ * the slice used, so U-Net concatenations (models/common_blocks.py:232-238) are slices of one buffer. */
+/* floats of the packed block of one 3x3x3 conv and the host-side packer (weights [Cout,Cin,3,3,3] as in
+ * nn.Conv3d, bias [Cout] or NULL; fold BatchNorm3d running stats into both before packing). */
+size_t pgrf_conv3d_packed_floats(int Cout, int Cin);
+int pgrf_pack_conv3d(const float* w_host, const float* bias_host, int Cout, int Cin, float* packed_host);
+/* 3x3x3 conv, padding 1 with zeros along D,H and CIRCULAR along W, stride 1|2, + bias + LeakyReLU(slope)
+ * (slope 1 = none) + optional residual added after the activation.  Replaces WrapPadding3D + nn.Conv3d
+ * (+ BatchNorm3d eval + LeakyReLU): models/common_blocks.py:458-503,366-455 (Conv3DBlockv2),
+ * models/cost_reg.py:15-57 (ConvBnReLU3DWrap, Conv3DWrap). */
+int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                     const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
+                     const float* residual, int res_cs, int res_coff, void* stream);
+/* nn.AvgPool3d(2) (common_blocks.py:380) and F.interpolate(scale_factor=2, mode="trilinear",
+ * align_corners=False) (common_blocks.py:221-236, cost_reg.py:85-88). */
+int pgrf_avgpool3d_2(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff, int B, int D, int H,
+                     int W, int C, void* stream);
+int pgrf_upsample3d_2(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff, int B, int D, int H,
+                      int W, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,12 @@ SYMBOLS = {
                                         C.c_int, _P, _P]),
     "pgrf_cost_volume_erp": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_int), C.c_int, C.c_float, C.c_int, _P, _P]),
+    "pgrf_conv3d_packed_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "pgrf_pack_conv3d": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "pgrf_conv3d_wrap": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P]),
+    "pgrf_avgpool3d_2": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "pgrf_upsample3d_2": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_render_workspace_bytes": (C.c_size_t, [C.POINTER(PgrfRenderCfg), C.c_int]),
     "pgrf_render_rays": (C.c_int, [C.POINTER(PgrfFrame), _P, _P, C.POINTER(PgrfRenderCfg), _P, C.c_int,
                                    C.POINTER(PgrfPassOut), C.POINTER(PgrfPassOut), _P, _P, C.c_size_t, _P]),

@@ -1,0 +1,213 @@
+"""Host mirror of the reference's two 3-D cost regularisers on top of the HIP conv primitives.
+
+`CostRegNet` (models/cost_reg.py:99-175) and `UNet2Reg` (the UNet2 of Conv3DBlockv2 blocks that
+models/test_models.py:84-146 builds by default) keep the reference's parameter names, so a reference
+state_dict loads unchanged; the torch modules inside are parameter HOLDERS only — forward() never
+calls them, it dispatches every conv / pool / upsample to libpanogrf_hip.so (no fallback).
+Interface: forward(x[B,C,D,H,W]) -> [B,1,D,H,W], like `self.unet3d(cost_volume)` at
+network/omni_mvsnet/pipeline3_model.py:855.  `forward_ndhwc` takes the channel-last volume that
+pgrf_cost_volume_erp writes, skipping the permute of pipeline3_model.py:847.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ._lib import lib, PgrfError
+from .engine import _ptr, _stream, _require_gpu, pack_map
+
+
+class _PackedConv:
+    def __init__(self, weight, bias, device):
+        cout, cin = weight.shape[:2]
+        w = weight.detach().to('cpu', torch.float32).contiguous()
+        b = None if bias is None else bias.detach().to('cpu', torch.float32).contiguous()
+        n = lib.pgrf_conv3d_packed_floats(cout, cin)
+        host = torch.empty(n, dtype=torch.float32)
+        lib.check(lib.pgrf_pack_conv3d(_ptr(w), _ptr(b), cout, cin, _ptr(host)))
+        self.dev = host.to(device)
+        self.cout, self.cin, self.has_bias = cout, cin, b is not None
+
+
+class _Vol:
+    """channel-last volume view: buffer [B,D,H,W,cs] + channel slice [coff, coff+C)"""
+
+    def __init__(self, buf, coff, C):
+        self.buf, self.coff, self.C = buf, coff, C
+        self.B, self.D, self.H, self.W, self.cs = buf.shape
+
+    @staticmethod
+    def empty(B, D, H, W, C, device):
+        return _Vol(torch.empty(B, D, H, W, C, dtype=torch.float32, device=device), 0, C)
+
+    def slice(self, coff, C):
+        return _Vol(self.buf, self.coff + coff, C)
+
+
+def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
+    lib.check(lib.pgrf_conv3d_wrap(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                   _ptr(pc.dev), int(pc.has_bias), x.B, x.D, x.H, x.W, stride, float(slope),
+                                   _ptr(residual.buf) if residual is not None else None,
+                                   residual.cs if residual is not None else 0,
+                                   residual.coff if residual is not None else 0, _stream()))
+    return out
+
+
+def _pool(x, out):
+    lib.check(lib.pgrf_avgpool3d_2(_ptr(x.buf), x.cs, x.coff, _ptr(out.buf), out.cs, out.coff, x.B, x.D, x.H, x.W, x.C, _stream()))
+    return out
+
+
+def _up(x, out):
+    lib.check(lib.pgrf_upsample3d_2(_ptr(x.buf), x.cs, x.coff, _ptr(out.buf), out.cs, out.coff, x.B, x.D, x.H, x.W, x.C, _stream()))
+    return out
+
+
+def _to_ndhwc(x):
+    B, Cc, D, H, W = x.shape
+    return pack_map(x.reshape(B, Cc, D * H, W)).view(B, D, H, W, -1)
+
+
+class _RegBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._packed = None
+        self._packed_key = None
+
+    def _key(self):
+        return tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict().items())
+
+    def _ensure_packed(self, device):
+        key = (self._key(), str(device))
+        if self._packed is None or self._packed_key != key:
+            self._packed = self._pack(device)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x):
+        _require_gpu()
+        out = self.forward_ndhwc(_to_ndhwc(x.float()))
+        B, D, H, W, _ = out.shape
+        return out.view(B, 1, D, H, W)       # C == 1: channel-last and channel-first coincide
+
+
+class _ConvBnHolder(nn.Module):
+    def __init__(self, cin, cout, bn=True):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, 3, bias=False)
+        if bn:
+            self.bn = nn.BatchNorm3d(cout)
+
+
+class CostRegNet(_RegBase):
+    """models/cost_reg.py:99-175 (norm_act=None branch: BatchNorm3d eval + LeakyReLU(0.01))."""
+
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        if cfg.get('inplace_abn', False):
+            raise PgrfError('inplace_abn variant is not implemented (no shipped config enables it)')
+        if not cfg.get('use_wrap_padding', True):
+            raise PgrfError('only use_wrap_padding=True is implemented')
+        chans = [(in_channels, 8), (8, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64)]
+        for i, (ci, co) in enumerate(chans):
+            setattr(self, f'conv{i}', _ConvBnHolder(ci, co))
+        self.conv7, self.conv9, self.conv11 = _ConvBnHolder(64, 32), _ConvBnHolder(32, 16), _ConvBnHolder(16, 8)
+        self.prob = _ConvBnHolder(8, 1, bn=False)
+
+    def _pack(self, device):
+        pk = {}
+        for name in ['conv0', 'conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'conv6', 'conv7', 'conv9', 'conv11']:
+            m = getattr(self, name)
+            scale = m.bn.weight.detach() / torch.sqrt(m.bn.running_var.detach() + m.bn.eps)
+            w = m.conv.weight.detach() * scale.view(-1, 1, 1, 1, 1)           # eval-mode BN folded into the conv
+            b = m.bn.bias.detach() - m.bn.running_mean.detach() * scale
+            pk[name] = _PackedConv(w, b, device)
+        pk['prob'] = _PackedConv(self.prob.conv.weight, None, device)
+        return pk
+
+    def forward_ndhwc(self, vol):
+        B, D, H, W, Cc = vol.shape
+        if D % 8 or H % 8 or W % 8:
+            raise PgrfError('CostRegNet needs D,H,W divisible by 8')
+        dev = vol.device
+        pk = self._ensure_packed(dev)
+        x = _Vol(vol.contiguous(), 0, Cc)
+        E = lambda s, c: _Vol.empty(B, D // s, H // s, W // s, c, dev)
+        c0 = _conv(pk['conv0'], x, E(1, 8))
+        c2 = _conv(pk['conv2'], _conv(pk['conv1'], c0, E(2, 16), stride=2), E(2, 16))
+        c4 = _conv(pk['conv4'], _conv(pk['conv3'], c2, E(4, 32), stride=2), E(4, 32))
+        t = _conv(pk['conv6'], _conv(pk['conv5'], c4, E(8, 64), stride=2), E(8, 64))
+        t = _conv(pk['conv7'], _up(t, E(4, 64)), E(4, 32), residual=c4)        # conv4 + conv7(x)
+        t = _conv(pk['conv9'], _up(t, E(2, 32)), E(2, 16), residual=c2)
+        t = _conv(pk['conv11'], _up(t, E(1, 16)), E(1, 8), residual=c0)
+        return _conv(pk['prob'], t, E(1, 1), slope=1.0).buf
+
+
+class _BlockHolder(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv3d(cin, cout, 3)
+        self.conv2 = nn.Conv3d(cout, cout, 3)
+
+
+class UNet2Reg(_RegBase):
+    """The default `unet3d`: UNet2 (models/common_blocks.py:187-242) over Conv3DBlockv2 blocks
+    (:366-455, no norm, LeakyReLU 0.01) wired as in models/test_models.py:84-146 with size=4."""
+
+    def __init__(self, in_channels=32, cnn3d_num_layer=3, size=4):
+        super().__init__()
+        n = cnn3d_num_layer
+        enc = [(2 ** (i + size + 1), 2 ** (i + size + 2)) for i in range(n)]
+        enc.append((2 ** (n + size + 1), 2 ** (n + size + 2)))
+        if enc[0][0] != in_channels:
+            raise PgrfError(f'UNet2Reg expects {enc[0][0]} input channels')
+        dec = [(2 ** (size + 3), 1)] + [(4 * 2 ** (i + size + 1), 2 ** (i + size + 1)) for i in range(1, n)]
+        self.encoders = nn.ModuleList([_BlockHolder(a, b) for a, b in enc])
+        self.decoders = nn.ModuleList([_BlockHolder(a, b) for a, b in dec])
+        self.n = n
+
+    def _pack(self, device):
+        pk = {}
+        for grp in ['encoders', 'decoders']:
+            for i, blk in enumerate(getattr(self, grp)):
+                pk[f'{grp}.{i}.1'] = _PackedConv(blk.conv1.weight, blk.conv1.bias, device)
+                pk[f'{grp}.{i}.2'] = _PackedConv(blk.conv2.weight, blk.conv2.bias, device)
+        return pk
+
+    def forward_ndhwc(self, vol):
+        B, D, H, W, Cc = vol.shape
+        n = self.n
+        if D % (1 << n) or H % (1 << n) or W % (1 << n):
+            raise PgrfError(f'UNet2Reg needs D,H,W divisible by {1 << n}')
+        dev = vol.device
+        pk = self._ensure_packed(dev)
+        E = lambda s, c: _Vol.empty(B, D >> s, H >> s, W >> s, c, dev)
+        x = _Vol(vol.contiguous(), 0, Cc)
+        cats = {}
+        for i in range(n + 1):
+            c1, c2 = pk[f'encoders.{i}.1'], pk[f'encoders.{i}.2']
+            t = _conv(c1, x, E(i, c1.cout))
+            if i < n - 1:
+                # unpooled output is the skip of decoder i: write it straight into the second half of the concat buffer
+                cat = E(i, 2 * c2.cout)
+                cats[i] = cat
+                u = _conv(c2, t, cat.slice(c2.cout, c2.cout))
+            else:
+                u = _conv(c2, t, E(i, c2.cout))
+            x = _pool(u, E(i + 1, c2.cout)) if i < n else u
+        d = pk[f'decoders.{n - 1}.1'], pk[f'decoders.{n - 1}.2']
+        x = _up(x, E(n - 1, x.C))
+        x = _conv(d[1], _conv(d[0], x, E(n - 1, d[0].cout)), E(n - 1, d[1].cout))
+        for i in range(n - 2, -1, -1):
+            cat = cats[i]
+            _up(x, cat.slice(0, x.C))                         # torch.cat((upsampled, skip), dim=1)
+            d = pk[f'decoders.{i}.1'], pk[f'decoders.{i}.2']
+            x = _conv(d[1], _conv(d[0], _Vol(cat.buf, 0, cat.cs), E(i, d[0].cout)), E(i, d[1].cout))
+        return x.buf
+
+
+def build_unet3d(args, in_channels=32):
+    """The `unet3d` branch of models/test_models.py:95-146."""
+    if args.get('use_new_reg3dnet', False):
+        return CostRegNet(args, in_channels=in_channels)
+    return UNet2Reg(in_channels=in_channels, cnn3d_num_layer=args.get('cnn3d_num_layer', 3))

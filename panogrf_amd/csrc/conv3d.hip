@@ -1,0 +1,365 @@
+// 3-D cost regularisation primitives for gfx950:
+//   * 3x3x3 convolution with the ERP "wrap" padding (zeros along D and H, circular along W;
+//     models/common_blocks.py:458-503) as an implicit GEMM on v_mfma_f32_32x32x2_f32, bias and
+//     LeakyReLU fused, stride 1 or 2, channel-sliced input/output so U-Net concatenations cost nothing
+//   * AvgPool3d(2), trilinear x2 upsampling (align_corners=False)
+// Activations are channel-last [B,D,H,W,Cs] (Cs = channel stride of the buffer) so that the 32 voxels of
+// an MFMA tile x 32 input channels are 32 consecutive 128-byte lines: each lane loads 64 contiguous
+// bytes (its voxel, its half of the channel chunk) straight into the B operand registers — no LDS
+// staging: the 27 taps re-read the same lines from L1/L2.  Output channels sit on the MFMA rows
+// (accumulator registers), so a lane writes 4 consecutive channels per 16-byte store.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "pgrf_internal.h"
+
+namespace pgrf {
+
+#define PGRF_CHECK_LAUNCH(what)                                                                       \
+  do {                                                                                                \
+    const hipError_t e__ = hipGetLastError();                                                         \
+    if (e__ != hipSuccess) return set_error(PGRF_ERR_LAUNCH, what " launch failed: %s", hipGetErrorString(e__)); \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int rho_(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct ConvArgs {
+  const float* in; int in_cs, in_coff, Cin;
+  float* out; int out_cs, out_coff, Cout;
+  const float* wpk;       // packed A operands (pgrf_pack_conv3d)
+  const float* bias;      // [ceil(Cout/32)*32] in accumulator order (pgrf_pack_conv3d), or null
+  int B, D, H, W;         // input dims
+  int Do, Ho, Wo;         // output dims
+  int stride;
+  float slope;            // LeakyReLU negative slope; 1.0 = identity
+  int chunks;             // ceil(Cin/32)
+  int cot_total;          // ceil(Cout/32)
+  const float* residual;  // optional tensor added AFTER the activation (CostRegNet skip adds), same slicing as out
+  int res_cs, res_coff;
+};
+
+// packed weight index helpers (shared with the host packer below)
+__host__ __device__ inline size_t wpk_index(int cot, int tap, int chunk, int chunks, int s, int lane) {
+  return ((((size_t)(cot * 27 + tap) * chunks + chunk) * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3);
+}
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 31, kk = lane >> 5;
+  const long long nvox = (long long)a.B * a.Do * a.Ho * a.Wo;
+  const long long tile0 = ((long long)blockIdx.x * 4 + wave) * NT;
+  const int cot0 = blockIdx.y * MT;
+  if (tile0 * 32 >= nvox) return;
+
+  // per-tile voxel decode
+  int vb[NT], vz[NT], vy[NT], vx[NT];
+  bool vok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    long long v = (tile0 + t) * 32 + j;
+    vok[t] = v < nvox;
+    if (!vok[t]) v = nvox - 1;
+    vx[t] = (int)(v % a.Wo); v /= a.Wo;
+    vy[t] = (int)(v % a.Ho); v /= a.Ho;
+    vz[t] = (int)(v % a.Do); vb[t] = (int)(v / a.Do);
+  }
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    f32x16 bv;
+    if (a.bias) {
+      const float4* bp = reinterpret_cast<const float4*>(a.bias + (cot0 + m) * 32 + kk * 16);
+      const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+      bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][m] = bv;
+  }
+
+  for (int tap = 0; tap < 27; ++tap) {
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    long long ioff[NT];
+    bool iok[NT];
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int zi = vz[t] * a.stride + dz, yi = vy[t] * a.stride + dy;
+      int xi = vx[t] * a.stride + dx;
+      xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);          // circular along W
+      iok[t] = vok[t] && zi >= 0 && zi < a.D && yi >= 0 && yi < a.H;   // zeros along D, H
+      ioff[t] = ((((long long)vb[t] * a.D + zi) * a.H + yi) * a.W + xi) * a.in_cs + a.in_coff + kk * 16;
+      any = any || iok[t];
+    }
+    if (!__any(any)) continue;                                         // whole wave outside: skip the tap
+    for (int ch = 0; ch < a.chunks; ++ch) {
+      float bop[NT][16];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float* ip = a.in + ioff[t] + ch * 32;
+        const int c0 = ch * 32 + kk * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (iok[t] && c0 + q * 4 + 4 <= a.Cin) v = *reinterpret_cast<const float4*>(ip + q * 4);
+          bop[t][q * 4 + 0] = v.x; bop[t][q * 4 + 1] = v.y; bop[t][q * 4 + 2] = v.z; bop[t][q * 4 + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float4* ap = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, tap, ch, a.chunks, 0, 0)) + lane;
+        const float4 a0 = ap[0], a1 = ap[64], a2 = ap[128], a3 = ap[192];
+        const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bop[t][s], acc[t][m], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: LeakyReLU, optional residual, 16-byte channel stores
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (!vok[t]) continue;
+    const long long ov = (((long long)vb[t] * a.Do + vz[t]) * a.Ho + vy[t]) * a.Wo + vx[t];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = (cot0 + m) * 32 + q * 8 + kk * 4;
+        if (c + 4 > a.Cout) continue;
+        float4 v = make_float4(acc[t][m][q * 4], acc[t][m][q * 4 + 1], acc[t][m][q * 4 + 2], acc[t][m][q * 4 + 3]);
+        v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+        v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+        if (a.residual) {
+          const float4 rr = *reinterpret_cast<const float4*>(a.residual + ov * a.res_cs + a.res_coff + c);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
+      }
+    }
+  }
+}
+
+// Cout == 1 (UNet2's last block, CostRegNet's prob head): VALU dot products, LPV lanes per voxel.
+// wlin: [27][Cin] (tap-major), bias scalar.
+__global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, const float* __restrict__ wlin, int has_bias, int lpv) {
+  const long long nvox = (long long)a.B * a.Do * a.Ho * a.Wo;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long v = gid / lpv;
+  const int sub = (int)(gid % lpv);
+  const bool ok = v < nvox;
+  if (!ok) v = nvox - 1;
+  const long long ov = v;
+  const int x = (int)(v % a.Wo); v /= a.Wo;
+  const int y = (int)(v % a.Ho); v /= a.Ho;
+  const int z = (int)(v % a.Do); const int b = (int)(v / a.Do);
+  float s = 0.f;
+  for (int tap = 0; tap < 27; ++tap) {
+    const int zi = z * a.stride + tap / 9 - 1, yi = y * a.stride + (tap / 3) % 3 - 1;
+    int xi = x * a.stride + tap % 3 - 1;
+    xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
+    if (zi < 0 || zi >= a.D || yi < 0 || yi >= a.H) continue;
+    const float* ip = a.in + ((((long long)b * a.D + zi) * a.H + yi) * a.W + xi) * a.in_cs + a.in_coff;
+    const float* wp = wlin + tap * a.Cin;
+    if ((a.Cin & 3) == 0) {
+      for (int c = sub * 4; c < a.Cin; c += lpv * 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(ip + c);
+        const float4 wv = *reinterpret_cast<const float4*>(wp + c);
+        s = fmaf(xv.x, wv.x, s); s = fmaf(xv.y, wv.y, s); s = fmaf(xv.z, wv.z, s); s = fmaf(xv.w, wv.w, s);
+      }
+    } else {
+      for (int c = sub; c < a.Cin; c += lpv) s = fmaf(ip[c], wp[c], s);
+    }
+  }
+  for (int off = lpv >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (ok && sub == 0) {
+    if (has_bias) s += wlin[27 * a.Cin];
+    s = s > 0.f ? s : s * a.slope;
+    if (a.residual) s += a.residual[ov * a.res_cs + a.res_coff];
+    a.out[ov * a.out_cs + a.out_coff] = s;
+  }
+}
+
+// AvgPool3d(2) on channel-last data; thread per (output voxel, 4-channel group)
+__global__ void avgpool3d_kernel(const float* __restrict__ in, int in_cs, int in_coff, float* __restrict__ out, int out_cs,
+                                 int out_coff, int B, int D, int H, int W, int C) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2, g = C / 4;
+  const long long total = (long long)B * Do * Ho * Wo * g;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % g);
+    long long v = i / g;
+    const int x = (int)(v % Wo); v /= Wo;
+    const int y = (int)(v % Ho); v /= Ho;
+    const int z = (int)(v % Do); const int b = (int)(v / Do);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zi = 2 * z + (k >> 2), yi = 2 * y + ((k >> 1) & 1), xi = 2 * x + (k & 1);
+      const float4 t = *reinterpret_cast<const float4*>(in + ((((long long)b * D + zi) * H + yi) * W + xi) * in_cs + in_coff + cg * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    s.x /= 8.f; s.y /= 8.f; s.z /= 8.f; s.w /= 8.f;
+    *reinterpret_cast<float4*>(out + (i / g) * out_cs + out_coff + cg * 4) = s;
+  }
+}
+
+// F.interpolate(scale_factor=2, mode='trilinear', align_corners=False) on channel-last data
+__device__ __forceinline__ void up_idx(int o, int n, int& i0, int& i1, float& l0, float& l1) {
+  float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+__global__ void upsample3d_kernel(const float* __restrict__ in, int in_cs, int in_coff, float* __restrict__ out, int out_cs,
+                                  int out_coff, int B, int D, int H, int W, int C) {
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W, g = C / 4;
+  const long long total = (long long)B * Do * Ho * Wo * g;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % g);
+    long long v = i / g;
+    const int x = (int)(v % Wo); v /= Wo;
+    const int y = (int)(v % Ho); v /= Ho;
+    const int z = (int)(v % Do); const int b = (int)(v / Do);
+    int z0, z1, y0, y1, x0, x1; float dz0, dz1, dy0, dy1, dx0, dx1;
+    up_idx(z, D, z0, z1, dz0, dz1); up_idx(y, H, y0, y1, dy0, dy1); up_idx(x, W, x0, x1, dx0, dx1);
+    auto ld = [&](int zi, int yi, int xi) {
+      return *reinterpret_cast<const float4*>(in + ((((long long)b * D + zi) * H + yi) * W + xi) * in_cs + in_coff + cg * 4);
+    };
+    const float4 v000 = ld(z0, y0, x0), v001 = ld(z0, y0, x1), v010 = ld(z0, y1, x0), v011 = ld(z0, y1, x1);
+    const float4 v100 = ld(z1, y0, x0), v101 = ld(z1, y0, x1), v110 = ld(z1, y1, x0), v111 = ld(z1, y1, x1);
+    float4 r;
+#define PGRF_TRI(c) r.c = dz0 * (dy0 * (dx0 * v000.c + dx1 * v001.c) + dy1 * (dx0 * v010.c + dx1 * v011.c)) + \
+                          dz1 * (dy0 * (dx0 * v100.c + dx1 * v101.c) + dy1 * (dx0 * v110.c + dx1 * v111.c));
+    PGRF_TRI(x) PGRF_TRI(y) PGRF_TRI(z) PGRF_TRI(w)
+#undef PGRF_TRI
+    *reinterpret_cast<float4*>(out + (i / g) * out_cs + out_coff + cg * 4) = r;
+  }
+}
+
+static int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace pgrf
+
+using namespace pgrf;
+
+extern "C" {
+
+size_t pgrf_conv3d_packed_floats(int Cout, int Cin) {
+  const size_t cot = (Cout + 31) / 32, chunks = (Cin + 31) / 32;
+  return cot * 27 * chunks * 1024 + cot * 32 + (size_t)27 * Cin + 4;
+}
+
+// layout of the packed block: [A operands | bias in accumulator order | linear copy [27][Cin] of output channel 0 | bias0]
+int pgrf_pack_conv3d(const float* w_host, const float* bias_host, int Cout, int Cin, float* packed_host) {
+  if (!w_host || !packed_host) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d: null pointer");
+  if (Cout < 1 || Cin < 1) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d: bad channels");
+  const int cot = (Cout + 31) / 32, chunks = (Cin + 31) / 32;
+  const size_t a_floats = (size_t)cot * 27 * chunks * 1024;
+  std::memset(packed_host, 0, sizeof(float) * pgrf_conv3d_packed_floats(Cout, Cin));
+  for (int ct = 0; ct < cot; ++ct)
+    for (int tap = 0; tap < 27; ++tap)
+      for (int ch = 0; ch < chunks; ++ch)
+        for (int s = 0; s < 16; ++s)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = 32 * ct + (lane & 31), ci = 32 * ch + 16 * (lane >> 5) + s;
+            if (co < Cout && ci < Cin) packed_host[wpk_index(ct, tap, ch, chunks, s, lane)] = w_host[((size_t)co * Cin + ci) * 27 + tap];
+          }
+  float* B = packed_host + a_floats;
+  for (int ct = 0; ct < cot; ++ct)
+    for (int h = 0; h < 2; ++h)
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * ct + rho_(r, h);
+        B[ct * 32 + h * 16 + r] = (bias_host && co < Cout) ? bias_host[co] : 0.f;
+      }
+  float* L = B + cot * 32;
+  for (int tap = 0; tap < 27; ++tap)
+    for (int ci = 0; ci < Cin; ++ci) L[tap * Cin + ci] = w_host[((size_t)0 * Cin + ci) * 27 + tap];
+  L[27 * Cin] = bias_host ? bias_host[0] : 0.f;
+  return PGRF_OK;
+}
+
+int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                     const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
+                     const float* residual, int res_cs, int res_coff, void* stream) {
+  if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wrap: null pointer");
+  if (stride != 1 && stride != 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wrap: stride %d", stride);
+  if (B < 1 || D < 1 || H < 1 || W < 2) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wrap: bad dims");
+  if (((Cin & 3) == 0 || Cout != 1) && ((in_cs & 3) || (in_coff & 3)))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wrap: input channel stride/offset must be multiples of 4");
+  if (Cout != 1 && ((Cin & 3) || (Cout & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3)))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wrap: channels/strides must be multiples of 4 (or Cout == 1)");
+  ConvArgs a;
+  a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff;
+  a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
+  a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+  a.chunks = (Cin + 31) / 32; a.cot_total = (Cout + 31) / 32;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff;
+  const size_t a_floats = (size_t)a.cot_total * 27 * a.chunks * 1024;
+  a.wpk = packed;
+  a.bias = has_bias ? packed + a_floats : nullptr;
+  const long long nvox = (long long)B * a.Do * a.Ho * a.Wo;
+  if (Cout == 1) {
+    const int lpv = ((Cin & 3) == 0 && Cin >= 32) ? 8 : 1;
+    const float* wlin = packed + a_floats + a.cot_total * 32;
+    const long long threads = nvox * lpv;
+    hipLaunchKernelGGL(conv3d_cout1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, wlin,
+                       has_bias ? 1 : 0, lpv);
+    PGRF_CHECK_LAUNCH("conv3d_cout1");
+    return PGRF_OK;
+  }
+  const long long tiles = (nvox + 31) / 32;
+  // tile shape per wave: more voxel tiles per wave when the layer is large enough to still fill 256 CUs
+  const int mt = (a.cot_total % 2 == 0) ? 2 : 1;
+  const long long waves_nt4 = (tiles + 3) / 4 * (a.cot_total / mt);
+  const int nt = waves_nt4 >= 2048 ? 4 : ((tiles + 1) / 2 * (a.cot_total / mt) >= 2048 ? 2 : 1);
+  dim3 grid((unsigned)((tiles + 4 * nt - 1) / (4 * nt)), (unsigned)(a.cot_total / mt));
+#define PGRF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv3d_wrap_kernel<MT_, NT_>), grid, dim3(256), 0, (hipStream_t)stream, a)
+  if (mt == 2 && nt == 4) PGRF_LAUNCH(2, 4);
+  else if (mt == 2 && nt == 2) PGRF_LAUNCH(2, 2);
+  else if (mt == 2) PGRF_LAUNCH(2, 1);
+  else if (nt == 4) PGRF_LAUNCH(1, 4);
+  else if (nt == 2) PGRF_LAUNCH(1, 2);
+  else PGRF_LAUNCH(1, 1);
+#undef PGRF_LAUNCH
+  PGRF_CHECK_LAUNCH("conv3d_wrap");
+  return PGRF_OK;
+}
+
+int pgrf_avgpool3d_2(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff, int B, int D, int H,
+                     int W, int C, void* stream) {
+  if (!in || !out) return set_error(PGRF_ERR_ARG, "pgrf_avgpool3d_2: null pointer");
+  if ((C & 3) || (in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (D & 1) || (H & 1) || (W & 1))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_avgpool3d_2: C and strides must be multiples of 4, dims even");
+  const long long total = (long long)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(avgpool3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_cs, in_coff, out, out_cs,
+                     out_coff, B, D, H, W, C);
+  PGRF_CHECK_LAUNCH("avgpool3d");
+  return PGRF_OK;
+}
+
+int pgrf_upsample3d_2(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff, int B, int D, int H,
+                      int W, int C, void* stream) {
+  if (!in || !out) return set_error(PGRF_ERR_ARG, "pgrf_upsample3d_2: null pointer");
+  if ((C & 3) || (in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_upsample3d_2: C and strides must be multiples of 4");
+  const long long total = (long long)B * 8 * D * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_cs, in_coff, out, out_cs,
+                     out_coff, B, D, H, W, C);
+  PGRF_CHECK_LAUNCH("upsample3d");
+  return PGRF_OK;
+}
+
+}  // extern "C"
