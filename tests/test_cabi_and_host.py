@@ -1,0 +1,131 @@
+"""CPU-side checks: the C-ABI library loads here (no GPU) and exports every symbol the header declares;
+host logic (weight packing, tiling, error paths) behaves; no compute kernels are launched."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'panogrf_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(pgrf_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from panogrf_amd._lib import lib, SYMBOLS, library_path
+    assert os.path.exists(library_path()), 'build with: make -C panogrf_amd/csrc -j8'
+    declared = _header_symbols()
+    assert len(declared) >= 18
+    dll = C.CDLL(library_path())
+    for name in declared:
+        assert hasattr(dll, name), f'{name} declared in include/panogrf_hip.h but not exported'
+    assert set(declared) == set(SYMBOLS), set(declared) ^ set(SYMBOLS)
+    assert lib.pgrf_abi_version() >= 1
+
+
+def test_argument_validation_returns_errors_not_crashes():
+    from panogrf_amd._lib import lib, PgrfError, PgrfFrame, PgrfPassOut
+    assert lib.pgrf_sample_coarse_depth(0.5, 15.0, 1, 4, 2, None, None) < 0       # null output
+    assert b'null' in lib.pgrf_last_error()
+    buf = torch.zeros(16)
+    assert lib.pgrf_sample_coarse_depth(0.5, 15.0, 1, 4, 2, C.c_void_p(buf.data_ptr()), None) < 0   # dn <= 2
+    assert lib.pgrf_sample_fine_depth(C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), 0.5, 15.0, 1, 0, 1, 500, 8,
+                                      C.c_void_p(buf.data_ptr()), None) == -3          # dn > 128 unsupported
+    fr = PgrfFrame()
+    out = PgrfPassOut()
+    rc = lib.pgrf_render_pass(C.byref(fr), C.c_void_p(buf.data_ptr()), 0, C.c_void_p(buf.data_ptr()),
+                              C.c_void_p(buf.data_ptr()), 4, 64, C.byref(out), None, None)
+    assert rc == -1 and b'rfn' in lib.pgrf_last_error()
+    with pytest.raises(PgrfError):
+        lib.check(rc)
+    # empty inputs are a no-op, not an error
+    assert lib.pgrf_sample_coarse_depth(0.5, 15.0, 1, 0, 64, C.c_void_p(buf.data_ptr()), None) == 0
+
+
+def test_product_path_refuses_to_run_without_gpu():
+    from panogrf_amd import engine as E
+    from panogrf_amd._lib import PgrfError
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(PgrfError):
+        E.sample_coarse_depth(0.5, 15.0, 4, 64)
+    with pytest.raises(PgrfError):
+        E.pack_map(torch.zeros(1, 3, 4, 4))
+
+
+def test_weight_packing_layout_on_host():
+    """pgrf_pack_weights is host code: check the packed A operands of two layers against the
+    accumulator-layout rule of pgrf_layout.h using a numpy emulation of the 32x32x2 MFMA."""
+    import numpy as np
+    from bench import synthetic_weights
+    from panogrf_amd import engine as E
+    sd = synthetic_weights(3, use_vis=True)
+    blob = E.pack_pass_weights(sd, 'dist_decoder', 'agg_net', True).numpy()
+    assert blob.shape[0] == E.lib.pgrf_blob_floats() and np.isfinite(blob).all()
+
+    def rho(r, h):
+        return (r & 3) + 8 * (r >> 2) + 4 * h
+
+    def emulate(a_off, ks, mt, x_regs):
+        """x_regs [ks] pairs (lo, hi) for ONE point; returns acc [mt][16 regs][2 halves] without bias"""
+        ks4 = (ks + 3) // 4
+        A = blob[a_off:a_off + mt * ks4 * 256].reshape(mt, ks4, 64, 4)
+        acc = np.zeros((mt, 32))
+        for m in range(mt):
+            for s in range(ks):
+                a = A[m, s // 4, :, s % 4]                  # lane -> A[i = lane & 31][k = lane >> 5]
+                acc[m] += a[:32] * x_regs[s][0] + a[32:] * x_regs[s][1]
+        return acc                                           # row index = output row rho
+
+    # layer offsets follow pgrf_layout.h: DD1 first (ks 16, mt 4, bias 128), then 4 x DD2 (ks 16, mt 1, bias 32), then PE1
+    off_pe1 = (4 * 4 * 256 + 128) + 4 * (4 * 256 + 32)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(34, generator=g)
+    regs = [(float(x[rho(s, 0)]), float(x[rho(s, 1)])) for s in range(16)] + [(float(x[32]), float(x[33]))]
+    acc = emulate(off_pe1, 17, 1, regs)[0]
+    ref = sd['agg_net.prob_embed.0.weight'].double() @ x.double()
+    assert np.allclose(acc, ref.numpy(), atol=1e-5)
+    # fused dist-decoder layer 0: tile m = MLP m (mean, var, aw, vis)
+    x32 = torch.randn(32, generator=g)
+    regs = [(float(x32[rho(s, 0)]), float(x32[rho(s, 1)])) for s in range(16)]
+    acc = emulate(0, 16, 4, regs)
+    for m, name in enumerate(['mean', 'var', 'aw', 'vis']):
+        ref = sd[f'dist_decoder.{name}_decoder.0.weight'].double() @ x32.double()
+        assert np.allclose(acc[m], ref.numpy(), atol=1e-5)
+
+
+def test_conv3d_packing_on_host():
+    import numpy as np
+    from panogrf_amd._lib import lib
+    g = torch.Generator().manual_seed(1)
+    cout, cin = 40, 36
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g)
+    b = torch.randn(cout, generator=g)
+    n = lib.pgrf_conv3d_packed_floats(cout, cin)
+    host = torch.empty(n)
+    assert lib.pgrf_pack_conv3d(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), cout, cin, C.c_void_p(host.data_ptr())) == 0
+    cot, chunks = 2, 2
+    A = host[:cot * 27 * chunks * 1024].reshape(cot, 27, chunks, 4, 64, 4).numpy()
+    wn = w.reshape(cout, cin, 27).numpy()
+    for (ct, tap, ch, s, lane) in [(0, 0, 0, 0, 0), (1, 13, 1, 3, 37), (1, 26, 0, 15, 63), (0, 5, 1, 2, 40)]:
+        co, ci = 32 * ct + (lane & 31), 32 * ch + 16 * (lane >> 5) + s
+        exp = wn[co, ci, tap] if (co < cout and ci < cin) else 0.0
+        assert A[ct, tap, ch, s // 4, lane, s % 4] == np.float32(exp)
+
+
+def test_tile_sharding_math():
+    from panogrf_amd import dist as D
+    for H in [512, 13, 7]:
+        for world in [1, 2, 3, 8]:
+            rows = [D.tile_rows(r, world, H) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == H
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in rows]
+            assert max(sizes) - min(sizes) <= 1
+    c = D.tile_coords(1, 2, 4, 3)
+    assert c.shape == (6, 2) and c[0].tolist() == [0.0, 2.0] and c[-1].tolist() == [2.0, 3.0]
