@@ -1,0 +1,276 @@
+"""Drop-in counterpart of the reference's renderer modules (network/renderer.py) for inference.
+
+`name2network['neuray_gen'|'neuray_base'](cfg)` builds an nn.Module with the reference's sub-module and
+parameter names (`image_encoder`, `vis_encoder`, `dist_decoder`, `agg_net.agg_impl.*`, `agg_net.prob_embed`,
+`fine_dist_decoder`, `fine_agg_net`, `sph_fitter.regs`), so `load_state_dict(ckpt['network_state_dict'])`
+works unchanged, and `renderer(data)` / `render(que_imgs_info, ref_imgs_info, is_train)` return the same
+dict keys and shapes (network/renderer.py:635-686, 777-786).  The per-frame 2-D encoders run on stock
+PyTorch-ROCm; everything per ray goes to the HIP library.  The Linear layers below are parameter HOLDERS:
+their forward is never called.  Eval only: training is out of scope.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ._lib import PgrfError
+from . import engine as E
+from .encoders import ResUNetLight, DefaultVisEncoder
+
+
+def _mlp(dims, acts):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        layers.append(acts[i]())
+    return nn.Sequential(*layers)
+
+
+class _AddBias(nn.Module):            # index placeholder for network/ops.py:119-125 (no parameters)
+    def __init__(self, val=0.05):
+        super().__init__()
+        self.val = val
+
+
+class MixtureLogisticsDistDecoder(nn.Module):
+    """Parameter holder; layout of network/dist_decoder.py:53-97."""
+    default_cfg = {'feats_dim': 32, 'bias_val': 0.05, 'use_vis': True}
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        if self.cfg['feats_dim'] != 32 or abs(self.cfg['bias_val'] - 0.05) > 1e-12:
+            raise PgrfError('dist decoder: only feats_dim=32, bias_val=0.05 are implemented')
+        self.mean_decoder = _mlp([32, 32, 32, 2], [nn.ELU, nn.ELU, nn.Softplus])
+        self.var_decoder = _mlp([32, 32, 32, 2], [nn.ELU, nn.ELU, nn.Softplus])
+        self.var_decoder.add_module('6', _AddBias(0.05))
+        self.aw_decoder = _mlp([32, 32, 32, 1], [nn.ELU, nn.ELU, nn.Sigmoid])
+        if self.cfg['use_vis']:
+            self.vis_decoder = _mlp([32, 32, 32, 1], [nn.ELU, nn.ELU, nn.Sigmoid])
+
+
+class _RayAttention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w_qs = nn.Linear(16, 16, bias=False)
+        self.w_ks = nn.Linear(16, 16, bias=False)
+        self.w_vs = nn.Linear(16, 16, bias=False)
+        self.fc = nn.Linear(16, 16, bias=False)
+        self.layer_norm = nn.LayerNorm(16, eps=1e-6)
+
+
+class IBRNetWithNeuRay(nn.Module):
+    """Parameter holder; layer shapes and init of network/ibrnet.py:239-300."""
+
+    def __init__(self, neuray_in_dim=32, in_feat_ch=32, n_samples=64):
+        super().__init__()
+        if neuray_in_dim != 32 or in_feat_ch != 32:
+            raise PgrfError('aggregation net: only neuray_dim=32, in_feat_ch=32 are implemented')
+        self.n_samples = n_samples
+        self.ray_dir_fc = _mlp([4, 16, 35], [nn.ELU, nn.ELU])
+        self.base_fc = _mlp([207, 64, 32], [nn.ELU, nn.ELU])
+        self.vis_fc = _mlp([32, 32, 33], [nn.ELU, nn.ELU])
+        self.vis_fc2 = _mlp([32, 32, 1], [nn.ELU, nn.Sigmoid])
+        self.geometry_fc = _mlp([65, 64, 16], [nn.ELU, nn.ELU])
+        self.ray_attention = _RayAttention()
+        self.out_geometry_fc = _mlp([16, 16, 1], [nn.ELU, nn.ReLU])
+        self.rgb_fc = nn.Sequential(nn.Linear(37, 16), nn.ELU(), nn.Linear(16, 8), nn.ELU(), nn.Linear(8, 1))
+        self.neuray_fc = nn.Sequential(nn.Linear(32, 8), nn.ELU(), nn.Linear(8, 1))
+        for seq in [self.base_fc, self.vis_fc2, self.vis_fc, self.geometry_fc, self.rgb_fc, self.neuray_fc]:
+            for m in seq:
+                if isinstance(m, nn.Linear):
+                    nn.init.kaiming_normal_(m.weight.data)
+                    nn.init.zeros_(m.bias.data)
+
+
+class DefaultAggregationNet(nn.Module):
+    """Parameter holder; network/aggregate_net.py:16-39."""
+    default_cfg = {'sample_num': 64, 'neuray_dim': 32, 'use_img_feats': False}
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        if self.cfg.get('level', 0) in [-1] or self.cfg.get('wo_geometry') or self.cfg.get('wo_appearance'):
+            raise PgrfError('aggregation net: level=-1 / wo_geometry / wo_appearance are not implemented')
+        self.agg_impl = IBRNetWithNeuRay(self.cfg['neuray_dim'], 32, self.cfg['sample_num'])
+        self.prob_embed = nn.Sequential(nn.Linear(2 + 32, 32), nn.ReLU(), nn.Linear(32, 32))
+
+
+class _SphHolder(nn.Module):
+    """Only the `regs` buffer of SphericalHarmonicsSolver(3) appears in checkpoints (network/sph_solver.py:5-13);
+    direct rendering itself is disabled in the reference."""
+
+    def __init__(self):
+        super().__init__()
+        regs = [0.0] + [0.001] * 3 + [0.005] * 5 + [0.05] * 7
+        self.register_buffer('regs', torch.tensor(regs, dtype=torch.float32))
+
+
+class NeuralRayBaseRenderer(nn.Module):
+    base_cfg = {
+        'vis_encoder_type': 'default', 'vis_encoder_cfg': {}, 'dist_decoder_type': 'mixture_logistics',
+        'dist_decoder_cfg': {}, 'autoencoder': False, 'agg_net_type': 'default', 'agg_net_cfg': {},
+        'use_hierarchical_sampling': False, 'fine_agg_net_cfg': {}, 'fine_dist_decoder_cfg': {},
+        'fine_depth_sample_num': 64, 'fine_depth_use_all': False, 'ray_batch_num': 2048, 'depth_sample_num': 64,
+        'alpha_value_ground_state': -15, 'use_dr_prediction': False, 'use_nr_color_for_dr': False,
+        'use_self_hit_prob': False, 'use_ray_mask': True, 'ray_mask_view_num': 1, 'ray_mask_point_num': 8,
+        'patchsize': (128, 128), 'render_depth': False,
+    }
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = {**self.base_cfg, **cfg}
+        c = self.cfg
+        c['agg_net_cfg'], c['fine_agg_net_cfg'] = dict(c['agg_net_cfg']), dict(c['fine_agg_net_cfg'])
+        if 'sample_num' in cfg:
+            c['agg_net_cfg']['sample_num'] = c['sample_num']
+            c['fine_agg_net_cfg']['sample_num'] = c['sample_num']
+        for key in ('level', 'wo_geometry', 'wo_appearance'):
+            if key in cfg:
+                c['agg_net_cfg'][key] = cfg[key]
+                c['fine_agg_net_cfg'][key] = cfg[key]
+        if c.get('dataset_name', 'm3d') != 'm3d':
+            raise PgrfError("only the 'm3d' ERP convention is implemented (SURVEY.md section 8 f-4)")
+        for key in ('debug', 'diner_depth_guided_sampling', 'render_uncert', 'autoencoder'):
+            if c.get(key):
+                raise PgrfError(f"cfg['{key}'] is not implemented on the HIP path")
+        if c.get('local_feature_type') == 'ERP+TP':
+            raise PgrfError('ERP+TP image encoder is out of scope')
+        self.vis_encoder = DefaultVisEncoder(c)
+        self.dist_decoder = MixtureLogisticsDistDecoder(c['dist_decoder_cfg'])
+        self.image_encoder = ResUNetLight(c, 3, [1, 2, 6, 4], 32, inplanes=16, use_wrap_padding=c.get('use_wrap_padding', True))
+        self.agg_net = DefaultAggregationNet(c['agg_net_cfg'])
+        if c['use_hierarchical_sampling'] and not c.get('one_mlp', False):
+            self.fine_dist_decoder = MixtureLogisticsDistDecoder(c['fine_dist_decoder_cfg'])
+            self.fine_agg_net = DefaultAggregationNet(c['fine_agg_net_cfg'])
+        self.sph_fitter = _SphHolder()
+        self._rr = None
+        self._rr_key = None
+
+    # ------------------------------------------------------------------ HIP engine plumbing
+    def _per_ray_state(self):
+        keep = ('dist_decoder.', 'agg_net.', 'fine_dist_decoder.', 'fine_agg_net.')
+        return {k: v for k, v in self.state_dict().items() if k.startswith(keep)}
+
+    def _engine(self, device):
+        sd = self._per_ray_state()
+        key = (tuple((k, v._version, v.data_ptr()) for k, v in sd.items()), str(device))
+        if self._rr is None or self._rr_key != key:
+            ecfg = dict(self.cfg)
+            ecfg['dist_decoder_cfg'] = {'use_vis': self.dist_decoder.cfg['use_vis']}
+            if hasattr(self, 'fine_dist_decoder'):
+                ecfg['fine_dist_decoder_cfg'] = {'use_vis': self.fine_dist_decoder.cfg['use_vis']}
+            # the reference adds pos_encoding [1,n_samples,16] to [rn,dn,16]: dn must equal sample_num (ibrnet.py:358)
+            ns = self.agg_net.agg_impl.n_samples
+            dn_f = (ecfg['depth_sample_num'] + ecfg['fine_depth_sample_num']) if ecfg['fine_depth_use_all'] else ecfg['fine_depth_sample_num']
+            if ecfg['depth_sample_num'] != ns or (ecfg['use_hierarchical_sampling'] and dn_f != ns):
+                raise PgrfError(f'samples per pass must equal agg_net sample_num={ns} (positional encoding)')
+            self._rr = E.RayRenderer(ecfg, sd, device=device)
+            self._rr_key = key
+        return self._rr
+
+    # ------------------------------------------------------------------ reference interface
+    def render_impl(self, que_imgs_info, ref_imgs_info, is_train, is_perspec=False):
+        """One ray batch (network/renderer.py:567-633).  `ref_imgs_info` must carry 'img_feats' and
+        (vis-encoded) 'ray_feats' like after lines 641-642 of the reference."""
+        if is_train:
+            raise NotImplementedError('training is out of scope: eval only')
+        if is_perspec:
+            raise PgrfError('perspective / cube-face query rays are not implemented (SURVEY.md section 8 f-4)')
+        imgs = ref_imgs_info['imgs']
+        dev = imgs.device
+        rr = self._engine(dev)
+        if que_imgs_info['c2w'].shape[0] != 1:
+            raise PgrfError('que_imgs_info c2w.shape[0]=1')
+        frame = ref_imgs_info.get('_pgrf_frame')
+        if frame is None:
+            frame = E.Frame(imgs, ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'], ref_imgs_info['w2c'],
+                            ref_imgs_info['depth_range'], que_imgs_info['c2w'][0], que_imgs_info['depth_range'][0],
+                            device=dev)
+        out = rr.render_rays(frame, que_imgs_info['coords'][0])
+        c = self.cfg
+        res = {}
+        rn = que_imgs_info['coords'].shape[1]
+        for suffix in ([''] + (['_fine'] if c['use_hierarchical_sampling'] else [])):
+            dn = out['density_nr' + suffix].shape[1]
+            for k in ('pixel_colors_nr', 'hit_prob_nr', 'colors_nr', 'density_nr'):
+                res[k + suffix] = out[k + suffix].unsqueeze(0)
+            if 'imgs' in que_imgs_info:
+                xy = que_imgs_info['coords'][0].long()
+                res['pixel_colors_gt' + suffix] = que_imgs_info['imgs'][:, :, xy[:, 1], xy[:, 0]].permute(0, 2, 1)
+            if c['use_ray_mask']:
+                ok = (imgs.shape[0] >= c['ray_mask_view_num']) and (dn > c['ray_mask_point_num'])
+                res['ray_mask' + suffix] = torch.full((1, rn), bool(ok), dtype=torch.bool, device=dev)
+            if c['render_depth']:
+                res['render_depth' + suffix] = out['render_depth' + suffix].unsqueeze(0)
+        return res
+
+    def render(self, que_imgs_info, ref_imgs_info, is_train, is_perspec=False):
+        """Whole query view (network/renderer.py:635-686).  Mutates ref_imgs_info['img_feats'/'ray_feats'] and
+        que_imgs_info['coords'] like the reference does."""
+        if is_train:
+            raise NotImplementedError('training is out of scope: eval only')
+        ref_img_feats = self.image_encoder(ref_imgs_info['imgs'])
+        ref_imgs_info['img_feats'] = ref_img_feats
+        ref_imgs_info['ray_feats'] = self.vis_encoder(ref_imgs_info['ray_feats'], ref_img_feats)
+        ref = dict(ref_imgs_info)
+        ref['_pgrf_frame'] = E.Frame(ref['imgs'], ref['img_feats'], ref['ray_feats'], ref['w2c'], ref['depth_range'],
+                                     que_imgs_info['c2w'][0], que_imgs_info['depth_range'][0], device=ref['imgs'].device)
+        coords = que_imgs_info['coords']
+        rb = self.cfg['ray_batch_num']
+        # rays are independent: the reference's batch loop (renderer.py:656-683) only bounds memory, so by default
+        # batches are merged up to `hip_ray_batch_num` rays per launch (results are batching-invariant)
+        rb = max(rb, int(self.cfg.get('hip_ray_batch_num', 1 << 20)))
+        parts = {}
+        for s in range(0, coords.shape[1], rb):
+            que_imgs_info['coords'] = coords[:, s:s + rb]
+            info = self.render_impl(que_imgs_info, ref, is_train, is_perspec)
+            for k, v in info.items():
+                if k.startswith('hit_prob'):
+                    continue
+                parts.setdefault(k, []).append(v)
+        return {k: torch.cat(v, 1) if len(v) > 1 else v[0] for k, v in parts.items()}
+
+    def forward(self, data):
+        ref = dict(data['ref_imgs_info'])
+        que = dict(data['que_imgs_info'])
+        return self.render(que, ref, 'eval' not in data)      # is_train = 'eval' not in data (renderer.py:780)
+
+
+class NeuralRayGenRenderer(NeuralRayBaseRenderer):
+    """Generalisable renderer (network/renderer.py:688-786).  The init net (mono-guided 360-degree MVS:
+    network/init_net.py + network/omni_mvsnet/pipeline3_model.py) is per-frame 2-D CNN work that SURVEY.md
+    section 8 f-2 ranks 'next'; pass any module with the reference's call signature
+    `init_net(ref_imgs_info, src_imgs_info, is_train) -> {'ray_feats','depth',...}` as `init_net=`.  Its
+    cost-volume and 3-D regulariser stages are available natively (panogrf_amd.cost_volume / cost_reg)."""
+    default_cfg = {'init_net_type': 'depth', 'init_net_cfg': {}, 'use_depth_loss': False, 'depth_loss_coords_num': 8192}
+
+    def __init__(self, cfg, init_net=None):
+        super().__init__({**self.default_cfg, **cfg})
+        if init_net is not None:
+            self.init_net = init_net
+
+    def render_call(self, que_imgs_info, ref_imgs_info, is_train, src_imgs_info=None):
+        if not hasattr(self, 'init_net'):
+            raise PgrfError('NeuralRayGenRenderer needs an init_net module (see class docstring); '
+                            'or put ray_feats into ref_imgs_info and call render()')
+        ret = self.init_net(ref_imgs_info, src_imgs_info, is_train)
+        ref_imgs_info['ray_feats'] = ret['ray_feats']
+        if 'mvs_depth' in ret:
+            ref_imgs_info['mvs_depth'] = ret['mvs_depth']
+        return self.render(que_imgs_info, ref_imgs_info, is_train)
+
+    def forward(self, data):
+        ref = dict(data['ref_imgs_info'])
+        que = dict(data['que_imgs_info'])
+        src = dict(data['src_imgs_info']) if 'src_imgs_info' in data else None
+        is_train = 'eval' not in data
+        if 'ray_feats' in ref and not hasattr(self, 'init_net'):
+            return self.render(que, ref, is_train)
+        return self.render_call(que, ref, is_train, src)
+
+
+name2network = {
+    'neuray_gen': NeuralRayGenRenderer,
+    'neuray_base': NeuralRayBaseRenderer,
+}

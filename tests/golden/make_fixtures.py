@@ -237,9 +237,44 @@ def frame_fixture(name, seed, rfn, H, W, dn, boost=True, c2f_all=False):
     print(name, os.path.getsize(path) // 1024, 'KiB', 'mean fine rgb', float(outs['pixel_colors_nr_fine'].mean()))
 
 
+def full_render_fixture(name, seed, rfn, H, W, dn):
+    """NeuralRayBaseRenderer.render end to end (2-D encoders + ray loop) with fully seeded weights."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from fixtures import seeded_renderer_state
+    from network.renderer import NeuralRayBaseRenderer
+    cfg = base_cfg(H, W, dn, ray_batch_num=700)
+    r = NeuralRayBaseRenderer(dict(cfg)).eval()
+    sd = r.state_dict()
+    shapes = [(k, tuple(v.shape)) for k, v in sd.items()]
+    r.load_state_dict(seeded_renderer_state(shapes, seed))
+    frame = make_frame(seed + 2, rfn, H, W)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(1, -1, 2)
+    que = {'c2w': frame['que_c2w'][None], 'w2c': frame['que_w2c'][None], 'coords': coords,
+           'depth_range': frame['que_depth_range'][None]}
+    ref = {'imgs': frame['imgs'], 'w2c': frame['w2c'], 'depth_range': frame['ref_depth_range'],
+           'ray_feats': frame['ray_feats']}
+    with torch.no_grad():
+        out = r.render(dict(que), dict(ref), False)
+    arrs = {}
+    arrs.update(to_np({k: v for k, v in frame.items() if k != 'img_feats'}, 'in.'))
+    keep = ['pixel_colors_nr', 'pixel_colors_nr_fine', 'render_depth', 'render_depth_fine', 'density_nr_fine', 'ray_mask_fine']
+    arrs.update(to_np({k: out[k] for k in keep}, 'out.'))
+    arrs['out.keys'] = np.frombuffer('\n'.join(sorted(out.keys())).encode(), np.uint8)
+    arrs['state.keys'] = np.frombuffer('\n'.join(f'{k}:{",".join(map(str, s))}' for k, s in shapes).encode(), np.uint8)
+    arrs['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print(name, os.path.getsize(path) // 1024, 'KiB', 'mean fine rgb', float(out['pixel_colors_nr_fine'].mean()),
+          sorted(out.keys()))
+
+
 def main():
     torch.set_num_threads(1)
     R.setup()
+    if '--full-only' in sys.argv:
+        full_render_fixture('render_full_v2_dn32', seed=800, rfn=2, H=32, W=64, dn=32)
+        return
     stage_fixture('render_stages_v2_dn32', seed=100, rfn=2, H=32, W=64, rn=24, dn=32)
     stage_fixture('render_stages_v2_dn64', seed=200, rfn=2, H=32, W=64, rn=12, dn=64, keep_big=False)
     stage_fixture('render_stages_v4_dn32', seed=300, rfn=4, H=32, W=64, rn=12, dn=32, keep_big=False)
@@ -247,6 +282,7 @@ def main():
     stage_fixture('render_stages_v2_randinit', seed=500, rfn=2, H=32, W=64, rn=12, dn=32, boost=False, keep_big=False)
     frame_fixture('render_frame_v2_dn32', seed=600, rfn=2, H=32, W=64, dn=32)
     frame_fixture('render_frame_v2_c2fall', seed=700, rfn=2, H=16, W=32, dn=32, c2f_all=True)
+    full_render_fixture('render_full_v2_dn32', seed=800, rfn=2, H=32, W=64, dn=32)
 
 
 if __name__ == '__main__':

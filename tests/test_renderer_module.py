@@ -1,0 +1,56 @@
+"""The drop-in nn.Module (panogrf_amd.renderer) against a full NeuralRayBaseRenderer.render() run of the
+reference (2-D encoders + ray loop), weights rebuilt from a seed (tests/fixtures.seeded_renderer_state)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import fixtures as FX
+
+
+def _load():
+    frame, _, cfg, g = FX.load('render_full_v2_dn32')
+    z = np.load(FX.GOLDEN + '/render_full_v2_dn32.npz')
+    shapes = []
+    for ln in bytes(z['state.keys']).decode().split('\n'):
+        k, s = ln.split(':')
+        shapes.append((k, tuple(int(t) for t in s.split(',')) if s else ()))
+    return frame, cfg, g['out'], shapes, bytes(z['out.keys']).decode().split('\n')
+
+
+def test_state_dict_keys_match_reference():
+    """CPU: a reference checkpoint's network_state_dict must load with strict=True."""
+    from panogrf_amd.renderer import name2network
+    frame, cfg, gold, shapes, out_keys = _load()
+    net = name2network['neuray_base'](cfg)
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert mine == dict(shapes)
+    net.load_state_dict(FX.seeded_renderer_state(shapes, 800), strict=True)
+    assert 'neuray_gen' in name2network
+
+
+@pytest.mark.gpu
+def test_render_end_to_end_vs_reference():
+    from panogrf_amd.renderer import name2network
+    frame, cfg, gold, shapes, out_keys = _load()
+    net = name2network['neuray_gen'](cfg)
+    net.load_state_dict(FX.seeded_renderer_state(shapes, 800))
+    net = net.cuda().eval()
+    H, W = frame['imgs'].shape[-2:]
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(1, -1, 2)
+    que = {'c2w': frame['que_c2w'][None].cuda(), 'w2c': frame['que_w2c'][None].cuda(), 'coords': coords.cuda(),
+           'depth_range': frame['que_depth_range'][None].cuda()}
+    ref = {'imgs': frame['imgs'].cuda(), 'w2c': frame['w2c'].cuda(), 'depth_range': frame['ref_depth_range'].cuda(),
+           'ray_feats': frame['ray_feats'].cuda()}
+    with torch.no_grad():
+        out = net({'que_imgs_info': que, 'ref_imgs_info': ref, 'eval': True})
+    assert sorted(out.keys()) == out_keys                       # same dict keys as the reference returns in eval
+    for k in ['pixel_colors_nr', 'render_depth']:
+        assert out[k].shape == gold[k].shape
+        assert FX.max_abs(out[k].cpu(), gold[k]) < 5e-4 * max(1.0, float(gold[k].abs().max())), k
+    assert FX.psnr(out['pixel_colors_nr'].cpu(), gold['pixel_colors_nr']) > 80
+    assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), gold['pixel_colors_nr_fine']) > 60
+    assert torch.equal(out['ray_mask_fine'].cpu(), gold['ray_mask_fine'])
+    # training mode is refused, not silently approximated
+    with pytest.raises(NotImplementedError):
+        net({'que_imgs_info': que, 'ref_imgs_info': ref})
