@@ -28,8 +28,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define PGRF_TWO_PI_F 6.28318530717958647692f
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+// ELU(x) = median(x, exp(x)-1, 0): x > 0 -> exp(x)-1 >= x > 0; x < 0 -> x <= exp(x)-1 < 0.  One v_med3 instead of cmp+cndmask.
+#ifdef PGRF_OLD_ELU
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
-__device__ __forceinline__ float sigmoid1(float x) { return 1.f / (1.f + __expf(-x)); }
+#else
+__device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
+#endif
+// 1-ulp reciprocal (v_rcp_f32) for quantities that are not pixel coordinates: the correctly rounded IEEE
+// division costs ~11 VALU instructions, and VALU time adds to f32-MFMA time on this chip.
+__device__ __forceinline__ float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoid1(float x) { return rcp1(1.f + __expf(-x)); }
 __device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
 
 __device__ __forceinline__ void elu16(f32x16& a) {
@@ -45,12 +53,11 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
   constexpr int KS4 = (KS + 3) / 4;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
+    f32x16 bv;
     if (INIT_BIAS) {
       const float4* bp = reinterpret_cast<const float4*>(B + m * 32 + (lane >> 5) * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-      f32x16 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][m] = bv;
+      bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
     }
 #pragma unroll
     for (int s4 = 0; s4 < KS4; ++s4) {
@@ -60,8 +67,18 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
       for (int j = 0; j < 4; ++j) {
         if (s4 * 4 + j < KS) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
-            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[t][s4 * 4 + j], acc[t][m], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {
+            // the bias vector is the C operand of the first MFMA of the tile (shared by the NT point tiles)
+#ifdef PGRF_OLD_BIAS
+            if (INIT_BIAS && s4 == 0 && j == 0) acc[t][m] = bv;
+            if (false)
+#else
+            if (INIT_BIAS && s4 == 0 && j == 0)
+#endif
+              acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[t][0], bv, 0, 0, 0);
+            else
+              acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[t][s4 * 4 + j], acc[t][m], 0, 0, 0);
+          }
         }
       }
     }
@@ -162,7 +179,8 @@ struct PointGeom {
 // ray_dir_fc.  Fills vs[V0..V0+NT).
 template <int V, int V0, int NT, bool DBG>
 __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& g, ViewState (&vs)[V], int lane,
-                                            size_t pt /* ray*DN+sample */, size_t npts, bool store_ok) {
+                                            size_t pt /* ray*DN+sample */, size_t npts, bool store_ok,
+                                            float* const* sdbg) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
   f32x16 rf[NT];
@@ -191,7 +209,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     const float ccz = -(M[2] * M[3] + M[6] * M[7] + M[10] * M[11]);
     float dx = g.p[0] - ccx, dy = g.p[1] - ccy, dz = g.p[2] - ccz;
     const float dn_ = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-5f);
-    dx = -dx / dn_; dy = -dy / dn_; dz = -dz / dn_;
+    { const float rd = -rcp1(dn_); dx *= rd; dy *= rd; dz *= rd; }
     vs[v].dd[0] = dx - g.qdir[0];
     vs[v].dd[1] = dy - g.qdir[1];
     vs[v].dd[2] = dz - g.qdir[2];
@@ -203,10 +221,10 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     rf[t] = gather32(p.ray_feats + (size_t)v * p.hr * p.wr * 32, brf, half);
     if (DBG && store_ok) {
       const size_t o = (size_t)v * npts + pt;
-      if (p.dbg.px && half == 0) { p.dbg.px[o * 2] = px; p.dbg.px[o * 2 + 1] = py; }
-      if (p.dbg.depth_v && half == 0) p.dbg.depth_v[o] = r;
-      if (p.dbg.ddiff && half == 0) for (int c = 0; c < 4; ++c) p.dbg.ddiff[o * 4 + c] = vs[v].dd[c];
-      if (p.dbg.ray_feats) dump_tile32(p.dbg.ray_feats + o * 32, rf[t], half);
+      if (sdbg[0] && half == 0) { sdbg[0][o * 2] = px; sdbg[0][o * 2 + 1] = py; }
+      if (sdbg[1] && half == 0) sdbg[1][o] = r;
+      if (sdbg[2] && half == 0) for (int c = 0; c < 4; ++c) sdbg[2][o * 4 + c] = vs[v].dd[c];
+      if (sdbg[5]) dump_tile32(sdbg[5] + o * 32, rf[t], half);
     }
   }
 
@@ -269,8 +287,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     hit_s[t] = hitp;
     if (DBG && store_ok && half == 0) {
       const size_t o = (size_t)v * npts + pt;
-      if (p.dbg.vis) p.dbg.vis[o] = visib;
-      if (p.dbg.hit) p.dbg.hit[o] = hitp;
+      if (sdbg[3]) sdbg[3][o] = visib;
+      if (sdbg[4]) sdbg[4][o] = hitp;
     }
   }
   // ---- prob_embed: [ray_feats(32), 2(hit-.5), 2(vis-.5)] -> 32 relu -> 32  (aggregate_net.py:53-61)
@@ -310,8 +328,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       for (int r = 0; r < 4; ++r) h[r] = elu1(h[r]);
       const float y = head_dot<4>(W + OFF_NFH_W, half, h) + W[OFF_NFH_B];
       vs[V0 + t].w0 = sigmoid1(y) * wgt;
-      if (DBG && store_ok && p.dbg.neuray)
-        dump_tile32(p.dbg.neuray + (pt * V + (V0 + t)) * 32, vs[V0 + t].nf, half);
+      if (DBG && store_ok && sdbg[8])
+        dump_tile32(sdbg[8] + (pt * V + (V0 + t)) * 32, vs[V0 + t].nf, half);
     }
   }
   // ---- ray_dir_fc 4 -> 16 elu -> 35 elu; rgb_feat = [rgb, img_feats] + dir_feat  (ibrnet.py:325-327)
@@ -348,8 +366,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       for (int c = 0; c < 3; ++c) vs[v].fb[c] = vs[v].rgb[c] + elu1(a2[t][1][c]);
       if (DBG && store_ok) {
         const size_t o = (size_t)v * npts + pt;
-        if (p.dbg.img_feats) dump_tile32(p.dbg.img_feats + o * 32, imf, half);
-        if (p.dbg.rgb && half == 0) for (int c = 0; c < 3; ++c) p.dbg.rgb[o * 3 + c] = vs[v].rgb[c];
+        if (sdbg[7]) dump_tile32(sdbg[7] + o * 32, imf, half);
+        if (sdbg[6] && half == 0) for (int c = 0; c < 3; ++c) sdbg[6][o * 3 + c] = vs[v].rgb[c];
       }
     }
   }
@@ -359,7 +377,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
 // Stage C for NT views: base_fc (per-view part, onto the shared partial G), vis_fc, vis_fc2.
 template <int V, int V0, int NT, bool DBG>
 __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2], ViewState (&vs)[V], int lane,
-                                          size_t pt, bool store_ok) {
+                                          size_t pt, bool store_ok, float* const* sdbg) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
   const float wgt = 1.f / ((float)V + 1e-8f);
@@ -394,7 +412,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       elu16(x[t][0]);
-      if (DBG && store_ok && p.dbg.base_x) dump_tile32(p.dbg.base_x + (pt * V + (V0 + t)) * 32, x[t][0], half);
+      if (DBG && store_ok && sdbg[9]) dump_tile32(sdbg[9] + (pt * V + (V0 + t)) * 32, x[t][0], half);
     }
   }
   // vis_fc(x * weight): 32 -> 32 elu -> 33 elu; x += x_res; vis = sigmoid(.)   (ibrnet.py:347-350)
@@ -485,6 +503,13 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   __shared__ float lds_k[128 * kKStride];
   __shared__ float lds_alpha[128];
   __shared__ float lds_red[4][4];
+  // debug builds: the 12 dump pointers live in LDS, not in SGPRs (24 live SGPRs made the compiler spill scalars)
+  __shared__ float* lds_dbg[DBG ? 12 : 1];
+  float* const* sdbg = lds_dbg;
+  if (DBG) {
+    if (threadIdx.x < 12) lds_dbg[threadIdx.x] = reinterpret_cast<float* const*>(&p.dbg)[threadIdx.x];
+    __syncthreads();
+  }
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -511,7 +536,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     const float sp = sinf(phi);
     float dx = sp * cosf(theta), dy = cosf(phi), dz = sp * sinf(theta);
     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-    dx /= nrm; dy /= nrm; dz /= nrm;
+    { const float rn_ = rcp1(nrm); dx *= rn_; dy *= rn_; dz *= rn_; }
     const float wx = p.c2w[0] * dx + p.c2w[1] * dy + p.c2w[2] * dz;
     const float wy = p.c2w[4] * dx + p.c2w[5] * dy + p.c2w[6] * dz;
     const float wz = p.c2w[8] * dx + p.c2w[9] * dy + p.c2w[10] * dz;
@@ -521,7 +546,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     g.p[1] = p.c2w[7] + wy * tdepth;
     g.p[2] = p.c2w[11] + wz * tdepth;
     const float wn = sqrtf(wx * wx + wy * wy + wz * wz);
-    g.qdir[0] = -wx / wn; g.qdir[1] = -wy / wn; g.qdir[2] = -wz / wn;
+    { const float rw = rcp1(wn); g.qdir[0] = -wx * rw; g.qdir[1] = -wy * rw; g.qdir[2] = -wz * rw; }
     // interval half-widths in normalised inverse depth (render_ops.py:110-122, dist_decoder.py:34-38)
     const float qn = -1.f / p.que_near, qf = -1.f / p.que_far;
     const float d_c = (-1.f / tdepth - qn) / (qf - qn);
@@ -537,9 +562,11 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   const bool store_ok = ray_ok;
 
   // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
-  stage_front<V, 0, (V >= 2 ? 2 : 1), DBG>(p, g, vs, lane, pt, npts, store_ok);
-  if constexpr (V > 2) stage_front<V, 2, V - 2, DBG>(p, g, vs, lane, pt, npts, store_ok);
+  stage_front<V, 0, (V >= 2 ? 2 : 1), DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (V > 2) stage_front<V, 2, V - 2, DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg);
 
+  if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage B: view statistics (ibrnet.py:112-116,339-342) and the view-shared part of base_fc.0
   f32x16 G[1][2];
   {
@@ -565,10 +592,13 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     mfma_layer<76, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b76, G);
   }
 
+  if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage C: per-view base_fc / vis_fc / vis_fc2
-  stage_mid<V, 0, (V >= 2 ? 2 : 1), DBG>(p, G[0], vs, lane, pt, store_ok);
-  if constexpr (V > 2) stage_mid<V, 2, V - 2, DBG>(p, G[0], vs, lane, pt, store_ok);
+  stage_mid<V, 0, (V >= 2 ? 2 : 1), DBG>(p, G[0], vs, lane, pt, store_ok, sdbg);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (V > 2) stage_mid<V, 2, V - 2, DBG>(p, G[0], vs, lane, pt, store_ok, sdbg);
 
+  if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage D: pooled geometry feature -> geometry_fc -> ray attention -> density
   float sigma;
   {
@@ -577,8 +607,9 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     for (int v = 0; v < V; ++v) vsum += vs[v].v2;
     float w2[V];
     float wmean = 0.f;
+    const float rvs = rcp1(vsum + 1e-8f);
 #pragma unroll
-    for (int v = 0; v < V; ++v) { w2[v] = vs[v].v2 / (vsum + 1e-8f); wmean += w2[v]; }
+    for (int v = 0; v < V; ++v) { w2[v] = vs[v].v2 * rvs; wmean += w2[v]; }
     wmean = wmean / (float)V;
     float b33[1][33];
 #pragma unroll
@@ -611,7 +642,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
         g2[0][0][r] = ge;
         gp[0][r] = ge + pe[r];
       }
-      if (DBG && store_ok && p.dbg.geo) dump_tile16(p.dbg.geo + pt * 16, g2[0][0], half);
+      if (DBG && store_ok && sdbg[10]) dump_tile16(sdbg[10] + pt * 16, g2[0][0], half);
     }
     // q|k and v projections (ibrnet.py:80-82); rows permuted so register 2*head+s carries dims (2s,2s+1)
     f32x16 qkv[1][2];
@@ -658,7 +689,8 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
         }
       l += xhalf(l);
       o0 += xhalf(o0); o1 += xhalf(o1); o2 += xhalf(o2); o3 += xhalf(o3);
-      oatt[hd * 4 + 0] = o0 / l; oatt[hd * 4 + 1] = o1 / l; oatt[hd * 4 + 2] = o2 / l; oatt[hd * 4 + 3] = o3 / l;
+      const float rl = rcp1(l);
+      oatt[hd * 4 + 0] = o0 * rl; oatt[hd * 4 + 1] = o1 * rl; oatt[hd * 4 + 2] = o2 * rl; oatt[hd * 4 + 3] = o3 * rl;
     }
     // fc + residual + LayerNorm(eps 1e-6)  (ibrnet.py:95-102)
     float bo[1][8];
@@ -674,20 +706,20 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
 #pragma unroll
       for (int r = 0; r < 8; ++r) sum += fo[0][0][r];
       sum += xhalf(sum);
-      const float mean = sum / 16.f;
+      const float mean = sum * 0.0625f;
       float sq = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) { const float d = fo[0][0][r] - mean; sq += d * d; }
       sq += xhalf(sq);
-      const float rstd = 1.f / sqrtf(sq / 16.f + 1e-6f);
+      const float rstd = __builtin_amdgcn_rsqf(sq * 0.0625f + 1e-6f);
 #pragma unroll
       for (int r = 0; r < 8; ++r)
         ln[0][r] = (fo[0][0][r] - mean) * rstd * W[OFF_LN_G + half * 8 + r] + W[OFF_LN_B + half * 8 + r];
-      if (DBG && store_ok && p.dbg.attn) {
+      if (DBG && store_ok && sdbg[11]) {
         f32x16 tmp;
 #pragma unroll
         for (int r = 0; r < 8; ++r) tmp[r] = ln[0][r];
-        dump_tile16(p.dbg.attn + pt * 16, tmp, half);
+        dump_tile16(sdbg[11] + pt * 16, tmp, half);
       }
     }
     // out_geometry_fc 16 -> 16 elu -> 1 relu  (ibrnet.py:361)
@@ -698,6 +730,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     sigma = fmaxf(head_dot<8>(W + OFF_OGH_W, half, og[0][0]) + W[OFF_OGH_B], 0.f);
   }
 
+  if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage E: colour blending over views (ibrnet.py:364-370)
   float col[3];
   {
@@ -711,14 +744,16 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
 #pragma unroll
     for (int v = 0; v < V; ++v) { e[v] = __expf(logit[v] - mx); es += e[v]; }
     col[0] = col[1] = col[2] = 0.f;
+    const float res_ = rcp1(es);
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const float bw = e[v] / es;
+      const float bw = e[v] * res_;
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[c] += vs[v].rgb[c] * bw;
     }
   }
 
+  if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage F: alpha compositing along the ray (renderer.py:216-218,291-304; render_ops.py:145-153)
   const float alpha = 1.f - __expf(-fmaxf(sigma, 0.f));
   if (half == 0) lds_alpha[pt_local] = alpha;

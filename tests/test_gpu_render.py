@@ -65,7 +65,7 @@ def test_stage_parity_vs_reference_fixtures(name):
         assert n >= 10
         # debug and production kernels are separate instantiations: they must agree
         out2 = E.render_pass(fr, blob, use_vis, frame['coords'], gold['depth'], debug=False)
-        assert FX.max_abs(out2['pixel_colors_nr'].cpu(), flat['pixel_colors_nr'].cpu()) < 1e-6
+        assert FX.max_abs(out2['pixel_colors_nr'].cpu(), flat['pixel_colors_nr'].cpu()) < 1e-5
         assert FX.max_abs(out2['density_nr'].cpu(), flat['density_nr'].cpu()) < 1e-4
 
 
