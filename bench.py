@@ -140,6 +140,27 @@ def cpu_baseline(case, budget_s=15.0):
                        f'({dt:.1f} s, torch CPU fp32)'), coords, out
 
 
+def eager_gpu_baseline(case, dev, ray_batch_num=2048, frames=1):
+    """'Reference single-GPU PyTorch rays/s': the oracle (an op-for-op port of the reference's eager PyTorch
+    path) moved to the GPU and run the way the reference runs it — the ray_batch_num loop of
+    network/renderer.py:656-683.  Reported next to the CPU baseline; never the product path."""
+    from oracle import render_oracle as O
+    fr = {k: v.to(dev) for k, v in case['frame'].items()}
+    w = {k: v.to(dev) for k, v in case['weights'].items()}
+    H, W = fr['imgs'].shape[-2:]
+    with torch.no_grad():
+        O.render_frame(w, {**fr, 'imgs': fr['imgs'][:, :, :32], 'img_feats': fr['img_feats'][:, :, :8], 'ray_feats': fr['ray_feats'][:, :, :4]},
+                       case['cfg'], ray_batch_num)                                  # warm-up on a 32-row strip
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            out = O.render_frame(w, fr, case['cfg'], ray_batch_num)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dict(value=H * W * frames / dt, unit='rays/s', ray_batch_num=ray_batch_num,
+                kind='port of the reference eager path on torch-ROCm, same GPU', ms_per_frame=dt / frames * 1e3), out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -151,6 +172,7 @@ def main():
     ap.add_argument('--samples', type=int, default=64)
     ap.add_argument('--fine', action='store_true', help='coarse + importance-sampled fine pass (BASELINE config 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager-baseline', action='store_true', help='also time the eager PyTorch-ROCm port on this GPU')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -239,6 +261,15 @@ def main():
         key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'
         mse = float(((img[idx].cpu().double() - cout[key].double()) ** 2).mean())
         res['psnr_vs_oracle_db'] = 10 * math.log10(1.0 / max(mse, 1e-20))
+    if rank == 0 and world == 1 and args.eager_baseline:
+        eg, eout = eager_gpu_baseline(case, dev, 2048)
+        eg4, _ = eager_gpu_baseline(case, dev, 4096)
+        key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'
+        mse = float(((img.double() - eout[key].double()) ** 2).mean())
+        eg['psnr_hip_vs_eager_db'] = 10 * math.log10(1.0 / max(mse, 1e-20))
+        eg['value_ray_batch_4096'] = eg4['value']
+        eg['speedup_hip_over_eager'] = rays_per_s / max(eg['value'], eg4['value'])
+        res['torch_eager_gpu_baseline'] = eg
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -28,18 +28,18 @@ def erp_ray_directions(H, W):
     return d / torch.norm(d, p=2, dim=-1, keepdim=True)
 
 
-def sample_coarse_depth(min_depth, max_depth, rn, dn, use_disp=True):
+def sample_coarse_depth(min_depth, max_depth, rn, dn, use_disp=True, device='cpu'):
     """Deterministic (eval) stratified depths, [rn,dn]. network/render_ops.py:292-339."""
-    near = torch.tensor(float(min_depth))
-    far = torch.tensor(float(max_depth))
-    val = torch.arange(1, dn - 1, dtype=torch.float32)
+    near = torch.tensor(float(min_depth), device=device)
+    far = torch.tensor(float(max_depth), device=device)
+    val = torch.arange(1, dn - 1, dtype=torch.float32, device=device)
     if use_disp:
         interval = (1 / far - 1 / near) / (dn - 1)
-        ticks = torch.cat([torch.zeros(1), interval * val, (1 / far - 1 / near).view(1)])
+        ticks = torch.cat([torch.zeros(1, device=device), interval * val, (1 / far - 1 / near).view(1)])
         depth = 1 / (1 / near + ticks)
     else:
         interval = (far - near) / (dn - 1)
-        ticks = torch.cat([torch.zeros(1), interval * val, (far - near).view(1)])
+        ticks = torch.cat([torch.zeros(1, device=device), interval * val, (far - near).view(1)])
         depth = near + ticks
     return depth.view(1, dn).expand(rn, dn).contiguous()
 
@@ -62,7 +62,7 @@ def ray_points(coords, c2w, depth, H, W):
     """World sample points and reversed unit view directions.
     coords [rn,2] (x,y), c2w [3,4], depth [rn,dn] -> pts [rn,dn,3], que_dir [rn,3].
     render_ops.py:76-106, ray_utils.py:53-71."""
-    dirs = erp_ray_directions(H, W)
+    dirs = erp_ray_directions(H, W).to(coords.device)
     d_cam = dirs[coords[:, 1].long(), coords[:, 0].long()]            # [rn,3]
     d = torch.matmul(c2w[:3, :3].view(1, 3, 3), d_cam.unsqueeze(-1)).squeeze(-1)
     o = c2w[:, 3].view(1, 3)
@@ -242,7 +242,7 @@ def aggregate(w, pre, rgb, img_feats, ray_feats, hit_prob, vis, ddiff, want_debu
 
     dfeat = F.elu(_lin(w, ag + '.ray_dir_fc.2', F.elu(_lin(w, ag + '.ray_dir_fc.0', rdiff))))
     rgb_feat = rgb_feat + dfeat
-    wgt = torch.full((rn, dn, rfn, 1), 1.0) / (rfn + 1e-8)
+    wgt = torch.full((rn, dn, rfn, 1), 1.0, device=rgb.device) / (rfn + 1e-8)
     nf = _lin(w, ag + '.neuray_fc.2', F.elu(_lin(w, ag + '.neuray_fc.0', neuray)))
     wgt0 = torch.sigmoid(nf) * wgt
     mean0, var0 = _wmean_var(rgb_feat, wgt0)
@@ -260,7 +260,7 @@ def aggregate(w, pre, rgb, img_feats, ray_feats, hit_prob, vis, ddiff, want_debu
     g = torch.cat([mean.squeeze(2), var.squeeze(2), wgt2.mean(dim=2)], -1)
     g = F.elu(_lin(w, ag + '.geometry_fc.2', F.elu(_lin(w, ag + '.geometry_fc.0', g))))
     dbg['geo'] = g
-    g = g + pos_encoding(dn).unsqueeze(0)
+    g = g + pos_encoding(dn).unsqueeze(0).to(g.device)
     g = ray_attention(w, ag + '.ray_attention', g)
     dbg['attn'] = g
     sigma = F.relu(_lin(w, ag + '.out_geometry_fc.2', F.elu(_lin(w, ag + '.out_geometry_fc.0', g))))
@@ -302,7 +302,7 @@ def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True):
     pdf = hp / torch.sum(hp, -1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)         # dn+1
     interval = 1 / fdn
-    u = (0.5 * interval + torch.arange(fdn) * interval).expand(*cdf.shape[:-1], fdn).contiguous()
+    u = (0.5 * interval + torch.arange(fdn) * interval).to(cdf.device).expand(*cdf.shape[:-1], fdn).contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.clamp(inds - 1, min=0)
     above = torch.clamp(inds, max=cdf.shape[-1] - 1)
@@ -374,7 +374,7 @@ def render_rays(weights, frame, coords, cfg, want_debug=False):
     leading qn=1 axis dropped."""
     rn = coords.shape[0]
     dn = cfg['depth_sample_num']
-    depth = sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn, cfg.get('use_disp', True))
+    depth = sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn, cfg.get('use_disp', True), coords.device)
     ccfg = {'use_vis': cfg.get('dist_decoder_cfg', {}).get('use_vis', True)}
     out = render_pass(weights, 'dist_decoder', 'agg_net', frame, coords, depth, ccfg, want_debug)
     out['depth'] = depth
@@ -403,7 +403,8 @@ def render_frame(weights, frame, cfg, ray_batch_num=None):
     """Whole panorama in ray batches; the result must not depend on the batch size.
     renderer.py:635-686 (without the per-frame 2-D encoders)."""
     H, W = frame['imgs'].shape[-2:]
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32),
+    dev = frame['imgs'].device
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev), torch.arange(W, dtype=torch.float32, device=dev),
                             indexing='ij')
     coords = torch.stack([xs, ys], -1).reshape(-1, 2)
     rb = ray_batch_num or cfg.get('ray_batch_num', 2048)

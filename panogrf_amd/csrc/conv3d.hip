@@ -10,6 +10,7 @@
 // (accumulator registers), so a lane writes 4 consecutive channels per 16-byte store.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "pgrf_internal.h"
@@ -83,45 +84,103 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
     for (int t = 0; t < NT; ++t) acc[t][m] = bv;
   }
 
+  const bool full_chunks = (a.Cin & 31) == 0;
+  // taps whose whole 32-voxel x NT footprint lies in the zero padding are skipped (wave-uniform bit mask)
+  unsigned tapmask = 0;
   for (int tap = 0; tap < 27; ++tap) {
-    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-    long long ioff[NT];
-    bool iok[NT];
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1;
     bool any = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int zi = vz[t] * a.stride + dz, yi = vy[t] * a.stride + dy;
+      any = any || (vok[t] && zi >= 0 && zi < a.D && yi >= 0 && yi < a.H);
+    }
+    if (__any(any)) tapmask |= 1u << tap;
+  }
+
+  // Operand buffers of one (tap, 32-channel chunk) step.  Two of them ping-pong: the loads of step i+1 are
+  // issued before the MFMAs of step i, so the L2/L1 round trip hides under 16*MT*NT MFMAs (the kernel runs at
+  // 1-2 waves per SIMD, there is nobody else to hide it).
+  struct Step {
+    float4 bv[NT][4];
+    float4 av[MT][4];
+    bool ok[NT];
+    bool need_mask;
+    int c0;
+  };
+  auto issue = [&](Step& st, int tap, int ch) {
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    bool all = true;
+    st.c0 = ch * 32 + kk * 16;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int zi = vz[t] * a.stride + dz, yi = vy[t] * a.stride + dy;
       int xi = vx[t] * a.stride + dx;
       xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);          // circular along W
-      iok[t] = vok[t] && zi >= 0 && zi < a.D && yi >= 0 && yi < a.H;   // zeros along D, H
-      ioff[t] = ((((long long)vb[t] * a.D + zi) * a.H + yi) * a.W + xi) * a.in_cs + a.in_coff + kk * 16;
-      any = any || iok[t];
-    }
-    if (!__any(any)) continue;                                         // whole wave outside: skip the tap
-    for (int ch = 0; ch < a.chunks; ++ch) {
-      float bop[NT][16];
+      st.ok[t] = vok[t] && zi >= 0 && zi < a.D && yi >= 0 && yi < a.H;  // zeros along D, H
+      // always-valid (clamped) address: loads are unconditional and issue back to back; padding and ragged
+      // tiles are applied by a select at use
+      const int zc = min(max(zi, 0), a.D - 1), yc = min(max(yi, 0), a.H - 1);
+      const float* ip = a.in + ((((long long)vb[t] * a.D + zc) * a.H + yc) * a.W + xi) * a.in_cs + a.in_coff;
+      all = all && st.ok[t];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float* ip = a.in + ioff[t] + ch * 32;
-        const int c0 = ch * 32 + kk * 16;
+      for (int q = 0; q < 4; ++q) {
+        const int cq = (st.c0 + q * 4 + 4 <= a.Cin) ? st.c0 + q * 4 : 0;
+        st.bv[t][q] = *reinterpret_cast<const float4*>(ip + cq);
+      }
+    }
+    st.need_mask = !__all(all) || !full_chunks;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4* ap = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, tap, ch, a.chunks, 0, 0)) + lane;
+      st.av[m][0] = ap[0]; st.av[m][1] = ap[64]; st.av[m][2] = ap[128]; st.av[m][3] = ap[192];
+    }
+  };
+  auto compute = [&](Step& st) {
+    if (st.need_mask) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (iok[t] && c0 + q * 4 + 4 <= a.Cin) v = *reinterpret_cast<const float4*>(ip + q * 4);
-          bop[t][q * 4 + 0] = v.x; bop[t][q * 4 + 1] = v.y; bop[t][q * 4 + 2] = v.z; bop[t][q * 4 + 3] = v.w;
+          const bool ok = st.ok[t] && (st.c0 + q * 4 + 4 <= a.Cin);
+          st.bv[t][q].x = ok ? st.bv[t][q].x : 0.f; st.bv[t][q].y = ok ? st.bv[t][q].y : 0.f;
+          st.bv[t][q].z = ok ? st.bv[t][q].z : 0.f; st.bv[t][q].w = ok ? st.bv[t][q].w : 0.f;
         }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float av[4] = {st.av[m][s4].x, st.av[m][s4].y, st.av[m][s4].z, st.av[m][s4].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float4 bq = st.bv[t][s4];
+            const float bs = (j == 0) ? bq.x : (j == 1) ? bq.y : (j == 2) ? bq.z : bq.w;
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bs, acc[t][m], 0, 0, 0);
+          }
       }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float4* ap = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, tap, ch, a.chunks, 0, 0)) + lane;
-        const float4 a0 = ap[0], a1 = ap[64], a2 = ap[128], a3 = ap[192];
-        const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bop[t][s], acc[t][m], 0, 0, 0);
-      }
+    }
+  };
+  // wave-uniform iterator over (valid tap, chunk)
+  unsigned rem = tapmask;
+  int tap = rem ? __ffs(rem) - 1 : -1, ch = 0;
+  auto advance = [&]() {
+    if (++ch == a.chunks) { ch = 0; rem &= rem - 1; tap = rem ? __ffs(rem) - 1 : -1; }
+  };
+  Step P, Q;
+  if (tap >= 0) {
+    issue(P, tap, ch); advance();
+    while (true) {
+      const bool hasQ = tap >= 0;
+      if (hasQ) { issue(Q, tap, ch); advance(); }
+      compute(P);
+      if (!hasQ) break;
+      const bool hasP = tap >= 0;
+      if (hasP) { issue(P, tap, ch); advance(); }
+      compute(Q);
+      if (!hasP) break;
     }
   }
   // epilogue: LeakyReLU, optional residual, 16-byte channel stores
@@ -324,7 +383,8 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   // tile shape per wave: more voxel tiles per wave when the layer is large enough to still fill 256 CUs
   const int mt = (a.cot_total % 2 == 0) ? 2 : 1;
   const long long waves_nt4 = (tiles + 3) / 4 * (a.cot_total / mt);
-  const int nt = waves_nt4 >= 2048 ? 4 : ((tiles + 1) / 2 * (a.cot_total / mt) >= 2048 ? 2 : 1);
+  int nt = waves_nt4 >= 2048 ? 4 : ((tiles + 1) / 2 * (a.cot_total / mt) >= 2048 ? 2 : 1);
+  if (const char* e = getenv("PGRF_CONV_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nt = v; }   // tuning knob
   dim3 grid((unsigned)((tiles + 4 * nt - 1) / (4 * nt)), (unsigned)(a.cot_total / mt));
 #define PGRF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv3d_wrap_kernel<MT_, NT_>), grid, dim3(256), 0, (hipStream_t)stream, a)
   if (mt == 2 && nt == 4) PGRF_LAUNCH(2, 4);
