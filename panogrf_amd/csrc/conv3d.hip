@@ -46,15 +46,19 @@ __host__ __device__ inline size_t wpk_index(int cot, int tap, int chunk, int chu
   return ((((size_t)(cot * 27 + tap) * chunks + chunk) * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3);
 }
 
-template <int MT, int NT>
+// SPLIT: the 4 waves of the workgroup share ONE output tile and split the (tap, chunk) reduction 4 ways
+// (partials combined through LDS) — for the deep, low-resolution layers whose plain decomposition yields
+// fewer waves than the chip has SIMDs.
+template <int MT, int NT, bool SPLIT>
 __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[SPLIT ? 3 * MT * NT * 16 * 64 : 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 31, kk = lane >> 5;
   const long long nvox = (long long)a.B * a.Do * a.Ho * a.Wo;
-  const long long tile0 = ((long long)blockIdx.x * 4 + wave) * NT;
+  const long long tile0 = SPLIT ? (long long)blockIdx.x * NT : ((long long)blockIdx.x * 4 + wave) * NT;
   const int cot0 = blockIdx.y * MT;
-  if (tile0 * 32 >= nvox) return;
+  if (!SPLIT && tile0 * 32 >= nvox) return;
 
   // per-tile voxel decode
   int vb[NT], vz[NT], vy[NT], vx[NT];
@@ -72,7 +76,7 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 bv;
-    if (a.bias) {
+    if (a.bias && (!SPLIT || wave == 0)) {
       const float4* bp = reinterpret_cast<const float4*>(a.bias + (cot0 + m) * 32 + kk * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
@@ -165,10 +169,16 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
   };
   // wave-uniform iterator over (valid tap, chunk)
   unsigned rem = tapmask;
-  int tap = rem ? __ffs(rem) - 1 : -1, ch = 0;
-  auto advance = [&]() {
+  int tap = rem ? __ffs(rem) - 1 : -1, ch = 0, sidx = 0;
+  auto next1 = [&]() {
     if (++ch == a.chunks) { ch = 0; rem &= rem - 1; tap = rem ? __ffs(rem) - 1 : -1; }
+    ++sidx;
   };
+  auto advance = [&]() {
+    next1();
+    if (SPLIT) while (tap >= 0 && (sidx & 3) != wave) next1();       // this wave's quarter of the steps
+  };
+  if (SPLIT) while (tap >= 0 && (sidx & 3) != wave) next1();
   Step P, Q;
   if (tap >= 0) {
     issue(P, tap, ch); advance();
@@ -182,6 +192,31 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
       compute(Q);
       if (!hasP) break;
     }
+  }
+  if (SPLIT) {
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(&red[((((wave - 1) * NT + t) * MT + m) * 4 + q) * 256 + lane * 4]) =
+                make_float4(acc[t][m][q * 4], acc[t][m][q * 4 + 1], acc[t][m][q * 4 + 2], acc[t][m][q * 4 + 3]);
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(&red[(((w * NT + t) * MT + m) * 4 + q) * 256 + lane * 4]);
+            acc[t][m][q * 4] += v.x; acc[t][m][q * 4 + 1] += v.y; acc[t][m][q * 4 + 2] += v.z; acc[t][m][q * 4 + 3] += v.w;
+          }
   }
   // epilogue: LeakyReLU, optional residual, 16-byte channel stores
 #pragma unroll
@@ -385,8 +420,18 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   const long long waves_nt4 = (tiles + 3) / 4 * (a.cot_total / mt);
   int nt = waves_nt4 >= 2048 ? 4 : ((tiles + 1) / 2 * (a.cot_total / mt) >= 2048 ? 2 : 1);
   if (const char* e = getenv("PGRF_CONV_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nt = v; }   // tuning knob
+  const long long waves_plain = (tiles + nt - 1) / nt * (a.cot_total / mt);
+  bool split = (nt == 1) && waves_plain < 1536 && (long long)27 * a.chunks >= 16;
+  if (const char* e = getenv("PGRF_CONV_SPLIT")) split = (nt == 1) && atoi(e) != 0;                       // tuning knob
+  if (split) {
+    dim3 sgrid((unsigned)tiles, (unsigned)(a.cot_total / mt));
+    if (mt == 2) hipLaunchKernelGGL((conv3d_wrap_kernel<2, 1, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv3d_wrap_kernel<1, 1, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
+    PGRF_CHECK_LAUNCH("conv3d_wrap(split)");
+    return PGRF_OK;
+  }
   dim3 grid((unsigned)((tiles + 4 * nt - 1) / (4 * nt)), (unsigned)(a.cot_total / mt));
-#define PGRF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv3d_wrap_kernel<MT_, NT_>), grid, dim3(256), 0, (hipStream_t)stream, a)
+#define PGRF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv3d_wrap_kernel<MT_, NT_, false>), grid, dim3(256), 0, (hipStream_t)stream, a)
   if (mt == 2 && nt == 4) PGRF_LAUNCH(2, 4);
   else if (mt == 2 && nt == 2) PGRF_LAUNCH(2, 2);
   else if (mt == 2) PGRF_LAUNCH(2, 1);

@@ -517,7 +517,17 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   const int pl = lane & 31;
   const int ray_local = wave / KT;
   const int kt = wave % KT;
-  const int ray_raw = blockIdx.x * RPW + ray_local;
+  // XCD-aware block -> ray mapping: consecutive workgroups are dispatched round-robin over the 8 XCDs, so give
+  // every XCD one CONTIGUOUS span of rays (a band of image rows): its private L2 then holds one band of the
+  // source maps instead of all of them.  Bijective for any grid size; speed only, never correctness.
+  int wg = blockIdx.x;
+#ifndef PGRF_NO_XCD_REMAP
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+#endif
+  const int ray_raw = wg * RPW + ray_local;
   const bool ray_ok = ray_raw < p.rn;
   const int ray = ray_ok ? ray_raw : p.rn - 1;
   const int si = kt * 32 + pl;                       // sample index on the ray
