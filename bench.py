@@ -119,7 +119,14 @@ def cpu_baseline(case, budget_s=15.0):
     """The CPU oracle (a port of the reference algorithm) timed on a bounded sample of the workload."""
     from oracle import render_oracle as O
     H, W = case['frame']['imgs'].shape[-2:]
-    cores = os.cpu_count() or 1
+    # host cores actually usable: the scheduler affinity mask, capped — GPU boxes often expose 256 logical
+    # CPUs behind a much smaller cgroup quota, where 256 OpenMP threads are far slower than 16
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get('PGRF_CPU_BASELINE_THREADS', '16'))))
+    prev_threads = torch.get_num_threads()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(7)
 
@@ -131,11 +138,12 @@ def cpu_baseline(case, budget_s=15.0):
             out = O.render_rays(case['weights'], case['frame'], coords, case['cfg'])
         return time.perf_counter() - t0, coords, out
 
-    t_probe, _, _ = run(256)
-    n = int(max(256, min(16384, 256 * budget_s / max(t_probe, 1e-3))))
-    n = n // 256 * 256
+    t_probe, _, _ = run(64)
+    n = int(max(64, min(65536, 64 * budget_s / max(t_probe, 1e-3))))
+    n = n // 64 * 64
     dt, coords, out = run(n)
-    return dict(value=n / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
+    torch.set_num_threads(prev_threads)
+    return dict(value=n / dt, unit='rays/s', cores=cores, kind='port',
                 sample=f'{n} random rays of the same frame through oracle.render_oracle.render_rays '
                        f'({dt:.1f} s, torch CPU fp32)'), coords, out
 
@@ -253,14 +261,6 @@ def main():
                      'kernel': 'render_pass_kernel', 'kernel_ms': k_ms / launches,
                      'flop_per_ray': flop_per_ray(V, dn, 1), 'rays_per_launch': rn},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, ccoords, cout = cpu_baseline(case)
-        res['cpu_baseline'] = base
-        # PSNR of the HIP image against the oracle on the sampled rays
-        idx = (ccoords[:, 1].long() * W + ccoords[:, 0].long()).to(dev)
-        key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'
-        mse = float(((img[idx].cpu().double() - cout[key].double()) ** 2).mean())
-        res['psnr_vs_oracle_db'] = 10 * math.log10(1.0 / max(mse, 1e-20))
     if rank == 0 and world == 1 and args.eager_baseline:
         eg, eout = eager_gpu_baseline(case, dev, 2048)
         eg4, _ = eager_gpu_baseline(case, dev, 4096)
@@ -270,6 +270,14 @@ def main():
         eg['value_ray_batch_4096'] = eg4['value']
         eg['speedup_hip_over_eager'] = rays_per_s / max(eg['value'], eg4['value'])
         res['torch_eager_gpu_baseline'] = eg
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, ccoords, cout = cpu_baseline(case)
+        res['cpu_baseline'] = base
+        # PSNR of the HIP image against the oracle on the sampled rays
+        idx = (ccoords[:, 1].long() * W + ccoords[:, 0].long()).to(dev)
+        key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'
+        mse = float(((img[idx].cpu().double() - cout[key].double()) ** 2).mean())
+        res['psnr_vs_oracle_db'] = 10 * math.log10(1.0 / max(mse, 1e-20))
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -191,6 +191,14 @@ int pgrf_pack_conv3d(const float* w_host, const float* bias_host, int Cout, int 
 int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                      const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
                      const float* residual, int res_cs, int res_coff, void* stream);
+/* Fast path of the same convolution for Cout == 1 and wide inputs (UNet2's last block, 128 -> 1): a pointwise MFMA
+ * pass projects every voxel onto the 27 tap vectors (y[B,D,H,W,32], caller-owned scratch), a 27-tap gather finishes
+ * (bias, LeakyReLU, residual).  `packed` is the block made by pgrf_pack_conv3d(Cout=1). */
+int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, const float* packed, float* y, int B,
+                              int D, int H, int W, void* stream);
+int pgrf_conv3d_cout1_gather(const float* y, const float* packed, int Cin, int has_bias, float* out, int out_cs, int out_coff,
+                             int B, int D, int H, int W, float lrelu_slope, const float* residual, int res_cs, int res_coff,
+                             void* stream);
 /* nn.AvgPool3d(2) (common_blocks.py:380) and F.interpolate(scale_factor=2, mode="trilinear",
  * align_corners=False) (common_blocks.py:221-236, cost_reg.py:85-88). */
 int pgrf_avgpool3d_2(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff, int B, int D, int H,

@@ -65,6 +65,9 @@ SYMBOLS = {
     "pgrf_pack_conv3d": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_wrap": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P]),
+    "pgrf_conv3d_cout1_project": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "pgrf_conv3d_cout1_gather": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_float, _P, C.c_int, C.c_int, _P]),
     "pgrf_avgpool3d_2": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_upsample3d_2": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_render_workspace_bytes": (C.c_size_t, [C.POINTER(PgrfRenderCfg), C.c_int]),

@@ -45,6 +45,16 @@ class _Vol:
 
 
 def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
+    if pc.cout == 1 and pc.cin >= 64 and pc.cin % 4 == 0 and stride == 1:
+        # wide-input single-channel conv: pointwise MFMA projection onto the 27 tap vectors + 27-tap gather
+        y = torch.empty(x.B, x.D, x.H, x.W, 32, dtype=torch.float32, device=x.buf.device)
+        lib.check(lib.pgrf_conv3d_cout1_project(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(pc.dev), _ptr(y), x.B, x.D, x.H, x.W, _stream()))
+        lib.check(lib.pgrf_conv3d_cout1_gather(_ptr(y), _ptr(pc.dev), pc.cin, int(pc.has_bias), _ptr(out.buf), out.cs, out.coff,
+                                               x.B, x.D, x.H, x.W, float(slope),
+                                               _ptr(residual.buf) if residual is not None else None,
+                                               residual.cs if residual is not None else 0,
+                                               residual.coff if residual is not None else 0, _stream()))
+        return out
     lib.check(lib.pgrf_conv3d_wrap(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
                                    _ptr(pc.dev), int(pc.has_bias), x.B, x.D, x.H, x.W, stride, float(slope),
                                    _ptr(residual.buf) if residual is not None else None,

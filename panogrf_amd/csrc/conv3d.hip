@@ -39,11 +39,12 @@ struct ConvArgs {
   int cot_total;          // ceil(Cout/32)
   const float* residual;  // optional tensor added AFTER the activation (CostRegNet skip adds), same slicing as out
   int res_cs, res_coff;
+  int wtaps;              // 27, or 1 = pointwise (1x1x1) product with the centre tap only
 };
 
 // packed weight index helpers (shared with the host packer below)
-__host__ __device__ inline size_t wpk_index(int cot, int tap, int chunk, int chunks, int s, int lane) {
-  return ((((size_t)(cot * 27 + tap) * chunks + chunk) * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3);
+__host__ __device__ inline size_t wpk_index(int cot, int tap, int chunk, int chunks, int s, int lane, int ntaps = 27) {
+  return ((((size_t)(cot * ntaps + tap) * chunks + chunk) * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3);
 }
 
 // SPLIT: the 4 waves of the workgroup share ONE output tile and split the (tap, chunk) reduction 4 ways
@@ -101,6 +102,7 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
     }
     if (__any(any)) tapmask |= 1u << tap;
   }
+  if (a.wtaps == 1) tapmask &= 1u << 13;                                // pointwise: centre tap only
 
   // Operand buffers of one (tap, 32-channel chunk) step.  Two of them ping-pong: the loads of step i+1 are
   // issued before the MFMAs of step i, so the L2/L1 round trip hides under 16*MT*NT MFMAs (the kernel runs at
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
     st.need_mask = !__all(all) || !full_chunks;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const float4* ap = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, tap, ch, a.chunks, 0, 0)) + lane;
+      const float4* ap = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, a.wtaps == 1 ? 0 : tap, ch, a.chunks, 0, 0, a.wtaps)) + lane;
       st.av[m][0] = ap[0]; st.av[m][1] = ap[64]; st.av[m][2] = ap[128]; st.av[m][3] = ap[192];
     }
   };
@@ -282,6 +284,32 @@ __global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, con
   }
 }
 
+// Second half of the Cout == 1 convolution: out[p] = act(bias + sum_tap y[p + tap][tap]) where y[q][tap] =
+// <w[:, tap], x[q, :]> was produced by the pointwise MFMA pass (27 of 32 columns used).
+__global__ void __launch_bounds__(256) cout1_gather_kernel(const float* __restrict__ y, const float* __restrict__ bias0, float* __restrict__ out,
+                                                           int out_cs, int out_coff, int B, int D, int H, int W, float slope,
+                                                           const float* __restrict__ residual, int res_cs, int res_coff) {
+  const long long nvox = (long long)B * D * H * W;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+    long long t = v;
+    const int x = (int)(t % W); t /= W;
+    const int yy = (int)(t % H); t /= H;
+    const int z = (int)(t % D); const int b = (int)(t / D);
+    float s = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int zi = z + tap / 9 - 1, yi = yy + (tap / 3) % 3 - 1;
+      int xi = x + tap % 3 - 1;
+      xi = xi < 0 ? xi + W : (xi >= W ? xi - W : xi);
+      if (zi >= 0 && zi < D && yi >= 0 && yi < H) s += y[((((long long)b * D + zi) * H + yi) * W + xi) * 32 + tap];
+    }
+    if (bias0) s += bias0[0];
+    s = s > 0.f ? s : s * slope;
+    if (residual) s += residual[v * res_cs + res_coff];
+    out[v * out_cs + out_coff] = s;
+  }
+}
+
 // AvgPool3d(2) on channel-last data; thread per (output voxel, 4-channel group)
 __global__ void avgpool3d_kernel(const float* __restrict__ in, int in_cs, int in_coff, float* __restrict__ out, int out_cs,
                                  int out_coff, int B, int D, int H, int W, int C) {
@@ -353,7 +381,9 @@ extern "C" {
 
 size_t pgrf_conv3d_packed_floats(int Cout, int Cin) {
   const size_t cot = (Cout + 31) / 32, chunks = (Cin + 31) / 32;
-  return cot * 27 * chunks * 1024 + cot * 32 + (size_t)27 * Cin + 4;
+  size_t n = cot * 27 * chunks * 1024 + cot * 32 + (((size_t)27 * Cin + 1 + 3) & ~(size_t)3);
+  if (Cout == 1) n += chunks * 1024;          // pointwise block: 27 tap-vectors as the rows of one 32 x Cin matrix
+  return n;
 }
 
 // layout of the packed block: [A operands | bias in accumulator order | linear copy [27][Cin] of output channel 0 | bias0]
@@ -382,6 +412,15 @@ int pgrf_pack_conv3d(const float* w_host, const float* bias_host, int Cout, int 
   for (int tap = 0; tap < 27; ++tap)
     for (int ci = 0; ci < Cin; ++ci) L[tap * Cin + ci] = w_host[((size_t)0 * Cin + ci) * 27 + tap];
   L[27 * Cin] = bias_host ? bias_host[0] : 0.f;
+  if (Cout == 1) {
+    float* PW = L + (((size_t)27 * Cin + 1 + 3) & ~(size_t)3);
+    for (int ch = 0; ch < chunks; ++ch)
+      for (int s = 0; s < 16; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int tap = lane & 31, ci = 32 * ch + 16 * (lane >> 5) + s;
+          if (tap < 27 && ci < Cin) PW[wpk_index(0, 0, ch, chunks, s, lane, 1)] = w_host[(size_t)ci * 27 + tap];
+        }
+  }
   return PGRF_OK;
 }
 
@@ -400,7 +439,7 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
   a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
   a.chunks = (Cin + 31) / 32; a.cot_total = (Cout + 31) / 32;
-  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27;
   const size_t a_floats = (size_t)a.cot_total * 27 * a.chunks * 1024;
   a.wpk = packed;
   a.bias = has_bias ? packed + a_floats : nullptr;
@@ -440,6 +479,42 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   else PGRF_LAUNCH(1, 1);
 #undef PGRF_LAUNCH
   PGRF_CHECK_LAUNCH("conv3d_wrap");
+  return PGRF_OK;
+}
+
+// Cout == 1 convolution in two passes (fast path for wide inputs): y[B,D,H,W,32] = per-voxel projections onto the 27
+// tap vectors (MFMA, pointwise), then a 27-tap gather.  y is caller-owned scratch of B*D*H*W*32 floats.
+int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, const float* packed, float* y, int B,
+                              int D, int H, int W, void* stream) {
+  if (!in || !packed || !y) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_cout1_project: null pointer");
+  if ((Cin & 3) || (in_cs & 3) || (in_coff & 3)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_cout1_project: channels/strides must be multiples of 4");
+  ConvArgs a;
+  a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = y; a.out_cs = 32; a.out_coff = 0; a.Cout = 32;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.stride = 1; a.slope = 1.f; a.Do = D; a.Ho = H; a.Wo = W;
+  a.chunks = (Cin + 31) / 32; a.cot_total = 1; a.residual = nullptr; a.res_cs = 0; a.res_coff = 0; a.wtaps = 1;
+  const size_t a_floats = (size_t)27 * a.chunks * 1024;
+  a.wpk = packed + a_floats + 32 + (((size_t)27 * Cin + 1 + 3) & ~(size_t)3);
+  a.bias = nullptr;
+  const long long tiles = ((long long)B * D * H * W + 31) / 32;
+  const int nt = tiles >= 8192 ? 4 : (tiles >= 4096 ? 2 : 1);
+  dim3 grid((unsigned)((tiles + 4 * nt - 1) / (4 * nt)), 1);
+  if (nt == 4) hipLaunchKernelGGL((conv3d_wrap_kernel<1, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (nt == 2) hipLaunchKernelGGL((conv3d_wrap_kernel<1, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((conv3d_wrap_kernel<1, 1, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  PGRF_CHECK_LAUNCH("conv3d_cout1_project");
+  return PGRF_OK;
+}
+
+int pgrf_conv3d_cout1_gather(const float* y, const float* packed, int Cin, int has_bias, float* out, int out_cs, int out_coff,
+                             int B, int D, int H, int W, float lrelu_slope, const float* residual, int res_cs, int res_coff,
+                             void* stream) {
+  if (!y || !packed || !out) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_cout1_gather: null pointer");
+  const int chunks = (Cin + 31) / 32;
+  const float* bias0 = has_bias ? packed + (size_t)27 * chunks * 1024 + 32 + (size_t)27 * Cin : nullptr;
+  const long long nvox = (long long)B * D * H * W;
+  hipLaunchKernelGGL(cout1_gather_kernel, dim3(grid_for(nvox)), dim3(256), 0, (hipStream_t)stream, y, bias0, out, out_cs, out_coff, B, D,
+                     H, W, lrelu_slope, residual, res_cs, res_coff);
+  PGRF_CHECK_LAUNCH("conv3d_cout1_gather");
   return PGRF_OK;
 }
 

@@ -145,3 +145,62 @@ def test_full_size_properties_and_oracle_strip():
     assert e_px < 5e-5, e_px
     assert e_den < 5e-4, e_den
     assert FX.psnr(px[strip], ref['pixel_colors_nr']) > 90.0
+
+
+@pytest.mark.parametrize('rn', [1, 3, 130])
+def test_ragged_ray_counts_vs_oracle(rn):
+    """Ray counts that do not fill a workgroup (4 rays at dn=32, 2 at dn=64) and odd sizes."""
+    from oracle import render_oracle as O
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(32, 64, 2, 64, seed=4, fine=True)
+    fr = _frame(E, case['frame'])
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    g = torch.Generator().manual_seed(rn)
+    idx = torch.randperm(32 * 64, generator=g)[:rn]
+    coords = torch.stack([(idx % 64).float(), (idx // 64).float()], -1)
+    out = rr.render_rays(fr, coords)
+    ref = O.render_rays(case['weights'], case['frame'], coords, case['cfg'])
+    assert out['pixel_colors_nr'].shape == (rn, 3)
+    assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 2e-5
+    assert FX.max_abs(out['pixel_colors_nr_fine'].cpu(), ref['pixel_colors_nr_fine']) < 2e-3
+    assert FX.max_abs(out['render_depth'].cpu(), ref['render_depth']) < 1e-4
+
+
+def test_empty_ray_batch_is_a_noop():
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(32, 64, 2, 32, seed=4)
+    fr = _frame(E, case['frame'])
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    out = rr.render_rays(fr, torch.zeros(0, 2))
+    assert out['pixel_colors_nr'].shape == (0, 3)
+
+
+def test_fine_depth_use_all_vs_oracle():
+    """cfg fine_depth_use_all: the fine pass runs on the sorted union (2x samples, 128-wide attention at dn=64)."""
+    from oracle import render_oracle as O
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(32, 64, 2, 64, seed=6, fine=True)
+    case['cfg']['fine_depth_use_all'] = True
+    fr = _frame(E, case['frame'])
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    idx = torch.arange(0, 32 * 64, 11)
+    coords = torch.stack([(idx % 64).float(), (idx // 64).float()], -1)
+    out = rr.render_rays(fr, coords)
+    ref = O.render_rays(case['weights'], case['frame'], coords, case['cfg'])
+    assert out['density_nr_fine'].shape[1] == 128
+    assert FX.max_abs(out['depth_fine'].cpu(), ref['depth_fine']) < 2e-3
+    assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), ref['pixel_colors_nr_fine']) > 60
+
+
+def test_unsupported_sample_count_fails_loudly():
+    from panogrf_amd import PgrfError
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(32, 64, 2, 48, seed=4)
+    fr = _frame(E, case['frame'])
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    with pytest.raises(PgrfError):
+        rr.render_rays(fr, torch.zeros(4, 2))

@@ -1,0 +1,42 @@
+#!/bin/bash
+# Collect the round's rocprof evidence on the GPU box:  bash tools/profile_round.sh r01
+# outputs under gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/
+TAG=$1
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. plain bench line (incl. cpu + eager baselines)
+python3 $R/bench.py --eager-baseline > $OUT/bench.json 2> $OUT/bench.err
+tail -c 2000 $OUT/bench.json
+# 2. kernel trace + stats of the bench command
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+cp $(find $OUT/bench_trace -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+# 3. PMC passes (counters only + kernel trace)
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+done
+python3 - > $OUT/pmc_summary.txt <<PY
+import csv, glob, collections
+print('# rocprofv3 --pmc passes on: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline  (per-launch averages)')
+for d in sorted(glob.glob('$OUT/pmc*/')):
+    for f in glob.glob(d + '**/*counter_collection.csv', recursive=True):
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for row in csv.DictReader(open(f)):
+            if 'render_pass' in row['Kernel_Name']:
+                agg[row['Counter_Name']][0] += float(row['Counter_Value']); agg[row['Counter_Name']][1] += 1
+        for cn, (v, n) in sorted(agg.items()):
+            print(f'render_pass_kernel<2,2,false>  {cn:28s} {v/n:.6e}  (launches={n})')
+PY
+cat $OUT/pmc_summary.txt
+# 4. cost volume + regularisers
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cv_trace -- python3 $R/tools/time_cost_volume.py 128 256 > $OUT/cv_128x256.log 2>&1
+grep -E "hypotheses|cost volume|CostRegNet|UNet2" $OUT/cv_128x256.log
+cp $(find $OUT/cv_trace -name "*kernel_stats.csv" | head -1) $OUT/cv_kernel_stats_128x256.csv
+python3 $R/tools/time_cost_volume.py 64 128 2>&1 | grep -E "hypotheses|cost volume|CostRegNet|UNet2" | tee $OUT/cv_64x128.log
+rm -rf $OUT/pmc[0-9] $OUT/bench_trace $OUT/cv_trace
+ls $OUT
