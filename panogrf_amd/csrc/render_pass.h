@@ -18,6 +18,13 @@
 #include "pgrf_layout.h"
 #include "render_pass_args.h"
 
+// timing experiment only: -DPGRF_NO_BARRIER removes the workgroup barriers (results are then wrong)
+#ifdef PGRF_NO_BARRIER
+#define PGRF_SYNC() do {} while (0)
+#else
+#define PGRF_SYNC() __syncthreads()
+#endif
+
 namespace pgrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,7 +68,11 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
     }
 #pragma unroll
     for (int s4 = 0; s4 < KS4; ++s4) {
+#ifdef PGRF_ABL_WEIGHTS   // ablation (timing only): every weight load hits the same 1 KiB -> L1 resident
+      const float4 a = reinterpret_cast<const float4*>(A)[lane + ((m * KS4 + s4) & 1) * 64];
+#else
       const float4 a = reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
+#endif
       const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -134,7 +145,13 @@ __device__ __forceinline__ Bilin bilin_setup(float px, float py, int H, int W, i
 // Gather one 32-channel NHWC map into the accumulator layout: register 4q+i of half h = channel 8q+4h+i.
 __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const Bilin& b, int half) {
   f32x16 out;
+#ifdef PGRF_ABL_GATHER    // ablation (timing only): all taps read pixel 0
+  const float* base = map + half * 4 - (size_t)b.o00 * 32 * 0;
+  Bilin bb = b; bb.o00 = bb.o01 = bb.o10 = bb.o11 = 0;
+#define b bb
+#else
   const float* base = map + half * 4;
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float4 a = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * 32 + q * 8);
@@ -146,6 +163,9 @@ __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const 
     out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
     out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
   }
+#ifdef PGRF_ABL_GATHER
+#undef b
+#endif
   return out;
 }
 
@@ -187,6 +207,9 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
   float vis_s[NT], hit_s[NT];
   float dv[NT];
   Bilin bimg[NT], bfeat[NT];
+#ifdef PGRF_EARLY_GATHER
+  f32x16 imf_early[NT];
+#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int v = V0 + t;
@@ -219,6 +242,9 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     bfeat[t] = bilin_setup(px, py, p.H, p.W, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
     bimg[t] = bilin_setup(px, py, p.H, p.W, p.H, p.W, true);
     rf[t] = gather32(p.ray_feats + (size_t)v * p.hr * p.wr * 32, brf, half);
+#ifdef PGRF_EARLY_GATHER
+    imf_early[t] = gather32(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
+#endif
     if (DBG && store_ok) {
       const size_t o = (size_t)v * npts + pt;
       if (sdbg[0] && half == 0) { sdbg[0][o * 2] = px; sdbg[0][o * 2 + 1] = py; }
@@ -351,7 +377,11 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int v = V0 + t;
+#ifdef PGRF_EARLY_GATHER
+      const f32x16 imf = imf_early[t];
+#else
       const f32x16 imf = gather32(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
+#endif
       const float* ib = p.imgs + (size_t)v * p.H * p.W * 4;
       const float4 c00 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o00 * 4);
       const float4 c01 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o01 * 4);
@@ -664,7 +694,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
       lds_v[pt_local * kVStride + 2 * r + half] = qkv[0][1][r];
     }
-    __syncthreads();
+    PGRF_SYNC();
     float oatt[16];
     const int key_base = ray_local * DN;
 #pragma unroll
@@ -767,7 +797,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   // ---- stage F: alpha compositing along the ray (renderer.py:216-218,291-304; render_ops.py:145-153)
   const float alpha = 1.f - __expf(-fmaxf(sigma, 0.f));
   if (half == 0) lds_alpha[pt_local] = alpha;
-  __syncthreads();
+  PGRF_SYNC();
   float T = 1.f;
   for (int j = 0; j < DN; ++j) {
     const float a = lds_alpha[ray_local * DN + j];
@@ -787,7 +817,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   if (lane == 0)
 #pragma unroll
     for (int c = 0; c < 4; ++c) lds_red[wave][c] = acc4[c];
-  __syncthreads();
+  PGRF_SYNC();
   if (kt == 0 && lane < 4 && store_ok) {
     float s = 0.f;
 #pragma unroll
