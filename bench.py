@@ -179,6 +179,10 @@ def main():
     ap.add_argument('--views', type=int, default=2)
     ap.add_argument('--samples', type=int, default=64)
     ap.add_argument('--fine', action='store_true', help='coarse + importance-sampled fine pass (BASELINE config 4)')
+    ap.add_argument('--with-cost-volume', action='store_true',
+                    help='BASELINE config 3: also build + regularise the D=64 spherical cost volume of every source view each step')
+    ap.add_argument('--cv-res', type=int, nargs=2, default=None, help='cost-volume h w (default H/4 W/4)')
+    ap.add_argument('--reg', choices=['unet2', 'costregnet'], default='unet2')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager-baseline', action='store_true', help='also time the eager PyTorch-ROCm port on this GPU')
     args = ap.parse_args()
@@ -207,11 +211,39 @@ def main():
     passes = 2 if args.fine else 1
 
     kern_ms = []
+    cv = None
+    if args.with_cost_volume:
+        # one cost volume per source view acting as MVS reference (network/init_net.py:164-171: B = rfn pairs)
+        from panogrf_amd import cost_volume as CVm
+        from panogrf_amd import cost_reg as CR
+        ch, cw = args.cv_res if args.cv_res else (H // 4, W // 4)
+        g = torch.Generator().manual_seed(7)
+        cv = dict(h=ch, w=cw, feats=torch.randn(V, 2, ch, cw, 32, generator=g).to(dev),
+                  ref_mu=(1.0 + 7.0 * torch.rand(V, 1, ch, cw, generator=g)).to(dev),
+                  rots=torch.eye(3).view(1, 1, 3, 3).repeat(V, 2, 1, 1).to(dev),
+                  trans=torch.tensor([[[0.5, 0.0, 0.0], [-0.5, 0.0, 0.0]]]).repeat(V, 1, 1).to(dev),
+                  k=CVm.depth_sampling(5, 3), args=dict(dataset_name='m3d', contain_dnet=True),
+                  net=(CR.UNet2Reg() if args.reg == 'unet2' else CR.CostRegNet(dict(use_wrap_padding=True), 32)).to(dev).eval(),
+                  CV=CVm, ms=[])
+        with torch.no_grad():
+            for prm in cv['net'].parameters():
+                prm.mul_(0.5)
 
     def step(timed):
         # per-frame: channel-last re-layout of the source maps (inputs stay NCHW in HBM like the reference's)
         fr = E.Frame(fr_in['imgs'], fr_in['img_feats'], fr_in['ray_feats'], fr_in['w2c'], fr_in['ref_depth_range'],
                      case['frame']['que_c2w'], case['frame']['que_depth_range'], device=dev)
+        if cv is not None and rank == 0:
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for v in range(V):            # the volumes are independent; on N>1 ranks they would shard by source view
+                dv = cv['CV'].build_depth_volume(cv['ref_mu'][v:v + 1], cv['k'], 0.5, 0.1, 10.0, 64)
+                vol = cv['CV'].calculate_cost_volume_erp(cv['args'], cv['feats'][v:v + 1], None, cv['trans'][v:v + 1],
+                                                         cv['rots'][v:v + 1], depth_volume=dv)
+                reg = cv['net'].forward_ndhwc(vol)
+            c1.record()
+            if timed:
+                cv['ms'].append((c0, c1))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = rr.render_rays(fr, coords)
@@ -261,6 +293,13 @@ def main():
                      'kernel': 'render_pass_kernel', 'kernel_ms': k_ms / launches,
                      'flop_per_ray': flop_per_ray(V, dn, 1), 'rays_per_launch': rn},
     }
+    if rank == 0 and cv is not None:
+        cms = sum(a.elapsed_time(b) for a, b in cv['ms']) / max(len(cv['ms']), 1)
+        gf = (438.5e9 if args.reg == 'unet2' else 16.2e9) * (cv['h'] * cv['w']) / (64 * 128) * V
+        res['cost_volume_stage'] = {'ms_per_step': cms, 'views': V, 'res': [cv['h'], cv['w']], 'D': 64, 'C': 32,
+                                    'regulariser': args.reg, 'reg_algorithmic_tflops': gf / (cms * 1e-3) / 1e12,
+                                    'note': 'hypotheses + spherical cost volume + 3-D regulariser per source view; included in ms_per_step/value'}
+        res['config']['workload'] += f' + D=64 cost volume {cv["h"]}x{cv["w"]} + {args.reg} per view (BASELINE configs[2])'
     if rank == 0 and world == 1 and args.eager_baseline:
         eg, eout = eager_gpu_baseline(case, dev, 2048)
         eg4, _ = eager_gpu_baseline(case, dev, 4096)
