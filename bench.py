@@ -192,12 +192,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the HIP renderer has no CPU fallback')
+    backend = os.environ.get('PGRF_BENCH_BACKEND', 'nccl')      # 'gloo' = test-only: ranks may then share one GPU
+    if backend != 'nccl':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from panogrf_amd import engine as E
     from panogrf_amd import dist as D

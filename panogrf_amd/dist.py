@@ -31,6 +31,9 @@ def allgather_rows(shard, H, W, group=None):
     if world == 1:
         return shard
     C = shard.shape[1]
+    if dist.get_backend(group) == 'gloo' and shard.is_cuda:
+        # test-only path (several ranks sharing one GPU cannot use RCCL): stage through host memory
+        return allgather_rows(shard.cpu(), H, W, group).to(shard.device)
     if H % world == 0:
         full = torch.empty(H * W, C, dtype=shard.dtype, device=shard.device)
         dist.all_gather_into_tensor(full, shard.contiguous(), group=group)

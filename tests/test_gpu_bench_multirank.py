@@ -1,0 +1,25 @@
+"""bench.py's N>1 code path (tile sharding, image all-gather, max-over-ranks timing) exercised on ONE GPU
+with 2 ranks over gloo (RCCL cannot run two ranks on one device; the 8-GPU run is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_one_gpu():
+    env = dict(os.environ, PGRF_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29517', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--height', '64', '--width', '128', '--samples', '32']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['config']['ray_tiles'] == 2 and d['scaling'] == 'strong'
+    assert d['roofline']['rays_per_launch'] == 64 * 128 // 2
+    assert d['value'] > 0
