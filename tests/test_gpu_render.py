@@ -204,3 +204,22 @@ def test_unsupported_sample_count_fails_loudly():
     rr = E.RayRenderer(case['cfg'], case['weights'])
     with pytest.raises(PgrfError):
         rr.render_rays(fr, torch.zeros(4, 2))
+
+
+@pytest.mark.parametrize('views,dn,use_all', [(3, 64, False), (4, 64, False), (4, 64, True), (3, 32, True)])
+def test_more_views_and_sample_counts_vs_oracle(views, dn, use_all):
+    """Kernel instantiations not covered by the reference fixtures: 3/4 source views at 64 and 128 samples per pass."""
+    from oracle import render_oracle as O
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(32, 64, views, dn, seed=10 + views, fine=True)
+    case['cfg']['fine_depth_use_all'] = use_all
+    fr = _frame(E, case['frame'])
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    idx = torch.arange(0, 32 * 64, 13)
+    coords = torch.stack([(idx % 64).float(), (idx // 64).float()], -1)
+    out = rr.render_rays(fr, coords)
+    ref = O.render_rays(case['weights'], case['frame'], coords, case['cfg'])
+    assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 2e-5
+    assert FX.max_abs(out['density_nr'].cpu(), ref['density_nr']) < 1e-4 * max(1.0, float(ref['density_nr'].max()))
+    assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), ref['pixel_colors_nr_fine']) > 60
