@@ -115,10 +115,14 @@ typedef struct PgrfPassDebug { /* intermediate tensors for stage-level parity te
  * predict_proj_ray_prob (renderer.py:120-136), get_img_feats (:180-188), network_rendering (:210-219),
  * DefaultAggregationNet.forward (network/aggregate_net.py:41-89), IBRNetWithNeuRay.forward
  * (network/ibrnet.py:315-373), MixtureLogisticsDistDecoder.forward/compute_prob
- * (network/dist_decoder.py:99-140). */
+ * (network/dist_decoder.py:99-140).
+ * `workspace` (>= pgrf_render_pass_workspace_bytes(frame), caller-owned device memory) receives the per-pixel
+ * projection of the ray_feats maps through this pass's first linear layers (W*bilinear(f)+b == bilinear(W*f+b)):
+ * 160 floats per ray_feats pixel, recomputed by every call. */
+size_t pgrf_render_pass_workspace_bytes(const PgrfFrame* frame);
 int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords,
                      const float* depth, int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg,
-                     void* stream);
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* `render_c2f_all` (network/renderer.py:484-518): one composite over the sorted union of the
  * coarse and fine samples.  Inputs [rn,dn_c]/[rn,dn_f]; outputs sized dn_c+dn_f. */
@@ -137,8 +141,8 @@ typedef struct PgrfRenderCfg {
   int use_vis_coarse, use_vis_fine;
 } PgrfRenderCfg;
 
-/* Bytes of scratch pgrf_render_rays needs for rn rays. */
-size_t pgrf_render_workspace_bytes(const PgrfRenderCfg* cfg, int rn);
+/* Bytes of scratch pgrf_render_rays needs for rn rays of this frame. */
+size_t pgrf_render_workspace_bytes(const PgrfFrame* frame, const PgrfRenderCfg* cfg, int rn);
 /* Coarse (+ importance-sampled fine) render of rn rays: NeuralRayBaseRenderer.render_impl
  * (network/renderer.py:567-633, non-DINER branch).  `fine` outputs may be NULL when
  * cfg->hierarchical == 0.  All rays of a frame can be passed at once: the result does not depend

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pgrf_internal.h"
+#include "pgrf_layout.h"
 
 namespace pgrf {
 
@@ -38,6 +39,47 @@ int launch_pack_map(const float* src, int n, int C, int h, int w, float* dst, vo
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_map_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, src, n, C, h * w, Cpad, dst);
   PGRF_CHECK_LAUNCH("pack_map");
+  return PGRF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-pixel projection of the channel-last ray_feats maps through every layer that consumes the gathered
+// ray feature linearly (pgrf_layout.h: OFF_PRJ_W).  out[pix][c] = b[c] + <W[c,:], f[pix,:]>, c < nch.
+// Tiny (V*hr*wr pixels x 160 x 32 MACs); one thread per (pixel, 4 outputs).
+__global__ void project_ray_feats_kernel(const float* __restrict__ rf, const float* __restrict__ blob, int npix, int nch,
+                                         float* __restrict__ out) {
+  const int groups = nch / 4;
+  const long long total = (long long)npix * groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int gq = (int)(i % groups);
+    const long long pix = i / groups;
+    const float4* f = reinterpret_cast<const float4*>(rf + pix * 32);
+    float4 fv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fv[k] = f[k];
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = gq * 4 + j;
+      const float4* w = reinterpret_cast<const float4*>(blob + OFF_PRJ_W + c * 32);
+      float s = blob[OFF_PRJ_B + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 wv = w[k];
+        s = fmaf(wv.x, fv[k].x, s); s = fmaf(wv.y, fv[k].y, s); s = fmaf(wv.z, fv[k].z, s); s = fmaf(wv.w, fv[k].w, s);
+      }
+      o[j] = s;
+    }
+    *reinterpret_cast<float4*>(out + pix * kPrjCh + gq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+int launch_project_ray_feats(const float* rf, const float* blob, int npix, int use_vis, float* out, void* stream) {
+  const int nch = use_vis ? kPrjCh : kPrjCh - 32;
+  const long long total = (long long)npix * (nch / 4);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(project_ray_feats_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, rf, blob, npix, nch, out);
+  PGRF_CHECK_LAUNCH("project_ray_feats");
   return PGRF_OK;
 }
 

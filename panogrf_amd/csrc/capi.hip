@@ -21,6 +21,7 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
+int launch_project_ray_feats(const float* rf, const float* blob, int npix, int use_vis, float* out, void* stream);
 int launch_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream);
 int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, float* depth, void* stream);
 int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
@@ -70,8 +71,11 @@ static int check_frame(const PgrfFrame* f, const char* who) {
   return PGRF_OK;
 }
 
+static size_t pass_ws_bytes(const PgrfFrame* f) { return (size_t)f->rfn * f->hr * f->wr * kPrjCh * sizeof(float); }
+
 static int do_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords, const float* depth,
-                          int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* stream) {
+                          int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* workspace,
+                          size_t ws_bytes, void* stream) {
   int rc = check_frame(frame, "pgrf_render_pass");
   if (rc) return rc;
   if (!blob || !coords || !depth || !out) return set_error(PGRF_ERR_ARG, "pgrf_render_pass: null blob/coords/depth/out");
@@ -79,9 +83,15 @@ static int do_render_pass(const PgrfFrame* frame, const float* blob, int use_vis
   if (dn != 32 && dn != 64 && dn != 128)
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass: dn=%d unsupported (32, 64 or 128 samples per ray)", dn);
   if (rn == 0) return PGRF_OK;
+  if (!workspace || ws_bytes < pass_ws_bytes(frame))
+    return set_error(PGRF_ERR_ARG, "pgrf_render_pass: workspace too small (%zu < %zu bytes)", ws_bytes, pass_ws_bytes(frame));
+  // per-pixel projection of the ray_feats maps with THIS pass's weights (tiny; see pgrf_layout.h kPrjCh)
+  rc = launch_project_ray_feats(frame->ray_feats, blob, frame->rfn * frame->hr * frame->wr, use_vis, (float*)workspace, stream);
+  if (rc) return rc;
   PassArgs a;
   std::memset(&a, 0, sizeof(a));
   a.imgs = frame->imgs; a.img_feats = frame->img_feats; a.ray_feats = frame->ray_feats;
+  a.prj = (const float*)workspace;
   a.w2c = frame->w2c; a.ref_dr = frame->ref_depth_range;
   std::memcpy(a.c2w, frame->que_c2w, sizeof(a.c2w));
   a.que_near = frame->que_depth_range[0]; a.que_far = frame->que_depth_range[1];
@@ -134,9 +144,15 @@ int pgrf_sample_fine_depth(const float* depth, const float* hit_prob, float que_
   return launch_fine_depth(depth, hit_prob, que_near, que_far, use_disp, use_all, rn, dn, fdn, out, stream);
 }
 
+size_t pgrf_render_pass_workspace_bytes(const PgrfFrame* frame) {
+  if (!frame || frame->rfn < 1 || frame->hr < 1 || frame->wr < 1) return 0;
+  return pass_ws_bytes(frame);
+}
+
 int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords, const float* depth,
-                     int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* stream) {
-  return do_render_pass(frame, blob, use_vis, coords, depth, rn, dn, out, dbg, stream);
+                     int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+  return do_render_pass(frame, blob, use_vis, coords, depth, rn, dn, out, dbg, workspace, workspace_bytes, stream);
 }
 
 int pgrf_merge_c2f(const float* depth_c, const float* colors_c, const float* density_c, int dn_c, const float* depth_f,
@@ -152,11 +168,11 @@ int pgrf_merge_c2f(const float* depth_c, const float* colors_c, const float* den
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t pgrf_render_workspace_bytes(const PgrfRenderCfg* cfg, int rn) {
-  if (!cfg || rn <= 0) return 0;
+size_t pgrf_render_workspace_bytes(const PgrfFrame* frame, const PgrfRenderCfg* cfg, int rn) {
+  if (!cfg || !frame || rn <= 0) return 0;
   const size_t r = (size_t)rn;
   const int fdn_eff = cfg->fine_use_all ? cfg->dn + cfg->fdn : cfg->fdn;
-  size_t b = 0;
+  size_t b = align256(pass_ws_bytes(frame));     // projection map, reused by the coarse and the fine pass
   b += align256(r * cfg->dn * 4);            // coarse depth
   b += align256(r * cfg->dn * 4);            // coarse hit_prob (when the caller does not ask for it)
   b += align256(r * fdn_eff * 4);            // fine depth
@@ -174,12 +190,15 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
   if (cfg->hierarchical && (!fine || !blob_fine)) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: hierarchical render needs fine outputs and weights");
   if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: rn < 0");
   if (rn == 0) return PGRF_OK;
-  const size_t need = pgrf_render_workspace_bytes(cfg, rn);
+  if (int rc0 = check_frame(frame, "pgrf_render_rays")) return rc0;
+  const size_t need = pgrf_render_workspace_bytes(frame, cfg, rn);
   if (!workspace || workspace_bytes < need)
     return set_error(PGRF_ERR_ARG, "pgrf_render_rays: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
   const size_t r = (size_t)rn;
   const int fdn_eff = cfg->fine_use_all ? cfg->dn + cfg->fdn : cfg->fdn;
   char* ws = (char*)workspace;
+  void* prj_ws = ws; ws += align256(pass_ws_bytes(frame));
+  const size_t prj_bytes = pass_ws_bytes(frame);
   float* depth_c = (float*)ws; ws += align256(r * cfg->dn * 4);
   float* hit_c = (float*)ws; ws += align256(r * cfg->dn * 4);
   float* depth_f = (float*)ws; ws += align256(r * fdn_eff * 4);
@@ -199,18 +218,18 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
   }
   int rc = pgrf_sample_coarse_depth(cfg->min_depth, cfg->max_depth, cfg->use_disp, rn, cfg->dn, depth_c, stream);
   if (rc) return rc;
-  rc = do_render_pass(frame, blob_coarse, cfg->use_vis_coarse, coords, depth_c, rn, cfg->dn, &oc, nullptr, stream);
+  rc = do_render_pass(frame, blob_coarse, cfg->use_vis_coarse, coords, depth_c, rn, cfg->dn, &oc, nullptr, prj_ws, prj_bytes, stream);
   if (rc || !cfg->hierarchical) return rc;
   float* fd = fine_depth_out ? fine_depth_out : depth_f;
   rc = pgrf_sample_fine_depth(depth_c, oc.hit_prob, frame->que_depth_range[0], frame->que_depth_range[1], cfg->use_disp,
                               cfg->fine_use_all, rn, cfg->dn, cfg->fdn, fd, stream);
   if (rc) return rc;
-  if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, cfg->use_vis_fine, coords, fd, rn, fdn_eff, &of, nullptr, stream);
+  if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, cfg->use_vis_fine, coords, fd, rn, fdn_eff, &of, nullptr, prj_ws, prj_bytes, stream);
   // fine pass into scratch, then one composite over the union (renderer.py:484-518)
   PgrfPassOut tmp;
   std::memset(&tmp, 0, sizeof(tmp));
   tmp.colors = col_f; tmp.density = den_f;
-  rc = do_render_pass(frame, blob_fine, cfg->use_vis_fine, coords, fd, rn, fdn_eff, &tmp, nullptr, stream);
+  rc = do_render_pass(frame, blob_fine, cfg->use_vis_fine, coords, fd, rn, fdn_eff, &tmp, nullptr, prj_ws, prj_bytes, stream);
   if (rc) return rc;
   return pgrf_merge_c2f(depth_c, col_c, den_c, cfg->dn, fd, col_f, den_f, fdn_eff, rn, &of, stream);
 }

@@ -190,6 +190,20 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
         const double ang = (double)p / std::pow(10000.0, 2.0 * (j / 2) / 16.0);
         blob[OFF_POS + p * 16 + h * 8 + r] = (float)((j & 1) ? std::cos(ang) : std::sin(ang));
       }
+  // ---- per-pixel projection block (pgrf_layout.h: kPrjCh rows)
+  {
+    const int src_w[5] = {R_DD_MEAN_0_W, R_DD_VAR_0_W, R_DD_AW_0_W, R_PE_0_W, R_DD_VIS_0_W};
+    const int in_dim[5] = {32, 32, 32, 34, 32};
+    for (int g = 0; g < 5; ++g) {
+      const bool off = (g == 4 && !use_vis);
+      const float* Wg = off ? nullptr : raw[src_w[g]];
+      const float* bg = off ? nullptr : raw[src_w[g] + 1];
+      for (int r = 0; r < 32; ++r) {
+        for (int k = 0; k < 32; ++k) blob[OFF_PRJ_W + (g * 32 + r) * 32 + k] = Wg ? Wg[r * in_dim[g] + k] : 0.f;
+        blob[OFF_PRJ_B + g * 32 + r] = bg ? bg[r] : 0.f;
+      }
+    }
+  }
   return PGRF_OK;
 }
 

@@ -94,7 +94,14 @@ constexpr int OFF_LN_B = OFF_LN_G + 16;
 // positional encoding [PGRF_MAX_DN][half][8]
 constexpr int kMaxDn = 128;
 constexpr int OFF_POS = OFF_LN_B + 16;
-constexpr int kBlobFloats = OFF_POS + kMaxDn * 16;
+// Per-pixel projection of the ray_feats maps (done once per pass and frame, see project_ray_feats_kernel):
+// the first layers that consume the gathered ray feature — dist-decoder layer 0 of every MLP and the 32
+// ray-feature columns of prob_embed.0 — are linear, and bilinear interpolation is linear with weights summing
+// to 1, so W*interp(f)+b == interp(W*f+b).  Rows: [mean(32) | var(32) | aw(32) | prob_embed.0(32) | vis(32)].
+constexpr int kPrjCh = 160;
+constexpr int OFF_PRJ_W = OFF_POS + kMaxDn * 16;          // [kPrjCh][32] row-major
+constexpr int OFF_PRJ_B = OFF_PRJ_W + kPrjCh * 32;        // [kPrjCh]
+constexpr int kBlobFloats = OFF_PRJ_B + kPrjCh;
 
 // attention feature permutation: accumulator row rho (< 16) of the q / k / v projections holds
 // head-feature  attn_feat(rho)  so that register 2*head+s carries dims (2s, 2s+1) in the two lane halves.

@@ -143,6 +143,7 @@ __device__ __forceinline__ Bilin bilin_setup(float px, float py, int H, int W, i
 }
 
 // Gather one 32-channel NHWC map into the accumulator layout: register 4q+i of half h = channel 8q+4h+i.
+template <int STRIDE = 32>
 __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const Bilin& b, int half) {
   f32x16 out;
 #ifdef PGRF_ABL_GATHER    // ablation (timing only): all taps read pixel 0
@@ -154,10 +155,10 @@ __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const 
 #endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float4 a = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * 32 + q * 8);
-    const float4 c = *reinterpret_cast<const float4*>(base + (size_t)b.o01 * 32 + q * 8);
-    const float4 d = *reinterpret_cast<const float4*>(base + (size_t)b.o10 * 32 + q * 8);
-    const float4 e = *reinterpret_cast<const float4*>(base + (size_t)b.o11 * 32 + q * 8);
+    const float4 a = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * STRIDE + q * 8);
+    const float4 c = *reinterpret_cast<const float4*>(base + (size_t)b.o01 * STRIDE + q * 8);
+    const float4 d = *reinterpret_cast<const float4*>(base + (size_t)b.o10 * STRIDE + q * 8);
+    const float4 e = *reinterpret_cast<const float4*>(base + (size_t)b.o11 * STRIDE + q * 8);
     out[4 * q + 0] = a.x * b.wnw + c.x * b.wne + d.x * b.wsw + e.x * b.wse;
     out[4 * q + 1] = a.y * b.wnw + c.y * b.wne + d.y * b.wsw + e.y * b.wse;
     out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
@@ -203,10 +204,10 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
                                             float* const* sdbg) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
-  f32x16 rf[NT];
   float vis_s[NT], hit_s[NT];
   float dv[NT];
-  Bilin bimg[NT], bfeat[NT];
+  Bilin bimg[NT], bfeat[NT], brf[NT];
+  const float* prj[NT];
 #ifdef PGRF_EARLY_GATHER
   f32x16 imf_early[NT];
 #endif
@@ -238,10 +239,10 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     vs[v].dd[2] = dz - g.qdir[2];
     vs[v].dd[3] = dx * g.qdir[0] + dy * g.qdir[1] + dz * g.qdir[2];   // aggregate_net.py:8-14
     // bilinear gathers (render_ops.py:243-245, renderer.py:180-188)
-    const Bilin brf = bilin_setup(px, py, p.H, p.W, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
+    brf[t] = bilin_setup(px, py, p.H, p.W, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
+    prj[t] = p.prj + (size_t)v * p.hr * p.wr * kPrjCh;
     bfeat[t] = bilin_setup(px, py, p.H, p.W, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
     bimg[t] = bilin_setup(px, py, p.H, p.W, p.H, p.W, true);
-    rf[t] = gather32(p.ray_feats + (size_t)v * p.hr * p.wr * 32, brf, half);
 #ifdef PGRF_EARLY_GATHER
     imf_early[t] = gather32(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
 #endif
@@ -250,29 +251,26 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       if (sdbg[0] && half == 0) { sdbg[0][o * 2] = px; sdbg[0][o * 2 + 1] = py; }
       if (sdbg[1] && half == 0) sdbg[1][o] = r;
       if (sdbg[2] && half == 0) for (int c = 0; c < 4; ++c) sdbg[2][o * 4 + c] = vs[v].dd[c];
-      if (sdbg[5]) dump_tile32(sdbg[5] + o * 32, rf[t], half);
+      if (sdbg[5]) dump_tile32(sdbg[5] + o * 32, gather32(p.ray_feats + (size_t)v * p.hr * p.wr * 32, brf[t], half), half);
     }
   }
 
   // ---- mixture-of-logistics decoder: 3 (4) MLPs 32 -> 32 -> 32 -> head  (dist_decoder.py:53-107)
-  float bin[NT][16];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) bin[t][s] = rf[t][s];
+  // layer 0 of each MLP is read from the per-pixel projection map (pre-activation incl. bias): no MFMA
   float head[NT][6];
 #pragma unroll
   for (int t = 0; t < NT; ++t) head[t][5] = 1.f;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     if (m == 3 && !p.use_vis) break;
-    f32x16 a1[NT][1], a2[NT][1];
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD1) + m * 4 * 256, W + layer_b_off(L_DD1) + m * 32, lane, bin, a1);
+    f32x16 a2[NT][1];
     float b2[NT][16];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      const f32x16 a1 = gather32<kPrjCh>(prj[t] + (m < 3 ? m : 4) * 32, brf[t], half);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[t][0][s]);
+      for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[s]);
+    }
     mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -319,15 +317,15 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
   }
   // ---- prob_embed: [ray_feats(32), 2(hit-.5), 2(vis-.5)] -> 32 relu -> 32  (aggregate_net.py:53-61)
   {
-    float b17[NT][17];
+    // the 32 ray-feature columns (+ bias) come from the projection map; only k-step 16 = (hit, vis) is left
+    f32x16 a1[NT][1], a2[NT][1];
+    const float a16 = reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) b17[t][s] = rf[t][s];
-      b17[t][16] = half ? (vis_s[t] - 0.5f) * 2.f : (hit_s[t] - 0.5f) * 2.f;
+      const f32x16 pe = gather32<kPrjCh>(prj[t] + 3 * 32, brf[t], half);
+      const float hv = half ? (vis_s[t] - 0.5f) * 2.f : (hit_s[t] - 0.5f) * 2.f;
+      a1[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a16, hv, pe, 0, 0, 0);
     }
-    f32x16 a1[NT][1], a2[NT][1];
-    mfma_layer<17, 1, NT, true>(W + layer_a_off(L_PE1), W + layer_b_off(L_PE1), lane, b17, a1);
     float b2[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t)

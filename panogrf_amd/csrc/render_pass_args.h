@@ -9,6 +9,7 @@ struct PassArgs {
   const float* imgs;        // [V,H,W,4]
   const float* img_feats;   // [V,hf,wf,32]
   const float* ray_feats;   // [V,hr,wr,32]
+  const float* prj;         // [V,hr,wr,kPrjCh] per-pixel projection of ray_feats (pgrf_layout.h), this pass's weights
   const float* w2c;         // [V,12]
   const float* ref_dr;      // [V,2]
   float c2w[12];

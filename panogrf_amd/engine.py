@@ -149,8 +149,10 @@ def render_pass(frame, blob_dev, use_vis, coords, depth, debug=False):
         dbg_t = {k: torch.zeros(*f(frame.rfn, rn, dn), device=frame.device) for k, f in _DEBUG_SHAPES.items()}
         dbg_s = PgrfPassDebug(*[dbg_t[n].data_ptr() for n, _ in PgrfPassDebug._fields_])
     fs = frame.c_struct()
+    nws = lib.pgrf_render_pass_workspace_bytes(C.byref(fs))
+    ws = torch.empty(nws, dtype=torch.uint8, device=frame.device)
     lib.check(lib.pgrf_render_pass(C.byref(fs), _ptr(blob_dev), int(bool(use_vis)), _ptr(coords), _ptr(depth), rn, dn,
-                                   C.byref(o), C.byref(dbg_s) if debug else None, _stream()))
+                                   C.byref(o), C.byref(dbg_s) if debug else None, _ptr(ws), C.c_size_t(nws), _stream()))
     if debug:
         t['dbg'] = dbg_t
     return t
@@ -194,8 +196,8 @@ class RayRenderer:
         self.device = torch.device(device)
         self._ws = None
 
-    def _workspace(self, rn):
-        need = lib.pgrf_render_workspace_bytes(C.byref(self.ccfg), rn)
+    def _workspace(self, fs, rn):
+        need = lib.pgrf_render_workspace_bytes(C.byref(fs), C.byref(self.ccfg), rn)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws, need
@@ -218,8 +220,8 @@ class RayRenderer:
             for k, v in tf.items():
                 out[k + '_fine'] = v
             out['depth_fine'] = fd
-        ws, nbytes = self._workspace(rn)
         fs = frame.c_struct()
+        ws, nbytes = self._workspace(fs, rn)
         lib.check(lib.pgrf_render_rays(C.byref(fs), _ptr(self.blob_c), _ptr(self.blob_f), C.byref(c), _ptr(coords), rn,
                                        C.byref(oc), C.byref(of) if of is not None else None, _ptr(fd), _ptr(ws),
                                        C.c_size_t(nbytes), _stream()))

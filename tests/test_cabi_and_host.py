@@ -39,7 +39,7 @@ def test_argument_validation_returns_errors_not_crashes():
     fr = PgrfFrame()
     out = PgrfPassOut()
     rc = lib.pgrf_render_pass(C.byref(fr), C.c_void_p(buf.data_ptr()), 0, C.c_void_p(buf.data_ptr()),
-                              C.c_void_p(buf.data_ptr()), 4, 64, C.byref(out), None, None)
+                              C.c_void_p(buf.data_ptr()), 4, 64, C.byref(out), None, None, 0, None)
     assert rc == -1 and b'rfn' in lib.pgrf_last_error()
     with pytest.raises(PgrfError):
         lib.check(rc)
