@@ -54,3 +54,25 @@ def test_render_end_to_end_vs_reference():
     # training mode is refused, not silently approximated
     with pytest.raises(NotImplementedError):
         net({'que_imgs_info': que, 'ref_imgs_info': ref})
+
+
+def test_imgs_info_builders_shapes():
+    import numpy as np
+    from panogrf_amd.imgs_info import build_imgs_info, build_render_imgs_info
+    pose = np.concatenate([np.eye(3), np.array([[0.1], [0.2], [0.3]])], 1)
+    q = build_render_imgs_info(pose, (4, 6), [0.5, 15.0])
+    assert q['coords'].shape == (1, 24, 2) and q['coords'][0, 1].tolist() == [1.0, 0.0] and q['coords'][0, 6].tolist() == [0.0, 1.0]
+    assert np.allclose(q['c2w'][0, :, 3], [-0.1, -0.2, -0.3]) and q['depth_range'].shape == (1, 2)
+    r = build_imgs_info(np.zeros((2, 3, 4, 6), np.float32), np.stack([pose, pose]), [[0.5, 15.0]] * 2)
+    assert set(r) >= {'imgs', 'rots', 'trans', 'c2w', 'w2c', 'depth_range', 'masks', 'polar_weights'}
+    assert r['polar_weights'].shape == (2, 1, 4, 6)
+
+
+@pytest.mark.gpu
+def test_render_script_runs(tmp_path):
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'render.py'), '--height', '64', '--width', '128', '--samples', '32',
+                        '--num-poses', '2', '--out', str(tmp_path)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert os.path.exists(tmp_path / '1-nr_fine.ppm') and os.path.exists(tmp_path / '1-depth.npy')
