@@ -183,6 +183,8 @@ def main():
                     help='BASELINE config 3: also build + regularise the D=64 spherical cost volume of every source view each step')
     ap.add_argument('--cv-res', type=int, nargs=2, default=None, help='cost-volume h w (default H/4 W/4)')
     ap.add_argument('--reg', choices=['unet2', 'costregnet'], default='unet2')
+    ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f32',
+                    help="f32 = exact fp32 MFMA (default); f16x3 = opt-in split-f16 MFMA (3 per product, fp32 accumulate)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager-baseline', action='store_true', help='also time the eager PyTorch-ROCm port on this GPU')
     args = ap.parse_args()
@@ -210,6 +212,7 @@ def main():
 
     H, W, V, dn = args.height, args.width, args.views, args.samples
     case = synthetic_case(H, W, V, dn, seed=0, fine=args.fine)
+    case['cfg']['hip_precision'] = args.precision
     fr_in = {k: v.to(dev) for k, v in case['frame'].items()}
     rr = E.RayRenderer(case['cfg'], case['weights'], device=dev)
     coords = D.tile_coords(rank, world, H, W, device=dev)
@@ -303,7 +306,7 @@ def main():
     res = {
         'metric': 'rendered rays/sec (512x1024 ERP, 64 samples)', 'value': rays_per_s, 'unit': 'rays/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'f16x3-split products, f32 accumulate', 'data': 'synthetic',
         'config': {'workload': f'{H}x{W} ERP query, {V} source views, {dn} samples/ray'
                                + (' coarse + ' + str(dn) + ' fine' if args.fine else ', single pass')
                                + ' (BASELINE configs[1])' * (not args.fine and (H, W, V, dn) == (512, 1024, 2, 64)),

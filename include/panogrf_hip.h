@@ -120,7 +120,10 @@ typedef struct PgrfPassDebug { /* intermediate tensors for stage-level parity te
  * projection of the ray_feats maps through this pass's first linear layers (W*bilinear(f)+b == bilinear(W*f+b)):
  * 160 floats per ray_feats pixel, recomputed by every call. */
 size_t pgrf_render_pass_workspace_bytes(const PgrfFrame* frame);
-int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords,
+#define PGRF_PASS_USE_VIS 1   /* the dist decoder has the 4th (visibility) MLP: dist_decoder_cfg.use_vis */
+#define PGRF_PASS_F16X3 2     /* opt-in: Linear layers as 3 split-f16 MFMAs per product (x = h1 + h2, fp32 accumulate,
+                                 ~2^-21 relative per product) instead of exact-fp32 MFMAs; |activations| must stay < 65504 */
+int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int flags, const float* coords,
                      const float* depth, int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg,
                      void* workspace, size_t workspace_bytes, void* stream);
 
@@ -139,6 +142,7 @@ typedef struct PgrfRenderCfg {
   int fine_use_all;            /* fine_depth_use_all */
   int c2f_all;                 /* render_c2f_all */
   int use_vis_coarse, use_vis_fine;
+  int precision;               /* 0 = f32 (default), 1 = split-f16 x3 (see PGRF_PASS_F16X3) */
 } PgrfRenderCfg;
 
 /* Bytes of scratch pgrf_render_rays needs for rn rays of this frame. */

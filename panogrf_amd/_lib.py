@@ -39,7 +39,7 @@ class PgrfPassDebug(C.Structure):
 class PgrfRenderCfg(C.Structure):
     _fields_ = [("min_depth", C.c_float), ("max_depth", C.c_float), ("use_disp", C.c_int), ("dn", C.c_int),
                 ("fdn", C.c_int), ("hierarchical", C.c_int), ("fine_use_all", C.c_int), ("c2f_all", C.c_int),
-                ("use_vis_coarse", C.c_int), ("use_vis_fine", C.c_int)]
+                ("use_vis_coarse", C.c_int), ("use_vis_fine", C.c_int), ("precision", C.c_int)]
 
 
 # every symbol include/panogrf_hip.h declares: name -> (restype, argtypes)

@@ -73,11 +73,14 @@ static int check_frame(const PgrfFrame* f, const char* who) {
 
 static size_t pass_ws_bytes(const PgrfFrame* f) { return (size_t)f->rfn * f->hr * f->wr * kPrjCh * sizeof(float); }
 
-static int do_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords, const float* depth,
+static int do_render_pass(const PgrfFrame* frame, const float* blob, int flags, const float* coords, const float* depth,
                           int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* workspace,
                           size_t ws_bytes, void* stream) {
+  const int use_vis = (flags & PGRF_PASS_USE_VIS) ? 1 : 0;
+  const int precision = (flags & PGRF_PASS_F16X3) ? 1 : 0;
   int rc = check_frame(frame, "pgrf_render_pass");
   if (rc) return rc;
+  if (dbg && precision) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass: debug dumps are only available at f32 precision");
   if (!blob || !coords || !depth || !out) return set_error(PGRF_ERR_ARG, "pgrf_render_pass: null blob/coords/depth/out");
   if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_render_pass: rn=%d < 0", rn);
   if (dn != 32 && dn != 64 && dn != 128)
@@ -100,7 +103,7 @@ static int do_render_pass(const PgrfFrame* frame, const float* blob, int use_vis
   a.out_pixel = out->pixel_colors; a.out_depth = out->render_depth; a.out_hit = out->hit_prob;
   a.out_colors = out->colors; a.out_density = out->density;
   if (dbg) a.dbg = *dbg;
-  return launch_render_pass(a, frame->rfn, dn, dbg != nullptr, stream);
+  return launch_render_pass(a, frame->rfn, dn, dbg != nullptr, precision, stream);
 }
 
 }  // namespace pgrf
@@ -110,7 +113,7 @@ using namespace pgrf;
 extern "C" {
 
 const char* pgrf_last_error(void) { return g_err; }
-int pgrf_abi_version(void) { return 1; }
+int pgrf_abi_version(void) { return 2; }
 
 int pgrf_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream) {
   if (!src || !dst) return set_error(PGRF_ERR_ARG, "pgrf_pack_map: null pointer");
@@ -149,10 +152,10 @@ size_t pgrf_render_pass_workspace_bytes(const PgrfFrame* frame) {
   return pass_ws_bytes(frame);
 }
 
-int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int use_vis, const float* coords, const float* depth,
+int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int flags, const float* coords, const float* depth,
                      int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* workspace, size_t workspace_bytes,
                      void* stream) {
-  return do_render_pass(frame, blob, use_vis, coords, depth, rn, dn, out, dbg, workspace, workspace_bytes, stream);
+  return do_render_pass(frame, blob, flags, coords, depth, rn, dn, out, dbg, workspace, workspace_bytes, stream);
 }
 
 int pgrf_merge_c2f(const float* depth_c, const float* colors_c, const float* density_c, int dn_c, const float* depth_f,
@@ -218,18 +221,20 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
   }
   int rc = pgrf_sample_coarse_depth(cfg->min_depth, cfg->max_depth, cfg->use_disp, rn, cfg->dn, depth_c, stream);
   if (rc) return rc;
-  rc = do_render_pass(frame, blob_coarse, cfg->use_vis_coarse, coords, depth_c, rn, cfg->dn, &oc, nullptr, prj_ws, prj_bytes, stream);
+  const int pf = cfg->precision == 1 ? PGRF_PASS_F16X3 : 0;
+  if (cfg->precision != 0 && cfg->precision != 1) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: precision must be 0 (f32) or 1 (f16x3)");
+  rc = do_render_pass(frame, blob_coarse, (cfg->use_vis_coarse ? PGRF_PASS_USE_VIS : 0) | pf, coords, depth_c, rn, cfg->dn, &oc, nullptr, prj_ws, prj_bytes, stream);
   if (rc || !cfg->hierarchical) return rc;
   float* fd = fine_depth_out ? fine_depth_out : depth_f;
   rc = pgrf_sample_fine_depth(depth_c, oc.hit_prob, frame->que_depth_range[0], frame->que_depth_range[1], cfg->use_disp,
                               cfg->fine_use_all, rn, cfg->dn, cfg->fdn, fd, stream);
   if (rc) return rc;
-  if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, cfg->use_vis_fine, coords, fd, rn, fdn_eff, &of, nullptr, prj_ws, prj_bytes, stream);
+  if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &of, nullptr, prj_ws, prj_bytes, stream);
   // fine pass into scratch, then one composite over the union (renderer.py:484-518)
   PgrfPassOut tmp;
   std::memset(&tmp, 0, sizeof(tmp));
   tmp.colors = col_f; tmp.density = den_f;
-  rc = do_render_pass(frame, blob_fine, cfg->use_vis_fine, coords, fd, rn, fdn_eff, &tmp, nullptr, prj_ws, prj_bytes, stream);
+  rc = do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &tmp, nullptr, prj_ws, prj_bytes, stream);
   if (rc) return rc;
   return pgrf_merge_c2f(depth_c, col_c, den_c, cfg->dn, fd, col_f, den_f, fdn_eff, rn, &of, stream);
 }

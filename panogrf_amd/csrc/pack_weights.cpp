@@ -204,6 +204,23 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
       }
     }
   }
+  // ---- split-f16 copies of all A blocks (pgrf_layout.h: layer_h_off) ----------------------------
+  for (int id = 0; id < L_COUNT; ++id) {
+    const int ks = kKS[id], mt = kMT[id], ks4 = (ks + 3) / 4, G = h_groups(ks);
+    const float* A = blob + layer_a_off(id);
+    _Float16* H = reinterpret_cast<_Float16*>(blob + layer_h_off(id));
+    for (int m = 0; m < mt; ++m)
+      for (int g = 0; g < G; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int s = 8 * g + e;
+            const float x = (s < ks) ? A[((size_t)(m * ks4 + s / 4) * 64 + lane) * 4 + (s & 3)] : 0.f;
+            const _Float16 h1 = (_Float16)x;
+            const _Float16 h2 = (_Float16)(x - (float)h1);
+            H[((((size_t)m * G + g) * 2 + 0) * 64 + lane) * 8 + e] = h1;
+            H[((((size_t)m * G + g) * 2 + 1) * 64 + lane) * 8 + e] = h2;
+          }
+  }
   return PGRF_OK;
 }
 

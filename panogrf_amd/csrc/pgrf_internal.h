@@ -15,6 +15,6 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
 
 // kernel launchers (each in its own .hip translation unit)
 struct PassArgs;
-int launch_render_pass(const PassArgs& a, int rfn, int dn, bool debug, void* stream);
+int launch_render_pass(const PassArgs& a, int rfn, int dn, bool debug, int precision, void* stream);
 
 }  // namespace pgrf

@@ -101,7 +101,20 @@ constexpr int OFF_POS = OFF_LN_B + 16;
 constexpr int kPrjCh = 160;
 constexpr int OFF_PRJ_W = OFF_POS + kMaxDn * 16;          // [kPrjCh][32] row-major
 constexpr int OFF_PRJ_B = OFF_PRJ_W + kPrjCh * 32;        // [kPrjCh]
-constexpr int kBlobFloats = OFF_PRJ_B + kPrjCh;
+// ---- optional split-f16 copy of every A block (precision mode "f16x3") ------------------------------
+// w = h1 + h2 (two IEEE halves, 22 significant bits); the kernel splits the activations the same way and
+// issues three v_mfma_f32_32x32x16_f16 per 16-deep k-group: h1*h1' + h1*h2' + h2*h1' (fp32 accumulate).
+//   H block of a layer: [mt][g][piece 0|1][lane][8 halves]   with g = group of 8 consecutive k-steps,
+//   value(mt, g, lane, e) = A-block value of k-step 8g+e (0 beyond KS).  Sizes below are in floats.
+constexpr int h_groups(int ks) { return (ks + 7) / 8; }
+constexpr int h_size(int ks, int mt) { return mt * h_groups(ks) * 2 * 64 * 4; }
+constexpr int OFF_H_BASE = OFF_PRJ_B + kPrjCh;
+constexpr int layer_h_off(int id) {
+  int off = OFF_H_BASE;
+  for (int i = 0; i < id; ++i) off += h_size(kKS[i], kMT[i]);
+  return off;
+}
+constexpr int kBlobFloats = layer_h_off(L_COUNT);
 
 // attention feature permutation: accumulator row rho (< 16) of the q / k / v projections holds
 // head-feature  attn_feat(rho)  so that register 2*head+s carries dims (2s, 2s+1) in the two lane halves.

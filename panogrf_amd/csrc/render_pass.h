@@ -25,8 +25,25 @@
 #define PGRF_SYNC() __syncthreads()
 #endif
 
-namespace pgrf {
+// Precision of the Linear layers, fixed per translation unit (-DPGRF_PREC=0|1); each value lives in its own
+// namespace so that both instantiations of the same template can be linked into one library.
+//   0  f32   : v_mfma_f32_32x32x2_f32, bit-wise an fp32 fmaf chain (default, reference-equivalent arithmetic)
+//   1  f16x3 : activations and weights split as x = h1 + h2 (two halves, 22 significant bits), three
+//              v_mfma_f32_32x32x16_f16 per 16-deep k-group (h1*h1' + h1*h2' + h2*h1'), fp32 accumulation:
+//              ~2^-21 relative error per product at 1/5 of the matrix-pipe time.  Opt-in.
+#ifndef PGRF_PREC
+#define PGRF_PREC 0
+#endif
+#if PGRF_PREC == 0
+#define PGRF_PREC_NS p32
+#else
+#define PGRF_PREC_NS p16
+#endif
 
+namespace pgrf {
+namespace PGRF_PREC_NS {
+
+constexpr int kPrec = PGRF_PREC;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
@@ -54,9 +71,66 @@ __device__ __forceinline__ void elu16(f32x16& a) {
 
 // One Linear layer on the matrix cores for NT point tiles sharing the A operand.
 //   acc[t][m] (+)= A(m) * b[t]   with b[t][s] = B operand of k-step s (see pgrf_layout.h)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+union H8 { f16x8 v; fp16x2 p[4]; uint4 u; };
+
+// x[0..7] (fp32) -> hi, lo halves with x ~= hi + lo: hi = rtz16(x), lo = rtz16(x - hi) (the difference is exact)
+__device__ __forceinline__ void split8(const float (&x)[8], H8& hi, H8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * e], x[2 * e + 1]);
+    hi.p[e] = h;
+    lo.p[e] = __builtin_amdgcn_cvt_pkrtz(x[2 * e] - (float)h[0], x[2 * e + 1] - (float)h[1]);
+  }
+}
+
+// split-f16 evaluation of one layer; Hblk = this layer's [mt][g][piece][lane][8] block (pgrf_layout.h)
+template <int KS, int MT, int NT, bool INIT_BIAS>
+__device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, const float* __restrict__ B, int lane,
+                                             const float (&b)[NT][KS], f32x16 (&acc)[NT][MT]) {
+  constexpr int G = (KS + 7) / 8;
+  H8 bh[NT][G], bl[NT][G];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[t][8 * g + e < KS ? 8 * g + e : 0] : 0.f;
+      split8(x, bh[t][g], bl[t][g]);
+    }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (INIT_BIAS) {
+      const float4* bp = reinterpret_cast<const float4*>(B + m * 32 + (lane >> 5) * 16);
+      const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+      const f32x16 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][m] = bv;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      H8 a1, a2;
+      a1.u = reinterpret_cast<const uint4*>(Hblk)[((m * G + g) * 2 + 0) * 64 + lane];
+      a2.u = reinterpret_cast<const uint4*>(Hblk)[((m * G + g) * 2 + 1) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2.v, bh[t][g].v, acc[t][m], 0, 0, 0);
+        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.v, bl[t][g].v, acc[t][m], 0, 0, 0);
+        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.v, bh[t][g].v, acc[t][m], 0, 0, 0);
+      }
+    }
+  }
+}
+
 template <int KS, int MT, int NT, bool INIT_BIAS>
 __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const float* __restrict__ B, int lane,
-                                           const float (&b)[NT][KS], f32x16 (&acc)[NT][MT]) {
+                                           const float (&b)[NT][KS], f32x16 (&acc)[NT][MT], const float* __restrict__ Hblk = nullptr) {
+  if constexpr (kPrec == 1) {
+    mfma_layer_h<KS, MT, NT, INIT_BIAS>(Hblk, B, lane, b, acc);
+    return;
+  }
   constexpr int KS4 = (KS + 3) / 4;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -271,7 +345,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
 #pragma unroll
       for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[s]);
     }
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2);
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2, W + layer_h_off(L_DD2_0 + m));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       elu16(a2[t][0]);
@@ -331,7 +405,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int s = 0; s < 16; ++s) b2[t][s] = fmaxf(a1[t][0][s], 0.f);
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_PE2), W + layer_b_off(L_PE2), lane, b2, a2);
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_PE2), W + layer_b_off(L_PE2), lane, b2, a2, W + layer_h_off(L_PE2));
 #pragma unroll
     for (int t = 0; t < NT; ++t) vs[V0 + t].nf = a2[t][0];
   }
@@ -343,7 +417,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
 #pragma unroll
       for (int s = 0; s < 16; ++s) b16[t][s] = vs[V0 + t].nf[s];
     f32x16 a1[NT][1];
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_NF1), W + layer_b_off(L_NF1), lane, b16, a1);
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_NF1), W + layer_b_off(L_NF1), lane, b16, a1, W + layer_h_off(L_NF1));
     const float wgt = 1.f / ((float)V + 1e-8f);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -365,13 +439,13 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       b2[t][1] = half ? vs[V0 + t].dd[3] : vs[V0 + t].dd[2];
     }
     f32x16 a1[NT][1], a2[NT][2];
-    mfma_layer<2, 1, NT, true>(W + layer_a_off(L_RD1), W + layer_b_off(L_RD1), lane, b2, a1);
+    mfma_layer<2, 1, NT, true>(W + layer_a_off(L_RD1), W + layer_b_off(L_RD1), lane, b2, a1, W + layer_h_off(L_RD1));
     float b8[NT][8];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
-    mfma_layer<8, 2, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2);
+    mfma_layer<8, 2, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2, W + layer_h_off(L_RD2));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int v = V0 + t;
@@ -424,7 +498,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
       h[t][0] = G[0];
       h[t][1] = G[1];
     }
-    mfma_layer<35, 2, NT, false>(W + layer_a_off(L_BV), nullptr, lane, b35, h);
+    mfma_layer<35, 2, NT, false>(W + layer_a_off(L_BV), nullptr, lane, b35, h, W + layer_h_off(L_BV));
   }
   f32x16 x[NT][1];
   {
@@ -436,7 +510,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
         b32[t][s] = elu1(h[t][0][s]);
         b32[t][16 + s] = elu1(h[t][1][s]);
       }
-    mfma_layer<32, 1, NT, true>(W + layer_a_off(L_B2), W + layer_b_off(L_B2), lane, b32, x);
+    mfma_layer<32, 1, NT, true>(W + layer_a_off(L_B2), W + layer_b_off(L_B2), lane, b32, x, W + layer_h_off(L_B2));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       elu16(x[t][0]);
@@ -452,7 +526,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
 #pragma unroll
       for (int s = 0; s < 16; ++s) b16[t][s] = x[t][0][s] * wgt;
     f32x16 a1[NT][1], a2[NT][1];
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF1), W + layer_b_off(L_VF1), lane, b16, a1);
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF1), W + layer_b_off(L_VF1), lane, b16, a1, W + layer_h_off(L_VF1));
     float c16[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -460,7 +534,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
 #pragma unroll
       for (int s = 0; s < 16; ++s) c16[t][s] = a1[t][0][s];
     }
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF2), W + layer_b_off(L_VF2), lane, c16, a2);
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF2), W + layer_b_off(L_VF2), lane, c16, a2, W + layer_h_off(L_VF2));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float raw = head_dot<16>(W + OFF_VFH_W, half, a1[t][0]) + W[OFF_VFH_B];
@@ -477,7 +551,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
 #pragma unroll
       for (int s = 0; s < 16; ++s) b16[t][s] = x[t][0][s] * vis1[t];
     f32x16 a1[NT][1];
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_V21), W + layer_b_off(L_V21), lane, b16, a1);
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_V21), W + layer_b_off(L_V21), lane, b16, a1, W + layer_h_off(L_V21));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       elu16(a1[t][0]);
@@ -504,13 +578,13 @@ __device__ __forceinline__ void stage_rgb(const PassArgs& p, const ViewState (&v
     b19[t][18] = half ? 0.f : vs[v].dd[3];
   }
   f32x16 a1[NT][1], a2[NT][1];
-  mfma_layer<19, 1, NT, true>(W + layer_a_off(L_RGB1), W + layer_b_off(L_RGB1), lane, b19, a1);
+  mfma_layer<19, 1, NT, true>(W + layer_a_off(L_RGB1), W + layer_b_off(L_RGB1), lane, b19, a1, W + layer_h_off(L_RGB1));
   float b8[NT][8];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
-  mfma_layer<8, 1, NT, true>(W + layer_a_off(L_RGB2), W + layer_b_off(L_RGB2), lane, b8, a2);
+  mfma_layer<8, 1, NT, true>(W + layer_a_off(L_RGB2), W + layer_b_off(L_RGB2), lane, b8, a2, W + layer_h_off(L_RGB2));
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     f32x16 hh = a2[t][0];
@@ -627,7 +701,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       }
       b76[0][j] = m0; b76[0][19 + j] = v0; b76[0][38 + j] = m1; b76[0][57 + j] = v1;
     }
-    mfma_layer<76, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b76, G);
+    mfma_layer<76, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b76, G, W + layer_h_off(L_BG));
   }
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
@@ -663,12 +737,12 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     }
     b33[0][32] = wmean;
     f32x16 g1[1][2];
-    mfma_layer<33, 2, 1, true>(W + layer_a_off(L_G1), W + layer_b_off(L_G1), lane, b33, g1);
+    mfma_layer<33, 2, 1, true>(W + layer_a_off(L_G1), W + layer_b_off(L_G1), lane, b33, g1, W + layer_h_off(L_G1));
     float b32[1][32];
 #pragma unroll
     for (int s = 0; s < 16; ++s) { b32[0][s] = elu1(g1[0][0][s]); b32[0][16 + s] = elu1(g1[0][1][s]); }
     f32x16 g2[1][1];
-    mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2);
+    mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2, W + layer_h_off(L_G2));
     float gp[1][8];     // geometry feature + positional encoding (ibrnet.py:356-358)
     {
       const float4* pp = reinterpret_cast<const float4*>(W + OFF_POS + si * 16 + half * 8);
@@ -686,7 +760,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     f32x16 qkv[1][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { qkv[0][0][r] = 0.f; qkv[0][1][r] = 0.f; }   // no bias on w_qs/w_ks/w_vs
-    mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv);
+    mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv, W + layer_h_off(L_QKV));
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
@@ -737,7 +811,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     f32x16 fo[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) fo[0][0][r] = (r < 8) ? gp[0][r < 8 ? r : 0] : 0.f;     // residual as the initial accumulator
-    mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo);
+    mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo, W + layer_h_off(L_FC));
     float ln[1][8];
     {
       float sum = 0.f;
@@ -762,7 +836,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     }
     // out_geometry_fc 16 -> 16 elu -> 1 relu  (ibrnet.py:361)
     f32x16 og[1][1];
-    mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og);
+    mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og, W + layer_h_off(L_OG1));
 #pragma unroll
     for (int r = 0; r < 8; ++r) og[0][0][r] = elu1(og[0][0][r]);
     sigma = fmaxf(head_dot<8>(W + OFF_OGH_W, half, og[0][0]) + W[OFF_OGH_B], 0.f);
@@ -835,4 +909,5 @@ int launch_instance(const PassArgs& a, void* stream) {
   return PGRF_OK;
 }
 
+}  // namespace PGRF_PREC_NS
 }  // namespace pgrf

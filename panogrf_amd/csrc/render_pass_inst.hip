@@ -1,12 +1,12 @@
 // One instantiation of the fused render-pass kernel per translation unit (compiled in parallel):
-//   -DPGRF_KT=<dn/32> -DPGRF_V=<source views> -DPGRF_DBG=<0|1>
+//   -DPGRF_KT=<dn/32> -DPGRF_V=<source views> -DPGRF_DBG=<0|1> -DPGRF_PREC=<0 f32 | 1 split-f16>
 #include "render_pass.h"
 
-#define PGRF_CAT2(a, b, c, d) a##_##b##_##c##_##d
-#define PGRF_CAT(a, b, c, d) PGRF_CAT2(a, b, c, d)
+#define PGRF_CAT2(a, b, c, d, e) a##_##b##_##c##_##d##_##e
+#define PGRF_CAT(a, b, c, d, e) PGRF_CAT2(a, b, c, d, e)
 
 namespace pgrf {
-int PGRF_CAT(launch_rp, PGRF_KT, PGRF_V, PGRF_DBG)(const PassArgs& a, void* stream) {
-  return launch_instance<PGRF_KT, PGRF_V, (PGRF_DBG != 0)>(a, stream);
+int PGRF_CAT(launch_rp, PGRF_KT, PGRF_V, PGRF_DBG, PGRF_PREC)(const PassArgs& a, void* stream) {
+  return PGRF_PREC_NS::launch_instance<PGRF_KT, PGRF_V, (PGRF_DBG != 0)>(a, stream);
 }
 }  // namespace pgrf

@@ -137,7 +137,10 @@ def _alloc_out(rn, dn, dev):
     return t, o
 
 
-def render_pass(frame, blob_dev, use_vis, coords, depth, debug=False):
+PRECISIONS = {'f32': 0, 'f16x3': 1}
+
+
+def render_pass(frame, blob_dev, use_vis, coords, depth, debug=False, precision='f32'):
     """One network pass; returns dict of [rn,...] CUDA tensors (reference key names without the
     leading qn axis).  `debug=True` also returns the intermediate tensors under 'dbg'."""
     _require_gpu()
@@ -151,7 +154,8 @@ def render_pass(frame, blob_dev, use_vis, coords, depth, debug=False):
     fs = frame.c_struct()
     nws = lib.pgrf_render_pass_workspace_bytes(C.byref(fs))
     ws = torch.empty(nws, dtype=torch.uint8, device=frame.device)
-    lib.check(lib.pgrf_render_pass(C.byref(fs), _ptr(blob_dev), int(bool(use_vis)), _ptr(coords), _ptr(depth), rn, dn,
+    flags = (1 if use_vis else 0) | (2 if PRECISIONS[precision] == 1 else 0)
+    lib.check(lib.pgrf_render_pass(C.byref(fs), _ptr(blob_dev), flags, _ptr(coords), _ptr(depth), rn, dn,
                                    C.byref(o), C.byref(dbg_s) if debug else None, _ptr(ws), C.c_size_t(nws), _stream()))
     if debug:
         t['dbg'] = dbg_t
@@ -170,6 +174,7 @@ def make_cfg(cfg):
     c.c2f_all = int(cfg.get('render_c2f_all', False))
     c.use_vis_coarse = int(cfg.get('dist_decoder_cfg', {}).get('use_vis', True))
     c.use_vis_fine = int(cfg.get('fine_dist_decoder_cfg', {}).get('use_vis', True))
+    c.precision = PRECISIONS[cfg.get('hip_precision', 'f32')]
     return c
 
 

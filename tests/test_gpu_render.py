@@ -223,3 +223,34 @@ def test_more_views_and_sample_counts_vs_oracle(views, dn, use_all):
     assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 2e-5
     assert FX.max_abs(out['density_nr'].cpu(), ref['density_nr']) < 1e-4 * max(1.0, float(ref['density_nr'].max()))
     assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), ref['pixel_colors_nr_fine']) > 60
+
+
+@pytest.mark.parametrize('name', STAGE_FIXTURES)
+def test_split_f16_precision_mode_vs_reference_fixtures(name):
+    """Opt-in `hip_precision='f16x3'` (three split-f16 MFMAs per product, fp32 accumulate): same acceptance
+    bounds on the pass outputs as the exact-fp32 path."""
+    E = _engine()
+    frame, w, cfg, g = FX.load(name)
+    fr = _frame(E, frame)
+    use_vis = cfg['dist_decoder_cfg']['use_vis']
+    for tag, dd, ag in [('coarse', 'dist_decoder', 'agg_net'), ('fine', 'fine_dist_decoder', 'fine_agg_net')]:
+        blob = E.pack_pass_weights(w, dd, ag, use_vis).cuda()
+        gold = g[tag]
+        out = E.render_pass(fr, blob, use_vis, frame['coords'], gold['depth'], precision='f16x3')
+        for k in ['density_nr', 'colors_nr', 'pixel_colors_nr', 'hit_prob_nr', 'render_depth']:
+            err = FX.max_abs(out[k].cpu(), gold[k])
+            assert err < TOL[k] * max(1.0, float(gold[k].abs().max())), (name, tag, k, err)
+
+
+def test_split_f16_full_frame_psnr_vs_f32():
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(128, 256, 2, 64, seed=2, fine=True)
+    fr = _frame(E, case['frame'])
+    H, W = 128, 256
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    a = E.RayRenderer(case['cfg'], case['weights']).render_rays(fr, coords)
+    b = E.RayRenderer({**case['cfg'], 'hip_precision': 'f16x3'}, case['weights']).render_rays(fr, coords)
+    assert FX.psnr(b['pixel_colors_nr'].cpu(), a['pixel_colors_nr'].cpu()) > 100.0
+    assert FX.psnr(b['pixel_colors_nr_fine'].cpu(), a['pixel_colors_nr_fine'].cpu()) > 70.0
