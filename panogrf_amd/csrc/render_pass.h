@@ -90,37 +90,44 @@ template <int KS, int MT, int NT, bool INIT_BIAS>
 __device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, const float* __restrict__ B, int lane,
                                              const float (&b)[NT][KS], f32x16 (&acc)[NT][MT]) {
   constexpr int G = (KS + 7) / 8;
-  H8 bh[NT][G], bl[NT][G];
+  if (INIT_BIAS) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float x[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[t][8 * g + e < KS ? 8 * g + e : 0] : 0.f;
-      split8(x, bh[t][g], bl[t][g]);
-    }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    if (INIT_BIAS) {
+    for (int m = 0; m < MT; ++m) {
       const float4* bp = reinterpret_cast<const float4*>(B + m * 32 + (lane >> 5) * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       const f32x16 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t][m] = bv;
     }
+  }
+  // k-group outermost: only one group's split operands (8 registers per point tile) are live at a time
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
+  for (int g = 0; g < G; ++g) {
+    H8 bh[NT], bl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (8 * g + e < KS) ? b[t][8 * g + e < KS ? 8 * g + e : 0] : 0.f;
+      split8(x, bh[t], bl[t]);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
       H8 a1, a2;
       a1.u = reinterpret_cast<const uint4*>(Hblk)[((m * G + g) * 2 + 0) * 64 + lane];
       a2.u = reinterpret_cast<const uint4*>(Hblk)[((m * G + g) * 2 + 1) * 64 + lane];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2.v, bh[t][g].v, acc[t][m], 0, 0, 0);
-        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.v, bl[t][g].v, acc[t][m], 0, 0, 0);
-        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.v, bh[t][g].v, acc[t][m], 0, 0, 0);
+        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2.v, bh[t].v, acc[t][m], 0, 0, 0);
+        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.v, bl[t].v, acc[t][m], 0, 0, 0);
+        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.v, bh[t].v, acc[t][m], 0, 0, 0);
       }
     }
+#ifndef PGRF_NO_GROUP_FENCE
+    // long layers: keep the scheduler from hoisting every group's f32->f16 split (and the values feeding it) in
+    // front of the first MFMA, which is what made the 140-input layer spill
+    if (G >= 4) __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
@@ -594,6 +601,24 @@ __device__ __forceinline__ void stage_rgb(const PassArgs& p, const ViewState (&v
   }
 }
 
+#ifdef PGRF_STAGE_TIMING
+// experiment builds only (tools/stage_timing.py): per-stage wave cycles summed into a device-global table
+__device__ unsigned long long g_stage_cycles[16];
+#define PGRF_TICK(i)                                                                    \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();                      \
+    if (lane == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stage_cycles[i], t_now - t_prev);                       \
+    t_prev = t_now;                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
+#elif defined(PGRF_NO_STAGE_FENCE)
+#define PGRF_TICK(i) do {} while (0)
+#else
+// stage boundaries are scheduling fences: measured 47.5 -> 46.3 ms/frame (fewer live ranges crossing stages)
+#define PGRF_TICK(i) __builtin_amdgcn_sched_barrier(0)
+#endif
+
 constexpr int kKStride = 17;   // K rows in LDS: odd stride -> conflict-free column reads (A operand)
 constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast float4 reads
 
@@ -603,7 +628,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   constexpr int RPW = 4 / KT;          // rays per workgroup
   __shared__ __attribute__((aligned(16))) float lds_v[128 * kVStride];
   __shared__ float lds_k[128 * kKStride];
-  __shared__ float lds_alpha[128];
+  __shared__ float lds_alpha[4];     // per-wave transmittance totals
   __shared__ float lds_red[4][4];
   // debug builds: the 12 dump pointers live in LDS, not in SGPRs (24 live SGPRs made the compiler spill scalars)
   __shared__ float* lds_dbg[DBG ? 12 : 1];
@@ -614,6 +639,9 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   }
 
   const int lane = threadIdx.x & 63;
+#ifdef PGRF_STAGE_TIMING
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   const int wave = threadIdx.x >> 6;
   const int half = lane >> 5;
   const int pl = lane & 31;
@@ -672,11 +700,13 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
 
   ViewState vs[V];
   const bool store_ok = ray_ok;
+  PGRF_TICK(0);   // ray generation
 
   // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
   stage_front<V, 0, (V >= 2 ? 2 : 1), DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (V > 2) stage_front<V, 2, V - 2, DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg);
+  PGRF_TICK(1);   // stage A
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage B: view statistics (ibrnet.py:112-116,339-342) and the view-shared part of base_fc.0
@@ -703,12 +733,14 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     }
     mfma_layer<76, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b76, G, W + layer_h_off(L_BG));
   }
+  PGRF_TICK(2);   // stage B
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage C: per-view base_fc / vis_fc / vis_fc2
   stage_mid<V, 0, (V >= 2 ? 2 : 1), DBG>(p, G[0], vs, lane, pt, store_ok, sdbg);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (V > 2) stage_mid<V, 2, V - 2, DBG>(p, G[0], vs, lane, pt, store_ok, sdbg);
+  PGRF_TICK(3);   // stage C
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage D: pooled geometry feature -> geometry_fc -> ray attention -> density
@@ -766,7 +798,9 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
       lds_v[pt_local * kVStride + 2 * r + half] = qkv[0][1][r];
     }
+    PGRF_TICK(4);   // stage D up to the q/k/v projections
     PGRF_SYNC();
+    PGRF_TICK(5);   // barrier wait
     float oatt[16];
     const int key_base = ray_local * DN;
 #pragma unroll
@@ -804,6 +838,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       const float rl = rcp1(l);
       oatt[hd * 4 + 0] = o0 * rl; oatt[hd * 4 + 1] = o1 * rl; oatt[hd * 4 + 2] = o2 * rl; oatt[hd * 4 + 3] = o3 * rl;
     }
+    PGRF_TICK(6);   // attention
     // fc + residual + LayerNorm(eps 1e-6)  (ibrnet.py:95-102)
     float bo[1][8];
 #pragma unroll
@@ -841,6 +876,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     for (int r = 0; r < 8; ++r) og[0][0][r] = elu1(og[0][0][r]);
     sigma = fmaxf(head_dot<8>(W + OFF_OGH_W, half, og[0][0]) + W[OFF_OGH_B], 0.f);
   }
+  PGRF_TICK(7);   // fc + LayerNorm + density head
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage E: colour blending over views (ibrnet.py:364-370)
@@ -864,23 +900,37 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       for (int c = 0; c < 3; ++c) col[c] += vs[v].rgb[c] * bw;
     }
   }
+  PGRF_TICK(8);   // stage E
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage F: alpha compositing along the ray (renderer.py:216-218,291-304; render_ops.py:145-153)
   const float alpha = 1.f - __expf(-fmaxf(sigma, 0.f));
-  if (half == 0) lds_alpha[pt_local] = alpha;
-  PGRF_SYNC();
-  float T = 1.f;
-  for (int j = 0; j < DN; ++j) {
-    const float a = lds_alpha[ray_local * DN + j];
-    if (j < si) T *= (1.f - a + 1e-10f);
+  // transmittance T(i) = prod_{j<i} (1 - alpha_j + 1e-10): inclusive product scan over the wave's 32 samples (both lane
+  // halves carry the same value), then the totals of the ray's earlier waves through LDS
+  float incl = 1.f - alpha + 1e-10f;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const float up = __shfl_up(incl, off, 32);
+    if (pl >= off) incl *= up;
   }
+  float T = __shfl_up(incl, 1, 32);
+  if (pl == 0) T = 1.f;
+  if (KT > 1) {
+    if (lane == 31) lds_alpha[wave] = incl;
+    PGRF_SYNC();
+  }
+  PGRF_TICK(10);  // composite: barrier
+#pragma unroll
+  for (int k2 = 0; k2 < KT - 1; ++k2)
+    if (k2 < kt) T *= lds_alpha[ray_local * KT + k2];
   const float hit = alpha * T;
+  PGRF_TICK(11);  // composite: transmittance scan
   if (store_ok && half == 0) {
     if (p.out_hit) p.out_hit[pt] = hit;
     if (p.out_density) p.out_density[pt] = sigma;
     if (p.out_colors) { p.out_colors[pt * 3] = col[0]; p.out_colors[pt * 3 + 1] = col[1]; p.out_colors[pt * 3 + 2] = col[2]; }
   }
+  PGRF_TICK(12);  // composite: per-point stores
   float acc4[4] = {hit * col[0], hit * col[1], hit * col[2], hit * tdepth};
 #pragma unroll
   for (int off = 16; off >= 1; off >>= 1)
@@ -897,6 +947,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     if (lane < 3) { if (p.out_pixel) p.out_pixel[(size_t)ray * 3 + lane] = s; }
     else if (p.out_depth) p.out_depth[ray] = s;
   }
+  PGRF_TICK(9);   // composite
 }
 
 template <int KT, int V, bool DBG>
