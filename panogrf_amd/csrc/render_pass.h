@@ -62,7 +62,25 @@ __device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(
 // division costs ~11 VALU instructions, and VALU time adds to f32-MFMA time on this chip.
 __device__ __forceinline__ float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sigmoid1(float x) { return rcp1(1.f + __expf(-x)); }
-__device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+// nn.Softplus (beta 1, threshold 20) as max(x,0) + log(1 + exp(-|x|)) on v_exp/v_log: absolute error ~1e-7, the size of one
+// fp32 rounding of the result's integer part; libm's log1pf is a ~140-instruction double-float routine (measured: the
+// 8 calls per wave were 4 % of the kernel).  For x > 20 the second term is below half an ulp of x: same as the threshold.
+__device__ __forceinline__ float softplus1(float x) {
+#ifdef PGRF_LIBM_SOFTPLUS
+  return x > 20.f ? x : log1pf(__expf(x));
+#else
+  const float t = __builtin_amdgcn_exp2f(-fabsf(x) * 1.4426950408889634f);
+  return fmaf(__builtin_amdgcn_logf(1.f + t), 0.6931471805599453f, fmaxf(x, 0.f));
+#endif
+}
+// logistic CDF 0.5 + 0.5 tanh(d) == 1 / (1 + exp(-2d))  (dist_decoder.py:129-130), 4 instructions instead of libm tanhf
+__device__ __forceinline__ float cdf1(float d) {
+#ifdef PGRF_LIBM_TANH
+  return 0.5f + 0.5f * tanhf(d);
+#else
+  return rcp1(1.f + __builtin_amdgcn_exp2f(d * -2.8853900817779268f));
+#endif
+}
 
 __device__ __forceinline__ void elu16(f32x16& a) {
 #pragma unroll
@@ -251,6 +269,44 @@ __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const 
   return out;
 }
 
+// The same gather in two halves, so the 16 tap loads of the NEXT block can be in flight while the matrix cores work on
+// the current one (the loads depend on computed pixel positions: nothing else hides their L2 latency).
+struct Taps { float4 t[16]; };
+template <int STRIDE = 32, int Q0 = 0, int Q1 = 4>
+__device__ __forceinline__ void gather_issue(Taps& r, const float* __restrict__ map, const Bilin& b, int half) {
+  const float* base = map + half * 4;
+#pragma unroll
+  for (int q = Q0; q < Q1; ++q) {
+    r.t[4 * q + 0] = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * STRIDE + q * 8);
+    r.t[4 * q + 1] = *reinterpret_cast<const float4*>(base + (size_t)b.o01 * STRIDE + q * 8);
+    r.t[4 * q + 2] = *reinterpret_cast<const float4*>(base + (size_t)b.o10 * STRIDE + q * 8);
+    r.t[4 * q + 3] = *reinterpret_cast<const float4*>(base + (size_t)b.o11 * STRIDE + q * 8);
+  }
+}
+template <int Q0 = 0, int Q1 = 4>
+__device__ __forceinline__ void gather_blend_q(f32x16& out, const Taps& r, const Bilin& b) {
+#pragma unroll
+  for (int q = Q0; q < Q1; ++q) {
+    const float4 a = r.t[4 * q], c = r.t[4 * q + 1], d = r.t[4 * q + 2], e = r.t[4 * q + 3];
+    out[4 * q + 0] = a.x * b.wnw + c.x * b.wne + d.x * b.wsw + e.x * b.wse;
+    out[4 * q + 1] = a.y * b.wnw + c.y * b.wne + d.y * b.wsw + e.y * b.wse;
+    out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
+    out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
+  }
+}
+__device__ __forceinline__ f32x16 gather_blend(const Taps& r, const Bilin& b) {
+  f32x16 out;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 a = r.t[4 * q], c = r.t[4 * q + 1], d = r.t[4 * q + 2], e = r.t[4 * q + 3];
+    out[4 * q + 0] = a.x * b.wnw + c.x * b.wne + d.x * b.wsw + e.x * b.wse;
+    out[4 * q + 1] = a.y * b.wnw + c.y * b.wne + d.y * b.wsw + e.y * b.wse;
+    out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
+    out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
+  }
+  return out;
+}
+
 __device__ __forceinline__ void dump_tile32(float* dst, const f32x16& x, int half) {   // dst -> 32 floats of this point
 #pragma unroll
   for (int r = 0; r < 16; ++r) dst[rho(r, half)] = x[r];
@@ -259,6 +315,24 @@ __device__ __forceinline__ void dump_tile16(float* dst, const f32x16& x, int hal
 #pragma unroll
   for (int r = 0; r < 8; ++r) dst[rho(r, half)] = x[r];
 }
+
+#ifdef PGRF_STAGE_TIMING
+// experiment builds only (tools/stage_timing.py): per-stage wave cycles summed into a device-global table
+__device__ unsigned long long g_stage_cycles[32];
+#define PGRF_TICK(i)                                                                    \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();                      \
+    if (lane == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stage_cycles[i], t_now - t_prev);                       \
+    t_prev = t_now;                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
+#elif defined(PGRF_NO_STAGE_FENCE)
+#define PGRF_TICK(i) do {} while (0)
+#else
+// stage boundaries are scheduling fences: measured 47.5 -> 46.3 ms/frame (fewer live ranges crossing stages)
+#define PGRF_TICK(i) __builtin_amdgcn_sched_barrier(0)
+#endif
 
 struct ViewState {
   f32x16 fa;      // rgb_feat tile A (img-feat part, + dir feat); later: x (base_fc output, 32)
@@ -282,7 +356,11 @@ struct PointGeom {
 template <int V, int V0, int NT, bool DBG>
 __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& g, ViewState (&vs)[V], int lane,
                                             size_t pt /* ray*DN+sample */, size_t npts, bool store_ok,
-                                            float* const* sdbg) {
+                                            float* const* sdbg
+#ifdef PGRF_STAGE_TIMING
+                                            , unsigned long long& t_prev
+#endif
+                                            ) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
   float vis_s[NT], hit_s[NT];
@@ -336,11 +414,21 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     }
   }
 
+  PGRF_TICK(16);  // A: projection + tap setup
   // ---- mixture-of-logistics decoder: 3 (4) MLPs 32 -> 32 -> 32 -> head  (dist_decoder.py:53-107)
   // layer 0 of each MLP is read from the per-pixel projection map (pre-activation incl. bias): no MFMA
   float head[NT][6];
 #pragma unroll
   for (int t = 0; t < NT; ++t) head[t][5] = 1.f;
+#ifdef PGRF_PIPE_GATHER
+#ifndef PGRF_PIPE_Q
+#define PGRF_PIPE_Q 4
+#endif
+  constexpr int PQ = PGRF_PIPE_Q;
+  Taps raw[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) gather_issue<kPrjCh, 0, PQ>(raw[t], prj[t], brf[t], half);
+#endif
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     if (m == 3 && !p.use_vis) break;
@@ -348,10 +436,26 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     float b2[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+#ifdef PGRF_PIPE_GATHER
+      f32x16 a1;
+      gather_issue<kPrjCh, PQ, 4>(raw[t], prj[t] + (m < 3 ? m : 4) * 32, brf[t], half);
+      gather_blend_q<0, PQ>(a1, raw[t], brf[t]);
+      gather_blend_q<PQ, 4>(a1, raw[t], brf[t]);
+#else
       const f32x16 a1 = gather32<kPrjCh>(prj[t] + (m < 3 ? m : 4) * 32, brf[t], half);
+#endif
 #pragma unroll
       for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[s]);
     }
+#ifdef PGRF_PIPE_GATHER
+    {   // next block of the projection map: MLP m+1, or (after the last MLP) the prob_embed block
+      const int nb = (m == 2 && p.use_vis) ? 4 : (m >= 2 ? 3 : m + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) gather_issue<kPrjCh, 0, PQ>(raw[t], prj[t] + nb * 32, brf[t], half);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2, W + layer_h_off(L_DD2_0 + m));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -369,6 +473,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       }
     }
   }
+  PGRF_TICK(17);  // A: dist decoder MLPs
   // ---- compute_prob (dist_decoder.py:6-51 is_ref branch, :109-140)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -381,8 +486,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const float mean = head[t][k], var = head[t][2 + k];
-      float c0 = 0.5f + 0.5f * tanhf((nearp - mean) * var);
-      float c1 = 0.5f + 0.5f * tanhf((farp - mean) * var);
+      float c0 = cdf1((nearp - mean) * var);
+      float c1 = cdf1((farp - mean) * var);
       if (p.use_vis) { c0 *= head[t][5]; c1 *= head[t][5]; }
       const float mix = (k == 0) ? aw : 1.f - aw;
       visib += (1.f - c0) * mix;
@@ -396,6 +501,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       if (sdbg[4]) sdbg[4][o] = hitp;
     }
   }
+  PGRF_TICK(18);  // A: compute_prob
   // ---- prob_embed: [ray_feats(32), 2(hit-.5), 2(vis-.5)] -> 32 relu -> 32  (aggregate_net.py:53-61)
   {
     // the 32 ray-feature columns (+ bias) come from the projection map; only k-step 16 = (hit, vis) is left
@@ -403,10 +509,23 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     const float a16 = reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+#ifdef PGRF_PIPE_GATHER
+      f32x16 pe;
+      gather_issue<kPrjCh, PGRF_PIPE_Q, 4>(raw[t], prj[t] + 3 * 32, brf[t], half);
+      gather_blend_q<0, PGRF_PIPE_Q>(pe, raw[t], brf[t]);
+      gather_blend_q<PGRF_PIPE_Q, 4>(pe, raw[t], brf[t]);
+#else
       const f32x16 pe = gather32<kPrjCh>(prj[t] + 3 * 32, brf[t], half);
+#endif
       const float hv = half ? (vis_s[t] - 0.5f) * 2.f : (hit_s[t] - 0.5f) * 2.f;
       a1[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a16, hv, pe, 0, 0, 0);
     }
+#ifdef PGRF_PIPE_GATHER
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) gather_issue<32, 0, PGRF_PIPE_Q>(raw[t], p.img_feats + (size_t)(V0 + t) * p.hf * p.wf * 32, bfeat[t], half);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     float b2[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -416,6 +535,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
 #pragma unroll
     for (int t = 0; t < NT; ++t) vs[V0 + t].nf = a2[t][0];
   }
+  PGRF_TICK(19);  // A: prob_embed
   // ---- neuray_fc 32 -> 8 elu -> 1, weight0 = sigmoid(.) * w   (ibrnet.py:337-338)
   {
     float b16[NT][16];
@@ -437,6 +557,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
         dump_tile32(sdbg[8] + (pt * V + (V0 + t)) * 32, vs[V0 + t].nf, half);
     }
   }
+  PGRF_TICK(20);  // A: neuray_fc
   // ---- ray_dir_fc 4 -> 16 elu -> 35 elu; rgb_feat = [rgb, img_feats] + dir_feat  (ibrnet.py:325-327)
   {
     float b2[NT][2];
@@ -458,6 +579,11 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       const int v = V0 + t;
 #ifdef PGRF_EARLY_GATHER
       const f32x16 imf = imf_early[t];
+#elif defined(PGRF_PIPE_GATHER)
+      f32x16 imf;
+      gather_issue<32, PGRF_PIPE_Q, 4>(raw[t], p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
+      gather_blend_q<0, PGRF_PIPE_Q>(imf, raw[t], bfeat[t]);
+      gather_blend_q<PGRF_PIPE_Q, 4>(imf, raw[t], bfeat[t]);
 #else
       const f32x16 imf = gather32(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
 #endif
@@ -601,24 +727,6 @@ __device__ __forceinline__ void stage_rgb(const PassArgs& p, const ViewState (&v
   }
 }
 
-#ifdef PGRF_STAGE_TIMING
-// experiment builds only (tools/stage_timing.py): per-stage wave cycles summed into a device-global table
-__device__ unsigned long long g_stage_cycles[16];
-#define PGRF_TICK(i)                                                                    \
-  do {                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-    const unsigned long long t_now = __builtin_amdgcn_s_memtime();                      \
-    if (lane == 0 && (blockIdx.x & 63) == 5) atomicAdd(&g_stage_cycles[i], t_now - t_prev);                       \
-    t_prev = t_now;                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-  } while (0)
-#elif defined(PGRF_NO_STAGE_FENCE)
-#define PGRF_TICK(i) do {} while (0)
-#else
-// stage boundaries are scheduling fences: measured 47.5 -> 46.3 ms/frame (fewer live ranges crossing stages)
-#define PGRF_TICK(i) __builtin_amdgcn_sched_barrier(0)
-#endif
-
 constexpr int kKStride = 17;   // K rows in LDS: odd stride -> conflict-free column reads (A operand)
 constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast float4 reads
 
@@ -639,6 +747,10 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   }
 
   const int lane = threadIdx.x & 63;
+#ifdef PGRF_ONE_WG_PER_CU   // experiment: 84 KB of LDS ballast -> one workgroup (one wave per SIMD) per CU
+  __shared__ float lds_ballast[21000];
+  if (p.rn < 0) lds_ballast[threadIdx.x * 80] = 1.f;
+#endif
 #ifdef PGRF_STAGE_TIMING
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -703,9 +815,17 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   PGRF_TICK(0);   // ray generation
 
   // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
-  stage_front<V, 0, (V >= 2 ? 2 : 1), DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg);
+  stage_front<V, 0, (V >= 2 ? 2 : 1), DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                           , t_prev
+#endif
+  );
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (V > 2) stage_front<V, 2, V - 2, DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg);
+  if constexpr (V > 2) stage_front<V, 2, V - 2, DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                           , t_prev
+#endif
+  );
   PGRF_TICK(1);   // stage A
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)

@@ -13,9 +13,9 @@ int PGRF_CAT(launch_rp, PGRF_KT, PGRF_V, PGRF_DBG, PGRF_PREC)(const PassArgs& a,
 
 #ifdef PGRF_STAGE_TIMING
 // experiment builds only: read (and clear) the per-stage cycle table
-extern "C" int pgrf_exp_stage_cycles(unsigned long long* out16) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pgrf::PGRF_PREC_NS::g_stage_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  unsigned long long z[16] = {};
+extern "C" int pgrf_exp_stage_cycles(unsigned long long* out32) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(pgrf::PGRF_PREC_NS::g_stage_cycles), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[32] = {};
   return hipMemcpyToSymbol(HIP_SYMBOL(pgrf::PGRF_PREC_NS::g_stage_cycles), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -11,7 +11,9 @@ from panogrf_amd import engine as E, dist as D, _lib
 
 NAMES = ['ray generation', 'stage A front end (per view)', 'stage B stats + base_fc shared', 'stage C base/vis (per view)',
          'stage D geometry_fc..qkv', 'barrier wait', 'attention', 'fc+LN+density head', 'stage E rgb blend', 'composite: reduce + pixel store',
-         'composite: alpha + barrier', 'composite: transmittance scan', 'composite: per-point stores']
+         'composite: alpha + barrier', 'composite: transmittance scan', 'composite: per-point stores', '', '', '',
+         'A: projection + tap setup', 'A: dist decoder MLPs', 'A: compute_prob', 'A: prob_embed', 'A: neuray_fc']
+NAMES[1] = 'A: ray_dir_fc + img gather (rest of A)'
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--precision', default='f32')
@@ -29,7 +31,7 @@ fr = E.Frame(fr_in['imgs'], fr_in['img_feats'], fr_in['ray_feats'], fr_in['w2c']
 lib = ctypes.CDLL(_lib.library_path())
 fn = lib.pgrf_exp_stage_cycles
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 32)()
 rr.render_rays(fr, coords); torch.cuda.synchronize()
 fn(buf)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,4 +41,5 @@ waves = H * W * dn / 32 / 64     # one workgroup in 64 records
 tot = sum(buf)
 print(f'{a.precision} V={a.views}: {e0.elapsed_time(e1):.2f} ms/frame (instrumented); s_memtime ticks per wave, summed {tot / waves:.0f}')
 for i, n in enumerate(NAMES):
+    if not n: continue
     print(f'  {n:34s} {buf[i] / waves:9.0f}  {100.0 * buf[i] / tot:5.1f}%')
