@@ -221,6 +221,21 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
             H[((((size_t)m * G + g) * 2 + 1) * 64 + lane) * 8 + e] = h2;
           }
   }
+  // ---- LDS images (pgrf_layout.h: img_layer_off) ----------------------------------------------------
+  for (int prec = 0; prec < 2; ++prec) {
+    float* img = blob + (prec ? OFF_IMG16 : OFF_IMG32);
+    std::memcpy(img, blob + OFF_DDH_W, sizeof(float) * kHeadFloats);
+    for (int id = 0; id < L_COUNT; ++id) {
+      if (img_chunk(id) < 0) continue;
+      float* dst = img + img_layer_off(id, prec);
+      if (prec == 0 || id == L_PE1)
+        std::memcpy(dst, blob + layer_a_off(id) + (size_t)img_chunk(id) * 256, sizeof(float) * 256);
+      else
+        std::memcpy(dst, blob + layer_h_off(id), sizeof(float) * 512);     // (m=0, g=0): [piece][lane][8 halves]
+      if (img_has_bias(id))
+        std::memcpy(dst + img_a_floats(prec), blob + layer_b_off(id), sizeof(float) * b_size(kMT[id]));
+    }
+  }
   return PGRF_OK;
 }
 

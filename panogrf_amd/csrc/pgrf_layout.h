@@ -114,7 +114,30 @@ constexpr int layer_h_off(int id) {
   for (int i = 0; i < id; ++i) off += h_size(kKS[i], kMT[i]);
   return off;
 }
-constexpr int kBlobFloats = layer_h_off(L_COUNT);
+constexpr int kSplitEnd = layer_h_off(L_COUNT);
+// ---- LDS image: what every workgroup copies into LDS once, so that the loads a layer cannot start without come from
+// LDS (~100 cycles) instead of L2 (several hundred, exposed once per layer with two waves per SIMD):
+//   [head/LayerNorm region OFF_DDH_W..OFF_POS, verbatim]
+//   per layer: [first A chunk of tile 0 (f32: [lane][4] floats; split-f16: [piece][lane][8] halves)] [bias block]
+// prob_embed.0 keeps only its k-step-16 chunk (the rest lives in the projection map); the fused dist-decoder layer 0
+// is never evaluated per point and has no entry.  One image per precision mode (index 0: f32, 1: split-f16).
+constexpr int kHeadFloats = OFF_POS - OFF_DDH_W;
+constexpr int img_chunk(int id) { return id == L_DD1 ? -1 : (id == L_PE1 ? 4 : 0); }
+constexpr bool img_has_bias(int id) { return kHasBias[id] && id != L_PE1 && id != L_DD1; }
+constexpr int img_a_floats(int prec) { return prec ? 512 : 256; }
+constexpr int img_layer_size(int id, int prec) {
+  return img_chunk(id) < 0 ? 0 : img_a_floats(prec) + (img_has_bias(id) ? b_size(kMT[id]) : 0);
+}
+constexpr int img_layer_off(int id, int prec) {
+  int off = kHeadFloats;
+  for (int i = 0; i < id; ++i) off += img_layer_size(i, prec);
+  return off;
+}
+constexpr int img_floats(int prec) { return img_layer_off(L_COUNT, prec); }
+constexpr int OFF_IMG32 = kSplitEnd;
+constexpr int OFF_IMG16 = OFF_IMG32 + img_floats(0);
+constexpr int kBlobFloats = OFF_IMG16 + img_floats(1);
+static_assert(kHeadFloats % 4 == 0 && img_floats(0) % 4 == 0 && img_floats(1) % 4 == 0 && OFF_IMG32 % 4 == 0, "LDS image is copied as float4");
 
 // attention feature permutation: accumulator row rho (< 16) of the q / k / v projections holds
 // head-feature  attn_feat(rho)  so that register 2*head+s carries dims (2s, 2s+1) in the two lane halves.

@@ -87,6 +87,20 @@ __device__ __forceinline__ void elu16(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = elu1(a[r]);
 }
 
+// LDS image of the blob (pgrf_layout.h): LI is the workgroup's copy; -DPGRF_NO_LDS_IMG reads everything from global memory.
+// Measured (512x1024, 2 views): f32 43.34 -> 43.04 ms; split-f16 29.3 -> 32.3 ms (its 51 KB image costs 20 more spilled
+// registers), so that mode keeps reading from global memory.
+#if PGRF_PREC == 1 && !defined(PGRF_FORCE_LDS_IMG) && !defined(PGRF_NO_LDS_IMG)
+#define PGRF_NO_LDS_IMG
+#endif
+#ifdef PGRF_NO_LDS_IMG
+#define PGRF_LIMG(id) ((const float*)nullptr)
+#define PGRF_LHEAD(off) (W + (off))
+#else
+#define PGRF_LIMG(id) (LI + img_layer_off((id), kPrec))
+#define PGRF_LHEAD(off) (LI + ((off) - OFF_DDH_W))
+#endif
+
 // One Linear layer on the matrix cores for NT point tiles sharing the A operand.
 //   acc[t][m] (+)= A(m) * b[t]   with b[t][s] = B operand of k-step s (see pgrf_layout.h)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -106,12 +120,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], H8& hi, H8& lo) {
 // split-f16 evaluation of one layer; Hblk = this layer's [mt][g][piece][lane][8] block (pgrf_layout.h)
 template <int KS, int MT, int NT, bool INIT_BIAS>
 __device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, const float* __restrict__ B, int lane,
-                                             const float (&b)[NT][KS], f32x16 (&acc)[NT][MT]) {
+                                             const float (&b)[NT][KS], f32x16 (&acc)[NT][MT], const float* Limg) {
   constexpr int G = (KS + 7) / 8;
   if (INIT_BIAS) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const float4* bp = reinterpret_cast<const float4*>(B + m * 32 + (lane >> 5) * 16);
+      const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + 512 : B) + m * 32 + (lane >> 5) * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       const f32x16 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
 #pragma unroll
@@ -132,8 +146,13 @@ __device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, con
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       H8 a1, a2;
-      a1.u = reinterpret_cast<const uint4*>(Hblk)[((m * G + g) * 2 + 0) * 64 + lane];
-      a2.u = reinterpret_cast<const uint4*>(Hblk)[((m * G + g) * 2 + 1) * 64 + lane];
+      if (Limg && m == 0 && g == 0) {
+        a1.u = reinterpret_cast<const uint4*>(Limg)[lane];
+        a2.u = reinterpret_cast<const uint4*>(Limg)[64 + lane];
+      } else {
+        a1.u = reinterpret_cast<const uint4*>(Hblk)[((m * G + g) * 2 + 0) * 64 + lane];
+        a2.u = reinterpret_cast<const uint4*>(Hblk)[((m * G + g) * 2 + 1) * 64 + lane];
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2.v, bh[t].v, acc[t][m], 0, 0, 0);
@@ -151,9 +170,10 @@ __device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, con
 
 template <int KS, int MT, int NT, bool INIT_BIAS>
 __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const float* __restrict__ B, int lane,
-                                           const float (&b)[NT][KS], f32x16 (&acc)[NT][MT], const float* __restrict__ Hblk = nullptr) {
+                                           const float (&b)[NT][KS], f32x16 (&acc)[NT][MT], const float* __restrict__ Hblk,
+                                           const float* Limg) {
   if constexpr (kPrec == 1) {
-    mfma_layer_h<KS, MT, NT, INIT_BIAS>(Hblk, B, lane, b, acc);
+    mfma_layer_h<KS, MT, NT, INIT_BIAS>(Hblk, B, lane, b, acc, Limg);
     return;
   }
   constexpr int KS4 = (KS + 3) / 4;
@@ -161,7 +181,7 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
   for (int m = 0; m < MT; ++m) {
     f32x16 bv;
     if (INIT_BIAS) {
-      const float4* bp = reinterpret_cast<const float4*>(B + m * 32 + (lane >> 5) * 16);
+      const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + 256 : B) + m * 32 + (lane >> 5) * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
     }
@@ -170,7 +190,8 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
 #ifdef PGRF_ABL_WEIGHTS   // ablation (timing only): every weight load hits the same 1 KiB -> L1 resident
       const float4 a = reinterpret_cast<const float4*>(A)[lane + ((m * KS4 + s4) & 1) * 64];
 #else
-      const float4 a = reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
+      const float4 a = (Limg && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
+                                                   : reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
 #endif
       const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -354,7 +375,7 @@ struct PointGeom {
 // Stage A for NT views starting at V0: projection, gathers, dist decoder, prob_embed, neuray_fc,
 // ray_dir_fc.  Fills vs[V0..V0+NT).
 template <int V, int V0, int NT, bool DBG>
-__device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& g, ViewState (&vs)[V], int lane,
+__device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, const PointGeom& g, ViewState (&vs)[V], int lane,
                                             size_t pt /* ray*DN+sample */, size_t npts, bool store_ok,
                                             float* const* sdbg
 #ifdef PGRF_STAGE_TIMING
@@ -456,20 +477,20 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       __builtin_amdgcn_sched_barrier(0);
     }
 #endif
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2, W + layer_h_off(L_DD2_0 + m));
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2, W + layer_h_off(L_DD2_0 + m), PGRF_LIMG(L_DD2_0 + m));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       elu16(a2[t][0]);
       if (m == 0) {
-        head[t][0] = softplus1(head_dot<16>(W + OFF_DDH_W + 0 * 32, half, a2[t][0]) + W[OFF_DDH_B + 0]);
-        head[t][1] = softplus1(head_dot<16>(W + OFF_DDH_W + 1 * 32, half, a2[t][0]) + W[OFF_DDH_B + 1]);
+        head[t][0] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 0 * 32, half, a2[t][0]) + W[OFF_DDH_B + 0]);
+        head[t][1] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 1 * 32, half, a2[t][0]) + W[OFF_DDH_B + 1]);
       } else if (m == 1) {   // softplus + AddBias(0.05)  (dist_decoder.py:73-81)
-        head[t][2] = softplus1(head_dot<16>(W + OFF_DDH_W + 2 * 32, half, a2[t][0]) + W[OFF_DDH_B + 2]) + 0.05f;
-        head[t][3] = softplus1(head_dot<16>(W + OFF_DDH_W + 3 * 32, half, a2[t][0]) + W[OFF_DDH_B + 3]) + 0.05f;
+        head[t][2] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 2 * 32, half, a2[t][0]) + W[OFF_DDH_B + 2]) + 0.05f;
+        head[t][3] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 3 * 32, half, a2[t][0]) + W[OFF_DDH_B + 3]) + 0.05f;
       } else if (m == 2) {
-        head[t][4] = sigmoid1(head_dot<16>(W + OFF_DDH_W + 4 * 32, half, a2[t][0]) + W[OFF_DDH_B + 4]);
+        head[t][4] = sigmoid1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 4 * 32, half, a2[t][0]) + W[OFF_DDH_B + 4]);
       } else {
-        head[t][5] = sigmoid1(head_dot<16>(W + OFF_DDH_W + 5 * 32, half, a2[t][0]) + W[OFF_DDH_B + 5]);
+        head[t][5] = sigmoid1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 5 * 32, half, a2[t][0]) + W[OFF_DDH_B + 5]);
       }
     }
   }
@@ -506,7 +527,11 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
   {
     // the 32 ray-feature columns (+ bias) come from the projection map; only k-step 16 = (hit, vis) is left
     f32x16 a1[NT][1], a2[NT][1];
+#ifdef PGRF_NO_LDS_IMG
     const float a16 = reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
+#else
+    const float a16 = PGRF_LIMG(L_PE1)[lane * 4];
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #ifdef PGRF_PIPE_GATHER
@@ -531,7 +556,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int s = 0; s < 16; ++s) b2[t][s] = fmaxf(a1[t][0][s], 0.f);
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_PE2), W + layer_b_off(L_PE2), lane, b2, a2, W + layer_h_off(L_PE2));
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_PE2), W + layer_b_off(L_PE2), lane, b2, a2, W + layer_h_off(L_PE2), PGRF_LIMG(L_PE2));
 #pragma unroll
     for (int t = 0; t < NT; ++t) vs[V0 + t].nf = a2[t][0];
   }
@@ -544,14 +569,14 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
 #pragma unroll
       for (int s = 0; s < 16; ++s) b16[t][s] = vs[V0 + t].nf[s];
     f32x16 a1[NT][1];
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_NF1), W + layer_b_off(L_NF1), lane, b16, a1, W + layer_h_off(L_NF1));
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_NF1), W + layer_b_off(L_NF1), lane, b16, a1, W + layer_h_off(L_NF1), PGRF_LIMG(L_NF1));
     const float wgt = 1.f / ((float)V + 1e-8f);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x16 h = a1[t][0];
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[r] = elu1(h[r]);
-      const float y = head_dot<4>(W + OFF_NFH_W, half, h) + W[OFF_NFH_B];
+      const float y = head_dot<4>(PGRF_LHEAD(OFF_NFH_W), half, h) + W[OFF_NFH_B];
       vs[V0 + t].w0 = sigmoid1(y) * wgt;
       if (DBG && store_ok && sdbg[8])
         dump_tile32(sdbg[8] + (pt * V + (V0 + t)) * 32, vs[V0 + t].nf, half);
@@ -567,13 +592,13 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
       b2[t][1] = half ? vs[V0 + t].dd[3] : vs[V0 + t].dd[2];
     }
     f32x16 a1[NT][1], a2[NT][2];
-    mfma_layer<2, 1, NT, true>(W + layer_a_off(L_RD1), W + layer_b_off(L_RD1), lane, b2, a1, W + layer_h_off(L_RD1));
+    mfma_layer<2, 1, NT, true>(W + layer_a_off(L_RD1), W + layer_b_off(L_RD1), lane, b2, a1, W + layer_h_off(L_RD1), PGRF_LIMG(L_RD1));
     float b8[NT][8];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
-    mfma_layer<8, 2, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2, W + layer_h_off(L_RD2));
+    mfma_layer<8, 2, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2, W + layer_h_off(L_RD2), PGRF_LIMG(L_RD2));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int v = V0 + t;
@@ -611,7 +636,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const PointGeom& 
 // ---------------------------------------------------------------------------------------------
 // Stage C for NT views: base_fc (per-view part, onto the shared partial G), vis_fc, vis_fc2.
 template <int V, int V0, int NT, bool DBG>
-__device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2], ViewState (&vs)[V], int lane,
+__device__ __forceinline__ void stage_mid(const PassArgs& p, const float* LI, const f32x16 (&G)[2], ViewState (&vs)[V], int lane,
                                           size_t pt, bool store_ok, float* const* sdbg) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
@@ -631,7 +656,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
       h[t][0] = G[0];
       h[t][1] = G[1];
     }
-    mfma_layer<35, 2, NT, false>(W + layer_a_off(L_BV), nullptr, lane, b35, h, W + layer_h_off(L_BV));
+    mfma_layer<35, 2, NT, false>(W + layer_a_off(L_BV), nullptr, lane, b35, h, W + layer_h_off(L_BV), PGRF_LIMG(L_BV));
   }
   f32x16 x[NT][1];
   {
@@ -643,7 +668,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
         b32[t][s] = elu1(h[t][0][s]);
         b32[t][16 + s] = elu1(h[t][1][s]);
       }
-    mfma_layer<32, 1, NT, true>(W + layer_a_off(L_B2), W + layer_b_off(L_B2), lane, b32, x, W + layer_h_off(L_B2));
+    mfma_layer<32, 1, NT, true>(W + layer_a_off(L_B2), W + layer_b_off(L_B2), lane, b32, x, W + layer_h_off(L_B2), PGRF_LIMG(L_B2));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       elu16(x[t][0]);
@@ -659,7 +684,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
 #pragma unroll
       for (int s = 0; s < 16; ++s) b16[t][s] = x[t][0][s] * wgt;
     f32x16 a1[NT][1], a2[NT][1];
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF1), W + layer_b_off(L_VF1), lane, b16, a1, W + layer_h_off(L_VF1));
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF1), W + layer_b_off(L_VF1), lane, b16, a1, W + layer_h_off(L_VF1), PGRF_LIMG(L_VF1));
     float c16[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -667,10 +692,10 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
 #pragma unroll
       for (int s = 0; s < 16; ++s) c16[t][s] = a1[t][0][s];
     }
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF2), W + layer_b_off(L_VF2), lane, c16, a2, W + layer_h_off(L_VF2));
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_VF2), W + layer_b_off(L_VF2), lane, c16, a2, W + layer_h_off(L_VF2), PGRF_LIMG(L_VF2));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const float raw = head_dot<16>(W + OFF_VFH_W, half, a1[t][0]) + W[OFF_VFH_B];
+      const float raw = head_dot<16>(PGRF_LHEAD(OFF_VFH_W), half, a1[t][0]) + W[OFF_VFH_B];
       vis1[t] = sigmoid1(elu1(raw));
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[t][0][r] += elu1(a2[t][0][r]);
@@ -684,11 +709,11 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
 #pragma unroll
       for (int s = 0; s < 16; ++s) b16[t][s] = x[t][0][s] * vis1[t];
     f32x16 a1[NT][1];
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_V21), W + layer_b_off(L_V21), lane, b16, a1, W + layer_h_off(L_V21));
+    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_V21), W + layer_b_off(L_V21), lane, b16, a1, W + layer_h_off(L_V21), PGRF_LIMG(L_V21));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       elu16(a1[t][0]);
-      vs[V0 + t].v2 = sigmoid1(head_dot<16>(W + OFF_V2H_W, half, a1[t][0]) + W[OFF_V2H_B]);
+      vs[V0 + t].v2 = sigmoid1(head_dot<16>(PGRF_LHEAD(OFF_V2H_W), half, a1[t][0]) + W[OFF_V2H_B]);
       vs[V0 + t].fa = x[t][0];
     }
   }
@@ -697,7 +722,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const f32x16 (&G)[2
 // ---------------------------------------------------------------------------------------------
 // Stage E for NT views: rgb_fc on [x, vis, ray_diff] -> blending logit   (ibrnet.py:365-366)
 template <int V, int V0, int NT>
-__device__ __forceinline__ void stage_rgb(const PassArgs& p, const ViewState (&vs)[V], int lane, float (&logit)[V]) {
+__device__ __forceinline__ void stage_rgb(const PassArgs& p, const float* LI, const ViewState (&vs)[V], int lane, float (&logit)[V]) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
   float b19[NT][19];
@@ -711,19 +736,19 @@ __device__ __forceinline__ void stage_rgb(const PassArgs& p, const ViewState (&v
     b19[t][18] = half ? 0.f : vs[v].dd[3];
   }
   f32x16 a1[NT][1], a2[NT][1];
-  mfma_layer<19, 1, NT, true>(W + layer_a_off(L_RGB1), W + layer_b_off(L_RGB1), lane, b19, a1, W + layer_h_off(L_RGB1));
+  mfma_layer<19, 1, NT, true>(W + layer_a_off(L_RGB1), W + layer_b_off(L_RGB1), lane, b19, a1, W + layer_h_off(L_RGB1), PGRF_LIMG(L_RGB1));
   float b8[NT][8];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
-  mfma_layer<8, 1, NT, true>(W + layer_a_off(L_RGB2), W + layer_b_off(L_RGB2), lane, b8, a2, W + layer_h_off(L_RGB2));
+  mfma_layer<8, 1, NT, true>(W + layer_a_off(L_RGB2), W + layer_b_off(L_RGB2), lane, b8, a2, W + layer_h_off(L_RGB2), PGRF_LIMG(L_RGB2));
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     f32x16 hh = a2[t][0];
 #pragma unroll
     for (int r = 0; r < 4; ++r) hh[r] = elu1(hh[r]);
-    logit[V0 + t] = head_dot<4>(W + OFF_RGBH_W, half, hh) + W[OFF_RGBH_B];
+    logit[V0 + t] = head_dot<4>(PGRF_LHEAD(OFF_RGBH_W), half, hh) + W[OFF_RGBH_B];
   }
 }
 
@@ -738,6 +763,16 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   __shared__ float lds_k[128 * kKStride];
   __shared__ float lds_alpha[4];     // per-wave transmittance totals
   __shared__ float lds_red[4][4];
+#ifdef PGRF_NO_LDS_IMG
+  const float* LI = nullptr;
+#else
+  __shared__ __attribute__((aligned(16))) float lds_img[img_floats(kPrec)];
+  const float* LI = lds_img;
+  {   // every workgroup copies the image once; the barrier sits after ray generation
+    const float4* src = reinterpret_cast<const float4*>(p.blob + (kPrec ? OFF_IMG16 : OFF_IMG32));
+    for (int i = threadIdx.x; i < img_floats(kPrec) / 4; i += 256) reinterpret_cast<float4*>(lds_img)[i] = src[i];
+  }
+#endif
   // debug builds: the 12 dump pointers live in LDS, not in SGPRs (24 live SGPRs made the compiler spill scalars)
   __shared__ float* lds_dbg[DBG ? 12 : 1];
   float* const* sdbg = lds_dbg;
@@ -812,16 +847,19 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
 
   ViewState vs[V];
   const bool store_ok = ray_ok;
+#ifndef PGRF_NO_LDS_IMG
+  __syncthreads();
+#endif
   PGRF_TICK(0);   // ray generation
 
   // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
-  stage_front<V, 0, (V >= 2 ? 2 : 1), DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg
+  stage_front<V, 0, (V >= 2 ? 2 : 1), DBG>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
 #ifdef PGRF_STAGE_TIMING
                                            , t_prev
 #endif
   );
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (V > 2) stage_front<V, 2, V - 2, DBG>(p, g, vs, lane, pt, npts, store_ok, sdbg
+  if constexpr (V > 2) stage_front<V, 2, V - 2, DBG>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
 #ifdef PGRF_STAGE_TIMING
                                            , t_prev
 #endif
@@ -851,15 +889,15 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       }
       b76[0][j] = m0; b76[0][19 + j] = v0; b76[0][38 + j] = m1; b76[0][57 + j] = v1;
     }
-    mfma_layer<76, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b76, G, W + layer_h_off(L_BG));
+    mfma_layer<76, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b76, G, W + layer_h_off(L_BG), PGRF_LIMG(L_BG));
   }
   PGRF_TICK(2);   // stage B
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage C: per-view base_fc / vis_fc / vis_fc2
-  stage_mid<V, 0, (V >= 2 ? 2 : 1), DBG>(p, G[0], vs, lane, pt, store_ok, sdbg);
+  stage_mid<V, 0, (V >= 2 ? 2 : 1), DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (V > 2) stage_mid<V, 2, V - 2, DBG>(p, G[0], vs, lane, pt, store_ok, sdbg);
+  if constexpr (V > 2) stage_mid<V, 2, V - 2, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
   PGRF_TICK(3);   // stage C
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
@@ -889,12 +927,12 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     }
     b33[0][32] = wmean;
     f32x16 g1[1][2];
-    mfma_layer<33, 2, 1, true>(W + layer_a_off(L_G1), W + layer_b_off(L_G1), lane, b33, g1, W + layer_h_off(L_G1));
+    mfma_layer<33, 2, 1, true>(W + layer_a_off(L_G1), W + layer_b_off(L_G1), lane, b33, g1, W + layer_h_off(L_G1), PGRF_LIMG(L_G1));
     float b32[1][32];
 #pragma unroll
     for (int s = 0; s < 16; ++s) { b32[0][s] = elu1(g1[0][0][s]); b32[0][16 + s] = elu1(g1[0][1][s]); }
     f32x16 g2[1][1];
-    mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2, W + layer_h_off(L_G2));
+    mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2, W + layer_h_off(L_G2), PGRF_LIMG(L_G2));
     float gp[1][8];     // geometry feature + positional encoding (ibrnet.py:356-358)
     {
       const float4* pp = reinterpret_cast<const float4*>(W + OFF_POS + si * 16 + half * 8);
@@ -912,7 +950,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     f32x16 qkv[1][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { qkv[0][0][r] = 0.f; qkv[0][1][r] = 0.f; }   // no bias on w_qs/w_ks/w_vs
-    mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv, W + layer_h_off(L_QKV));
+    mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv, W + layer_h_off(L_QKV), PGRF_LIMG(L_QKV));
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
@@ -966,7 +1004,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     f32x16 fo[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) fo[0][0][r] = (r < 8) ? gp[0][r < 8 ? r : 0] : 0.f;     // residual as the initial accumulator
-    mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo, W + layer_h_off(L_FC));
+    mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo, W + layer_h_off(L_FC), PGRF_LIMG(L_FC));
     float ln[1][8];
     {
       float sum = 0.f;
@@ -991,10 +1029,10 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
     }
     // out_geometry_fc 16 -> 16 elu -> 1 relu  (ibrnet.py:361)
     f32x16 og[1][1];
-    mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og, W + layer_h_off(L_OG1));
+    mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og, W + layer_h_off(L_OG1), PGRF_LIMG(L_OG1));
 #pragma unroll
     for (int r = 0; r < 8; ++r) og[0][0][r] = elu1(og[0][0][r]);
-    sigma = fmaxf(head_dot<8>(W + OFF_OGH_W, half, og[0][0]) + W[OFF_OGH_B], 0.f);
+    sigma = fmaxf(head_dot<8>(PGRF_LHEAD(OFF_OGH_W), half, og[0][0]) + W[OFF_OGH_B], 0.f);
   }
   PGRF_TICK(7);   // fc + LayerNorm + density head
 
@@ -1003,8 +1041,8 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   float col[3];
   {
     float logit[V];
-    stage_rgb<V, 0, (V >= 2 ? 2 : 1)>(p, vs, lane, logit);
-    if constexpr (V > 2) stage_rgb<V, 2, V - 2>(p, vs, lane, logit);
+    stage_rgb<V, 0, (V >= 2 ? 2 : 1)>(p, LI, vs, lane, logit);
+    if constexpr (V > 2) stage_rgb<V, 2, V - 2>(p, LI, vs, lane, logit);
     float mx = logit[0];
 #pragma unroll
     for (int v = 1; v < V; ++v) mx = fmaxf(mx, logit[v]);
