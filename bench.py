@@ -288,6 +288,9 @@ def main():
     launches = passes
     flops_launch = flop_per_ray(V, dn, 1) * rn
     achieved = flops_launch / (k_ms / launches * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    # f32 mode: the dense f32 MFMA peak.  f16x3 mode executes three f16 MFMA products per algorithmic product, so its
+    # roof for ALGORITHMIC flops is a third of the dense f16 peak (2.5 PF, MI355X_MICROARCH.md).
+    peak_tf = PEAK_F32_MFMA_TFLOPS if args.precision == 'f32' else 2500.0 / 3.0
 
     # HBM-side traffic of the dominant kernel comes from rocprofv3 PMC passes of this same command (they cannot be
     # collected from inside the process): profiles/<round>_render_pass_pmc.txt, FETCH_SIZE doubled per the gfx950
@@ -311,8 +314,8 @@ def main():
                                + (' coarse + ' + str(dn) + ' fine' if args.fine else ', single pass')
                                + ' (BASELINE configs[1])' * (not args.fine and (H, W, V, dn) == (512, 1024, 2, 64)),
                    'rays_per_step': H * W, 'ray_tiles': world, 'parallelism': f'ray-tile x{world} + all-gather'},
-        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
+                     'frac': achieved / peak_tf, 'traffic': traffic,
                      'kernel': 'render_pass_kernel', 'kernel_ms': k_ms / launches,
                      'flop_per_ray': flop_per_ray(V, dn, 1), 'rays_per_launch': rn},
     }

@@ -55,6 +55,8 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); 
 // ELU(x) = median(x, exp(x)-1, 0): x > 0 -> exp(x)-1 >= x > 0; x < 0 -> x <= exp(x)-1 < 0.  One v_med3 instead of cmp+cndmask.
 #ifdef PGRF_OLD_ELU
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
+#elif defined(PGRF_ELU_TIMING_HACK)   // timing experiment only (wrong numbers): instruction mix of a log2e-scaled carry
+__device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, fmaf(__builtin_amdgcn_exp2f(x), 1.4426950408889634f, -1.4426950408889634f), 0.f); }
 #else
 __device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
 #endif
@@ -978,7 +980,8 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const float a = lds_k[(key_base + k2 * 32 + pl) * kKStride + hd * 4 + 2 * s + half];
-          const float q = qkv[0][0][2 * hd + s] * 0.5f;          // q / temperature, temperature = sqrt(d_k) = 2
+          // q / temperature (sqrt(d_k) = 2), times log2(e) so that the softmax below is a bare v_exp_f32
+          const float q = qkv[0][0][2 * hd + s] * (0.5f * 1.4426950408889634f);
           S[k2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, q, S[k2], 0, 0, 0);
         }
       }
@@ -993,7 +996,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       for (int k2 = 0; k2 < KT; ++k2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pe = __expf(S[k2][r] - mx);
+          const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
           const float4 vv = *reinterpret_cast<const float4*>(&lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4]);
           l += pe;
           o0 = fmaf(pe, vv.x, o0); o1 = fmaf(pe, vv.y, o1); o2 = fmaf(pe, vv.z, o2); o3 = fmaf(pe, vv.w, o3);
