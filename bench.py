@@ -237,21 +237,27 @@ def main():
         with torch.no_grad():
             for prm in cv['net'].parameters():
                 prm.mul_(0.5)
+            cv['reg_numel'] = cv['net'].forward_ndhwc(torch.zeros(1, 64, ch, cw, 32, device=dev)).numel()
 
     def step(timed):
         # per-frame: channel-last re-layout of the source maps (inputs stay NCHW in HBM like the reference's)
         fr = E.Frame(fr_in['imgs'], fr_in['img_feats'], fr_in['ray_feats'], fr_in['w2c'], fr_in['ref_depth_range'],
                      case['frame']['que_c2w'], case['frame']['que_depth_range'], device=dev)
-        if cv is not None and rank == 0:
+        if cv is not None:
+            # one cost volume per reference view, independent of each other: sharded by view over the ranks
+            # (panogrf_amd/dist.py view_shard), regularised volumes all-gathered in view order
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
-            for v in range(V):            # the volumes are independent; on N>1 ranks they would shard by source view
+            regs = []
+            for v in D.view_shard(rank, world, V):
                 dv = cv['CV'].build_depth_volume(cv['ref_mu'][v:v + 1], cv['k'], 0.5, 0.1, 10.0, 64)
                 vol = cv['CV'].calculate_cost_volume_erp(cv['args'], cv['feats'][v:v + 1], None, cv['trans'][v:v + 1],
                                                          cv['rots'][v:v + 1], depth_volume=dv)
-                reg = cv['net'].forward_ndhwc(vol)
+                regs.append(cv['net'].forward_ndhwc(vol).reshape(-1))
+            local = torch.stack(regs, 0) if regs else torch.zeros(0, cv['reg_numel'], device=dev)
+            cv['reg_all'] = D.allgather_views(local, V)
             c1.record()
-            if timed:
+            if timed and rank == 0:
                 cv['ms'].append((c0, c1))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -324,7 +330,8 @@ def main():
         gf = (438.5e9 if args.reg == 'unet2' else 16.2e9) * (cv['h'] * cv['w']) / (64 * 128) * V
         res['cost_volume_stage'] = {'ms_per_step': cms, 'views': V, 'res': [cv['h'], cv['w']], 'D': 64, 'C': 32,
                                     'regulariser': args.reg, 'reg_algorithmic_tflops': gf / (cms * 1e-3) / 1e12,
-                                    'note': 'hypotheses + spherical cost volume + 3-D regulariser per source view; included in ms_per_step/value'}
+                                    'view_shards': min(world, V),
+                                    'note': 'hypotheses + spherical cost volume + 3-D regulariser per source view, views sharded over ranks + all-gather; included in ms_per_step/value'}
         res['config']['workload'] += f' + D=64 cost volume {cv["h"]}x{cv["w"]} + {args.reg} per view (BASELINE configs[2])'
     if rank == 0 and world == 1 and args.eager_baseline:
         eg, eout = eager_gpu_baseline(case, dev, 2048)

@@ -48,3 +48,33 @@ def allgather_rows(shard, H, W, group=None):
         r0, r1 = tile_rows(g, world, H)
         out.append(parts[g][:(r1 - r0) * W])
     return torch.cat(out, 0)
+
+
+# ---- MVS stage: one cost volume per reference view (network/init_net.py:164-171 builds B = rfn pairs), each
+# independent of the others -> shard BY REFERENCE VIEW, then all-gather the per-view result.
+
+def view_shard(rank, world, n_views):
+    """Reference views handled by `rank`: round-robin, so 2 or 4 views spread over the first 2 or 4 ranks and the
+    remaining ranks (a node has 8) idle through the MVS stage."""
+    return list(range(rank, n_views, world))
+
+
+def allgather_views(local, n_views, group=None):
+    """local [len(view_shard(rank)), ...] of every rank -> [n_views, ...] in view order on every rank.  Ranks own
+    different numbers of views (including none), so every rank contributes ceil(n_views/world) padded slots."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    if dist.get_backend(group) == 'gloo' and local.is_cuda:      # test-only: ranks sharing one GPU
+        return allgather_views(local.cpu(), n_views, group).to(local.device)
+    slots = -(-n_views // world)
+    pad = torch.zeros((slots,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    full = torch.empty((world * slots,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, pad.contiguous(), group=group)
+    full = full.view((world, slots) + tuple(local.shape[1:]))
+    out = [None] * n_views
+    for g in range(world):
+        for i, v in enumerate(view_shard(g, world, n_views)):
+            out[v] = full[g, i]
+    return torch.stack(out, 0)

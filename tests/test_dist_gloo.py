@@ -47,3 +47,41 @@ def test_allgather_equal_tiles_world2():
 
 def test_allgather_ragged_tiles_world2():
     _run(2, 7, 5)
+
+
+def _view_worker(rank, world, port, n_views, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from panogrf_amd import dist as D
+    mine = D.view_shard(rank, world, n_views)
+    local = torch.stack([torch.full((3, 4), float(v)) + torch.arange(4.0) for v in mine], 0) if mine else torch.zeros(0, 3, 4)
+    full = D.allgather_views(local, n_views)
+    exp = torch.stack([torch.full((3, 4), float(v)) + torch.arange(4.0) for v in range(n_views)], 0)
+    ret[rank] = torch.equal(full, exp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_views(world, n_views):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_view_worker, args=(world, _free_port(), n_views, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def test_view_shard_partition():
+    from panogrf_amd import dist as D
+    for world in (1, 2, 3, 4, 8):
+        for nv in (1, 2, 3, 4):
+            got = sorted(v for r in range(world) for v in D.view_shard(r, world, nv))
+            assert got == list(range(nv))
+
+
+def test_allgather_views_world2_even():
+    _run_views(2, 4)
+
+
+def test_allgather_views_world2_ragged_and_idle_rank():
+    _run_views(2, 3)
+    _run_views(2, 1)

@@ -23,3 +23,15 @@ def test_bench_two_ranks_one_gpu():
     assert d['n_gpus'] == 2 and d['config']['ray_tiles'] == 2 and d['scaling'] == 'strong'
     assert d['roofline']['rays_per_launch'] == 64 * 128 // 2
     assert d['value'] > 0
+
+
+def test_bench_two_ranks_cost_volume_sharded_by_view():
+    env = dict(os.environ, PGRF_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29519', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--height', '64', '--width', '128', '--samples', '32', '--with-cost-volume', '--cv-res', '16', '32',
+           '--reg', 'costregnet']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['cost_volume_stage']['view_shards'] == 2 and d['cost_volume_stage']['ms_per_step'] > 0

@@ -1,0 +1,27 @@
+"""Time the per-frame 2-D encoders (torch ops on ROCm) next to the HIP render pass: the Amdahl remainder of render()."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from panogrf_amd import encoders as EN
+
+dev = torch.device('cuda', 0)
+torch.manual_seed(0)
+H, W, V = 512, 1024, 2
+enc = EN.ResUNetLight().to(dev).eval()
+vis = EN.DefaultVisEncoder().to(dev).eval()
+imgs = torch.rand(V, 3, H, W, device=dev)
+ray_feats = torch.randn(V, 32, H // 8, W // 8, device=dev)
+
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+
+with torch.no_grad():
+    feats = enc(imgs)
+    print('ResUNetLight out', tuple(feats.shape))
+    print(f'ResUNetLight {V}x{H}x{W}: {timeit(lambda: enc(imgs)):.2f} ms')
+    out = vis(ray_feats, feats)
+    print('DefaultVisEncoder out', tuple(out.shape))
+    print(f'DefaultVisEncoder: {timeit(lambda: vis(ray_feats, feats)):.2f} ms')
