@@ -222,18 +222,20 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
           }
   }
   // ---- LDS images (pgrf_layout.h: img_layer_off) ----------------------------------------------------
-  for (int prec = 0; prec < 2; ++prec) {
-    float* img = blob + (prec ? OFF_IMG16 : OFF_IMG32);
+  for (int mode = 0; mode < kImgModes; ++mode) {
+    float* img = blob + img_blob_off(mode);
     std::memcpy(img, blob + OFF_DDH_W, sizeof(float) * kHeadFloats);
     for (int id = 0; id < L_COUNT; ++id) {
       if (img_chunk(id) < 0) continue;
-      float* dst = img + img_layer_off(id, prec);
-      if (prec == 0 || id == L_PE1)
-        std::memcpy(dst, blob + layer_a_off(id) + (size_t)img_chunk(id) * 256, sizeof(float) * 256);
-      else
+      float* dst = img + img_layer_off(id, mode);
+      if (mode == 1 && id != L_PE1)
         std::memcpy(dst, blob + layer_h_off(id), sizeof(float) * 512);     // (m=0, g=0): [piece][lane][8 halves]
+      else if (mode == 2 && img_full(id))
+        std::memcpy(dst, blob + layer_a_off(id), sizeof(float) * a_size(kKS[id], kMT[id]));
+      else
+        std::memcpy(dst, blob + layer_a_off(id) + (size_t)img_chunk(id) * 256, sizeof(float) * 256);
       if (img_has_bias(id))
-        std::memcpy(dst + img_a_floats(prec), blob + layer_b_off(id), sizeof(float) * b_size(kMT[id]));
+        std::memcpy(dst + img_a_floats(id, mode), blob + layer_b_off(id), sizeof(float) * b_size(kMT[id]));
     }
   }
   return PGRF_OK;

@@ -124,20 +124,31 @@ constexpr int kSplitEnd = layer_h_off(L_COUNT);
 constexpr int kHeadFloats = OFF_POS - OFF_DDH_W;
 constexpr int img_chunk(int id) { return id == L_DD1 ? -1 : (id == L_PE1 ? 4 : 0); }
 constexpr bool img_has_bias(int id) { return kHasBias[id] && id != L_PE1 && id != L_DD1; }
-constexpr int img_a_floats(int prec) { return prec ? 512 : 256; }
-constexpr int img_layer_size(int id, int prec) {
-  return img_chunk(id) < 0 ? 0 : img_a_floats(prec) + (img_has_bias(id) ? b_size(kMT[id]) : 0);
+// image modes: 0 = f32, first chunk per layer; 1 = split-f16, first k-group per layer; 2 = f32, the WHOLE A block of
+// every layer except the three largest (base_fc.0 shared/per-view, geometry_fc.0) — used by the kernels for more than
+// two views, which run one workgroup per CU (so have the LDS) and one wave per SIMD (so cannot hide an L2 round trip).
+constexpr int kImgModes = 3;
+constexpr bool img_full(int id) { return id != L_BG && id != L_BV && id != L_G1 && id != L_PE1 && id != L_DD1; }
+constexpr int img_a_floats(int id, int mode) {
+  return mode == 1 ? 512 : ((mode == 2 && img_full(id)) ? a_size(kKS[id], kMT[id]) : 256);
 }
-constexpr int img_layer_off(int id, int prec) {
+constexpr int img_layer_size(int id, int mode) {
+  return img_chunk(id) < 0 ? 0 : img_a_floats(id, mode) + (img_has_bias(id) ? b_size(kMT[id]) : 0);
+}
+constexpr int img_layer_off(int id, int mode) {
   int off = kHeadFloats;
-  for (int i = 0; i < id; ++i) off += img_layer_size(i, prec);
+  for (int i = 0; i < id; ++i) off += img_layer_size(i, mode);
   return off;
 }
-constexpr int img_floats(int prec) { return img_layer_off(L_COUNT, prec); }
-constexpr int OFF_IMG32 = kSplitEnd;
-constexpr int OFF_IMG16 = OFF_IMG32 + img_floats(0);
-constexpr int kBlobFloats = OFF_IMG16 + img_floats(1);
-static_assert(kHeadFloats % 4 == 0 && img_floats(0) % 4 == 0 && img_floats(1) % 4 == 0 && OFF_IMG32 % 4 == 0, "LDS image is copied as float4");
+constexpr int img_floats(int mode) { return img_layer_off(L_COUNT, mode); }
+constexpr int img_blob_off(int mode) {
+  int off = kSplitEnd;
+  for (int i = 0; i < mode; ++i) off += img_floats(i);
+  return off;
+}
+constexpr int kBlobFloats = img_blob_off(kImgModes);
+static_assert(kHeadFloats % 4 == 0 && img_floats(0) % 4 == 0 && img_floats(1) % 4 == 0 && img_floats(2) % 4 == 0 && kSplitEnd % 4 == 0,
+              "LDS image is copied as float4");
 
 // attention feature permutation: accumulator row rho (< 16) of the q / k / v projections holds
 // head-feature  attn_feat(rho)  so that register 2*head+s carries dims (2s, 2s+1) in the two lane halves.

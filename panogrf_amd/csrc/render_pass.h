@@ -96,11 +96,18 @@ __device__ __forceinline__ void elu16(f32x16& a) {
 #define PGRF_NO_LDS_IMG
 #endif
 #ifdef PGRF_NO_LDS_IMG
-#define PGRF_LIMG(id) ((const float*)nullptr)
+#define PGRF_LIMG(id) ((const float*)nullptr), false, 0
 #define PGRF_LHEAD(off) (W + (off))
 #else
-#define PGRF_LIMG(id) (LI + img_layer_off((id), kPrec))
+#define PGRF_LIMG(id) (LI + img_layer_off((id), kImgMode<V>)), (kImgMode<V> == 2 && img_full(id)), img_a_floats((id), kImgMode<V>)
 #define PGRF_LHEAD(off) (LI + ((off) - OFF_DDH_W))
+#endif
+
+// which LDS image a kernel instance uses (pgrf_layout.h)
+#ifdef PGRF_NO_FULL_IMG
+template <int V> constexpr int kImgMode = kPrec;
+#else
+template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (V > 2 ? 2 : 0);
 #endif
 
 // One Linear layer on the matrix cores for NT point tiles sharing the A operand.
@@ -122,12 +129,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], H8& hi, H8& lo) {
 // split-f16 evaluation of one layer; Hblk = this layer's [mt][g][piece][lane][8] block (pgrf_layout.h)
 template <int KS, int MT, int NT, bool INIT_BIAS>
 __device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, const float* __restrict__ B, int lane,
-                                             const float (&b)[NT][KS], f32x16 (&acc)[NT][MT], const float* Limg) {
+                                             const float (&b)[NT][KS], f32x16 (&acc)[NT][MT], const float* Limg, int limg_a) {
   constexpr int G = (KS + 7) / 8;
   if (INIT_BIAS) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + 512 : B) + m * 32 + (lane >> 5) * 16);
+      const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       const f32x16 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
 #pragma unroll
@@ -173,9 +180,9 @@ __device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, con
 template <int KS, int MT, int NT, bool INIT_BIAS>
 __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const float* __restrict__ B, int lane,
                                            const float (&b)[NT][KS], f32x16 (&acc)[NT][MT], const float* __restrict__ Hblk,
-                                           const float* Limg) {
+                                           const float* Limg, bool limg_full, int limg_a) {
   if constexpr (kPrec == 1) {
-    mfma_layer_h<KS, MT, NT, INIT_BIAS>(Hblk, B, lane, b, acc, Limg);
+    mfma_layer_h<KS, MT, NT, INIT_BIAS>(Hblk, B, lane, b, acc, Limg, limg_a);
     return;
   }
   constexpr int KS4 = (KS + 3) / 4;
@@ -183,7 +190,7 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
   for (int m = 0; m < MT; ++m) {
     f32x16 bv;
     if (INIT_BIAS) {
-      const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + 256 : B) + m * 32 + (lane >> 5) * 16);
+      const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
     }
@@ -192,8 +199,9 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
 #ifdef PGRF_ABL_WEIGHTS   // ablation (timing only): every weight load hits the same 1 KiB -> L1 resident
       const float4 a = reinterpret_cast<const float4*>(A)[lane + ((m * KS4 + s4) & 1) * 64];
 #else
-      const float4 a = (Limg && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
-                                                   : reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
+      const float4 a = (Limg && limg_full)          ? reinterpret_cast<const float4*>(Limg)[(m * KS4 + s4) * 64 + lane]
+                       : (Limg && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
+                                                     : reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
 #endif
       const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -532,7 +540,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #ifdef PGRF_NO_LDS_IMG
     const float a16 = reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
 #else
-    const float a16 = PGRF_LIMG(L_PE1)[lane * 4];
+    const float a16 = (LI + img_layer_off(L_PE1, kImgMode<V>))[lane * 4];
 #endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -775,11 +783,11 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
 #ifdef PGRF_NO_LDS_IMG
   const float* LI = nullptr;
 #else
-  __shared__ __attribute__((aligned(16))) float lds_img[img_floats(kPrec)];
+  __shared__ __attribute__((aligned(16))) float lds_img[img_floats(kImgMode<V>)];
   const float* LI = lds_img;
   {   // every workgroup copies the image once; the barrier sits after ray generation
-    const float4* src = reinterpret_cast<const float4*>(p.blob + (kPrec ? OFF_IMG16 : OFF_IMG32));
-    for (int i = threadIdx.x; i < img_floats(kPrec) / 4; i += 256) reinterpret_cast<float4*>(lds_img)[i] = src[i];
+    const float4* src = reinterpret_cast<const float4*>(p.blob + img_blob_off(kImgMode<V>));
+    for (int i = threadIdx.x; i < img_floats(kImgMode<V>) / 4; i += 256) reinterpret_cast<float4*>(lds_img)[i] = src[i];
   }
 #endif
   // debug builds: the 12 dump pointers live in LDS, not in SGPRs (24 live SGPRs made the compiler spill scalars)

@@ -2,6 +2,7 @@
 reference and against the CPU oracle.  Needs an MI355X: `pytest -m gpu`."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -104,6 +105,35 @@ def test_frame_end_to_end_vs_reference(name):
     parts = [rr.render_rays(fr, coords[s:s + 301]) for s in range(0, coords.shape[0], 301)]
     cat = torch.cat([p['pixel_colors_nr_fine'] for p in parts], 0)
     assert FX.max_abs(cat.cpu(), out['pixel_colors_nr_fine'].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize('name', ['render_frame_v2_dn32', 'render_frame_v2_c2fall'])
+def test_psnr_against_ground_truth_matches_reference(name):
+    """BASELINE north star / SURVEY 8d: PSNR against a held-out ground-truth panorama must agree with the
+    reference renderer's PSNR against the same panorama within 0.05 dB and 1e-4 relative, in the float form and in the
+    uint8 form of network/metrics.py:17-32 (color_map_backward: clip, *255, uint8)."""
+    E = _engine()
+    frame, w, cfg, g = FX.load(name)
+    fr = _frame(E, frame)
+    rr = E.RayRenderer(cfg, w)
+    H, W = frame['imgs'].shape[-2:]
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    out = rr.render_rays(fr, coords)
+    # ground truth: the mean of the source panoramas (what a perfect blend of static, distant content would show)
+    gt = frame['imgs'].mean(0).permute(1, 2, 0).reshape(-1, 3)
+
+    def psnr_u8(a, b):
+        qa = (a.clamp(0, 1) * 255).to(torch.uint8).double()
+        qb = (b.clamp(0, 1) * 255).to(torch.uint8).double()
+        return 10 * np.log10(255.0 ** 2 / max(float(((qa - qb) ** 2).mean()), 1e-30))
+
+    for key in ('pixel_colors_nr', 'pixel_colors_nr_fine'):
+        mine, ref = out[key].cpu(), g['out'][key]
+        for fn in (FX.psnr, psnr_u8):
+            a, b = fn(mine, gt), fn(ref, gt)
+            assert abs(a - b) <= 0.05, (key, a, b)
+            assert abs(a - b) / abs(b) <= 1e-4, (key, a, b)
 
 
 def test_full_size_properties_and_oracle_strip():
