@@ -114,7 +114,7 @@ template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (V > 2 ? 2 : 0);
 //   acc[t][m] (+)= A(m) * b[t]   with b[t][s] = B operand of k-step s (see pgrf_layout.h)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-union H8 { f16x8 v; fp16x2 p[4]; uint4 u; };
+union H8 { f16x8 v; fp16x2 p[4]; uint4 u; unsigned u4[4]; };
 
 // x[0..7] (fp32) -> hi, lo halves with x ~= hi + lo: hi = rtz16(x), lo = rtz16(x - hi) (the difference is exact)
 __device__ __forceinline__ void split8(const float (&x)[8], H8& hi, H8& lo) {
@@ -122,7 +122,17 @@ __device__ __forceinline__ void split8(const float (&x)[8], H8& hi, H8& lo) {
   for (int e = 0; e < 4; ++e) {
     const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * e], x[2 * e + 1]);
     hi.p[e] = h;
+#ifndef PGRF_SPLIT_MIX
     lo.p[e] = __builtin_amdgcn_cvt_pkrtz(x[2 * e] - (float)h[0], x[2 * e + 1] - (float)h[1]);
+#else
+    // experiment: x - hi in ONE v_fma_mix_f32 reading the packed half (the compiler emits v_cvt_f32_f16 + v_sub_f32).
+    // 570 fewer VALU instructions per wave, but the asm operands cost 72 more spilled registers: 29.2 -> 34.4 ms.
+    float r0, r1;
+    const unsigned hb = hi.u4[e];
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x[2 * e]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x[2 * e + 1]));
+    lo.p[e] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+#endif
   }
 }
 
