@@ -42,6 +42,24 @@ void pack_layer(float* blob, int id, const float* W, int in_dim, const float* bi
   }
 }
 
+// "small" layer block for the 4x4x1 MFMA path (pgrf_layout.h): rows [0, nout) of W, features in_feat(r, half)
+void pack_small(float* A, float* B, const float* W, int in_dim, const float* bias, int ks, int ng, int nout, int row0,
+                const InMap& in_feat) {
+  const int ks4 = (ks + 3) / 4;
+  for (int g = 0; g < ng; ++g) {
+    for (int r = 0; r < ks4 * 4; ++r)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int o = 4 * g + (lane & 3);
+        const int col = r < ks ? in_feat(r, lane >> 5) : -1;
+        A[((size_t)(g * ks4 + r / 4) * 64 + lane) * 4 + (r & 3)] = (o < nout && col >= 0) ? W[(size_t)(row0 + o) * in_dim + col] : 0.f;
+      }
+    for (int i = 0; i < 4; ++i) {
+      B[(g * 2 + 0) * 4 + i] = (4 * g + i < nout && bias) ? bias[row0 + 4 * g + i] : 0.f;
+      B[(g * 2 + 1) * 4 + i] = 0.f;
+    }
+  }
+}
+
 // head block [half][R]: value = w[col(r, half)]
 void pack_head(float* dst, const float* w, int R, const std::function<int(int, int)>& col) {
   for (int h = 0; h < 2; ++h)
@@ -204,6 +222,12 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
       }
     }
   }
+  // ---- small layers for the 4x4x1 MFMA path (pgrf_layout.h: OFF_S_*)
+  pack_small(blob + OFF_S_NF1_A, blob + OFF_S_NF1_B, raw[R_NF_0_W], 32, raw[R_NF_0_B], 16, 2, 8, 0, ident_in);
+  for (int o = 0; o < 8; ++o) blob[OFF_S_NF1_H + o] = raw[R_NF_2_W][o];
+  pack_small(blob + OFF_S_RDC_A, blob + OFF_S_RDC_B, raw[R_RD_2_W], 16, raw[R_RD_2_B], 8, 1, 3, 0, ident_in);
+  pack_small(blob + OFF_S_RGB2_A, blob + OFF_S_RGB2_B, raw[R_RGB_2_W], 16, raw[R_RGB_2_B], 8, 2, 8, 0, ident_in);
+  for (int o = 0; o < 8; ++o) blob[OFF_S_RGB2_H + o] = raw[R_RGB_4_W][o];
   // ---- split-f16 copies of all A blocks (pgrf_layout.h: layer_h_off) ----------------------------
   for (int id = 0; id < L_COUNT; ++id) {
     const int ks = kKS[id], mt = kMT[id], ks4 = (ks + 3) / 4, G = h_groups(ks);

@@ -108,7 +108,30 @@ constexpr int OFF_PRJ_B = OFF_PRJ_W + kPrjCh * 32;        // [kPrjCh]
 //   value(mt, g, lane, e) = A-block value of k-step 8g+e (0 beyond KS).  Sizes below are in floats.
 constexpr int h_groups(int ks) { return (ks + 7) / 8; }
 constexpr int h_size(int ks, int mt) { return mt * h_groups(ks) * 2 * 64 * 4; }
-constexpr int OFF_H_BASE = OFF_PRJ_B + kPrjCh;
+// ---- "small" layers (f32 mode): layers with <= 8 outputs waste 3/4 of a 32-row MFMA tile.  They are evaluated with
+// v_mfma_f32_4x4x1_16b_f32 instead: 16 independent 4x4 blocks, block = 4 consecutive lanes = 4 points, the B operand
+// is the lane's own activation register (k = 1 feature pair per instruction, one feature per lane half), the A operand
+// holds 4 output rows, and D leaves output row i of the lane's own point in register i.  The two lane halves hold
+// partial sums over their half of the features (combined with one v_permlane32_swap + add per output).
+//   S block:  [g][r4][lane 0..63][4]  value(g, r, lane) = W[4g + (lane & 3)][in_feat(r, lane >> 5)]   (r = k-register)
+//   S bias:   [g][half][4]            bias[4g + i] in half 0, zeros in half 1 (the halves are summed)
+// followed by the layer's output head in natural row order where it has one.
+constexpr int s_a_size(int ks, int ng) { return ng * ((ks + 3) / 4) * 256; }
+constexpr int s_b_size(int ng) { return ng * 8; }
+constexpr int OFF_S_BASE = OFF_PRJ_B + kPrjCh;
+// neuray_fc.0 32 -> 8 (+ neuray_fc.2 head 8 -> 1)
+constexpr int OFF_S_NF1_A = OFF_S_BASE;
+constexpr int OFF_S_NF1_B = OFF_S_NF1_A + s_a_size(16, 2);
+constexpr int OFF_S_NF1_H = OFF_S_NF1_B + s_b_size(2);        // [8] head weights
+// ray_dir_fc.2 rows 0..2 (the rgb part of its 35 outputs) 16 -> 3
+constexpr int OFF_S_RDC_A = OFF_S_NF1_H + 8;
+constexpr int OFF_S_RDC_B = OFF_S_RDC_A + s_a_size(8, 1);
+// rgb_fc.2 16 -> 8 (+ rgb_fc.4 head 8 -> 1)
+constexpr int OFF_S_RGB2_A = OFF_S_RDC_B + s_b_size(1);
+constexpr int OFF_S_RGB2_B = OFF_S_RGB2_A + s_a_size(8, 2);
+constexpr int OFF_S_RGB2_H = OFF_S_RGB2_B + s_b_size(2);     // [8] head weights
+constexpr int OFF_S_END = OFF_S_RGB2_H + 8;
+constexpr int OFF_H_BASE = OFF_S_END;
 constexpr int layer_h_off(int id) {
   int off = OFF_H_BASE;
   for (int i = 0; i < id; ++i) off += h_size(kKS[i], kMT[i]);

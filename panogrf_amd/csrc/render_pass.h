@@ -51,7 +51,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define PGRF_HALF_PI_F 1.57079632679489661923f
 #define PGRF_TWO_PI_F 6.28318530717958647692f
 
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+// Combine a value with the same value of lane ^ 32 (the other half of the point's features).  v_permlane32_swap (gfx950)
+// exchanges the upper half of one register with the lower half of another on the VALU: no LDS round trip as with
+// ds_bpermute.  With both operands = v it yields [lo,lo] and [hi,hi]; their sum / max is the cross-half result in all lanes.
+#ifdef PGRF_BPERMUTE_XHALF
+__device__ __forceinline__ float xsum(float v) { return v + __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float xmax(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+#else
+__device__ __forceinline__ float xsum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xmax(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+#endif
 // ELU(x) = median(x, exp(x)-1, 0): x > 0 -> exp(x)-1 >= x > 0; x < 0 -> x <= exp(x)-1 < 0.  One v_med3 instead of cmp+cndmask.
 #ifdef PGRF_OLD_ELU
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
@@ -101,6 +116,13 @@ __device__ __forceinline__ void elu16(f32x16& a) {
 #else
 #define PGRF_LIMG(id) (LI + img_layer_off((id), kImgMode<V>)), (kImgMode<V> == 2 && img_full(id)), img_a_floats((id), kImgMode<V>)
 #define PGRF_LHEAD(off) (LI + ((off) - OFF_DDH_W))
+#endif
+
+// layers with <= 8 outputs on the 4x4x1 MFMA (f32 mode only; -DPGRF_NO_SMALL = padded 32-row tiles)
+#ifdef PGRF_NO_SMALL
+constexpr bool kSmall = false;
+#else
+constexpr bool kSmall = (kPrec == 0);
 #endif
 
 // which LDS image a kernel instance uses (pgrf_layout.h)
@@ -236,6 +258,46 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
   }
 }
 
+// Layer with few outputs on v_mfma_f32_4x4x1_16b_f32 (pgrf_layout.h "small layers"): out[t][4g+i] = row 4g+i of
+// W x + bias for the lane's own point, complete in every lane.  10 cycles per (4 rows x 2 features) against 64 cycles
+// per (32 rows x 2 features) for the padded 32x32x2 tile.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int KS, int NG, int NT>
+__device__ __forceinline__ void mfma_small(const float* __restrict__ S, const float* __restrict__ SB, int lane,
+                                           const float (&b)[NT][KS], float (&out)[NT][NG * 4]) {
+  constexpr int KS4 = (KS + 3) / 4;
+  f32x4 acc[NT][NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const float4 bb = *reinterpret_cast<const float4*>(SB + (g * 2 + (lane >> 5)) * 4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][g] = (f32x4){bb.x, bb.y, bb.z, bb.w};
+  }
+#pragma unroll
+  for (int r4 = 0; r4 < KS4; ++r4) {
+    float4 a[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a[g] = reinterpret_cast<const float4*>(S)[(g * KS4 + r4) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (r4 * 4 + j < KS) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const float av = j == 0 ? a[g].x : j == 1 ? a[g].y : j == 2 ? a[g].z : a[g].w;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, b[t][r4 * 4 + j], acc[t][g], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[t][4 * g + i] = xsum(acc[t][g][i]);
+}
+
 // VALU head: out = sum_r w[half][r] * x[r], summed over both lane halves (bias added by caller).
 template <int R>
 __device__ __forceinline__ float head_dot(const float* __restrict__ w, int half, const f32x16& x) {
@@ -243,7 +305,7 @@ __device__ __forceinline__ float head_dot(const float* __restrict__ w, int half,
   float s = 0.f;
 #pragma unroll
   for (int r = 0; r < R; ++r) s = fmaf(wp[r], x[r], s);
-  return s + xhalf(s);
+  return xsum(s);
 }
 
 struct Bilin {
@@ -588,19 +650,32 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int s = 0; s < 16; ++s) b16[t][s] = vs[V0 + t].nf[s];
-    f32x16 a1[NT][1];
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_NF1), W + layer_b_off(L_NF1), lane, b16, a1, W + layer_h_off(L_NF1), PGRF_LIMG(L_NF1));
     const float wgt = 1.f / ((float)V + 1e-8f);
+    if constexpr (kSmall) {
+      float o8[NT][8];
+      mfma_small<16, 2, NT>(W + OFF_S_NF1_A, W + OFF_S_NF1_B, lane, b16, o8);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x16 h = a1[t][0];
+      for (int t = 0; t < NT; ++t) {
+        float y = W[OFF_NFH_B];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = elu1(h[r]);
-      const float y = head_dot<4>(PGRF_LHEAD(OFF_NFH_W), half, h) + W[OFF_NFH_B];
-      vs[V0 + t].w0 = sigmoid1(y) * wgt;
-      if (DBG && store_ok && sdbg[8])
-        dump_tile32(sdbg[8] + (pt * V + (V0 + t)) * 32, vs[V0 + t].nf, half);
+        for (int o = 0; o < 8; ++o) y = fmaf(W[OFF_S_NF1_H + o], elu1(o8[t][o]), y);
+        vs[V0 + t].w0 = sigmoid1(y) * wgt;
+      }
+    } else {
+      f32x16 a1[NT][1];
+      mfma_layer<16, 1, NT, true>(W + layer_a_off(L_NF1), W + layer_b_off(L_NF1), lane, b16, a1, W + layer_h_off(L_NF1), PGRF_LIMG(L_NF1));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x16 h = a1[t][0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = elu1(h[r]);
+        const float y = head_dot<4>(PGRF_LHEAD(OFF_NFH_W), half, h) + W[OFF_NFH_B];
+        vs[V0 + t].w0 = sigmoid1(y) * wgt;
+      }
     }
+    if (DBG && store_ok && sdbg[8])
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dump_tile32(sdbg[8] + (pt * V + (V0 + t)) * 32, vs[V0 + t].nf, half);
   }
   PGRF_TICK(20);  // A: neuray_fc
   // ---- ray_dir_fc 4 -> 16 elu -> 35 elu; rgb_feat = [rgb, img_feats] + dir_feat  (ibrnet.py:325-327)
@@ -618,7 +693,20 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
-    mfma_layer<8, 2, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2, W + layer_h_off(L_RD2), PGRF_LIMG(L_RD2));
+    float rgbdir[NT][4];      // ray_dir_fc.2 rows 0..2: the direction feature added to the source colour
+    if constexpr (kSmall) {
+      f32x16 a2m[NT][1];
+      mfma_layer<8, 1, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2m, W + layer_h_off(L_RD2), PGRF_LIMG(L_RD2));
+      mfma_small<8, 1, NT>(W + OFF_S_RDC_A, W + OFF_S_RDC_B, lane, b8, rgbdir);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a2[t][0] = a2m[t][0];
+    } else {
+      mfma_layer<8, 2, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2, W + layer_h_off(L_RD2), PGRF_LIMG(L_RD2));
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgbdir[t][c] = a2[t][1][c];
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int v = V0 + t;
@@ -643,7 +731,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) vs[v].fa[r] = imf[r] + elu1(a2[t][0][r]);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) vs[v].fb[c] = vs[v].rgb[c] + elu1(a2[t][1][c]);
+      for (int c = 0; c < 3; ++c) vs[v].fb[c] = vs[v].rgb[c] + elu1(rgbdir[t][c]);
       if (DBG && store_ok) {
         const size_t o = (size_t)v * npts + pt;
         if (sdbg[7]) dump_tile32(sdbg[7] + o * 32, imf, half);
@@ -762,13 +850,25 @@ __device__ __forceinline__ void stage_rgb(const PassArgs& p, const float* LI, co
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
-  mfma_layer<8, 1, NT, true>(W + layer_a_off(L_RGB2), W + layer_b_off(L_RGB2), lane, b8, a2, W + layer_h_off(L_RGB2), PGRF_LIMG(L_RGB2));
+  if constexpr (kSmall) {
+    float o8[NT][8];
+    mfma_small<8, 2, NT>(W + OFF_S_RGB2_A, W + OFF_S_RGB2_B, lane, b8, o8);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    f32x16 hh = a2[t][0];
+    for (int t = 0; t < NT; ++t) {
+      float y = W[OFF_RGBH_B];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hh[r] = elu1(hh[r]);
-    logit[V0 + t] = head_dot<4>(PGRF_LHEAD(OFF_RGBH_W), half, hh) + W[OFF_RGBH_B];
+      for (int o = 0; o < 8; ++o) y = fmaf(W[OFF_S_RGB2_H + o], elu1(o8[t][o]), y);
+      logit[V0 + t] = y;
+    }
+  } else {
+    mfma_layer<8, 1, NT, true>(W + layer_a_off(L_RGB2), W + layer_b_off(L_RGB2), lane, b8, a2, W + layer_h_off(L_RGB2), PGRF_LIMG(L_RGB2));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 hh = a2[t][0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hh[r] = elu1(hh[r]);
+      logit[V0 + t] = head_dot<4>(PGRF_LHEAD(OFF_RGBH_W), half, hh) + W[OFF_RGBH_B];
+    }
   }
 }
 
@@ -1008,7 +1108,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       for (int k2 = 0; k2 < KT; ++k2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[k2][r]);
-      mx = fmaxf(mx, xhalf(mx));
+      mx = xmax(mx);
       float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
       for (int k2 = 0; k2 < KT; ++k2)
@@ -1019,8 +1119,8 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
           l += pe;
           o0 = fmaf(pe, vv.x, o0); o1 = fmaf(pe, vv.y, o1); o2 = fmaf(pe, vv.z, o2); o3 = fmaf(pe, vv.w, o3);
         }
-      l += xhalf(l);
-      o0 += xhalf(o0); o1 += xhalf(o1); o2 += xhalf(o2); o3 += xhalf(o3);
+      l = xsum(l);
+      o0 = xsum(o0); o1 = xsum(o1); o2 = xsum(o2); o3 = xsum(o3);
       const float rl = rcp1(l);
       oatt[hd * 4 + 0] = o0 * rl; oatt[hd * 4 + 1] = o1 * rl; oatt[hd * 4 + 2] = o2 * rl; oatt[hd * 4 + 3] = o3 * rl;
     }
@@ -1038,12 +1138,12 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) sum += fo[0][0][r];
-      sum += xhalf(sum);
+      sum = xsum(sum);
       const float mean = sum * 0.0625f;
       float sq = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) { const float d = fo[0][0][r] - mean; sq += d * d; }
-      sq += xhalf(sq);
+      sq = xsum(sq);
       const float rstd = __builtin_amdgcn_rsqf(sq * 0.0625f + 1e-6f);
 #pragma unroll
       for (int r = 0; r < 8; ++r)

@@ -9,6 +9,7 @@ from panogrf_amd import cost_volume as CV
 from panogrf_amd import cost_reg as R
 
 h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 128)
+only = sys.argv[3] if len(sys.argv) > 3 else None     # 'costregnet' | 'unet2': time just that regulariser
 B, D, C = 1, 64, 32
 g = torch.Generator().manual_seed(0)
 feats = torch.randn(B, 2, h, w, C, generator=g).cuda()
@@ -38,6 +39,8 @@ nbytes = B * D * h * w * (C + 1) * 4 + B * 2 * h * w * C * 4
 print(f'cost volume {h}x{w}xD{D}: {t*1e3:.1f} us  -> {nbytes/t/1e6:.1f} GB/s algorithmic ({nbytes/1e6:.1f} MB)')
 for name, net, gf in [('CostRegNet', R.CostRegNet(dict(use_wrap_padding=True), 32), 16.2e9 * (h * w) / (64 * 128)),
                       ('UNet2', R.UNet2Reg(), 438.5e9 * (h * w) / (64 * 128))]:
+    if only and name.lower() != only:
+        continue
     net = net.cuda().eval()
     with torch.no_grad():
         for p in net.parameters():
