@@ -430,6 +430,8 @@ __device__ unsigned long long g_stage_cycles[32];
     t_prev = t_now;                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                  \
   } while (0)
+#elif defined(PGRF_STAGE_SYNC)   // experiment: re-align the 4 waves at every stage boundary so their weight loads coincide in L1
+#define PGRF_TICK(i) do { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #elif defined(PGRF_NO_STAGE_FENCE)
 #define PGRF_TICK(i) do {} while (0)
 #else
