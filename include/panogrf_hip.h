@@ -199,6 +199,16 @@ int pgrf_pack_conv3d(const float* w_host, const float* bias_host, int Cout, int 
 int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                      const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
                      const float* residual, int res_cs, int res_coff, void* stream);
+/* Narrow layers of CostRegNet (models/cost_reg.py:99-175: 8/16/32-channel convs): the same wrap-padded 3x3x3 conv,
+ * but the reduction is cut into 32-deep steps over (tap, channel) (two or four taps per step when Cin is 16 or 8) and
+ * `nshift` consecutive output depths share one 32-row tile (nshift * Cout <= 32; nshift > 1 needs stride 1 and
+ * D % nshift == 0).  Cin in {8,16,32}; Cout a multiple of 4.  `packed` from pgrf_pack_conv3d_small with the same
+ * (Cout, Cin, nshift).  Results equal pgrf_conv3d_wrap up to fp32 summation order. */
+size_t pgrf_conv3d_small_packed_floats(int Cout, int Cin, int nshift);
+int pgrf_pack_conv3d_small(const float* w_host, const float* bias_host, int Cout, int Cin, int nshift, float* packed_host);
+int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                      const float* packed, int has_bias, int nshift, int B, int D, int H, int W, int stride, float lrelu_slope,
+                      const float* residual, int res_cs, int res_coff, void* stream);
 /* Fast path of the same convolution for Cout == 1 and wide inputs (UNet2's last block, 128 -> 1): a pointwise MFMA
  * pass projects every voxel onto the 27 tap vectors (y[B,D,H,W,32], caller-owned scratch), a 27-tap gather finishes
  * (bias, LeakyReLU, residual).  `packed` is the block made by pgrf_pack_conv3d(Cout=1). */

@@ -66,6 +66,10 @@ SYMBOLS = {
     "pgrf_pack_conv3d": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_wrap": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P]),
+    "pgrf_conv3d_small_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "pgrf_pack_conv3d_small": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "pgrf_conv3d_small": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_cout1_project": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_cout1_gather": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_float, _P, C.c_int, C.c_int, _P]),

@@ -10,6 +10,8 @@ pgrf_cost_volume_erp writes, skipping the permute of pipeline3_model.py:847.
 """
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -27,6 +29,16 @@ class _PackedConv:
         lib.check(lib.pgrf_pack_conv3d(_ptr(w), _ptr(b), cout, cin, _ptr(host)))
         self.dev = host.to(device)
         self.cout, self.cin, self.has_bias = cout, cin, b is not None
+        self._w, self._b, self._device, self._small = w, b, device, {}
+
+    def small(self, nshift):
+        """Packed block of the narrow-layer kernel (pgrf_conv3d_small), built on first use per depth-shift count."""
+        if nshift not in self._small:
+            n = lib.pgrf_conv3d_small_packed_floats(self.cout, self.cin, nshift)
+            host = torch.empty(n, dtype=torch.float32)
+            lib.check(lib.pgrf_pack_conv3d_small(_ptr(self._w), _ptr(self._b), self.cout, self.cin, nshift, _ptr(host)))
+            self._small[nshift] = host.to(self._device)
+        return self._small[nshift]
 
 
 class _Vol:
@@ -44,6 +56,20 @@ class _Vol:
         return _Vol(self.buf, self.coff + coff, C)
 
 
+def _small_shift(pc, x, stride):
+    """Depth-shift count for the narrow-layer kernel, or 0 to use the general one.  PANOGRF_CONV_SMALL=0 disables."""
+    if os.environ.get('PANOGRF_CONV_SMALL', '1') == '0':
+        return 0
+    if pc.cin not in (8, 16, 32) or pc.cout % 4 or pc.cout > 32 or pc.cout < 4:
+        return 0
+    Do = (x.D - 1) // stride + 1
+    if stride == 1 and pc.cout <= 8 and Do % 4 == 0:
+        return 4
+    if stride == 1 and pc.cout <= 16 and Do % 2 == 0:
+        return 2
+    return 1 if pc.cin < 32 else 0
+
+
 def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
     if pc.cout == 1 and pc.cin >= 64 and pc.cin % 4 == 0 and stride == 1:
         # wide-input single-channel conv: pointwise MFMA projection onto the 27 tap vectors + 27-tap gather
@@ -54,6 +80,14 @@ def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
                                                _ptr(residual.buf) if residual is not None else None,
                                                residual.cs if residual is not None else 0,
                                                residual.coff if residual is not None else 0, _stream()))
+        return out
+    ns = _small_shift(pc, x, stride)
+    if ns:
+        lib.check(lib.pgrf_conv3d_small(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                        _ptr(pc.small(ns)), int(pc.has_bias), ns, x.B, x.D, x.H, x.W, stride, float(slope),
+                                        _ptr(residual.buf) if residual is not None else None,
+                                        residual.cs if residual is not None else 0,
+                                        residual.coff if residual is not None else 0, _stream()))
         return out
     lib.check(lib.pgrf_conv3d_wrap(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
                                    _ptr(pc.dev), int(pc.has_bias), x.B, x.D, x.H, x.W, stride, float(slope),

@@ -244,6 +244,153 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow layers (CostRegNet: 8/16/32 channels).  Two kinds of padding waste in the general kernel above:
+//  * K side: a (tap, chunk) step is 32 channels deep, so Cin = 16 (8) fills half (a quarter) of it.  Here the
+//    reduction index is k = tap * CIN + c, cut into 32-deep steps: a step holds 2 (4) taps when CIN = 16 (8).
+//  * M side: Cout = 8 (16) fills 8 (16) of the tile's 32 rows.  Here the rows carry NS = 4 (2) copies of the output
+//    channels for NS consecutive output depths z = NS*zq + delta: row = delta * (32/NS) + cout.  The input taps then
+//    span NS + 2 depth planes and the weight of row (delta, c) at depth offset dz' is W[c][dz' - delta] (zero outside
+//    the 3-tap support — a block-Toeplitz operand): (NS+2)/3 times the steps for NS times the outputs.
+// NS > 1 needs stride 1 and Do % NS == 0.  One 32-row tile (MT = 1), NT voxel tiles per wave, ping-pong prefetch.
+struct SmallArgs {
+  ConvArgs c;
+  int ns;        // depth shifts packed on the rows
+  int nsteps;    // ceil((ns + 2) * 9 * Cin / 32)
+};
+
+template <int CIN, int NS, int NT>
+__global__ void __launch_bounds__(256) conv3d_small_kernel(const SmallArgs sa) {
+  const ConvArgs& a = sa.c;
+  constexpr int NTAP = (NS + 2) * 9;
+  constexpr int TPH = CIN >= 16 ? 1 : 16 / CIN;        // taps per lane half per step
+  constexpr int QPT = CIN >= 16 ? 4 : CIN / 4;         // float4 loads per tap and lane
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 31, kk = lane >> 5;
+  const int Dq = a.Do / NS;
+  const long long nbase = (long long)a.B * Dq * a.Ho * a.Wo;
+  const long long tile0 = ((long long)blockIdx.x * 4 + wave) * NT;
+  if (tile0 * 32 >= nbase) return;
+  int vb[NT], vz[NT], vy[NT], vx[NT];
+  bool vok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    long long v = (tile0 + t) * 32 + j;
+    vok[t] = v < nbase;
+    if (!vok[t]) v = nbase - 1;
+    vx[t] = (int)(v % a.Wo); v /= a.Wo;
+    vy[t] = (int)(v % a.Ho); v /= a.Ho;
+    vz[t] = (int)(v % Dq) * NS; vb[t] = (int)(v / Dq);      // first output depth of the group
+  }
+  f32x16 acc[NT];
+  {
+    f32x16 bv;
+    if (a.bias) {
+      const float4* bp = reinterpret_cast<const float4*>(a.bias + kk * 16);
+      const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+      bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = bv;
+  }
+  struct Step {
+    float4 bv[NT][4];
+    float4 av[4];
+    bool ok[NT][TPH];
+    bool need_mask;
+  };
+  auto issue = [&](Step& st, int step) {
+    bool all = true;
+#pragma unroll
+    for (int u = 0; u < TPH; ++u) {
+      // CIN 32: step = tap, the half takes channels kk*16..; CIN 16: tap = 2*step + kk; CIN 8: tap = 4*step + 2*kk + u
+      const int tap = CIN == 32 ? step : (CIN == 16 ? 2 * step + kk : 4 * step + 2 * kk + u);
+      const bool tap_ok = tap < NTAP;
+      const int tp = tap_ok ? tap : 0;
+      const int dz = tp / 9 - 1, dy = (tp / 3) % 3 - 1, dx = tp % 3 - 1;
+      const int c0 = CIN == 32 ? kk * 16 : 0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int zi = vz[t] * a.stride + dz, yi = vy[t] * a.stride + dy;
+        int xi = vx[t] * a.stride + dx;
+        xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
+        st.ok[t][u] = vok[t] && tap_ok && zi >= 0 && zi < a.D && yi >= 0 && yi < a.H;
+        all = all && st.ok[t][u];
+        const int zc = min(max(zi, 0), a.D - 1), yc = min(max(yi, 0), a.H - 1);
+        const float* ip = a.in + ((((long long)vb[t] * a.D + zc) * a.H + yc) * a.W + xi) * a.in_cs + a.in_coff + c0;
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) st.bv[t][u * QPT + q] = *reinterpret_cast<const float4*>(ip + q * 4);
+      }
+    }
+    st.need_mask = !__all(all);
+    const float4* ap = reinterpret_cast<const float4*>(a.wpk) + (size_t)step * 256 + lane;
+    st.av[0] = ap[0]; st.av[1] = ap[64]; st.av[2] = ap[128]; st.av[3] = ap[192];
+  };
+  auto compute = [&](Step& st) {
+    if (st.need_mask)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < TPH; ++u)
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+          float4& v = st.bv[t][u * QPT + q];
+          const bool ok = st.ok[t][u];
+          v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float av[4] = {st.av[s4].x, st.av[s4].y, st.av[s4].z, st.av[s4].w};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 bq = st.bv[t][s4];
+          const float bs = (jj == 0) ? bq.x : (jj == 1) ? bq.y : (jj == 2) ? bq.z : bq.w;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], bs, acc[t], 0, 0, 0);
+        }
+    }
+  };
+  Step P, Q;
+  int step = 0;
+  issue(P, step++);
+  while (true) {
+    const bool hasQ = step < sa.nsteps;
+    if (hasQ) issue(Q, step++);
+    compute(P);
+    if (!hasQ) break;
+    const bool hasP = step < sa.nsteps;
+    if (hasP) issue(P, step++);
+    compute(Q);
+    if (!hasP) break;
+  }
+  // epilogue: row = q*8 + kk*4 + i  ->  depth shift = row / (32/NS), channel = row % (32/NS)
+  constexpr int RPS = 32 / NS;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (!vok[t]) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 8 + kk * 4;
+      const int delta = row / RPS, c = row % RPS;
+      if (c + 4 > a.Cout) continue;
+      const long long ov = (((long long)vb[t] * a.Do + vz[t] + delta) * a.Ho + vy[t]) * a.Wo + vx[t];
+      float4 v = make_float4(acc[t][q * 4], acc[t][q * 4 + 1], acc[t][q * 4 + 2], acc[t][q * 4 + 3]);
+      v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+      v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+      if (a.residual) {
+        const float4 rr = *reinterpret_cast<const float4*>(a.residual + ov * a.res_cs + a.res_coff + c);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
+    }
+  }
+}
+
 // Cout == 1 (UNet2's last block, CostRegNet's prob head): VALU dot products, LPV lanes per voxel.
 // wlin: [27][Cin] (tap-major), bias scalar.
 __global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, const float* __restrict__ wlin, int has_bias, int lpv) {
@@ -479,6 +626,91 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   else PGRF_LAUNCH(1, 1);
 #undef PGRF_LAUNCH
   PGRF_CHECK_LAUNCH("conv3d_wrap");
+  return PGRF_OK;
+}
+
+// ---- narrow layers (conv3d_small_kernel) -------------------------------------------------------------------------
+// packed block: [steps][4][64 lanes][4] A operands | [32] bias in accumulator order
+static int small_steps(int Cin, int ns) { return ((ns + 2) * 9 * Cin + 31) / 32; }
+
+size_t pgrf_conv3d_small_packed_floats(int Cout, int Cin, int nshift) {
+  (void)Cout;
+  return (size_t)small_steps(Cin, nshift) * 1024 + 32;
+}
+
+int pgrf_pack_conv3d_small(const float* w_host, const float* bias_host, int Cout, int Cin, int nshift, float* packed_host) {
+  if (!w_host || !packed_host) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d_small: null pointer");
+  if (!(Cin == 8 || Cin == 16 || Cin == 32) || !(nshift == 1 || nshift == 2 || nshift == 4) || Cout < 4 || (Cout & 3) ||
+      Cout > 32 / nshift)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv3d_small: Cin %d, Cout %d, nshift %d", Cin, Cout, nshift);
+  const int steps = small_steps(Cin, nshift), ntap = (nshift + 2) * 9, rps = 32 / nshift;
+  std::memset(packed_host, 0, sizeof(float) * pgrf_conv3d_small_packed_floats(Cout, Cin, nshift));
+  for (int st = 0; st < steps; ++st)
+    for (int s = 0; s < 16; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = lane & 31, kk = lane >> 5;
+        const int k = st * 32 + kk * 16 + s;             // reduction index = tap * Cin + channel
+        const int tap = k / Cin, ci = k % Cin;
+        const int delta = row / rps, co = row % rps;
+        if (tap >= ntap || co >= Cout) continue;
+        const int kz = tap / 9 - 1 - delta;               // which of the 3 depth taps of output (delta, co) this plane is
+        if (kz < -1 || kz > 1) continue;
+        const int t27 = (kz + 1) * 9 + tap % 9;
+        packed_host[(((size_t)st * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3)] = w_host[((size_t)co * Cin + ci) * 27 + t27];
+      }
+  float* Bv = packed_host + (size_t)steps * 1024;
+  for (int h = 0; h < 2; ++h)
+    for (int r = 0; r < 16; ++r) {
+      const int co = rho_(r, h) % rps;
+      Bv[h * 16 + r] = (bias_host && co < Cout) ? bias_host[co] : 0.f;
+    }
+  return PGRF_OK;
+}
+
+int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                      const float* packed, int has_bias, int nshift, int B, int D, int H, int W, int stride, float lrelu_slope,
+                      const float* residual, int res_cs, int res_coff, void* stream) {
+  if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_small: null pointer");
+  if (stride != 1 && stride != 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small: stride %d", stride);
+  if (!(Cin == 8 || Cin == 16 || Cin == 32) || !(nshift == 1 || nshift == 2 || nshift == 4) || Cout < 4 || (Cout & 3) ||
+      Cout > 32 / nshift)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small: Cin %d, Cout %d, nshift %d", Cin, Cout, nshift);
+  if (B < 1 || D < 1 || H < 1 || W < 2) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_small: bad dims");
+  if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small: channel strides/offsets must be multiples of 4");
+  SmallArgs sa;
+  ConvArgs& a = sa.c;
+  a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff;
+  a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
+  a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+  a.chunks = 1; a.cot_total = 1; a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27;
+  if (nshift > 1 && (stride != 1 || a.Do % nshift))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small: nshift %d needs stride 1 and D %% nshift == 0", nshift);
+  sa.ns = nshift; sa.nsteps = small_steps(Cin, nshift);
+  a.wpk = packed;
+  a.bias = has_bias ? packed + (size_t)sa.nsteps * 1024 : nullptr;
+  const long long nbase = (long long)B * (a.Do / nshift) * a.Ho * a.Wo;
+  const long long tiles = (nbase + 31) / 32;
+  const int nt = tiles >= 4 * 2048 ? 4 : (tiles >= 2 * 2048 ? 2 : 1);
+  dim3 grid((unsigned)((tiles + 4 * nt - 1) / (4 * nt)));
+#define PGRF_LS(CIN_, NS_)                                                                                         \
+  do {                                                                                                             \
+    if (nt == 4) hipLaunchKernelGGL((conv3d_small_kernel<CIN_, NS_, 4>), grid, dim3(256), 0, (hipStream_t)stream, sa);  \
+    else if (nt == 2) hipLaunchKernelGGL((conv3d_small_kernel<CIN_, NS_, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa); \
+    else hipLaunchKernelGGL((conv3d_small_kernel<CIN_, NS_, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);     \
+  } while (0)
+#define PGRF_LS_NS(CIN_)                       \
+  do {                                         \
+    if (nshift == 4) PGRF_LS(CIN_, 4);         \
+    else if (nshift == 2) PGRF_LS(CIN_, 2);    \
+    else PGRF_LS(CIN_, 1);                     \
+  } while (0)
+  if (Cin == 8) PGRF_LS_NS(8);
+  else if (Cin == 16) PGRF_LS_NS(16);
+  else PGRF_LS_NS(32);
+#undef PGRF_LS_NS
+#undef PGRF_LS
+  PGRF_CHECK_LAUNCH("conv3d_small");
   return PGRF_OK;
 }
 
