@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <vector>
 
 #include "pgrf_internal.h"
 #include "pgrf_layout.h"
@@ -84,6 +85,39 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
   }
   std::memset(blob, 0, sizeof(float) * kBlobFloats);
 
+  // ---- prob_embed.2 folded into its two consumers.  Its output ("neuray feature", aggregate_net.py:61) carries no
+  // activation and only enters neuray_fc.0 and columns 175..206 of base_fc.0 (ibrnet.py:338,344), both Linear:
+  //   W_c (W_pe2 r + b_pe2) + b_c = (W_c W_pe2) r + (W_c b_pe2 + b_c),   r = relu(prob_embed.0(.))
+  // so the per-point 32x32 layer disappears (16 of the 441 MFMAs per view and wave); products accumulated in double.
+  std::vector<float> base_fused(raw[R_BASE_0_W], raw[R_BASE_0_W] + 64 * 207), base_bias(raw[R_BASE_0_B], raw[R_BASE_0_B] + 64);
+  std::vector<float> nf_fused(8 * 32), nf_bias(8);
+  {
+    const float* Wp = raw[R_PE_2_W];   // [32 out][32 in]
+    const float* bp = raw[R_PE_2_B];
+    for (int o = 0; o < 64; ++o) {
+      const float* Wc = raw[R_BASE_0_W] + (size_t)o * 207 + 175;
+      for (int j = 0; j < 32; ++j) {
+        double acc = 0.0;
+        for (int k = 0; k < 32; ++k) acc += (double)Wc[k] * (double)Wp[k * 32 + j];
+        base_fused[(size_t)o * 207 + 175 + j] = (float)acc;
+      }
+      double accb = raw[R_BASE_0_B][o];
+      for (int k = 0; k < 32; ++k) accb += (double)Wc[k] * (double)bp[k];
+      base_bias[o] = (float)accb;
+    }
+    for (int o = 0; o < 8; ++o) {
+      const float* Wc = raw[R_NF_0_W] + (size_t)o * 32;
+      for (int j = 0; j < 32; ++j) {
+        double acc = 0.0;
+        for (int k = 0; k < 32; ++k) acc += (double)Wc[k] * (double)Wp[k * 32 + j];
+        nf_fused[o * 32 + j] = (float)acc;
+      }
+      double accb = raw[R_NF_0_B][o];
+      for (int k = 0; k < 32; ++k) accb += (double)Wc[k] * (double)bp[k];
+      nf_bias[o] = (float)accb;
+    }
+  }
+
   // ---- dist decoder -----------------------------------------------------------------
   const int dec0[4] = {R_DD_MEAN_0_W, R_DD_VAR_0_W, R_DD_AW_0_W, R_DD_VIS_0_W};
   {  // fused layer 0: tile m = MLP m
@@ -120,7 +154,7 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
              [](int s, int h) { return s < 16 ? rho(s, h) : 32 + h; }, ident_out);
   pack_layer(blob, L_PE2, raw[R_PE_2_W], 32, raw[R_PE_2_B], ident_in, ident_out);
   // ---- neuray_fc --------------------------------------------------------------------
-  pack_layer(blob, L_NF1, raw[R_NF_0_W], 32, raw[R_NF_0_B], ident_in, [](int, int r) { return r < 8 ? r : -1; });
+  pack_layer(blob, L_NF1, nf_fused.data(), 32, nf_bias.data(), ident_in, [](int, int r) { return r < 8 ? r : -1; });   // on relu(prob_embed.0)
   pack_head(blob + OFF_NFH_W, raw[R_NF_2_W], 4, [](int r, int h) { return rho(r, h); });
   blob[OFF_NFH_B] = raw[R_NF_2_B][0];
   // ---- ray_dir_fc -------------------------------------------------------------------
@@ -131,14 +165,14 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
              [](int m, int r) { return m == 0 ? 3 + r : (r < 3 ? r : -1); });
   // ---- base_fc ----------------------------------------------------------------------
   // columns of base_fc.0: [mean0(35) var0(35) mean1(35) var1(35) | rgb_feat(35) neuray(32)]
-  pack_layer(blob, L_BG, raw[R_BASE_0_W], 207, raw[R_BASE_0_B],
+  pack_layer(blob, L_BG, base_fused.data(), 207, base_bias.data(),
              [](int s, int h) {
                const int stat = s / 19, j = s % 19;
                if (j < 16) return 35 * stat + 3 + rho(j, h);
                return h == 0 ? 35 * stat + (j - 16) : -1;
              },
              [](int m, int r) { return 32 * m + r; });
-  pack_layer(blob, L_BV, raw[R_BASE_0_W], 207, nullptr,
+  pack_layer(blob, L_BV, base_fused.data(), 207, nullptr,
              [](int s, int h) {
                if (s < 16) return 140 + 3 + rho(s, h);
                if (s < 19) return h == 0 ? 140 + (s - 16) : -1;
@@ -223,7 +257,7 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
     }
   }
   // ---- small layers for the 4x4x1 MFMA path (pgrf_layout.h: OFF_S_*)
-  pack_small(blob + OFF_S_NF1_A, blob + OFF_S_NF1_B, raw[R_NF_0_W], 32, raw[R_NF_0_B], 16, 2, 8, 0, ident_in);
+  pack_small(blob + OFF_S_NF1_A, blob + OFF_S_NF1_B, nf_fused.data(), 32, nf_bias.data(), 16, 2, 8, 0, ident_in);
   for (int o = 0; o < 8; ++o) blob[OFF_S_NF1_H + o] = raw[R_NF_2_W][o];
   pack_small(blob + OFF_S_RDC_A, blob + OFF_S_RDC_B, raw[R_RD_2_W], 16, raw[R_RD_2_B], 8, 1, 3, 0, ident_in);
   pack_small(blob + OFF_S_RGB2_A, blob + OFF_S_RGB2_B, raw[R_RGB_2_W], 16, raw[R_RGB_2_B], 8, 2, 8, 0, ident_in);

@@ -442,7 +442,7 @@ __device__ unsigned long long g_stage_cycles[32];
 struct ViewState {
   f32x16 fa;      // rgb_feat tile A (img-feat part, + dir feat); later: x (base_fc output, 32)
   float fb[3];    // rgb_feat tile B (rgb part + dir feat), meaningful in lanes 0..31
-  f32x16 nf;      // prob_embed output ("neuray feat")
+  f32x16 nf;      // relu(prob_embed.0): prob_embed.2 ("neuray feat") is folded into its consumers' weights
   float dd[4];    // [prj_dir - que_dir, <prj_dir,que_dir>]
   float rgb[3];   // gathered source colour (blended at the end)
   float w0;       // sigmoid(neuray_fc) * w
@@ -640,9 +640,18 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int s = 0; s < 16; ++s) b2[t][s] = fmaxf(a1[t][0][s], 0.f);
-    mfma_layer<16, 1, NT, true>(W + layer_a_off(L_PE2), W + layer_b_off(L_PE2), lane, b2, a2, W + layer_h_off(L_PE2), PGRF_LIMG(L_PE2));
+    // prob_embed.2 is folded into neuray_fc.0 and base_fc.0 on the host (pack_weights.cpp): the state kept per view
+    // is r = relu(prob_embed.0(.)).  Debug builds still evaluate the layer, for the "neuray" dump only.
 #pragma unroll
-    for (int t = 0; t < NT; ++t) vs[V0 + t].nf = a2[t][0];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) vs[V0 + t].nf[s] = b2[t][s];
+    if (DBG && sdbg[8]) {
+      mfma_layer<16, 1, NT, true>(W + layer_a_off(L_PE2), W + layer_b_off(L_PE2), lane, b2, a2, W + layer_h_off(L_PE2), PGRF_LIMG(L_PE2));
+      if (store_ok)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dump_tile32(sdbg[8] + (pt * V + (V0 + t)) * 32, a2[t][0], half);
+    }
   }
   PGRF_TICK(19);  // A: prob_embed
   // ---- neuray_fc 32 -> 8 elu -> 1, weight0 = sigmoid(.) * w   (ibrnet.py:337-338)
@@ -675,9 +684,6 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
         vs[V0 + t].w0 = sigmoid1(y) * wgt;
       }
     }
-    if (DBG && store_ok && sdbg[8])
-#pragma unroll
-      for (int t = 0; t < NT; ++t) dump_tile32(sdbg[8] + (pt * V + (V0 + t)) * 32, vs[V0 + t].nf, half);
   }
   PGRF_TICK(20);  // A: neuray_fc
   // ---- ray_dir_fc 4 -> 16 elu -> 35 elu; rgb_feat = [rgb, img_feats] + dir_feat  (ibrnet.py:325-327)
