@@ -313,7 +313,7 @@ def main():
             if len(vals) == 2:
                 traffic = (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
     res = {
-        'metric': 'rendered rays/sec (512x1024 ERP, 64 samples)', 'value': rays_per_s, 'unit': 'rays/s',
+        'metric': f'rendered rays/sec ({H}x{W} ERP, {dn} samples)', 'value': rays_per_s, 'unit': 'rays/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'f16x3-split products, f32 accumulate', 'data': 'synthetic',
         'config': {'workload': f'{H}x{W} ERP query, {V} source views, {dn} samples/ray'
