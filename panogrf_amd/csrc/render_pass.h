@@ -54,10 +54,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Combine a value with the same value of lane ^ 32 (the other half of the point's features).  v_permlane32_swap (gfx950)
 // exchanges the upper half of one register with the lower half of another on the VALU: no LDS round trip as with
 // ds_bpermute.  With both operands = v it yields [lo,lo] and [hi,hi]; their sum / max is the cross-half result in all lanes.
-#ifdef PGRF_BPERMUTE_XHALF
-__device__ __forceinline__ float xsum(float v) { return v + __shfl_xor(v, 32, 64); }
-__device__ __forceinline__ float xmax(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
-#else
 __device__ __forceinline__ float xsum(float v) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -66,15 +62,8 @@ __device__ __forceinline__ float xmax(float v) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
-#endif
 // ELU(x) = median(x, exp(x)-1, 0): x > 0 -> exp(x)-1 >= x > 0; x < 0 -> x <= exp(x)-1 < 0.  One v_med3 instead of cmp+cndmask.
-#ifdef PGRF_OLD_ELU
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : (__expf(x) - 1.f); }
-#elif defined(PGRF_ELU_TIMING_HACK)   // timing experiment only (wrong numbers): instruction mix of a log2e-scaled carry
-__device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, fmaf(__builtin_amdgcn_exp2f(x), 1.4426950408889634f, -1.4426950408889634f), 0.f); }
-#else
 __device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
-#endif
 // 1-ulp reciprocal (v_rcp_f32) for quantities that are not pixel coordinates: the correctly rounded IEEE
 // division costs ~11 VALU instructions, and VALU time adds to f32-MFMA time on this chip.
 __device__ __forceinline__ float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -83,20 +72,12 @@ __device__ __forceinline__ float sigmoid1(float x) { return rcp1(1.f + __expf(-x
 // fp32 rounding of the result's integer part; libm's log1pf is a ~140-instruction double-float routine (measured: the
 // 8 calls per wave were 4 % of the kernel).  For x > 20 the second term is below half an ulp of x: same as the threshold.
 __device__ __forceinline__ float softplus1(float x) {
-#ifdef PGRF_LIBM_SOFTPLUS
-  return x > 20.f ? x : log1pf(__expf(x));
-#else
   const float t = __builtin_amdgcn_exp2f(-fabsf(x) * 1.4426950408889634f);
   return fmaf(__builtin_amdgcn_logf(1.f + t), 0.6931471805599453f, fmaxf(x, 0.f));
-#endif
 }
 // logistic CDF 0.5 + 0.5 tanh(d) == 1 / (1 + exp(-2d))  (dist_decoder.py:129-130), 4 instructions instead of libm tanhf
 __device__ __forceinline__ float cdf1(float d) {
-#ifdef PGRF_LIBM_TANH
-  return 0.5f + 0.5f * tanhf(d);
-#else
   return rcp1(1.f + __builtin_amdgcn_exp2f(d * -2.8853900817779268f));
-#endif
 }
 
 __device__ __forceinline__ void elu16(f32x16& a) {
@@ -144,17 +125,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], H8& hi, H8& lo) {
   for (int e = 0; e < 4; ++e) {
     const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * e], x[2 * e + 1]);
     hi.p[e] = h;
-#ifndef PGRF_SPLIT_MIX
     lo.p[e] = __builtin_amdgcn_cvt_pkrtz(x[2 * e] - (float)h[0], x[2 * e + 1] - (float)h[1]);
-#else
-    // experiment: x - hi in ONE v_fma_mix_f32 reading the packed half (the compiler emits v_cvt_f32_f16 + v_sub_f32).
-    // 570 fewer VALU instructions per wave, but the asm operands cost 72 more spilled registers: 29.2 -> 34.4 ms.
-    float r0, r1;
-    const unsigned hb = hi.u4[e];
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x[2 * e]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x[2 * e + 1]));
-    lo.p[e] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-#endif
   }
 }
 
@@ -242,12 +213,7 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             // the bias vector is the C operand of the first MFMA of the tile (shared by the NT point tiles)
-#ifdef PGRF_OLD_BIAS
-            if (INIT_BIAS && s4 == 0 && j == 0) acc[t][m] = bv;
-            if (false)
-#else
             if (INIT_BIAS && s4 == 0 && j == 0)
-#endif
               acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[t][0], bv, 0, 0, 0);
             else
               acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[t][s4 * 4 + j], acc[t][m], 0, 0, 0);
@@ -372,44 +338,6 @@ __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const 
   return out;
 }
 
-// The same gather in two halves, so the 16 tap loads of the NEXT block can be in flight while the matrix cores work on
-// the current one (the loads depend on computed pixel positions: nothing else hides their L2 latency).
-struct Taps { float4 t[16]; };
-template <int STRIDE = 32, int Q0 = 0, int Q1 = 4>
-__device__ __forceinline__ void gather_issue(Taps& r, const float* __restrict__ map, const Bilin& b, int half) {
-  const float* base = map + half * 4;
-#pragma unroll
-  for (int q = Q0; q < Q1; ++q) {
-    r.t[4 * q + 0] = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * STRIDE + q * 8);
-    r.t[4 * q + 1] = *reinterpret_cast<const float4*>(base + (size_t)b.o01 * STRIDE + q * 8);
-    r.t[4 * q + 2] = *reinterpret_cast<const float4*>(base + (size_t)b.o10 * STRIDE + q * 8);
-    r.t[4 * q + 3] = *reinterpret_cast<const float4*>(base + (size_t)b.o11 * STRIDE + q * 8);
-  }
-}
-template <int Q0 = 0, int Q1 = 4>
-__device__ __forceinline__ void gather_blend_q(f32x16& out, const Taps& r, const Bilin& b) {
-#pragma unroll
-  for (int q = Q0; q < Q1; ++q) {
-    const float4 a = r.t[4 * q], c = r.t[4 * q + 1], d = r.t[4 * q + 2], e = r.t[4 * q + 3];
-    out[4 * q + 0] = a.x * b.wnw + c.x * b.wne + d.x * b.wsw + e.x * b.wse;
-    out[4 * q + 1] = a.y * b.wnw + c.y * b.wne + d.y * b.wsw + e.y * b.wse;
-    out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
-    out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
-  }
-}
-__device__ __forceinline__ f32x16 gather_blend(const Taps& r, const Bilin& b) {
-  f32x16 out;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 a = r.t[4 * q], c = r.t[4 * q + 1], d = r.t[4 * q + 2], e = r.t[4 * q + 3];
-    out[4 * q + 0] = a.x * b.wnw + c.x * b.wne + d.x * b.wsw + e.x * b.wse;
-    out[4 * q + 1] = a.y * b.wnw + c.y * b.wne + d.y * b.wsw + e.y * b.wse;
-    out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
-    out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
-  }
-  return out;
-}
-
 __device__ __forceinline__ void dump_tile32(float* dst, const f32x16& x, int half) {   // dst -> 32 floats of this point
 #pragma unroll
   for (int r = 0; r < 16; ++r) dst[rho(r, half)] = x[r];
@@ -430,8 +358,6 @@ __device__ unsigned long long g_stage_cycles[32];
     t_prev = t_now;                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                  \
   } while (0)
-#elif defined(PGRF_STAGE_SYNC)   // experiment: re-align the 4 waves at every stage boundary so their weight loads coincide in L1
-#define PGRF_TICK(i) do { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #elif defined(PGRF_NO_STAGE_FENCE)
 #define PGRF_TICK(i) do {} while (0)
 #else
@@ -472,9 +398,6 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
   float dv[NT];
   Bilin bimg[NT], bfeat[NT], brf[NT];
   const float* prj[NT];
-#ifdef PGRF_EARLY_GATHER
-  f32x16 imf_early[NT];
-#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int v = V0 + t;
@@ -507,9 +430,6 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     prj[t] = p.prj + (size_t)v * p.hr * p.wr * kPrjCh;
     bfeat[t] = bilin_setup(px, py, p.H, p.W, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
     bimg[t] = bilin_setup(px, py, p.H, p.W, p.H, p.W, true);
-#ifdef PGRF_EARLY_GATHER
-    imf_early[t] = gather32(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
-#endif
     if (DBG && store_ok) {
       const size_t o = (size_t)v * npts + pt;
       if (sdbg[0] && half == 0) { sdbg[0][o * 2] = px; sdbg[0][o * 2 + 1] = py; }
@@ -525,15 +445,6 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
   float head[NT][6];
 #pragma unroll
   for (int t = 0; t < NT; ++t) head[t][5] = 1.f;
-#ifdef PGRF_PIPE_GATHER
-#ifndef PGRF_PIPE_Q
-#define PGRF_PIPE_Q 4
-#endif
-  constexpr int PQ = PGRF_PIPE_Q;
-  Taps raw[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) gather_issue<kPrjCh, 0, PQ>(raw[t], prj[t], brf[t], half);
-#endif
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     if (m == 3 && !p.use_vis) break;
@@ -541,26 +452,10 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     float b2[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-#ifdef PGRF_PIPE_GATHER
-      f32x16 a1;
-      gather_issue<kPrjCh, PQ, 4>(raw[t], prj[t] + (m < 3 ? m : 4) * 32, brf[t], half);
-      gather_blend_q<0, PQ>(a1, raw[t], brf[t]);
-      gather_blend_q<PQ, 4>(a1, raw[t], brf[t]);
-#else
       const f32x16 a1 = gather32<kPrjCh>(prj[t] + (m < 3 ? m : 4) * 32, brf[t], half);
-#endif
 #pragma unroll
       for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[s]);
     }
-#ifdef PGRF_PIPE_GATHER
-    {   // next block of the projection map: MLP m+1, or (after the last MLP) the prob_embed block
-      const int nb = (m == 2 && p.use_vis) ? 4 : (m >= 2 ? 3 : m + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) gather_issue<kPrjCh, 0, PQ>(raw[t], prj[t] + nb * 32, brf[t], half);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
     mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2, W + layer_h_off(L_DD2_0 + m), PGRF_LIMG(L_DD2_0 + m));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -618,23 +513,10 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-#ifdef PGRF_PIPE_GATHER
-      f32x16 pe;
-      gather_issue<kPrjCh, PGRF_PIPE_Q, 4>(raw[t], prj[t] + 3 * 32, brf[t], half);
-      gather_blend_q<0, PGRF_PIPE_Q>(pe, raw[t], brf[t]);
-      gather_blend_q<PGRF_PIPE_Q, 4>(pe, raw[t], brf[t]);
-#else
       const f32x16 pe = gather32<kPrjCh>(prj[t] + 3 * 32, brf[t], half);
-#endif
       const float hv = half ? (vis_s[t] - 0.5f) * 2.f : (hit_s[t] - 0.5f) * 2.f;
       a1[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a16, hv, pe, 0, 0, 0);
     }
-#ifdef PGRF_PIPE_GATHER
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) gather_issue<32, 0, PGRF_PIPE_Q>(raw[t], p.img_feats + (size_t)(V0 + t) * p.hf * p.wf * 32, bfeat[t], half);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     float b2[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -718,16 +600,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int v = V0 + t;
-#ifdef PGRF_EARLY_GATHER
-      const f32x16 imf = imf_early[t];
-#elif defined(PGRF_PIPE_GATHER)
-      f32x16 imf;
-      gather_issue<32, PGRF_PIPE_Q, 4>(raw[t], p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
-      gather_blend_q<0, PGRF_PIPE_Q>(imf, raw[t], bfeat[t]);
-      gather_blend_q<PGRF_PIPE_Q, 4>(imf, raw[t], bfeat[t]);
-#else
       const f32x16 imf = gather32(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
-#endif
       const float* ib = p.imgs + (size_t)v * p.H * p.W * 4;
       const float4 c00 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o00 * 4);
       const float4 c01 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o01 * 4);
