@@ -287,3 +287,41 @@ def test_split_f16_full_frame_psnr_vs_f32():
     b = E.RayRenderer({**case['cfg'], 'hip_precision': 'f16x3'}, case['weights']).render_rays(fr, coords)
     assert FX.psnr(b['pixel_colors_nr'].cpu(), a['pixel_colors_nr'].cpu()) > 100.0
     assert FX.psnr(b['pixel_colors_nr_fine'].cpu(), a['pixel_colors_nr_fine'].cpu()) > 70.0
+
+
+def _random_rotation(g):
+    """Uniformly random rotation (QR of a Gaussian matrix, determinant fixed to +1)."""
+    q, r = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    q = q * torch.sign(torch.diagonal(r))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q.float()
+
+
+@pytest.mark.parametrize('seed,rfn', [(0, 2), (1, 2), (2, 3), (3, 4), (4, 2), (5, 2)])
+def test_arbitrary_poses_vs_oracle(seed, rfn):
+    """Query and source cameras with ARBITRARY rotations (the fixtures only tilt by +-0.15 rad) and source centres up
+    to 1.5 m away, so rays pass close to source cameras, cross the ERP seam and hit the poles of the source panoramas."""
+    from oracle import render_oracle as O
+    from bench import synthetic_case
+    E = _engine()
+    H, W, dn = 16, 32, 32
+    case = synthetic_case(H, W, rfn, dn, seed=seed)
+    g = torch.Generator().manual_seed(900 + seed)
+    fr = case['frame']
+    for v in range(rfn):
+        R = _random_rotation(g)
+        c = (torch.rand(3, generator=g) - 0.5) * 3.0
+        fr['w2c'][v, :, :3] = R
+        fr['w2c'][v, :, 3] = -R @ c
+    Rq = _random_rotation(g)
+    fr['que_c2w'] = torch.cat([Rq, ((torch.rand(3, generator=g) - 0.5) * 0.4)[:, None]], 1)
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    out = rr.render_rays(_frame(E, fr), coords)
+    ref = O.render_rays(case['weights'], fr, coords, case['cfg'])
+    assert FX.max_abs(out['render_depth'].cpu(), ref['render_depth']) < 2e-4 * 15.0
+    assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 5e-5
+    scale = max(1.0, float(ref['density_nr'].abs().max()))
+    assert FX.max_abs(out['density_nr'].cpu(), ref['density_nr']) / scale < 5e-4
