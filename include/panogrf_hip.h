@@ -52,7 +52,17 @@ typedef struct PgrfFrame {
   const float* ref_depth_range;/* [rfn,2] near,far of every source view */
   float que_c2w[12];           /* [3,4] camera->world of the query view (host values) */
   float que_depth_range[2];    /* near,far of the query view (host values) */
+  int dataset;                 /* PGRF_DATASET_*: spherical convention of network/spt_utils.py (cfg dataset_name) */
+  int perspective;             /* 0: the query is an ERP panorama (render_ops.py:76-106 depth2points_spherical);
+                                * 1: pinhole query, rays K^-1 [x,y,1] (render_ops.py:35-74 coords2rays /
+                                *    depth2points_perspec, is_perspec=True, render_cubes.py) */
+  float que_kinv[9];           /* inverse intrinsics of a pinhole query (host values), unused otherwise */
 } PgrfFrame;
+/* ERP pixel <-> sphere <-> cartesian conventions (network/spt_utils.py:45-83, :106-124, :134-156, :176-192) */
+#define PGRF_DATASET_M3D 0
+#define PGRF_DATASET_REPLICA_TEST 1
+#define PGRF_DATASET_RESIDENTIAL 2
+#define PGRF_DATASET_COFFEEAREA 3
 
 /* NCHW [n,C,h,w] -> NHWC [n,h,w,Cpad] (Cpad = 4 for C = 3, else C); replaces nothing in the
  * reference (layout change only). */

@@ -15,16 +15,31 @@ import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------- geometry (a-1, a-2)
-def erp_ray_directions(H, W):
-    """Unit camera-frame direction of every ERP pixel, [H,W,3].
-    network/ray_utils.py:4-16, network/spt_utils.py:21-35 (pixel grid), :45-58 (m3d angles),
-    :106-111 (m3d sphere->cartesian)."""
+def erp_ray_directions(H, W, dataset='m3d'):
+    """Unit camera-frame direction of every ERP pixel, [H,W,3], in the dataset's spherical convention.
+    network/ray_utils.py:4-16, network/spt_utils.py:21-35 (pixel grid), :45-83 (pixel -> angles per dataset),
+    :106-124 (angles -> cartesian per dataset)."""
     x = torch.linspace(0, W - 1, W).view(1, W).expand(H, W)
     y = torch.linspace(0, H - 1, H).view(H, 1).expand(H, W)
-    theta = x / (W - 1) * 2 * math.pi - 0.5 * math.pi
-    phi = y / (H - 1) * math.pi
-    s = torch.sin(phi)
-    d = torch.stack([s * torch.cos(theta), torch.cos(phi), s * torch.sin(theta)], -1)
+    if dataset == 'm3d':
+        theta = x / (W - 1) * 2 * math.pi - 0.5 * math.pi
+        phi = y / (H - 1) * math.pi
+        s = torch.sin(phi)
+        d = torch.stack([s * torch.cos(theta), torch.cos(phi), s * torch.sin(theta)], -1)
+    elif dataset == 'replica_test':
+        theta = x * 2 * math.pi / (W - 1) - math.pi
+        phi = -y * math.pi / (H - 1) + math.pi * 0.5
+        d = torch.stack([torch.sin(theta) * torch.cos(phi), -torch.sin(phi), torch.cos(theta) * torch.cos(phi)], -1)
+    elif dataset == 'residential':
+        theta = math.pi * (2 * x / (W - 1) - 1.5)
+        phi = math.pi * (0.5 - y / (H - 1))
+        d = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(phi), torch.sin(theta) * torch.cos(phi)], -1)
+    elif dataset == 'CoffeeArea':
+        theta = (-2 * math.pi / (W - 1)) * x + 2 * math.pi
+        phi = (math.pi / (H - 1)) * y
+        d = torch.stack([torch.sin(phi) * torch.cos(theta), torch.sin(phi) * torch.sin(theta), torch.cos(phi)], -1)
+    else:
+        raise ValueError(f'unknown dataset convention {dataset!r}')
     return d / torch.norm(d, p=2, dim=-1, keepdim=True)
 
 
@@ -58,11 +73,11 @@ def inv_dists(depth, que_depth_range):
     return torch.cat([d, torch.full_like(di[..., :1], 1e6)], -1)
 
 
-def ray_points(coords, c2w, depth, H, W):
-    """World sample points and reversed unit view directions.
+def ray_points(coords, c2w, depth, H, W, dataset='m3d'):
+    """World sample points and reversed unit view directions of an ERP query.
     coords [rn,2] (x,y), c2w [3,4], depth [rn,dn] -> pts [rn,dn,3], que_dir [rn,3].
     render_ops.py:76-106, ray_utils.py:53-71."""
-    dirs = erp_ray_directions(H, W).to(coords.device)
+    dirs = erp_ray_directions(H, W, dataset).to(coords.device)
     d_cam = dirs[coords[:, 1].long(), coords[:, 0].long()]            # [rn,3]
     d = torch.matmul(c2w[:3, :3].view(1, 3, 3), d_cam.unsqueeze(-1)).squeeze(-1)
     o = c2w[:, 3].view(1, 3)
@@ -71,18 +86,57 @@ def ray_points(coords, c2w, depth, H, W):
     return pts, que_dir
 
 
+def ray_points_perspective(coords, pose, K, depth):
+    """Pinhole query (is_perspec=True): coords [rn,2] pinhole pixels, pose [3,4] world->camera, K [3,3].
+    Directions are NOT normalised (depth is the camera-space z).  render_ops.py:35-74."""
+    rot = pose[:, :3].t()
+    trans = -rot @ pose[:, 3:]                                          # [3,1] camera centre
+    rn = coords.shape[0]
+    hc = torch.cat([coords, torch.ones(rn, 1, dtype=torch.float32, device=coords.device)], 1)
+    cam = torch.inverse(K).view(1, 3, 3) @ hc.unsqueeze(-1)              # [rn,3,1]
+    cam = rot.view(1, 3, 3) @ cam + trans.view(1, 3, 1)
+    centers = trans.view(1, 3).expand(rn, 3)
+    d = cam.squeeze(-1) - centers
+    pts = centers.unsqueeze(1) + d.unsqueeze(1) * depth.unsqueeze(-1)
+    que_dir = -d / torch.norm(d, dim=1, keepdim=True)
+    return pts, que_dir
+
+
 # --------------------------------------------------------------------------- projection (a-3, a-4)
-def project_to_views(pts, w2c, H, W):
+def project_to_views(pts, w2c, H, W, dataset='m3d'):
     """pts [pn,3], w2c [rfn,3,4] -> px [rfn,pn,2] (x,y in full-image pixels), depth [rfn,pn].
-    render_ops.py:158-191, ray_utils.py:18-22, spt_utils.py:134-138 (m3d), :176-179 (m3d)."""
+    render_ops.py:158-191, ray_utils.py:18-22, spt_utils.py:128-156 (cartesian -> angles per dataset),
+    :172-192 (angles -> pixel per dataset)."""
     R, t = w2c[:, :, :3], w2c[:, :, 3]
     pc = torch.einsum('vij,pj->vpi', R, pts) + t[:, None, :]
     r = torch.linalg.norm(pc, dim=-1)
-    theta = torch.atan2(pc[..., 2], pc[..., 0])
-    phi = torch.acos(pc[..., 1] / (r + 1e-5))
-    theta = torch.remainder(theta + 0.5 * math.pi, 2 * math.pi)
-    x = theta / (2 * math.pi) * (W - 1)
-    y = phi / math.pi * (H - 1)
+    xc, yc, zc = pc[..., 0], pc[..., 1], pc[..., 2]
+    if dataset == 'm3d':
+        theta = torch.atan2(zc, xc)
+        phi = torch.acos(yc / (r + 1e-5))
+        theta = torch.remainder(theta + 0.5 * math.pi, 2 * math.pi)
+        x = theta / (2 * math.pi) * (W - 1)
+        y = phi / math.pi * (H - 1)
+    elif dataset == 'replica_test':
+        theta = torch.atan2(xc, zc)
+        phi = -torch.asin(yc / r)
+        x = ((W - 1) / (2 * math.pi)) * (theta + math.pi)
+        y = (H - 1) / math.pi * (-phi + 0.5 * math.pi)
+    elif dataset == 'residential':
+        theta = -torch.atan2(-zc, xc)
+        phi = torch.asin(yc / r)
+        mask = torch.logical_and(theta.gt(math.pi * 0.5), theta.le(2 * math.pi))
+        theta = torch.where(mask, theta - 2 * math.pi, theta)
+        x = ((1 / (2.0 * math.pi)) * theta + (3 / 4.0)) * (W - 1)
+        y = (0.5 - phi / math.pi) * (H - 1)
+    elif dataset == 'CoffeeArea':
+        theta = torch.atan2(yc, xc)
+        phi = torch.acos(zc / r)
+        theta = torch.where(theta.lt(0), theta + 2 * math.pi, theta)
+        x = (W - 1) * (1 - theta / (2.0 * math.pi))
+        y = phi * (H - 1) / math.pi
+    else:
+        raise ValueError(f'unknown dataset convention {dataset!r}')
     return torch.stack([x, y], -1), r
 
 
@@ -321,15 +375,20 @@ def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True):
 def render_pass(weights, dd_pre, agg_pre, frame, coords, depth, cfg, want_debug=False):
     """One network pass (coarse or fine) over rays `coords` [rn,2] at sample depths [rn,dn].
     frame: dict(imgs [rfn,3,H,W], img_feats [rfn,32,hf,wf], ray_feats [rfn,32,hr,wr], w2c [rfn,3,4],
-                ref_depth_range [rfn,2], que_c2w [3,4], que_depth_range [2]).
+                ref_depth_range [rfn,2], que_c2w [3,4], que_depth_range [2]; optional dataset_name,
+                and for a pinhole query que_pose [3,4] + que_K [3,3]).
     renderer.py:223-304 (render_by_depth, non-debug branch)."""
     H, W = frame['imgs'].shape[-2:]
     rfn = frame['imgs'].shape[0]
     rn, dn = depth.shape
     qd = inv_dists(depth, frame['que_depth_range'])
-    pts, que_dir = ray_points(coords, frame['que_c2w'], depth, H, W)
+    ds = frame.get('dataset_name', 'm3d')
+    if frame.get('que_K') is not None:        # pinhole query: is_perspec=True
+        pts, que_dir = ray_points_perspective(coords, frame['que_pose'], frame['que_K'], depth)
+    else:
+        pts, que_dir = ray_points(coords, frame['que_c2w'], depth, H, W, ds)
     flat = pts.reshape(rn * dn, 3)
-    px, dv = project_to_views(flat, frame['w2c'], H, W)
+    px, dv = project_to_views(flat, frame['w2c'], H, W, ds)
     pdir = project_directions(flat, frame['w2c'])
     rf = gather_map(frame['ray_feats'], px, H, W)
     rgb = gather_map(frame['imgs'], px, H, W)

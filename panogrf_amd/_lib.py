@@ -23,7 +23,12 @@ class PgrfFrame(C.Structure):
                 ("hr", C.c_int), ("wr", C.c_int),
                 ("imgs", C.c_void_p), ("img_feats", C.c_void_p), ("ray_feats", C.c_void_p),
                 ("w2c", C.c_void_p), ("ref_depth_range", C.c_void_p),
-                ("que_c2w", C.c_float * 12), ("que_depth_range", C.c_float * 2)]
+                ("que_c2w", C.c_float * 12), ("que_depth_range", C.c_float * 2),
+                ("dataset", C.c_int), ("perspective", C.c_int), ("que_kinv", C.c_float * 9)]
+
+
+# PGRF_DATASET_*: cfg['dataset_name'] of the reference -> spherical convention of network/spt_utils.py
+DATASETS = {'m3d': 0, 'replica_test': 1, 'residential': 2, 'CoffeeArea': 3}
 
 
 class PgrfPassOut(C.Structure):

@@ -98,6 +98,10 @@ static int do_render_pass(const PgrfFrame* frame, const float* blob, int flags, 
   a.w2c = frame->w2c; a.ref_dr = frame->ref_depth_range;
   std::memcpy(a.c2w, frame->que_c2w, sizeof(a.c2w));
   a.que_near = frame->que_depth_range[0]; a.que_far = frame->que_depth_range[1];
+  if (frame->dataset < PGRF_DATASET_M3D || frame->dataset > PGRF_DATASET_COFFEEAREA)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass: dataset convention %d unknown", frame->dataset);
+  a.dataset = frame->dataset; a.perspective = frame->perspective ? 1 : 0;
+  std::memcpy(a.kinv, frame->que_kinv, sizeof(a.kinv));
   a.H = frame->H; a.W = frame->W; a.hf = frame->hf; a.wf = frame->wf; a.hr = frame->hr; a.wr = frame->wr;
   a.coords = coords; a.depth = depth; a.rn = rn; a.blob = blob; a.use_vis = use_vis ? 1 : 0;
   a.out_pixel = out->pixel_colors; a.out_depth = out->render_depth; a.out_hit = out->hit_prob;
@@ -113,7 +117,7 @@ using namespace pgrf;
 extern "C" {
 
 const char* pgrf_last_error(void) { return g_err; }
-int pgrf_abi_version(void) { return 2; }
+int pgrf_abi_version(void) { return 3; }
 
 int pgrf_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream) {
   if (!src || !dst) return set_error(PGRF_ERR_ARG, "pgrf_pack_map: null pointer");

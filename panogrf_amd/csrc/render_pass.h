@@ -43,6 +43,7 @@
 namespace pgrf {
 namespace PGRF_PREC_NS {
 
+
 constexpr int kPrec = PGRF_PREC;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -384,7 +385,7 @@ struct PointGeom {
 // ---------------------------------------------------------------------------------------------
 // Stage A for NT views starting at V0: projection, gathers, dist decoder, prob_embed, neuray_fc,
 // ray_dir_fc.  Fills vs[V0..V0+NT).
-template <int V, int V0, int NT, bool DBG>
+template <int V, int V0, int NT, bool DBG, bool GEN>
 __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, const PointGeom& g, ViewState (&vs)[V], int lane,
                                             size_t pt /* ray*DN+sample */, size_t npts, bool store_ok,
                                             float* const* sdbg
@@ -412,12 +413,32 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     const float cy = M[4] * g.p[0] + M[5] * g.p[1] + M[6] * g.p[2] + M[7];
     const float cz = M[8] * g.p[0] + M[9] * g.p[1] + M[10] * g.p[2] + M[11];
     const float r = sqrtf(cx * cx + cy * cy + cz * cz);
-    // m3d cartesian -> sphere -> ERP pixel (spt_utils.py:134-138, :176-179)
-    float th = atan2f(cz, cx) + PGRF_HALF_PI_F;
-    if (th < 0.f) th += PGRF_TWO_PI_F;                      // python-style remainder, |th| < 2pi
-    const float ph = acosf(cy / (r + 1e-5f));
-    const float px = th / PGRF_TWO_PI_F * (float)(p.W - 1);
-    const float py = ph / PGRF_PI_F * (float)(p.H - 1);
+    // cartesian -> sphere -> ERP pixel in the dataset's convention (spt_utils.py:128-156, :172-192)
+    float px, py;
+    if (!GEN || p.dataset == PGRF_DATASET_M3D) {
+      float th = atan2f(cz, cx) + PGRF_HALF_PI_F;
+      if (th < 0.f) th += PGRF_TWO_PI_F;                      // python-style remainder, |th| < 2pi
+      const float ph = acosf(cy / (r + 1e-5f));
+      px = th / PGRF_TWO_PI_F * (float)(p.W - 1);
+      py = ph / PGRF_PI_F * (float)(p.H - 1);
+    } else if (p.dataset == PGRF_DATASET_REPLICA_TEST) {
+      const float th = atan2f(cx, cz);
+      const float ph = -asinf(cy / r);
+      px = (float)((double)(p.W - 1) / (2.0 * 3.14159265358979323846)) * (th + PGRF_PI_F);
+      py = (float)((double)(p.H - 1) / 3.14159265358979323846) * (-ph + PGRF_HALF_PI_F);
+    } else if (p.dataset == PGRF_DATASET_RESIDENTIAL) {
+      float th = -atan2f(-cz, cx);
+      const float ph = asinf(cy / r);
+      if (th > PGRF_HALF_PI_F && th <= PGRF_TWO_PI_F) th -= PGRF_TWO_PI_F;
+      px = (0.15915494309189535f * th + 0.75f) * (float)(p.W - 1);
+      py = (0.5f - ph / PGRF_PI_F) * (float)(p.H - 1);
+    } else {   // CoffeeArea
+      float th = atan2f(cy, cx);
+      const float ph = acosf(cz / r);
+      if (th < 0.f) th += PGRF_TWO_PI_F;
+      px = (float)(p.W - 1) * (1.f - th / PGRF_TWO_PI_F);
+      py = ph * (float)(p.H - 1) / PGRF_PI_F;
+    }
     dv[t] = r;
     // direction towards the source camera centre  (render_ops.py:195-209): c = -R^T t
     const float ccx = -(M[0] * M[3] + M[4] * M[7] + M[8] * M[11]);
@@ -779,7 +800,10 @@ template <int V> constexpr int kNT0 = V;
 constexpr int kKStride = 17;   // K rows in LDS: odd stride -> conflict-free column reads (A operand)
 constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast float4 reads
 
-template <int KT, int V, bool DBG>
+// GEN = false: the m3d ERP convention only (the shipped configuration; the other conventions and the pinhole branch
+// compiled in cost 1.2 % through 5 more spilled registers); GEN = true: run-time switch over PgrfFrame.dataset /
+// .perspective.
+template <int KT, int V, bool DBG, bool GEN>
 __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(const PassArgs p) {
   constexpr int DN = 32 * KT;
   constexpr int RPW = 4 / KT;          // rays per workgroup
@@ -841,16 +865,51 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   PointGeom g;
   float tdepth;
   {
-    const int ix = (int)p.coords[2 * ray], iy = (int)p.coords[2 * ray + 1];
-    const float theta = (float)ix / (float)(p.W - 1) * 2.f * PGRF_PI_F - PGRF_HALF_PI_F;
-    const float phi = (float)iy / (float)(p.H - 1) * PGRF_PI_F;
-    const float sp = sinf(phi);
-    float dx = sp * cosf(theta), dy = cosf(phi), dz = sp * sinf(theta);
-    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-    { const float rn_ = rcp1(nrm); dx *= rn_; dy *= rn_; dz *= rn_; }
-    const float wx = p.c2w[0] * dx + p.c2w[1] * dy + p.c2w[2] * dz;
-    const float wy = p.c2w[4] * dx + p.c2w[5] * dy + p.c2w[6] * dz;
-    const float wz = p.c2w[8] * dx + p.c2w[9] * dy + p.c2w[10] * dz;
+    float wx, wy, wz;
+    if (!GEN || !p.perspective) {
+      // ERP query: unit direction of the pixel in the dataset's spherical convention (spt_utils.py:45-83, :106-124),
+      // normalised (ray_utils.py:13-15), rotated into the world (ray_utils.py:53-71)
+      const int ix = (int)p.coords[2 * ray], iy = (int)p.coords[2 * ray + 1];
+      const float fx = (float)ix, fy = (float)iy, W1 = (float)(p.W - 1), H1 = (float)(p.H - 1);
+      float dx, dy, dz;
+      if (!GEN || p.dataset == PGRF_DATASET_M3D) {
+        const float theta = fx / W1 * 2.f * PGRF_PI_F - PGRF_HALF_PI_F;
+        const float phi = fy / H1 * PGRF_PI_F;
+        const float sp = sinf(phi);
+        dx = sp * cosf(theta); dy = cosf(phi); dz = sp * sinf(theta);
+      } else if (p.dataset == PGRF_DATASET_REPLICA_TEST) {
+        const float theta = fx * 2.f * PGRF_PI_F / W1 - PGRF_PI_F;
+        const float phi = -fy * PGRF_PI_F / H1 + PGRF_PI_F * 0.5f;
+        const float cp = cosf(phi);
+        dx = sinf(theta) * cp; dy = -sinf(phi); dz = cosf(theta) * cp;
+      } else if (p.dataset == PGRF_DATASET_RESIDENTIAL) {
+        const float theta = PGRF_PI_F * (2.f * fx / W1 - 1.5f);
+        const float phi = PGRF_PI_F * (0.5f - fy / H1);
+        const float cp = cosf(phi);
+        dx = cosf(theta) * cp; dz = sinf(theta) * cp; dy = sinf(phi);
+      } else {   // CoffeeArea
+        // the reference folds these scalars in Python doubles before they meet the float tensor
+        const float theta = (float)(-2.0 * 3.14159265358979323846 / (double)(p.W - 1)) * fx + PGRF_TWO_PI_F;
+        const float phi = (float)(3.14159265358979323846 / (double)(p.H - 1)) * fy;
+        const float sp = sinf(phi);
+        dx = sp * cosf(theta); dy = sp * sinf(theta); dz = cosf(phi);
+      }
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+      { const float rn_ = rcp1(nrm); dx *= rn_; dy *= rn_; dz *= rn_; }
+      wx = p.c2w[0] * dx + p.c2w[1] * dy + p.c2w[2] * dz;
+      wy = p.c2w[4] * dx + p.c2w[5] * dy + p.c2w[6] * dz;
+      wz = p.c2w[8] * dx + p.c2w[9] * dy + p.c2w[10] * dz;
+    } else {
+      // pinhole query (render_ops.py:35-57): cam = K^-1 [x,y,1]; world = R^T cam + c; direction = world - c, NOT
+      // normalised (the sample depth is the camera-space z)
+      const float cx_ = p.coords[2 * ray], cy_ = p.coords[2 * ray + 1];
+      const float kx = p.kinv[0] * cx_ + p.kinv[1] * cy_ + p.kinv[2];
+      const float ky = p.kinv[3] * cx_ + p.kinv[4] * cy_ + p.kinv[5];
+      const float kz = p.kinv[6] * cx_ + p.kinv[7] * cy_ + p.kinv[8];
+      wx = (p.c2w[0] * kx + p.c2w[1] * ky + p.c2w[2] * kz + p.c2w[3]) - p.c2w[3];
+      wy = (p.c2w[4] * kx + p.c2w[5] * ky + p.c2w[6] * kz + p.c2w[7]) - p.c2w[7];
+      wz = (p.c2w[8] * kx + p.c2w[9] * ky + p.c2w[10] * kz + p.c2w[11]) - p.c2w[11];
+    }
     const float* drow = p.depth + (size_t)ray * DN;
     tdepth = drow[si];
     g.p[0] = p.c2w[3] + wx * tdepth;
@@ -877,13 +936,13 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   PGRF_TICK(0);   // ray generation
 
   // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
-  stage_front<V, 0, kNT0<V>, DBG>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
+  stage_front<V, 0, kNT0<V>, DBG, GEN>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
 #ifdef PGRF_STAGE_TIMING
                                            , t_prev
 #endif
   );
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (V > kNT0<V>) stage_front<V, 2, V - 2, DBG>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
+  if constexpr (V > kNT0<V>) stage_front<V, 2, V - 2, DBG, GEN>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
 #ifdef PGRF_STAGE_TIMING
                                            , t_prev
 #endif
@@ -1137,7 +1196,10 @@ template <int KT, int V, bool DBG>
 int launch_instance(const PassArgs& a, void* stream) {
   constexpr int RPW = 4 / KT;
   const int blocks = (a.rn + RPW - 1) / RPW;
-  hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  // debug instances exist in the general form only (they serve every convention at test sizes)
+  const bool general = DBG || a.dataset != PGRF_DATASET_M3D || a.perspective;
+  if (general) hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG, DBG>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(PGRF_ERR_LAUNCH, "render_pass launch failed: %s", hipGetErrorString(e));
   return PGRF_OK;

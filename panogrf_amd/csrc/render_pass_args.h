@@ -14,6 +14,9 @@ struct PassArgs {
   const float* ref_dr;      // [V,2]
   float c2w[12];
   float que_near, que_far;
+  int dataset;              // PGRF_DATASET_*
+  int perspective;          // pinhole query
+  float kinv[9];
   int H, W, hf, wf, hr, wr;
   // rays
   const float* coords;      // [rn,2]

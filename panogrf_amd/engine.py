@@ -7,7 +7,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, PgrfError, PgrfFrame, PgrfPassOut, PgrfPassDebug, PgrfRenderCfg
+from ._lib import DATASETS, lib, PgrfError, PgrfFrame, PgrfPassOut, PgrfPassDebug, PgrfRenderCfg
 
 FEAT_CH = 32
 
@@ -74,8 +74,23 @@ def pack_map(t):
 class Frame:
     """Source-view data of one frame in the layout the kernels read (PgrfFrame)."""
 
-    def __init__(self, imgs, img_feats, ray_feats, w2c, ref_depth_range, que_c2w, que_depth_range, device='cuda'):
+    def __init__(self, imgs, img_feats, ray_feats, w2c, ref_depth_range, que_c2w, que_depth_range, device='cuda',
+                 dataset_name='m3d', que_pose=None, que_K=None):
+        """ERP query: que_c2w [3,4] (que_imgs_info['c2w']).  Pinhole query (is_perspec=True, render_cubes.py): pass
+        que_pose [3,4] world->camera and que_K [3,3] instead (que_imgs_info['poses'], ['Ks']); coords are then pinhole
+        pixels and que_c2w is derived exactly as network/render_ops.py:45-46 does (rot = R^T, trans = -rot @ t)."""
         _require_gpu()
+        if dataset_name not in DATASETS:
+            raise PgrfError(f'dataset_name {dataset_name!r}: spherical convention not implemented (have {sorted(DATASETS)})')
+        self.dataset = DATASETS[dataset_name]
+        self.perspective = que_K is not None
+        self.que_kinv = [0.0] * 9
+        if self.perspective:
+            pose = _f32c(que_pose, 'cpu').reshape(3, 4)
+            rot = pose[:, :3].t().contiguous()
+            trans = -rot @ pose[:, 3:]
+            que_c2w = torch.cat([rot, trans], 1)
+            self.que_kinv = [float(x) for x in torch.inverse(_f32c(que_K, 'cpu').reshape(3, 3)).reshape(-1)]
         dev = torch.device(device)
         imgs, img_feats, ray_feats = _f32c(imgs, dev), _f32c(img_feats, dev), _f32c(ray_feats, dev)
         if img_feats.shape[1] != FEAT_CH or ray_feats.shape[1] != FEAT_CH or imgs.shape[1] != 3:
@@ -99,6 +114,8 @@ class Frame:
         f.w2c, f.ref_depth_range = self.w2c.data_ptr(), self.ref_dr.data_ptr()
         f.que_c2w = (C.c_float * 12)(*self.que_c2w)
         f.que_depth_range = (C.c_float * 2)(*self.que_dr)
+        f.dataset, f.perspective = self.dataset, int(self.perspective)
+        f.que_kinv = (C.c_float * 9)(*self.que_kinv)
         return f
 
 

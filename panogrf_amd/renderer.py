@@ -129,8 +129,9 @@ class NeuralRayBaseRenderer(nn.Module):
             if key in cfg:
                 c['agg_net_cfg'][key] = cfg[key]
                 c['fine_agg_net_cfg'][key] = cfg[key]
-        if c.get('dataset_name', 'm3d') != 'm3d':
-            raise PgrfError("only the 'm3d' ERP convention is implemented (SURVEY.md section 8 f-4)")
+        if c.get('dataset_name', 'm3d') not in E.DATASETS:
+            raise PgrfError(f"dataset_name {c.get('dataset_name')!r}: spherical convention not implemented "
+                            f"(have {sorted(E.DATASETS)}; network/spt_utils.py)")
         for key in ('debug', 'diner_depth_guided_sampling', 'render_uncert', 'autoencoder'):
             if c.get(key):
                 raise PgrfError(f"cfg['{key}'] is not implemented on the HIP path")
@@ -175,18 +176,12 @@ class NeuralRayBaseRenderer(nn.Module):
         (vis-encoded) 'ray_feats' like after lines 641-642 of the reference."""
         if is_train:
             raise NotImplementedError('training is out of scope: eval only')
-        if is_perspec:
-            raise PgrfError('perspective / cube-face query rays are not implemented (SURVEY.md section 8 f-4)')
         imgs = ref_imgs_info['imgs']
         dev = imgs.device
         rr = self._engine(dev)
-        if que_imgs_info['c2w'].shape[0] != 1:
-            raise PgrfError('que_imgs_info c2w.shape[0]=1')
         frame = ref_imgs_info.get('_pgrf_frame')
         if frame is None:
-            frame = E.Frame(imgs, ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'], ref_imgs_info['w2c'],
-                            ref_imgs_info['depth_range'], que_imgs_info['c2w'][0], que_imgs_info['depth_range'][0],
-                            device=dev)
+            frame = self._make_frame(que_imgs_info, ref_imgs_info, is_perspec)
         out = rr.render_rays(frame, que_imgs_info['coords'][0])
         c = self.cfg
         res = {}
@@ -205,6 +200,20 @@ class NeuralRayBaseRenderer(nn.Module):
                 res['render_depth' + suffix] = out['render_depth' + suffix].unsqueeze(0)
         return res
 
+    def _make_frame(self, que, ref, is_perspec):
+        """ERP query: que['c2w'] (render_ops.py:76-106).  Pinhole query (is_perspec, render_cubes.py): que['poses'] and
+        que['Ks'] (render_ops.py:35-74)."""
+        kw = dict(device=ref['imgs'].device, dataset_name=self.cfg.get('dataset_name', 'm3d'))
+        if is_perspec:
+            if que['poses'].shape[0] != 1:
+                raise PgrfError('one query view per call (qn = 1)')
+            return E.Frame(ref['imgs'], ref['img_feats'], ref['ray_feats'], ref['w2c'], ref['depth_range'], None,
+                           que['depth_range'][0], que_pose=que['poses'][0], que_K=que['Ks'][0], **kw)
+        if que['c2w'].shape[0] != 1:
+            raise PgrfError('que_imgs_info c2w.shape[0]=1')
+        return E.Frame(ref['imgs'], ref['img_feats'], ref['ray_feats'], ref['w2c'], ref['depth_range'], que['c2w'][0],
+                       que['depth_range'][0], **kw)
+
     def render(self, que_imgs_info, ref_imgs_info, is_train, is_perspec=False):
         """Whole query view (network/renderer.py:635-686).  Mutates ref_imgs_info['img_feats'/'ray_feats'] and
         que_imgs_info['coords'] like the reference does."""
@@ -214,8 +223,7 @@ class NeuralRayBaseRenderer(nn.Module):
         ref_imgs_info['img_feats'] = ref_img_feats
         ref_imgs_info['ray_feats'] = self.vis_encoder(ref_imgs_info['ray_feats'], ref_img_feats)
         ref = dict(ref_imgs_info)
-        ref['_pgrf_frame'] = E.Frame(ref['imgs'], ref['img_feats'], ref['ray_feats'], ref['w2c'], ref['depth_range'],
-                                     que_imgs_info['c2w'][0], que_imgs_info['depth_range'][0], device=ref['imgs'].device)
+        ref['_pgrf_frame'] = self._make_frame(que_imgs_info, ref, is_perspec)
         coords = que_imgs_info['coords']
         rb = self.cfg['ray_batch_num']
         # rays are independent: the reference's batch loop (renderer.py:656-683) only bounds memory, so by default

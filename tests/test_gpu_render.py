@@ -325,3 +325,77 @@ def test_arbitrary_poses_vs_oracle(seed, rfn):
     assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 5e-5
     scale = max(1.0, float(ref['density_nr'].abs().max()))
     assert FX.max_abs(out['density_nr'].cpu(), ref['density_nr']) / scale < 5e-4
+
+
+def _seam_px_err(a, b, W):
+    dx = (a[..., 0] - b[..., 0]).abs()
+    dx = torch.minimum(dx, (W - 1) - dx)
+    return max(float(dx.max()), float((a[..., 1] - b[..., 1]).abs().max()))
+
+
+@pytest.mark.parametrize('ds', ['replica_test', 'residential', 'CoffeeArea'])
+def test_other_dataset_conventions_vs_oracle(ds):
+    """cfg dataset_name selects the ERP pixel <-> sphere <-> cartesian convention (network/spt_utils.py); the oracle's
+    version of each is pinned to the reference by tests/test_oracle_render.py."""
+    from oracle import render_oracle as O
+    from bench import synthetic_case
+    E = _engine()
+    H, W, dn, rfn = 16, 32, 32, 2
+    case = synthetic_case(H, W, rfn, dn, seed=3)
+    fr = dict(case['frame'], dataset_name=ds)
+    g = torch.Generator().manual_seed(5)
+    for v in range(rfn):
+        R = _random_rotation(g)
+        fr['w2c'][v, :, :3] = R
+        fr['w2c'][v, :, 3] = -R @ ((torch.rand(3, generator=g) - 0.5) * 2.0)
+    fr['que_c2w'] = torch.cat([_random_rotation(g), torch.tensor([[0.02], [0.01], [-0.03]])], 1)
+    frame = E.Frame(fr['imgs'], fr['img_feats'], fr['ray_feats'], fr['w2c'], fr['ref_depth_range'], fr['que_c2w'],
+                    fr['que_depth_range'], dataset_name=ds)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    depth = O.sample_coarse_depth(0.5, 15.0, coords.shape[0], dn)
+    blob = E.pack_pass_weights(case['weights'], 'dist_decoder', 'agg_net', False).cuda()
+    out = E.render_pass(frame, blob, False, coords, depth, debug=True)
+    ref = O.render_pass(case['weights'], 'dist_decoder', 'agg_net', fr, coords, depth, dict(use_vis=False), want_debug=True)
+    assert _seam_px_err(out['dbg']['px'].cpu(), ref['dbg']['px'], W) < 2e-4
+    assert FX.max_abs(out['dbg']['depth_v'].cpu(), ref['dbg']['depth_v']) < 1e-5 * 20
+    assert FX.max_abs(out['dbg']['ddiff'].cpu(), ref['dbg']['ddiff']) < 1e-5
+    assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 5e-5
+    assert FX.max_abs(out['render_depth'].cpu(), ref['render_depth']) < 2e-4 * 15.0
+
+
+def test_pinhole_query_vs_oracle():
+    """is_perspec=True (render_cubes.py): pinhole query rays K^-1 [x,y,1] against ERP source views."""
+    from oracle import render_oracle as O
+    from bench import synthetic_case
+    E = _engine()
+    H, W, dn, rfn = 16, 32, 32, 2
+    case = synthetic_case(H, W, rfn, dn, seed=8)
+    g = torch.Generator().manual_seed(11)
+    Hp = Wp = 12
+    K = torch.tensor([[Wp / 2.0, 0.0, Wp / 2.0], [0.0, Hp / 2.0, Hp / 2.0], [0.0, 0.0, 1.0]])
+    Rq = _random_rotation(g)
+    pose = torch.cat([Rq, torch.tensor([[0.05], [-0.02], [0.03]])], 1)
+    fr = dict(case['frame'], que_pose=pose, que_K=K)
+    frame = E.Frame(fr['imgs'], fr['img_feats'], fr['ray_feats'], fr['w2c'], fr['ref_depth_range'], None,
+                    fr['que_depth_range'], que_pose=pose, que_K=K)
+    ys, xs = torch.meshgrid(torch.arange(Hp, dtype=torch.float32), torch.arange(Wp, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    depth = O.sample_coarse_depth(0.5, 15.0, coords.shape[0], dn)
+    blob = E.pack_pass_weights(case['weights'], 'dist_decoder', 'agg_net', False).cuda()
+    out = E.render_pass(frame, blob, False, coords, depth, debug=True)
+    ref = O.render_pass(case['weights'], 'dist_decoder', 'agg_net', fr, coords, depth, dict(use_vis=False), want_debug=True)
+    assert _seam_px_err(out['dbg']['px'].cpu(), ref['dbg']['px'], W) < 2e-4
+    assert FX.max_abs(out['dbg']['ddiff'].cpu(), ref['dbg']['ddiff']) < 1e-5
+    assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 5e-5
+    assert FX.max_abs(out['render_depth'].cpu(), ref['render_depth']) < 2e-4 * 15.0
+
+
+def test_unknown_dataset_convention_fails_loudly():
+    from panogrf_amd import PgrfError
+    from bench import synthetic_case
+    E = _engine()
+    fr = synthetic_case(16, 32, 2, 32, seed=1)['frame']
+    with pytest.raises(PgrfError):
+        E.Frame(fr['imgs'], fr['img_feats'], fr['ray_feats'], fr['w2c'], fr['ref_depth_range'], fr['que_c2w'],
+                fr['que_depth_range'], dataset_name='kitti')

@@ -68,3 +68,36 @@ def test_frame_parity_and_chunk_invariance(name):
     assert FX.max_abs(out['render_depth_fine'], gold['render_depth_fine']) < 5e-3
     out2 = O.render_frame(w, frame, cfg, ray_batch_num=173)
     assert FX.max_abs(out2['pixel_colors_nr_fine'], out['pixel_colors_nr_fine']) < 1e-4
+
+
+# ---- spherical conventions of the other datasets and pinhole queries, pinned to the reference's own
+# outputs (tests/golden/make_geometry_fixtures.py -> geometry_conventions.npz)
+import os as _os
+
+import numpy as _np
+import pytest as _pytest
+
+
+def _geo():
+    z = _np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'golden', 'geometry_conventions.npz'))
+    return {k: (torch.from_numpy(z[k]) if z[k].ndim else int(z[k])) for k in z.files}
+
+
+@_pytest.mark.parametrize('ds', ['m3d', 'replica_test', 'residential', 'CoffeeArea'])
+def test_oracle_dataset_conventions_vs_reference(ds):
+    from oracle import render_oracle as O
+    g = _geo()
+    pts, qdir = O.ray_points(g['coords'], g['que_c2w'], g['depth'], g['H'], g['W'], ds)
+    assert float((pts - g[f'{ds}.pts']).abs().max()) < 2e-6
+    assert float((qdir - g[f'{ds}.que_dir']).abs().max()) < 1e-6
+    px, dv = O.project_to_views(g[f'{ds}.pts'].reshape(-1, 3), g['w2c'], g['H'], g['W'], ds)
+    assert float((dv - g[f'{ds}.depth_v']).abs().max()) < 2e-6
+    assert float((px - g[f'{ds}.px']).abs().max()) < 2e-5          # pixels, W = 32
+
+
+def test_oracle_perspective_rays_vs_reference():
+    from oracle import render_oracle as O
+    g = _geo()
+    pts, qdir = O.ray_points_perspective(g['persp.coords'], g['persp.pose'], g['persp.K'], g['depth'])
+    assert float((pts - g['persp.pts']).abs().max()) < 2e-6
+    assert float((qdir - g['persp.que_dir']).abs().max()) < 1e-6

@@ -76,3 +76,36 @@ def test_render_script_runs(tmp_path):
                         '--num-poses', '2', '--out', str(tmp_path)], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-1500:]
     assert os.path.exists(tmp_path / '1-nr_fine.ppm') and os.path.exists(tmp_path / '1-depth.npy')
+
+
+@pytest.mark.gpu
+def test_render_pinhole_query_through_the_module():
+    """renderer.render(..., is_perspec=True) (render_cubes.py): same numbers as the oracle's pinhole rays through the
+    same per-ray weights and the module's own encoders."""
+    from oracle import render_oracle as O
+    from panogrf_amd.renderer import name2network
+    frame, cfg, gold, shapes, out_keys = _load()
+    net = name2network['neuray_base'](cfg)
+    sd = FX.seeded_renderer_state(shapes, 800)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    Hp = Wp = 10
+    K = torch.tensor([[Wp / 2.0, 0.0, Wp / 2.0], [0.0, Hp / 2.0, Hp / 2.0], [0.0, 0.0, 1.0]])
+    ys, xs = torch.meshgrid(torch.arange(Hp, dtype=torch.float32), torch.arange(Wp, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(1, -1, 2)
+    que = {'poses': frame['que_w2c'][None].cuda(), 'Ks': K[None].cuda(), 'coords': coords.cuda(),
+           'depth_range': frame['que_depth_range'][None].cuda()}
+    ref = {'imgs': frame['imgs'].cuda(), 'w2c': frame['w2c'].cuda(), 'depth_range': frame['ref_depth_range'].cuda(),
+           'ray_feats': frame['ray_feats'].cuda()}
+    with torch.no_grad():
+        out = net.render(que, ref, False, is_perspec=True)
+    # oracle on the encoder outputs the module left in `ref` (render() stores them like the reference does)
+    fr = dict(imgs=frame['imgs'], img_feats=ref['img_feats'].cpu(), ray_feats=ref['ray_feats'].cpu(), w2c=frame['w2c'],
+              ref_depth_range=frame['ref_depth_range'], que_depth_range=frame['que_depth_range'],
+              que_pose=frame['que_w2c'], que_K=K)
+    dn = cfg['depth_sample_num']
+    depth = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], coords.shape[1], dn, cfg.get('use_disp', True))
+    w = {k: v for k, v in sd.items() if k.startswith(('dist_decoder', 'agg_net'))}
+    want = O.render_pass(w, 'dist_decoder', 'agg_net', fr, coords[0], depth, dict(use_vis=cfg['dist_decoder_cfg']['use_vis']))
+    assert FX.max_abs(out['pixel_colors_nr'][0].cpu(), want['pixel_colors_nr']) < 5e-5
+    assert FX.max_abs(out['render_depth'][0].cpu(), want['render_depth']) < 2e-4 * 15.0
