@@ -18,6 +18,14 @@ def build_render_imgs_info(que_pose, que_shape, que_depth_range):
             'coords': coords, 'depth_range': np.asarray(que_depth_range, np.float32)[None, :], 'shape': (h, w)}
 
 
+def build_render_cube_imgs_info(que_pose, que_K, que_shape, que_depth_range):
+    """Pinhole (cube-face) query info for renderer(data, is_perspec=True) (utils/imgs_info.py:253-264)."""
+    h, w = int(que_shape[0]), int(que_shape[1])
+    coords = np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1).reshape(1, -1, 2).astype(np.float32)
+    return {'poses': np.asarray(que_pose, np.float32)[None], 'Ks': np.asarray(que_K, np.float32)[None], 'coords': coords,
+            'depth_range': np.asarray(que_depth_range, np.float32)[None, :], 'shape': (h, w)}
+
+
 def build_imgs_info(imgs, w2c, depth_range):
     """Source-view info from in-memory panoramas (the reference reads them from its M3D database,
     utils/imgs_info.py:105-156): imgs [n,3,H,W] in [0,1], w2c [n,3,4], depth_range [n,2]."""

@@ -239,10 +239,10 @@ class NeuralRayBaseRenderer(nn.Module):
                 parts.setdefault(k, []).append(v)
         return {k: torch.cat(v, 1) if len(v) > 1 else v[0] for k, v in parts.items()}
 
-    def forward(self, data):
+    def forward(self, data, is_perspec=False):
         ref = dict(data['ref_imgs_info'])
         que = dict(data['que_imgs_info'])
-        return self.render(que, ref, 'eval' not in data)      # is_train = 'eval' not in data (renderer.py:780)
+        return self.render(que, ref, 'eval' not in data, is_perspec)      # is_train = 'eval' not in data (renderer.py:780)
 
 
 class NeuralRayGenRenderer(NeuralRayBaseRenderer):
@@ -258,7 +258,7 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         if init_net is not None:
             self.init_net = init_net
 
-    def render_call(self, que_imgs_info, ref_imgs_info, is_train, src_imgs_info=None):
+    def render_call(self, que_imgs_info, ref_imgs_info, is_train, src_imgs_info=None, is_perspec=False):
         if not hasattr(self, 'init_net'):
             raise PgrfError('NeuralRayGenRenderer needs an init_net module (see class docstring); '
                             'or put ray_feats into ref_imgs_info and call render()')
@@ -266,16 +266,16 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         ref_imgs_info['ray_feats'] = ret['ray_feats']
         if 'mvs_depth' in ret:
             ref_imgs_info['mvs_depth'] = ret['mvs_depth']
-        return self.render(que_imgs_info, ref_imgs_info, is_train)
+        return self.render(que_imgs_info, ref_imgs_info, is_train, is_perspec)
 
-    def forward(self, data):
+    def forward(self, data, is_perspec=False):          # renderer(data, is_perspec=True): render_cubes.py:274
         ref = dict(data['ref_imgs_info'])
         que = dict(data['que_imgs_info'])
         src = dict(data['src_imgs_info']) if 'src_imgs_info' in data else None
         is_train = 'eval' not in data
         if 'ray_feats' in ref and not hasattr(self, 'init_net'):
-            return self.render(que, ref, is_train)
-        return self.render_call(que, ref, is_train, src)
+            return self.render(que, ref, is_train, is_perspec)
+        return self.render_call(que, ref, is_train, src, is_perspec)
 
 
 name2network = {

@@ -58,7 +58,9 @@ def test_render_end_to_end_vs_reference():
 
 def test_imgs_info_builders_shapes():
     import numpy as np
-    from panogrf_amd.imgs_info import build_imgs_info, build_render_imgs_info
+    from panogrf_amd.imgs_info import build_imgs_info, build_render_imgs_info, build_render_cube_imgs_info
+    cq = build_render_cube_imgs_info(np.eye(4)[:3], np.eye(3), (3, 5), [0.5, 15.0])
+    assert cq['poses'].shape == (1, 3, 4) and cq['Ks'].shape == (1, 3, 3) and cq['coords'].shape == (1, 15, 2) and cq['shape'] == (3, 5)
     pose = np.concatenate([np.eye(3), np.array([[0.1], [0.2], [0.3]])], 1)
     q = build_render_imgs_info(pose, (4, 6), [0.5, 15.0])
     assert q['coords'].shape == (1, 24, 2) and q['coords'][0, 1].tolist() == [1.0, 0.0] and q['coords'][0, 6].tolist() == [0.0, 1.0]
