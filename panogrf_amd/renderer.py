@@ -200,6 +200,36 @@ class NeuralRayBaseRenderer(nn.Module):
                 res['render_depth' + suffix] = out['render_depth' + suffix].unsqueeze(0)
         return res
 
+    def _encode(self, imgs, ray_feats):
+        """The two per-frame 2-D encoders (network/renderer.py:639-642).  On a GPU their ~70 small kernels are
+        launch-bound (3.4 ms eager for 2x512x1024), so the launch sequence is captured once per input shape into a
+        hipGraph and replayed (1.9 ms); cfg['hip_graph_encoders']=False keeps eager launches."""
+        if not (imgs.is_cuda and self.cfg.get('hip_graph_encoders', True)) or torch.is_grad_enabled():
+            feats = self.image_encoder(imgs)
+            return feats, self.vis_encoder(ray_feats, feats)
+        key = (tuple(imgs.shape), tuple(ray_feats.shape), imgs.device, imgs.dtype, ray_feats.dtype)
+        graphs = self.__dict__.setdefault('_enc_graphs', {})
+        ent = graphs.get(key)
+        if ent is None:
+            s_imgs, s_rf = imgs.clone(), ray_feats.clone()
+            side = torch.cuda.Stream(device=imgs.device)
+            side.wait_stream(torch.cuda.current_stream(imgs.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):                      # warm-up outside capture (MIOpen find, workspace allocations)
+                    f = self.image_encoder(s_imgs)
+                    self.vis_encoder(s_rf, f)
+            torch.cuda.current_stream(imgs.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                o_feats = self.image_encoder(s_imgs)
+                o_rf = self.vis_encoder(s_rf, o_feats)
+            ent = graphs[key] = (g, s_imgs, s_rf, o_feats, o_rf)
+        g, s_imgs, s_rf, o_feats, o_rf = ent
+        s_imgs.copy_(imgs)
+        s_rf.copy_(ray_feats)
+        g.replay()
+        return o_feats.clone(), o_rf.clone()            # the graph's output buffers are overwritten by the next frame
+
     def _make_frame(self, que, ref, is_perspec):
         """ERP query: que['c2w'] (render_ops.py:76-106).  Pinhole query (is_perspec, render_cubes.py): que['poses'] and
         que['Ks'] (render_ops.py:35-74)."""
@@ -219,9 +249,9 @@ class NeuralRayBaseRenderer(nn.Module):
         que_imgs_info['coords'] like the reference does."""
         if is_train:
             raise NotImplementedError('training is out of scope: eval only')
-        ref_img_feats = self.image_encoder(ref_imgs_info['imgs'])
+        ref_img_feats, ray_feats = self._encode(ref_imgs_info['imgs'], ref_imgs_info['ray_feats'])
         ref_imgs_info['img_feats'] = ref_img_feats
-        ref_imgs_info['ray_feats'] = self.vis_encoder(ref_imgs_info['ray_feats'], ref_img_feats)
+        ref_imgs_info['ray_feats'] = ray_feats
         ref = dict(ref_imgs_info)
         ref['_pgrf_frame'] = self._make_frame(que_imgs_info, ref, is_perspec)
         coords = que_imgs_info['coords']

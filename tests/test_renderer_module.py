@@ -111,3 +111,28 @@ def test_render_pinhole_query_through_the_module():
     want = O.render_pass(w, 'dist_decoder', 'agg_net', fr, coords[0], depth, dict(use_vis=cfg['dist_decoder_cfg']['use_vis']))
     assert FX.max_abs(out['pixel_colors_nr'][0].cpu(), want['pixel_colors_nr']) < 5e-5
     assert FX.max_abs(out['render_depth'][0].cpu(), want['render_depth']) < 2e-4 * 15.0
+
+
+@pytest.mark.gpu
+def test_encoder_graph_replay_equals_eager():
+    """The per-frame encoders run as a replayed hipGraph: same numbers as eager launches (to MIOpen's own run-to-run
+    round-off), also for a second frame with different pixels, and re-captured for a new resolution."""
+    from panogrf_amd.renderer import name2network
+    frame, cfg, gold, shapes, out_keys = _load()
+    net = name2network['neuray_base'](cfg)
+    net.load_state_dict(FX.seeded_renderer_state(shapes, 800))
+    net = net.cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for scale in (1, 2):
+            for rep in range(2):
+                imgs = torch.rand(2, 3, 32 * scale, 64 * scale, generator=g).cuda()
+                rf = torch.randn(2, 32, 4 * scale, 8 * scale, generator=g).cuda()
+                a_f, a_r = net._encode(imgs, rf)
+                e_f = net.image_encoder(imgs)
+                e_r = net.vis_encoder(rf, e_f)
+                e_f2 = net.image_encoder(imgs)
+                noise = max(float((e_f - e_f2).abs().max()), 1e-6)        # eager vs eager
+                assert float((a_f - e_f).abs().max()) <= 4 * noise + 1e-5 * float(e_f.abs().max())
+                assert float((a_r - e_r).abs().max()) <= 1e-4 * max(1.0, float(e_r.abs().max()))
+    assert len(net._enc_graphs) == 2

@@ -25,3 +25,16 @@ with torch.no_grad():
     out = vis(ray_feats, feats)
     print('DefaultVisEncoder out', tuple(out.shape))
     print(f'DefaultVisEncoder: {timeit(lambda: vis(ray_feats, feats)):.2f} ms')
+
+# hipGraph replay of the same launch sequence (are the encoders launch-bound?)
+with torch.no_grad():
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            feats = enc(imgs); out = vis(ray_feats, feats)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        feats_g = enc(imgs)
+        out_g = vis(ray_feats, feats_g)
+    print(f'encoders, hipGraph replay: {timeit(g.replay):.2f} ms (eager {timeit(lambda: vis(ray_feats, enc(imgs))):.2f} ms)')
