@@ -98,6 +98,10 @@ typedef struct PgrfPassOut {   /* any pointer may be NULL = not wanted */
   float* hit_prob;             /* [rn,dn]    'hit_prob_nr'     */
   float* colors;               /* [rn,dn,3]  'colors_nr'       */
   float* density;              /* [rn,dn]    'density_nr'      */
+  int* nan_flag;               /* device int, caller zeroes it: set to 1 when a NaN reaches an output of this pass.  The
+                                * reference stops in ipdb there (renderer.py:264-265,459-462; render_ops.py:251-252);
+                                * the library never blocks or prints.  NaNs in the source FEATURE maps can be absorbed inside
+                                * the MLPs (ELU/ReLU are v_med3/v_max, which return the non-NaN operand) */
 } PgrfPassOut;
 
 typedef struct PgrfPassDebug { /* intermediate tensors for stage-level parity tests; NULL = skip */

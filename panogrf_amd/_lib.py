@@ -33,7 +33,7 @@ DATASETS = {'m3d': 0, 'replica_test': 1, 'residential': 2, 'CoffeeArea': 3}
 
 class PgrfPassOut(C.Structure):
     _fields_ = [("pixel_colors", C.c_void_p), ("render_depth", C.c_void_p), ("hit_prob", C.c_void_p),
-                ("colors", C.c_void_p), ("density", C.c_void_p)]
+                ("colors", C.c_void_p), ("density", C.c_void_p), ("nan_flag", C.c_void_p)]
 
 
 class PgrfPassDebug(C.Structure):

@@ -105,7 +105,7 @@ static int do_render_pass(const PgrfFrame* frame, const float* blob, int flags, 
   a.H = frame->H; a.W = frame->W; a.hf = frame->hf; a.wf = frame->wf; a.hr = frame->hr; a.wr = frame->wr;
   a.coords = coords; a.depth = depth; a.rn = rn; a.blob = blob; a.use_vis = use_vis ? 1 : 0;
   a.out_pixel = out->pixel_colors; a.out_depth = out->render_depth; a.out_hit = out->hit_prob;
-  a.out_colors = out->colors; a.out_density = out->density;
+  a.out_colors = out->colors; a.out_density = out->density; a.nan_flag = out->nan_flag;
   if (dbg) a.dbg = *dbg;
   return launch_render_pass(a, frame->rfn, dn, dbg != nullptr, precision, stream);
 }
@@ -237,7 +237,7 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
   // fine pass into scratch, then one composite over the union (renderer.py:484-518)
   PgrfPassOut tmp;
   std::memset(&tmp, 0, sizeof(tmp));
-  tmp.colors = col_f; tmp.density = den_f;
+  tmp.colors = col_f; tmp.density = den_f; tmp.nan_flag = of.nan_flag;
   rc = do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &tmp, nullptr, prj_ws, prj_bytes, stream);
   if (rc) return rc;
   return pgrf_merge_c2f(depth_c, col_c, den_c, cfg->dn, fd, col_f, den_f, fdn_eff, rn, &of, stream);

@@ -1166,6 +1166,9 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
   for (int k2 = 0; k2 < KT - 1; ++k2)
     if (k2 < kt) T *= lds_alpha[ray_local * KT + k2];
   const float hit = alpha * T;
+  // NaN report (the reference's ipdb breakpoints): a NaN in density, colour or weight of any sample sets the flag
+  if (p.nan_flag && store_ok && (hit != hit || sigma != sigma || col[0] != col[0] || col[1] != col[1] || col[2] != col[2]))
+    *p.nan_flag = 1;
   PGRF_TICK(11);  // composite: transmittance scan
   if (store_ok && half == 0) {
     if (p.out_hit) p.out_hit[pt] = hit;

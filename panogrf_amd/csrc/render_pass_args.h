@@ -31,6 +31,7 @@ struct PassArgs {
   float* out_hit;
   float* out_colors;
   float* out_density;
+  int* nan_flag;
   PgrfPassDebug dbg;
 };
 

@@ -145,12 +145,13 @@ def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True, use_
     return out
 
 
-def _alloc_out(rn, dn, dev):
+def _alloc_out(rn, dn, dev, nan_flag=None):
     t = dict(pixel_colors_nr=torch.empty(rn, 3, device=dev), render_depth=torch.empty(rn, device=dev),
              hit_prob_nr=torch.empty(rn, dn, device=dev), colors_nr=torch.empty(rn, dn, 3, device=dev),
              density_nr=torch.empty(rn, dn, device=dev))
     o = PgrfPassOut(t['pixel_colors_nr'].data_ptr(), t['render_depth'].data_ptr(), t['hit_prob_nr'].data_ptr(),
-                    t['colors_nr'].data_ptr(), t['density_nr'].data_ptr())
+                    t['colors_nr'].data_ptr(), t['density_nr'].data_ptr(),
+                    nan_flag.data_ptr() if nan_flag is not None else None)
     return t, o
 
 
@@ -232,12 +233,15 @@ class RayRenderer:
         c = self.ccfg
         fdn_eff = c.dn + c.fdn if c.fine_use_all else c.fdn
         dn_f_out = c.dn + fdn_eff if c.c2f_all else fdn_eff
-        tc, oc = _alloc_out(rn, c.dn, self.device)
+        # cfg['hip_check_nan']: the reference drops into ipdb when a NaN shows up (renderer.py:264-265,459-462); here the
+        # kernels raise a device flag and the host turns it into an exception (costs one device->host sync per call)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device) if self.cfg.get('hip_check_nan') else None
+        tc, oc = _alloc_out(rn, c.dn, self.device, flag)
         out = dict(tc)
         of = None
         fd = None
         if c.hierarchical:
-            tf, of = _alloc_out(rn, dn_f_out, self.device)
+            tf, of = _alloc_out(rn, dn_f_out, self.device, flag)
             fd = torch.empty(rn, fdn_eff, device=self.device)
             for k, v in tf.items():
                 out[k + '_fine'] = v
@@ -247,4 +251,6 @@ class RayRenderer:
         lib.check(lib.pgrf_render_rays(C.byref(fs), _ptr(self.blob_c), _ptr(self.blob_f), C.byref(c), _ptr(coords), rn,
                                        C.byref(oc), C.byref(of) if of is not None else None, _ptr(fd), _ptr(ws),
                                        C.c_size_t(nbytes), _stream()))
+        if flag is not None and int(flag.item()):
+            raise PgrfError('NaN in the rendered samples (density / colour / hit probability)')
         return out

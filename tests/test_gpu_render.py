@@ -399,3 +399,24 @@ def test_unknown_dataset_convention_fails_loudly():
     with pytest.raises(PgrfError):
         E.Frame(fr['imgs'], fr['img_feats'], fr['ray_feats'], fr['w2c'], fr['ref_depth_range'], fr['que_c2w'],
                 fr['que_depth_range'], dataset_name='kitti')
+
+
+def test_nan_in_the_inputs_raises_instead_of_blocking():
+    """The reference stops in ipdb on NaN (renderer.py:264-265); the library sets PgrfPassOut.nan_flag and the host
+    (cfg hip_check_nan) raises."""
+    from panogrf_amd import PgrfError
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(16, 32, 2, 32, seed=2)
+    cfg = dict(case['cfg'], hip_check_nan=True)
+    rr = E.RayRenderer(cfg, case['weights'])
+    ys, xs = torch.meshgrid(torch.arange(16, dtype=torch.float32), torch.arange(32, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    out = rr.render_rays(_frame(E, case['frame']), coords)           # clean inputs: no exception
+    assert not torch.isnan(out['pixel_colors_nr']).any()
+    bad = dict(case['frame'])
+    bad['imgs'] = bad['imgs'].clone()
+    bad['imgs'][0, 1] = float('nan')          # a colour NaN reaches every blended sample (NaNs inside the MLPs may be
+                                              # absorbed by v_med3 / v_max, which return the non-NaN operand)
+    with pytest.raises(PgrfError, match='NaN'):
+        rr.render_rays(_frame(E, bad), coords)
