@@ -196,7 +196,8 @@ int pgrf_depth_hypotheses(const float* ref_mu, int B, int hw, const float* guide
  * Both call get_cv_per_depth (:135-230) D times; helpers/my_torch_helpers.py:34-38,62-96. */
 int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const float* rots, const float* trans, int B,
                          int S, int h, int w, int C, int D, int ref_idx, const int* src_idx_host, int n_src,
-                         float src_div, int cost_type, float* out, void* stream);
+                         float src_div, int cost_type, int dataset /* PGRF_DATASET_* = args["dataset_name"] */,
+                         float* out, void* stream);
 
 
 /* ------------------------------------------------------------------ 3-D cost regularisation -- */

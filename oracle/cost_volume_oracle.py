@@ -38,33 +38,67 @@ def depth_hypotheses(ref_mu, k_list, fixed_sigma, min_depth, max_depth, n_total=
 
 
 # --------------------------------------------------------------------------- cost volume (a-11)
-def _centre_dirs(h, w):
-    """Unit directions at pixel centres, [h,w,3]. spherical_cost_volume.py:268-297,
-    my_torch_helpers.py:34-38 (m3d)."""
-    phi = (torch.arange(0, h, dtype=torch.float32) + 0.5) * (np.pi / h)
-    theta = (torch.arange(0, w, dtype=torch.float32) + 0.5) * (2 * np.pi / w) - np.pi / 2
+def _centre_dirs(h, w, dataset='m3d'):
+    """Unit directions at the pixel positions the dataset's convention uses, [h,w,3].
+    spherical_cost_volume.py:268-297, my_torch_helpers.py:34-56."""
+    phi = torch.arange(0, h, dtype=torch.float32)
+    theta = torch.arange(0, w, dtype=torch.float32)
+    if dataset == 'm3d':
+        phi = (phi + 0.5) * (np.pi / h)
+        theta = (theta + 0.5) * (2 * np.pi / w) - np.pi / 2
+    elif dataset == 'replica_test':
+        theta = (2 * np.pi / w) * (theta + 0.5) - np.pi
+        phi = -(phi + 0.5) * np.pi / h + np.pi * 0.5
+    elif dataset == 'residential':
+        theta = np.pi * (2 * theta / (w - 1) - 1.5)
+        phi = np.pi * (0.5 - phi / (h - 1))
+    elif dataset == 'CoffeeArea':
+        theta = (-2 * np.pi / (w - 1)) * theta + 2 * np.pi
+        phi = (np.pi / (h - 1)) * phi
+    else:
+        raise ValueError(f'unknown dataset convention {dataset!r}')
     phi, theta = torch.meshgrid(phi, theta, indexing='ij')
-    s = torch.sin(phi)
-    return torch.stack((s * torch.cos(theta), torch.cos(phi), s * torch.sin(theta)), -1)
+    if dataset == 'm3d':
+        s = torch.sin(phi)
+        return torch.stack((s * torch.cos(theta), torch.cos(phi), s * torch.sin(theta)), -1)
+    if dataset == 'replica_test':
+        return torch.stack((torch.sin(theta) * torch.cos(phi), -torch.sin(phi), torch.cos(theta) * torch.cos(phi)), -1)
+    if dataset == 'residential':
+        return torch.stack((torch.cos(theta) * torch.cos(phi), torch.sin(phi), torch.sin(theta) * torch.cos(phi)), -1)
+    return torch.stack((torch.sin(phi) * torch.cos(theta), torch.sin(phi) * torch.sin(theta), torch.cos(phi)), -1)
 
 
-def _cart_to_sph(xyz, lin=np.deg2rad(10)):
-    """theta, phi with the acos linearised within 10 degrees of the poles.
-    my_torch_helpers.py:62-96 (m3d)."""
+def _cart_to_sph(xyz, lin=np.deg2rad(10), dataset='m3d'):
+    """theta, phi per dataset; m3d linearises acos within 10 degrees of the poles.  my_torch_helpers.py:62-120
+    (replica_test takes -asin(z / r): reproduced as written there)."""
     cos_deg = np.cos(lin)
     radius = torch.norm(xyz, dim=-1)
     x, y, z = torch.unbind(xyz, dim=-1)
-    theta = torch.atan2(z, x)
-    yor = y / radius
-    valid = yor.abs() < cos_deg
-    zero = torch.zeros((), dtype=xyz.dtype)
-    phi = torch.where(valid, torch.acos(torch.where(valid, yor, zero)),
-                      torch.where(y >= 0, lin * (1 - yor) / (1 - cos_deg),
-                                  np.pi - lin * (yor + 1) / (-cos_deg + 1)))
+    if dataset == 'm3d':
+        theta = torch.atan2(z, x)
+        yor = y / radius
+        valid = yor.abs() < cos_deg
+        zero = torch.zeros((), dtype=xyz.dtype)
+        phi = torch.where(valid, torch.acos(torch.where(valid, yor, zero)),
+                          torch.where(y >= 0, lin * (1 - yor) / (1 - cos_deg),
+                                      np.pi - lin * (yor + 1) / (-cos_deg + 1)))
+    elif dataset == 'replica_test':
+        theta = torch.atan2(x, z)
+        phi = -torch.asin(z / radius)
+    elif dataset == 'residential':
+        theta = -torch.atan2(-z, x)
+        phi = torch.asin(y / radius)
+        theta = torch.where(torch.logical_and(theta.gt(np.pi * 0.5), theta.le(2 * np.pi)), theta - 2 * np.pi, theta)
+    elif dataset == 'CoffeeArea':
+        theta = torch.atan2(y, x)
+        phi = torch.acos(z / radius)
+        theta = torch.where(theta.lt(0), theta + 2 * np.pi, theta)
+    else:
+        raise ValueError(f'unknown dataset convention {dataset!r}')
     return theta, phi
 
 
-def _warp_plane(depth, dirs, rot_ref, t_ref, rot_src, t_src, src_cf):
+def _warp_plane(depth, dirs, rot_ref, t_ref, rot_src, t_src, src_cf, dataset='m3d'):
     """One hypothesis plane: back-project the reference pixels to `depth`, move them into the
     source camera, sample the source features.  depth [B,h,w]; src_cf [B,C,h,w] -> [B,C,h,w].
     spherical_cost_volume.py:135-198."""
@@ -72,22 +106,34 @@ def _warp_plane(depth, dirs, rot_ref, t_ref, rot_src, t_src, src_cf):
     m = (depth.unsqueeze(-1) * dirs).view(B, -1, 3, 1)
     wpt = torch.matmul(torch.inverse(rot_ref.unsqueeze(1)), m - t_ref.view(B, 1, 3, 1))
     c = torch.matmul(rot_src.unsqueeze(1), wpt) + t_src.view(B, 1, 3, 1)
-    theta, phi = _cart_to_sph(c.view(B, h, w, 3))
-    u = torch.fmod(theta + np.pi / 2 + 2 * np.pi, 2 * np.pi) / np.pi - 1
-    v = 2 * phi / np.pi - 1
+    theta, phi = _cart_to_sph(c.view(B, h, w, 3), dataset=dataset)
+    if dataset == 'm3d':
+        u = torch.fmod(theta + np.pi / 2 + 2 * np.pi, 2 * np.pi)
+        v = phi
+    elif dataset == 'replica_test':
+        u = torch.fmod(theta + np.pi + 2 * np.pi, 2 * np.pi)
+        v = -phi + 0.5 * np.pi
+    elif dataset == 'residential':
+        u = torch.fmod(theta + 3 / 4.0 * 2 * np.pi, 2 * np.pi)
+        v = 0.5 * np.pi - phi
+    else:
+        u = 2 * np.pi - theta
+        v = phi
+    u = u / np.pi - 1
+    v = 2 * v / np.pi - 1
     return F.grid_sample(src_cf, torch.stack((u, v), -1), mode='bilinear', align_corners=True)
 
 
-def cost_volume_erp(feats, depth_volume, rots, trans, cost_type='abs_diff'):
+def cost_volume_erp(feats, depth_volume, rots, trans, cost_type='abs_diff', dataset='m3d'):
     """2-view volume.  feats [B,2,h,w,C] (0 = source, 1 = reference), depth_volume [B,D,h,w],
     rots [B,2,3,3], trans [B,2,3] -> [B,D,h,w,C].  spherical_cost_volume.py:231-341."""
     B, _, h, w, C = feats.shape
-    dirs = _centre_dirs(h, w).unsqueeze(0).expand(B, h, w, 3)
+    dirs = _centre_dirs(h, w, dataset).unsqueeze(0).expand(B, h, w, 3)
     src_cf = feats[:, 0].permute(0, 3, 1, 2)
     ref_cf = feats[:, 1].permute(0, 3, 1, 2)
     planes = []
     for d in range(depth_volume.shape[1]):
-        warped = _warp_plane(depth_volume[:, d], dirs, rots[:, 1], trans[:, 1], rots[:, 0], trans[:, 0], src_cf)
+        warped = _warp_plane(depth_volume[:, d], dirs, rots[:, 1], trans[:, 1], rots[:, 0], trans[:, 0], src_cf, dataset)
         planes.append(_cost(warped, ref_cf, cost_type))
     return torch.stack(planes, 1).permute(0, 1, 3, 4, 2)
 
@@ -102,12 +148,12 @@ def _cost(warped, ref_cf, cost_type):
     raise ValueError('Unknown cost type')
 
 
-def cost_volume_erp_multiview(feats, depth_volume, rots, trans, curr_idx=0, cost_type='abs_diff'):
+def cost_volume_erp_multiview(feats, depth_volume, rots, trans, curr_idx=0, cost_type='abs_diff', dataset='m3d'):
     """Multi-view volume: mean over the source views, where view `curr_idx` (the reference) and the
     LAST view of the stack are skipped (range(seq_len-1)).  spherical_cost_volume_mv.py:219-347."""
     B, S, h, w, C = feats.shape
     assert S > 2
-    dirs = _centre_dirs(h, w).unsqueeze(0).expand(B, h, w, 3)
+    dirs = _centre_dirs(h, w, dataset).unsqueeze(0).expand(B, h, w, 3)
     ref_cf = feats[:, curr_idx].permute(0, 3, 1, 2)
     total = 0
     for v in range(S - 1):
@@ -117,7 +163,7 @@ def cost_volume_erp_multiview(feats, depth_volume, rots, trans, curr_idx=0, cost
         planes = []
         for d in range(depth_volume.shape[1]):
             warped = _warp_plane(depth_volume[:, d], dirs, rots[:, curr_idx], trans[:, curr_idx], rots[:, v],
-                                 trans[:, v], src_cf)
+                                 trans[:, v], src_cf, dataset)
             planes.append(_cost(warped, ref_cf, cost_type))
         total = total + torch.stack(planes, 1).permute(0, 1, 3, 4, 2) / (S - 2)
     return total

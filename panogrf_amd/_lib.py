@@ -66,7 +66,7 @@ SYMBOLS = {
     "pgrf_depth_hypotheses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, _P,
                                         C.c_int, _P, _P]),
     "pgrf_cost_volume_erp": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                       C.POINTER(C.c_int), C.c_int, C.c_float, C.c_int, _P, _P]),
+                                       C.POINTER(C.c_int), C.c_int, C.c_float, C.c_int, C.c_int, _P, _P]),
     "pgrf_conv3d_packed_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "pgrf_pack_conv3d": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_wrap": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int,

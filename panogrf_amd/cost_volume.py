@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import lib, PgrfError
+from ._lib import DATASETS, lib, PgrfError
 from .engine import _f32c, _ptr, _stream, _require_gpu
 
 _COST = {'abs_diff': 0, 'dot': 1, 'none': 2}
@@ -42,7 +42,14 @@ def build_depth_volume(ref_mu, k_list, fixed_sigma, min_depth, max_depth, n_tota
     return out
 
 
-def _run(images, depth_volume, trans, rots, ref_idx, src_idx, div, cost_type):
+def _dataset(args):
+    name = args.get('dataset_name', 'm3d')
+    if name not in DATASETS:
+        raise PgrfError(f'dataset_name {name!r}: spherical convention not implemented (have {sorted(DATASETS)})')
+    return DATASETS[name]
+
+
+def _run(images, depth_volume, trans, rots, ref_idx, src_idx, div, cost_type, dataset):
     _require_gpu()
     if cost_type not in _COST:
         raise ValueError('Unknown cost type')
@@ -53,8 +60,8 @@ def _run(images, depth_volume, trans, rots, ref_idx, src_idx, div, cost_type):
     out = torch.empty(B, D, h, w, Cc, dtype=torch.float32, device=images.device)
     idx = (C.c_int * len(src_idx))(*src_idx)
     lib.check(lib.pgrf_cost_volume_erp(_ptr(images), _ptr(depth_volume), _ptr(rots), _ptr(trans), B, S, h, w, Cc, D,
-                                       int(ref_idx), idx, len(src_idx), float(div), _COST[cost_type], _ptr(out),
-                                       _stream()))
+                                       int(ref_idx), idx, len(src_idx), float(div), _COST[cost_type], int(dataset),
+                                       _ptr(out), _stream()))
     return out
 
 
@@ -71,20 +78,16 @@ def _volume_from(args, images, depths, depth_volume):
 def calculate_cost_volume_erp(args, images, depths, trans, rots, depth_volume=None, cost_type='abs_diff',
                               ref_gmms=None, nghbr_gmms=None, thres=None, direction='up'):
     """images [B,2,H,W,C] (index 0 = source, 1 = reference) -> [B,D,H,W,C]."""
-    if args.get('dataset_name', 'm3d') != 'm3d':
-        raise PgrfError("only the 'm3d' ERP convention is implemented")
     dv = _volume_from(args, images, depths, depth_volume)
-    return _run(images, dv, trans, rots, 1, [0], 1.0, cost_type)
+    return _run(images, dv, trans, rots, 1, [0], 1.0, cost_type, _dataset(args))
 
 
 def calculate_cost_volume_erp_multiview(args, images, depths, trans, rots, depth_volume=None, cost_type='abs_diff',
                                         ref_gmms=None, nghbr_gmms=None, thres=None, direction='up', curr_idx=0):
     """images [B,S,H,W,C]; the reference view is `curr_idx`; like the reference, the LAST view of the
     stack and the reference itself are skipped and the rest are averaged with 1/(S-2)."""
-    if args.get('dataset_name', 'm3d') != 'm3d':
-        raise PgrfError("only the 'm3d' ERP convention is implemented")
     S = images.shape[1]
     assert S > 2
     src = [v for v in range(S - 1) if v != curr_idx]
     dv = _volume_from(args, images, depths, depth_volume)
-    return _run(images, dv, trans, rots, curr_idx, src, float(S - 2), cost_type)
+    return _run(images, dv, trans, rots, curr_idx, src, float(S - 2), cost_type, _dataset(args))

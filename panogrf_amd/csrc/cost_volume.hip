@@ -86,6 +86,7 @@ struct CvArgs {
   int src_idx[kMaxSrc];
   float div;              // each view's cost is divided by this before accumulation (mv: S-2)
   int cost_type;          // 0 abs_diff, 1 dot, 2 none
+  int dataset;            // PGRF_DATASET_*: spherical convention (spherical_cost_volume.py:153-190,281-296)
 };
 
 struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
@@ -103,10 +104,33 @@ __device__ __forceinline__ void inv3(const float* m, float* o) {   // adjugate /
 // spherical_cost_volume.py:135-198 + my_torch_helpers.py:34-38,62-96 for one (voxel, source view)
 __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y, int x, float depth) {
   const float PI_F = 3.14159265358979323846f, HALF_PI_F = 1.57079632679489661923f, TWO_PI_F = 6.28318530717958647692f;
-  const float phi = ((float)y + 0.5f) * (float)(3.14159265358979323846 / (double)a.h);
-  const float theta = ((float)x + 0.5f) * (float)(2.0 * 3.14159265358979323846 / (double)a.w) - HALF_PI_F;
-  const float sp = sinf(phi);
-  const float mx = depth * (sp * cosf(theta)), my = depth * cosf(phi), mz = depth * (sp * sinf(theta));
+  const double PI_D = 3.14159265358979323846;
+  // pixel centre -> angles -> unit direction, per dataset (spherical_cost_volume.py:281-296, my_torch_helpers.py:34-56);
+  // Python folds the scalar factors in double before they meet the float tensors
+  float ux, uy, uz;
+  const float fx = (float)x, fy = (float)y;
+  if (a.dataset == PGRF_DATASET_M3D) {
+    const float phi = (fy + 0.5f) * (float)(PI_D / (double)a.h);
+    const float theta = (fx + 0.5f) * (float)(2.0 * PI_D / (double)a.w) - HALF_PI_F;
+    const float sp = sinf(phi);
+    ux = sp * cosf(theta); uy = cosf(phi); uz = sp * sinf(theta);
+  } else if (a.dataset == PGRF_DATASET_REPLICA_TEST) {
+    const float theta = (float)(2.0 * PI_D / (double)a.w) * (fx + 0.5f) - PI_F;
+    const float phi = -(fy + 0.5f) * PI_F / (float)a.h + HALF_PI_F;
+    const float cp = cosf(phi);
+    ux = sinf(theta) * cp; uy = -sinf(phi); uz = cosf(theta) * cp;
+  } else if (a.dataset == PGRF_DATASET_RESIDENTIAL) {
+    const float theta = PI_F * (2.f * fx / (float)(a.w - 1) - 1.5f);
+    const float phi = PI_F * (0.5f - fy / (float)(a.h - 1));
+    const float cp = cosf(phi);
+    ux = cosf(theta) * cp; uz = sinf(theta) * cp; uy = sinf(phi);
+  } else {   // CoffeeArea
+    const float theta = (float)(-2.0 * PI_D / (double)(a.w - 1)) * fx + TWO_PI_F;
+    const float phi = (float)(PI_D / (double)(a.h - 1)) * fy;
+    const float sp = sinf(phi);
+    ux = sp * cosf(theta); uy = sp * sinf(theta); uz = cosf(phi);
+  }
+  const float mx = depth * ux, my = depth * uy, mz = depth * uz;
   const float* Rr = a.rots + ((size_t)b * a.S + a.ref_idx) * 9;
   const float* tr = a.trans + ((size_t)b * a.S + a.ref_idx) * 3;
   float Ri[9];
@@ -121,15 +145,37 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
   const float cy = Rs[3] * wx + Rs[4] * wy + Rs[5] * wz + ts[1];
   const float cz = Rs[6] * wx + Rs[7] * wy + Rs[8] * wz + ts[2];
   const float radius = sqrtf(cx * cx + cy * cy + cz * cz);
-  const float th = atan2f(cz, cx);
-  const float yor = cy / radius;
-  const float LIN = 0.17453292519943295f, COSD = 0.984807753012208f, ONE_M_COSD = 0.01519224698779198f;
-  float ph;
-  if (fabsf(yor) < COSD) ph = acosf(yor);
-  else if (cy >= 0.f) ph = LIN * (1.f - yor) / ONE_M_COSD;
-  else ph = PI_F - LIN * (yor + 1.f) / ONE_M_COSD;
-  const float u = fmodf(th + HALF_PI_F + TWO_PI_F, TWO_PI_F) / PI_F - 1.f;
-  const float v = 2.f * ph / PI_F - 1.f;
+  // cartesian -> (theta, phi) -> grid coordinates u, v in [-1,1] (my_torch_helpers.py:62-120,
+  // spherical_cost_volume.py:153-190)
+  float u, v;
+  if (a.dataset == PGRF_DATASET_M3D) {
+    const float th = atan2f(cz, cx);
+    const float yor = cy / radius;
+    const float LIN = 0.17453292519943295f, COSD = 0.984807753012208f, ONE_M_COSD = 0.01519224698779198f;
+    float ph;
+    if (fabsf(yor) < COSD) ph = acosf(yor);
+    else if (cy >= 0.f) ph = LIN * (1.f - yor) / ONE_M_COSD;
+    else ph = PI_F - LIN * (yor + 1.f) / ONE_M_COSD;
+    u = fmodf(th + HALF_PI_F + TWO_PI_F, TWO_PI_F) / PI_F - 1.f;
+    v = 2.f * ph / PI_F - 1.f;
+  } else if (a.dataset == PGRF_DATASET_REPLICA_TEST) {
+    const float th = atan2f(cx, cz);
+    const float ph = -asinf(cz / radius);          // the reference takes z here (my_torch_helpers.py:99)
+    u = fmodf(th + PI_F + TWO_PI_F, TWO_PI_F) / PI_F - 1.f;
+    v = 2.f * (-ph + HALF_PI_F) / PI_F - 1.f;
+  } else if (a.dataset == PGRF_DATASET_RESIDENTIAL) {
+    float th = -atan2f(-cz, cx);
+    const float ph = asinf(cy / radius);
+    if (th > HALF_PI_F && th <= TWO_PI_F) th -= TWO_PI_F;
+    u = fmodf(th + 4.71238898038469f, TWO_PI_F) / PI_F - 1.f;
+    v = 2.f * (HALF_PI_F - ph) / PI_F - 1.f;
+  } else {   // CoffeeArea
+    float th = atan2f(cy, cx);
+    const float ph = acosf(cz / radius);
+    if (th < 0.f) th += TWO_PI_F;
+    u = (TWO_PI_F - th) / PI_F - 1.f;
+    v = 2.f * ph / PI_F - 1.f;
+  }
   // grid_sample(bilinear, zeros, align_corners=True)
   const float ix = (u + 1.f) / 2.f * (float)(a.w - 1);
   const float iy = (v + 1.f) / 2.f * (float)(a.h - 1);
@@ -237,7 +283,9 @@ int pgrf_depth_hypotheses(const float* ref_mu, int B, int hw, const float* guide
 
 int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const float* rots, const float* trans, int B,
                          int S, int h, int w, int C, int D, int ref_idx, const int* src_idx_host, int n_src,
-                         float src_div, int cost_type, float* out, void* stream) {
+                         float src_div, int cost_type, int dataset, float* out, void* stream) {
+  if (dataset < PGRF_DATASET_M3D || dataset > PGRF_DATASET_COFFEEAREA)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_cost_volume_erp: dataset convention %d unknown", dataset);
   if (!feats || !depth_volume || !rots || !trans || !out || !src_idx_host)
     return set_error(PGRF_ERR_ARG, "pgrf_cost_volume_erp: null pointer");
   if (B < 0 || S < 2 || h < 2 || w < 2 || D < 1) return set_error(PGRF_ERR_ARG, "pgrf_cost_volume_erp: bad shape");
@@ -251,7 +299,7 @@ int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const fl
   CvArgs a;
   a.feats = feats; a.depth = depth_volume; a.rots = rots; a.trans = trans; a.out = out;
   a.B = B; a.S = S; a.h = h; a.w = w; a.C = C; a.D = D; a.ref_idx = ref_idx; a.n_src = n_src; a.div = src_div;
-  a.cost_type = cost_type;
+  a.cost_type = cost_type; a.dataset = dataset;
   for (int i = 0; i < kMaxSrc; ++i) {
     a.src_idx[i] = i < n_src ? src_idx_host[i] : 0;
     if (i < n_src && (src_idx_host[i] < 0 || src_idx_host[i] >= S)) return set_error(PGRF_ERR_ARG, "pgrf_cost_volume_erp: src_idx out of range");

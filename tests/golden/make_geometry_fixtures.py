@@ -2,6 +2,7 @@
 CoffeeArea; network/spt_utils.py) and of pinhole queries (is_perspec=True; network/render_ops.py:35-74), produced by
 the REFERENCE's own functions.  Build container only (needs /root/reference).  Re-run:
     python tests/golden/make_geometry_fixtures.py
+(add --cv for the cost-volume conventions -> cv_conventions.npz)
 Writes tests/golden/geometry_conventions.npz: inputs (coords, poses, depths) and the reference's sample points, view
 directions, projected pixels and projected depths."""
 import os
@@ -66,5 +67,34 @@ def main():
     print('wrote geometry_conventions.npz', {k: tuple(np.asarray(v).shape) for k, v in out.items()})
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and '--cv' not in sys.argv:
     main()
+
+
+def cost_volume_conventions():
+    """2-view and multi-view spherical cost volumes of the REFERENCE in every dataset convention
+    (models/spherical_cost_volume.py:231-341, spherical_cost_volume_mv.py) -> cv_conventions.npz"""
+    torch.set_num_threads(1)
+    R.setup()
+    from models.spherical_cost_volume import calculate_cost_volume_erp
+    from models.spherical_cost_volume_mv import calculate_cost_volume_erp_multiview
+    g = torch.Generator().manual_seed(123)
+    B, h, w, C, D, S = 1, 8, 16, 4, 5, 4
+    feats = torch.randn(B, S, h, w, C, generator=g)
+    rots = torch.stack([torch.from_numpy(rot_xyz(*((torch.rand(3, generator=g) - 0.5) * 1.0).tolist())) for _ in range(S)])[None]
+    trans = (torch.rand(B, S, 3, generator=g) - 0.5) * 0.8
+    dv = (0.6 + 7.0 * torch.rand(B, D, h, w, generator=g))
+    out = dict(feats=feats, rots=rots, trans=trans, depth_volume=dv)
+    for ds in ['m3d', 'replica_test', 'residential', 'CoffeeArea']:
+        args = dict(dataset_name=ds, contain_dnet=True, mono_uncertainty=False)
+        two = calculate_cost_volume_erp(args, feats[:, :2], None, trans[:, :2], rots[:, :2], depth_volume=dv)
+        mv = calculate_cost_volume_erp_multiview(args, feats, None, trans, rots, depth_volume=dv, curr_idx=1)
+        out[f'{ds}.two'] = two
+        out[f'{ds}.mv'] = mv
+    np.savez_compressed(os.path.join(HERE, 'cv_conventions.npz'),
+                        **{k: v.detach().numpy() for k, v in out.items()})
+    print('wrote cv_conventions.npz', {k: tuple(v.shape) for k, v in out.items()})
+
+
+if __name__ == '__main__' and '--cv' in sys.argv:
+    cost_volume_conventions()

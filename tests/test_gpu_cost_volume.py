@@ -68,3 +68,22 @@ def test_cost_volume_full_size_vs_oracle_planes():
     err = (cv[:, sel].cpu() - ref).abs()
     # warp coordinates carry ~1e-4 px of float32 noise at w=256; features are white noise (gradient ~2/px)
     assert float(err.max()) < 5e-3 and float(err.mean()) < 2e-5
+
+
+@pytest.mark.parametrize('ds', ['m3d', 'replica_test', 'residential', 'CoffeeArea'])
+def test_cost_volume_dataset_conventions_vs_reference(ds):
+    """args['dataset_name'] selects the spherical convention; expected volumes come from the reference itself
+    (tests/golden/cv_conventions.npz)."""
+    import os
+    import numpy as np
+    from panogrf_amd import cost_volume as CV
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cv_conventions.npz'))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    args = dict(dataset_name=ds, contain_dnet=True)
+    two = CV.calculate_cost_volume_erp(args, g['feats'][:, :2].cuda(), None, g['trans'][:, :2].cuda(), g['rots'][:, :2].cuda(),
+                                       depth_volume=g['depth_volume'].cuda())
+    mv = CV.calculate_cost_volume_erp_multiview(args, g['feats'].cuda(), None, g['trans'].cuda(), g['rots'].cuda(),
+                                                depth_volume=g['depth_volume'].cuda(), curr_idx=1)
+    # 8x16 maps of N(0,1) noise: one float ulp of an angle moves a tap weight by ~1e-6 of a unit-variance difference
+    assert float((two.cpu() - g[f'{ds}.two']).abs().max()) < 2e-4
+    assert float((mv.cpu() - g[f'{ds}.mv']).abs().max()) < 2e-4

@@ -47,3 +47,27 @@ def test_unet2():
     w = CF.seeded_params(CF.key_shapes(fx['keys']), 51)
     out = CV.unet2(w, fx['x'])
     assert max_abs(out, fx['out']) < 2e-5
+
+
+# ---- the other datasets' spherical conventions, pinned to the reference's own cost volumes
+# (tests/golden/make_geometry_fixtures.py --cv -> cv_conventions.npz)
+import os as _os
+
+import numpy as _np
+import pytest as _pytest
+import torch as _torch
+
+
+def _cvc():
+    z = _np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'golden', 'cv_conventions.npz'))
+    return {k: _torch.from_numpy(z[k]) for k in z.files}
+
+
+@_pytest.mark.parametrize('ds', ['m3d', 'replica_test', 'residential', 'CoffeeArea'])
+def test_oracle_cost_volume_conventions_vs_reference(ds):
+    from oracle import cost_volume_oracle as O
+    g = _cvc()
+    two = O.cost_volume_erp(g['feats'][:, :2], g['depth_volume'], g['rots'][:, :2], g['trans'][:, :2], dataset=ds)
+    mv = O.cost_volume_erp_multiview(g['feats'], g['depth_volume'], g['rots'], g['trans'], curr_idx=1, dataset=ds)
+    assert float((two - g[f'{ds}.two']).abs().max()) < 1e-5
+    assert float((mv - g[f'{ds}.mv']).abs().max()) < 1e-5
