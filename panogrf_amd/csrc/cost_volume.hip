@@ -102,6 +102,7 @@ __device__ __forceinline__ void inv3(const float* m, float* o) {   // adjugate /
 }
 
 // spherical_cost_volume.py:135-198 + my_torch_helpers.py:34-38,62-96 for one (voxel, source view)
+template <bool GEN>
 __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y, int x, float depth) {
   const float PI_F = 3.14159265358979323846f, HALF_PI_F = 1.57079632679489661923f, TWO_PI_F = 6.28318530717958647692f;
   const double PI_D = 3.14159265358979323846;
@@ -109,7 +110,7 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
   // Python folds the scalar factors in double before they meet the float tensors
   float ux, uy, uz;
   const float fx = (float)x, fy = (float)y;
-  if (a.dataset == PGRF_DATASET_M3D) {
+  if (!GEN || a.dataset == PGRF_DATASET_M3D) {
     const float phi = (fy + 0.5f) * (float)(PI_D / (double)a.h);
     const float theta = (fx + 0.5f) * (float)(2.0 * PI_D / (double)a.w) - HALF_PI_F;
     const float sp = sinf(phi);
@@ -148,7 +149,7 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
   // cartesian -> (theta, phi) -> grid coordinates u, v in [-1,1] (my_torch_helpers.py:62-120,
   // spherical_cost_volume.py:153-190)
   float u, v;
-  if (a.dataset == PGRF_DATASET_M3D) {
+  if (!GEN || a.dataset == PGRF_DATASET_M3D) {
     const float th = atan2f(cz, cx);
     const float yor = cy / radius;
     const float LIN = 0.17453292519943295f, COSD = 0.984807753012208f, ONE_M_COSD = 0.01519224698779198f;
@@ -194,6 +195,8 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
   return t;
 }
 
+// GEN = false: m3d convention only (the other conventions compiled in cost 113 -> 176 us at 128x256x64)
+template <bool GEN>
 __global__ void __launch_bounds__(256) cost_volume_kernel(const CvArgs a) {
   const int lane = threadIdx.x & 63;
   const int lpv = a.C / 4;                  // lanes per voxel (power of two <= 64)
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(256) cost_volume_kernel(const CvArgs a) {
     Taps tp[kMaxSrc];
 #pragma unroll
     for (int s = 0; s < kMaxSrc; ++s)
-      if (s < a.n_src) tp[s] = warp_taps(a, b, a.src_idx[s], y, x, depth);
+      if (s < a.n_src) tp[s] = warp_taps<GEN>(a, b, a.src_idx[s], y, x, depth);
     const int mypix = (int)(vox % hw);
     for (int it = 0; it < 64 / vpi; ++it) {
       const int owner = it * vpi + sub;        // lane holding this voxel's geometry
@@ -257,7 +260,8 @@ int launch_cost_volume(const CvArgs& a, void* stream) {
   const size_t waves = (nvox + 63) / 64;
   size_t blocks = (waves + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(cost_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.dataset == PGRF_DATASET_M3D) hipLaunchKernelGGL(cost_volume_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(cost_volume_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   PGRF_CHECK_LAUNCH("cost_volume");
   return PGRF_OK;
 }
