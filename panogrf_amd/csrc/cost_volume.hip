@@ -196,7 +196,7 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
 }
 
 // GEN = false: m3d convention only (the other conventions compiled in cost 113 -> 176 us at 128x256x64)
-template <bool GEN>
+template <bool GEN, int NSRC>      // NSRC: source views accumulated (tap setups kept in registers: 8 per view)
 __global__ void __launch_bounds__(256) cost_volume_kernel(const CvArgs a) {
   const int lane = threadIdx.x & 63;
   const int lpv = a.C / 4;                  // lanes per voxel (power of two <= 64)
@@ -214,10 +214,9 @@ __global__ void __launch_bounds__(256) cost_volume_kernel(const CvArgs a) {
     const float depth = a.depth[vox];          // [B,D,h,w] has the same linear voxel order as the output
     const int sub = lane / lpv, cg = lane % lpv;
     // tap setup once per (voxel, source view), kept in registers (static indexing only)
-    Taps tp[kMaxSrc];
+    Taps tp[NSRC];
 #pragma unroll
-    for (int s = 0; s < kMaxSrc; ++s)
-      if (s < a.n_src) tp[s] = warp_taps<GEN>(a, b, a.src_idx[s], y, x, depth);
+    for (int s = 0; s < NSRC; ++s) tp[s] = warp_taps<GEN>(a, b, a.src_idx[s], y, x, depth);
     const int mypix = (int)(vox % hw);
     for (int it = 0; it < 64 / vpi; ++it) {
       const int owner = it * vpi + sub;        // lane holding this voxel's geometry
@@ -227,8 +226,7 @@ __global__ void __launch_bounds__(256) cost_volume_kernel(const CvArgs a) {
       const int pix = __shfl(mypix, owner, 64);
       const float4 rv = *reinterpret_cast<const float4*>(a.feats + (((size_t)ob * a.S + a.ref_idx) * hw + pix) * a.C + cg * 4);
 #pragma unroll
-      for (int s = 0; s < kMaxSrc; ++s) {
-        if (s >= a.n_src) break;
+      for (int s = 0; s < NSRC; ++s) {
         const Taps& t = tp[s];
         const int o00 = __shfl(t.o00, owner, 64), o01 = __shfl(t.o01, owner, 64);
         const int o10 = __shfl(t.o10, owner, 64), o11 = __shfl(t.o11, owner, 64);
@@ -260,8 +258,13 @@ int launch_cost_volume(const CvArgs& a, void* stream) {
   const size_t waves = (nvox + 63) / 64;
   size_t blocks = (waves + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (a.dataset == PGRF_DATASET_M3D) hipLaunchKernelGGL(cost_volume_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(cost_volume_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+#define PGRF_CV(GEN_, N_) hipLaunchKernelGGL((cost_volume_kernel<GEN_, N_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a)
+  if (a.dataset == PGRF_DATASET_M3D) {
+    if (a.n_src == 1) PGRF_CV(false, 1); else if (a.n_src == 2) PGRF_CV(false, 2); else if (a.n_src == 3) PGRF_CV(false, 3); else PGRF_CV(false, 4);
+  } else {
+    if (a.n_src == 1) PGRF_CV(true, 1); else if (a.n_src == 2) PGRF_CV(true, 2); else if (a.n_src == 3) PGRF_CV(true, 3); else PGRF_CV(true, 4);
+  }
+#undef PGRF_CV
   PGRF_CHECK_LAUNCH("cost_volume");
   return PGRF_OK;
 }
