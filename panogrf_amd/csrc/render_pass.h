@@ -400,7 +400,11 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
   // Two-wave kernels (<= 2 views, f32): the tap setup of the two late gathers (img_feats, rgb) is recomputed where they
   // happen instead of living through the whole stage (16 registers per view; 41.5 -> 41.0 ms).  The one-wave kernels
   // have registers to spare and would only pay the recomputation (4 views: 93.6 -> 101.6 ms).
+#ifdef PGRF_NO_LAZY_TAPS
+  constexpr bool kLazyTaps = false;
+#else
   constexpr bool kLazyTaps = (V <= 2 && kPrec == 0);
+#endif
   Bilin brf[NT], bfeat_e[NT], bimg_e[NT];
   float pxy[NT][2];
   const float* prj[NT];
