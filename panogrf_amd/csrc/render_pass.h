@@ -111,7 +111,16 @@ constexpr bool kSmall = (kPrec == 0);
 #ifdef PGRF_NO_FULL_IMG
 template <int V> constexpr int kImgMode = kPrec;
 #else
-template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (V > 2 ? 2 : 0);
+// Kernels for up to PGRF_TWO_WAVE_MAX_V views are built for two waves per SIMD (<= 256 registers): first-chunk LDS
+// image, lazily recomputed tap setups, LDS-parked view directions; beyond that one wave per SIMD with the registers
+// (and the LDS, for the full weight image) of the whole SIMD.
+// Measured with every view count at two waves: 3 views 73.7 -> 63.4 ms, 4 views 92.7 -> 84.9 ms, although those
+// kernels spill 170 / 333 registers to scratch (the second wave hides it; -DPGRF_TWO_WAVE_MAX_V=2 restores one wave).
+#ifndef PGRF_TWO_WAVE_MAX_V
+#define PGRF_TWO_WAVE_MAX_V 4
+#endif
+template <int V> constexpr bool kTwoWave = (V <= PGRF_TWO_WAVE_MAX_V);
+template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (kTwoWave<V> ? 0 : 2);
 #endif
 
 // One Linear layer on the matrix cores for NT point tiles sharing the A operand.
@@ -403,7 +412,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #ifdef PGRF_NO_LAZY_TAPS
   constexpr bool kLazyTaps = false;
 #else
-  constexpr bool kLazyTaps = (V <= 2 && kPrec == 0);
+  constexpr bool kLazyTaps = (kTwoWave<V> && kPrec == 0);
 #endif
   Bilin brf[NT], bfeat_e[NT], bimg_e[NT];
   float pxy[NT][2];
@@ -799,7 +808,7 @@ __device__ __forceinline__ void stage_rgb(const PassArgs& p, const float* LI, co
 #ifdef PGRF_NT_PAIRS
 template <int V> constexpr int kNT0 = (V >= 2 ? 2 : 1);
 #else
-template <int V> constexpr int kNT0 = V;
+template <int V> constexpr int kNT0 = (V <= 2 || !kTwoWave<V>) ? V : 2;
 #endif
 constexpr int kKStride = 17;   // K rows in LDS: odd stride -> conflict-free column reads (A operand)
 constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast float4 reads
@@ -808,7 +817,7 @@ constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast flo
 // compiled in cost 1.2 % through 5 more spilled registers); GEN = true: run-time switch over PgrfFrame.dataset /
 // .perspective.
 template <int KT, int V, bool DBG, bool GEN>
-__global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(const PassArgs p) {
+__global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel(const PassArgs p) {
   constexpr int DN = 32 * KT;
   constexpr int RPW = 4 / KT;          // rays per workgroup
   __shared__ __attribute__((aligned(16))) float lds_v[128 * kVStride];
@@ -958,7 +967,7 @@ __global__ void __launch_bounds__(256, (V <= 2 ? 2 : 1)) render_pass_kernel(cons
 #ifdef PGRF_NO_PARK
   constexpr bool kPark = false;
 #else
-  constexpr bool kPark = (V <= 2);
+  constexpr bool kPark = kTwoWave<V>;
 #endif
   __shared__ float lds_park[kPark ? V * 7 : 1][256];
   if constexpr (kPark) {
