@@ -89,16 +89,10 @@ __device__ __forceinline__ void elu16(f32x16& a) {
 // LDS image of the blob (pgrf_layout.h): LI is the workgroup's copy; -DPGRF_NO_LDS_IMG reads everything from global memory.
 // Measured (512x1024, 2 views): f32 43.34 -> 43.04 ms; split-f16 29.3 -> 32.3 ms (its 51 KB image costs 20 more spilled
 // registers), so that mode keeps reading from global memory.
-#if PGRF_PREC == 1 && !defined(PGRF_FORCE_LDS_IMG) && !defined(PGRF_NO_LDS_IMG)
-#define PGRF_NO_LDS_IMG
-#endif
-#ifdef PGRF_NO_LDS_IMG
-#define PGRF_LIMG(id) ((const float*)nullptr), false, 0
-#define PGRF_LHEAD(off) (W + (off))
-#else
-#define PGRF_LIMG(id) (LI + img_layer_off((id), kImgMode<V>)), (kImgMode<V> == 2 && img_full(id)), img_a_floats((id), kImgMode<V>)
-#define PGRF_LHEAD(off) (LI + ((off) - OFF_DDH_W))
-#endif
+// kHasImg<V> (below, with the other per-instance policies) says which instances carry an image.
+#define PGRF_LIMG(id) (kHasImg<V> ? LI + img_layer_off((id), kImgMode<V>) : (const float*)nullptr), \
+                      (kHasImg<V> && kImgMode<V> == 2 && img_full(id)), img_a_floats((id), kImgMode<V>)
+#define PGRF_LHEAD(off) (kHasImg<V> ? LI + ((off) - OFF_DDH_W) : W + (off))
 
 // layers with <= 8 outputs on the 4x4x1 MFMA (f32 mode only; -DPGRF_NO_SMALL = padded 32-row tiles)
 #ifdef PGRF_NO_SMALL
@@ -121,6 +115,13 @@ template <int V> constexpr int kImgMode = kPrec;
 #endif
 template <int V> constexpr bool kTwoWave = (V <= PGRF_TWO_WAVE_MAX_V);
 template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (kTwoWave<V> ? 0 : 2);
+// no image in the split-f16 mode (see above).  (Tried for > 2 views at two waves: image dropped in favour of parking the
+// first view group's prob_embed features through stage B — the register allocator answered with MORE spills, 170 -> 289.)
+#ifdef PGRF_NO_LDS_IMG
+template <int V> constexpr bool kHasImg = false;
+#else
+template <int V> constexpr bool kHasImg = (kPrec == 0);
+#endif
 #endif
 
 // One Linear layer on the matrix cores for NT point tiles sharing the A operand.
@@ -548,11 +549,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
   {
     // the 32 ray-feature columns (+ bias) come from the projection map; only k-step 16 = (hit, vis) is left
     f32x16 a1[NT][1], a2[NT][1];
-#ifdef PGRF_NO_LDS_IMG
-    const float a16 = reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
-#else
-    const float a16 = (LI + img_layer_off(L_PE1, kImgMode<V>))[lane * 4];
-#endif
+    const float a16 = kHasImg<V> ? (LI + img_layer_off(L_PE1, kImgMode<V>))[lane * 4]
+                                 : reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const f32x16 pe = gather32<kPrjCh>(prj[t] + 3 * 32, brf[t], half);
@@ -808,7 +806,12 @@ __device__ __forceinline__ void stage_rgb(const PassArgs& p, const float* LI, co
 #ifdef PGRF_NT_PAIRS
 template <int V> constexpr int kNT0 = (V >= 2 ? 2 : 1);
 #else
-template <int V> constexpr int kNT0 = (V <= 2 || !kTwoWave<V>) ? V : 2;
+// (at two waves: 3 views in one group 60.1 ms vs 63.5 in groups 2+1; 4 views in one group 88.2 ms vs 85.2 in pairs)
+#ifdef PGRF_NT_ALL
+template <int V> constexpr int kNT0 = V;
+#else
+template <int V> constexpr int kNT0 = (V <= 3 || !kTwoWave<V>) ? V : 2;
+#endif
 #endif
 constexpr int kKStride = 17;   // K rows in LDS: odd stride -> conflict-free column reads (A operand)
 constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast float4 reads
@@ -824,16 +827,12 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
   __shared__ float lds_k[128 * kKStride];
   __shared__ float lds_alpha[4];     // per-wave transmittance totals
   __shared__ float lds_red[4][4];
-#ifdef PGRF_NO_LDS_IMG
-  const float* LI = nullptr;
-#else
-  __shared__ __attribute__((aligned(16))) float lds_img[img_floats(kImgMode<V>)];
+  __shared__ __attribute__((aligned(16))) float lds_img[kHasImg<V> ? img_floats(kImgMode<V>) : 4];
   const float* LI = lds_img;
-  {   // every workgroup copies the image once; the barrier sits after ray generation
+  if constexpr (kHasImg<V>) {   // every workgroup copies the image once; the barrier sits after ray generation
     const float4* src = reinterpret_cast<const float4*>(p.blob + img_blob_off(kImgMode<V>));
     for (int i = threadIdx.x; i < img_floats(kImgMode<V>) / 4; i += 256) reinterpret_cast<float4*>(lds_img)[i] = src[i];
   }
-#endif
   // debug builds: the 12 dump pointers live in LDS, not in SGPRs (24 live SGPRs made the compiler spill scalars)
   __shared__ float* lds_dbg[DBG ? 12 : 1];
   float* const* sdbg = lds_dbg;
@@ -943,9 +942,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
 
   ViewState vs[V];
   const bool store_ok = ray_ok;
-#ifndef PGRF_NO_LDS_IMG
-  __syncthreads();
-#endif
+  if constexpr (kHasImg<V>) __syncthreads();
   PGRF_TICK(0);   // ray generation
 
   // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
