@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pgrf_internal.h"
+#include "ray_dir.h"
 #include "pgrf_layout.h"
 
 namespace pgrf {
@@ -265,6 +266,29 @@ int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int 
   const int blocks = (rn + 3) / 4;
   hipLaunchKernelGGL(merge_c2f_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, zc, colc, denc, dnc, zf, colf, denf, dnf, rn, o);
   PGRF_CHECK_LAUNCH("merge_c2f");
+  return PGRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-ray direction table of pgrf_render_rays: the render pass would otherwise recompute the same ~250 instructions
+// (sin/cos of the pixel angles, normalisation, rotation) in all 64 lanes of every wave of every pass.
+template <bool GEN>
+__global__ void ray_dirs_kernel(const PassArgs p, float* __restrict__ tab) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= p.rn) return;
+  float wx, wy, wz;
+  ray_direction<GEN>(p, ray, wx, wy, wz);
+  reinterpret_cast<float4*>(tab)[ray] = make_float4(wx, wy, wz, 0.f);
+}
+
+int launch_ray_dirs(const PassArgs& a, float* tab, void* stream) {
+  const int blocks = (a.rn + 255) / 256;
+  if (a.dataset != PGRF_DATASET_M3D || a.perspective)
+    hipLaunchKernelGGL(ray_dirs_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, tab);
+  else
+    hipLaunchKernelGGL(ray_dirs_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, tab);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(PGRF_ERR_LAUNCH, "ray_dirs launch failed: %s", hipGetErrorString(e));
   return PGRF_OK;
 }
 

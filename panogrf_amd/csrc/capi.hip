@@ -60,6 +60,8 @@ static const char* kRawNames[R_COUNT] = {
     "agg_net.agg_impl.neuray_fc.2.bias",
 };
 
+int launch_ray_dirs(const PassArgs& a, float* tab, void* stream);
+
 static int check_frame(const PgrfFrame* f, const char* who) {
   if (!f) return set_error(PGRF_ERR_ARG, "%s: frame is null", who);
   if (f->rfn < 1 || f->rfn > PGRF_MAX_VIEWS) return set_error(PGRF_ERR_ARG, "%s: rfn=%d not in [1,%d]", who, f->rfn, PGRF_MAX_VIEWS);
@@ -73,9 +75,20 @@ static int check_frame(const PgrfFrame* f, const char* who) {
 
 static size_t pass_ws_bytes(const PgrfFrame* f) { return (size_t)f->rfn * f->hr * f->wr * kPrjCh * sizeof(float); }
 
+// the query-side fields the ray generation reads (ray_dir.h)
+static int fill_query(PassArgs& a, const PgrfFrame* frame, const float* coords, int rn, const char* who) {
+  if (frame->dataset < PGRF_DATASET_M3D || frame->dataset > PGRF_DATASET_COFFEEAREA)
+    return set_error(PGRF_ERR_UNSUPPORTED, "%s: dataset convention %d unknown", who, frame->dataset);
+  std::memcpy(a.c2w, frame->que_c2w, sizeof(a.c2w));
+  a.dataset = frame->dataset; a.perspective = frame->perspective ? 1 : 0;
+  std::memcpy(a.kinv, frame->que_kinv, sizeof(a.kinv));
+  a.H = frame->H; a.W = frame->W; a.coords = coords; a.rn = rn;
+  return PGRF_OK;
+}
+
 static int do_render_pass(const PgrfFrame* frame, const float* blob, int flags, const float* coords, const float* depth,
                           int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg, void* workspace,
-                          size_t ws_bytes, void* stream) {
+                          size_t ws_bytes, void* stream, const float* raytab = nullptr) {
   const int use_vis = (flags & PGRF_PASS_USE_VIS) ? 1 : 0;
   const int precision = (flags & PGRF_PASS_F16X3) ? 1 : 0;
   int rc = check_frame(frame, "pgrf_render_pass");
@@ -96,14 +109,11 @@ static int do_render_pass(const PgrfFrame* frame, const float* blob, int flags, 
   a.imgs = frame->imgs; a.img_feats = frame->img_feats; a.ray_feats = frame->ray_feats;
   a.prj = (const float*)workspace;
   a.w2c = frame->w2c; a.ref_dr = frame->ref_depth_range;
-  std::memcpy(a.c2w, frame->que_c2w, sizeof(a.c2w));
+  rc = fill_query(a, frame, coords, rn, "pgrf_render_pass");
+  if (rc) return rc;
   a.que_near = frame->que_depth_range[0]; a.que_far = frame->que_depth_range[1];
-  if (frame->dataset < PGRF_DATASET_M3D || frame->dataset > PGRF_DATASET_COFFEEAREA)
-    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass: dataset convention %d unknown", frame->dataset);
-  a.dataset = frame->dataset; a.perspective = frame->perspective ? 1 : 0;
-  std::memcpy(a.kinv, frame->que_kinv, sizeof(a.kinv));
-  a.H = frame->H; a.W = frame->W; a.hf = frame->hf; a.wf = frame->wf; a.hr = frame->hr; a.wr = frame->wr;
-  a.coords = coords; a.depth = depth; a.rn = rn; a.blob = blob; a.use_vis = use_vis ? 1 : 0;
+  a.hf = frame->hf; a.wf = frame->wf; a.hr = frame->hr; a.wr = frame->wr;
+  a.depth = depth; a.raytab = raytab; a.blob = blob; a.use_vis = use_vis ? 1 : 0;
   a.out_pixel = out->pixel_colors; a.out_depth = out->render_depth; a.out_hit = out->hit_prob;
   a.out_colors = out->colors; a.out_density = out->density; a.nan_flag = out->nan_flag;
   if (dbg) a.dbg = *dbg;
@@ -183,6 +193,7 @@ size_t pgrf_render_workspace_bytes(const PgrfFrame* frame, const PgrfRenderCfg* 
   b += align256(r * cfg->dn * 4);            // coarse depth
   b += align256(r * cfg->dn * 4);            // coarse hit_prob (when the caller does not ask for it)
   b += align256(r * fdn_eff * 4);            // fine depth
+  b += align256(r * 16);                     // per-ray directions (ray_dir.h), shared by both passes
   if (cfg->c2f_all) {
     b += align256(r * cfg->dn * 12) + align256(r * cfg->dn * 4);        // coarse colors, density
     b += align256(r * fdn_eff * 12) + align256(r * fdn_eff * 4);        // fine colors, density
@@ -209,6 +220,13 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
   float* depth_c = (float*)ws; ws += align256(r * cfg->dn * 4);
   float* hit_c = (float*)ws; ws += align256(r * cfg->dn * 4);
   float* depth_f = (float*)ws; ws += align256(r * fdn_eff * 4);
+  float* raytab = (float*)ws; ws += align256(r * 16);
+  {
+    PassArgs q;
+    std::memset(&q, 0, sizeof(q));
+    if (int rcq = fill_query(q, frame, coords, rn, "pgrf_render_rays")) return rcq;
+    if (int rcq = launch_ray_dirs(q, raytab, stream)) return rcq;
+  }
   PgrfPassOut oc = *coarse;
   if (!oc.hit_prob) oc.hit_prob = hit_c;
   PgrfPassOut of;
@@ -227,18 +245,18 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
   if (rc) return rc;
   const int pf = cfg->precision == 1 ? PGRF_PASS_F16X3 : 0;
   if (cfg->precision != 0 && cfg->precision != 1) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: precision must be 0 (f32) or 1 (f16x3)");
-  rc = do_render_pass(frame, blob_coarse, (cfg->use_vis_coarse ? PGRF_PASS_USE_VIS : 0) | pf, coords, depth_c, rn, cfg->dn, &oc, nullptr, prj_ws, prj_bytes, stream);
+  rc = do_render_pass(frame, blob_coarse, (cfg->use_vis_coarse ? PGRF_PASS_USE_VIS : 0) | pf, coords, depth_c, rn, cfg->dn, &oc, nullptr, prj_ws, prj_bytes, stream, raytab);
   if (rc || !cfg->hierarchical) return rc;
   float* fd = fine_depth_out ? fine_depth_out : depth_f;
   rc = pgrf_sample_fine_depth(depth_c, oc.hit_prob, frame->que_depth_range[0], frame->que_depth_range[1], cfg->use_disp,
                               cfg->fine_use_all, rn, cfg->dn, cfg->fdn, fd, stream);
   if (rc) return rc;
-  if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &of, nullptr, prj_ws, prj_bytes, stream);
+  if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &of, nullptr, prj_ws, prj_bytes, stream, raytab);
   // fine pass into scratch, then one composite over the union (renderer.py:484-518)
   PgrfPassOut tmp;
   std::memset(&tmp, 0, sizeof(tmp));
   tmp.colors = col_f; tmp.density = den_f; tmp.nan_flag = of.nan_flag;
-  rc = do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &tmp, nullptr, prj_ws, prj_bytes, stream);
+  rc = do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &tmp, nullptr, prj_ws, prj_bytes, stream, raytab);
   if (rc) return rc;
   return pgrf_merge_c2f(depth_c, col_c, den_c, cfg->dn, fd, col_f, den_f, fdn_eff, rn, &of, stream);
 }

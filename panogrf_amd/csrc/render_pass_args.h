@@ -21,6 +21,7 @@ struct PassArgs {
   // rays
   const float* coords;      // [rn,2]
   const float* depth;       // [rn,dn]
+  const float* raytab;      // [rn,4] world-space ray directions (ray_dir.h) or null = compute per sample
   int rn;
   // network
   const float* blob;
