@@ -287,9 +287,13 @@ struct Bilin {
 
 // grid_sample(bilinear, padding_mode=border) tap setup for a point given in FULL-image pixels.
 // network/render_ops.py:126-143, network/ops.py:32-52 (x/(W-1)*2-1 with the full-image W,H).
-__device__ __forceinline__ Bilin bilin_setup(float px, float py, int H, int W, int fh, int fw, bool align) {
-  const float xn = px / (float)(W - 1) * 2.f - 1.f;
-  const float yn = py / (float)(H - 1) * 2.f - 1.f;
+// normalised sampling position of a full-image pixel coordinate (ops.py:32-52): computed once per view, shared by the
+// three maps sampled there (the two divisions are IEEE: these are pixel coordinates)
+__device__ __forceinline__ void norm_pos(float px, float py, int H, int W, float& xn, float& yn) {
+  xn = px / (float)(W - 1) * 2.f - 1.f;
+  yn = py / (float)(H - 1) * 2.f - 1.f;
+}
+__device__ __forceinline__ Bilin bilin_setup(float xn, float yn, int fh, int fw, bool align) {
   float ix, iy;
   if (align) {
     ix = (xn + 1.f) / 2.f * (float)(fw - 1);
@@ -461,12 +465,14 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     vs[v].dd[2] = dz - g.qdir[2];
     vs[v].dd[3] = dx * g.qdir[0] + dy * g.qdir[1] + dz * g.qdir[2];   // aggregate_net.py:8-14
     // bilinear gathers (render_ops.py:243-245, renderer.py:180-188)
-    brf[t] = bilin_setup(px, py, p.H, p.W, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
+    float xn, yn;
+    norm_pos(px, py, p.H, p.W, xn, yn);
+    brf[t] = bilin_setup(xn, yn, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
     prj[t] = p.prj + (size_t)v * p.hr * p.wr * kPrjCh;
-    pxy[t][0] = px; pxy[t][1] = py;
+    pxy[t][0] = xn; pxy[t][1] = yn;       // normalised position (bit-identical tap setups later)
     if constexpr (!kLazyTaps) {
-      bfeat_e[t] = bilin_setup(px, py, p.H, p.W, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
-      bimg_e[t] = bilin_setup(px, py, p.H, p.W, p.H, p.W, true);
+      bfeat_e[t] = bilin_setup(xn, yn, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
+      bimg_e[t] = bilin_setup(xn, yn, p.H, p.W, true);
     }
     if (DBG && store_ok) {
       const size_t o = (size_t)v * npts + pt;
@@ -637,8 +643,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
       const int v = V0 + t;
       Bilin bfeat[NT], bimg[NT];
       if constexpr (kLazyTaps) {
-        bfeat[t] = bilin_setup(pxy[t][0], pxy[t][1], p.H, p.W, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
-        bimg[t] = bilin_setup(pxy[t][0], pxy[t][1], p.H, p.W, p.H, p.W, true);
+        bfeat[t] = bilin_setup(pxy[t][0], pxy[t][1], p.hf, p.wf, p.hf == p.H && p.wf == p.W);
+        bimg[t] = bilin_setup(pxy[t][0], pxy[t][1], p.H, p.W, true);
       } else {
         bfeat[t] = bfeat_e[t];
         bimg[t] = bimg_e[t];
