@@ -1056,7 +1056,9 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[k2][r]);
       mx = xmax(mx);
-      float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+      float l = 0.f, o0, o1, o2, o3;
+#ifndef PGRF_PV_MFMA
+      o0 = o1 = o2 = o3 = 0.f;
 #pragma unroll
       for (int k2 = 0; k2 < KT; ++k2)
 #pragma unroll
@@ -1066,6 +1068,28 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
           l += pe;
           o0 = fmaf(pe, vv.x, o0); o1 = fmaf(pe, vv.y, o1); o2 = fmaf(pe, vv.z, o2); o3 = fmaf(pe, vv.w, o3);
         }
+#else
+      // experiment (measured slower: 38.2 -> 39.0 ms): softmax-weighted values on v_mfma_f32_4x4x1_16b_f32: block = 4
+      // consecutive lanes = 4 queries with the SAME key (k2, r, half); B = the lane's own weight for that key, A = value
+      // dimension (lane & 3) of that key, so D leaves the 4 output dimensions of the lane's own query in registers 0..3.
+      {
+        f32x4 ov[KT];
+#pragma unroll
+        for (int k2 = 0; k2 < KT; ++k2) ov[k2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int k2 = 0; k2 < KT; ++k2) {
+            const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
+            const float vd = lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4 + (lane & 3)];
+            l += pe;
+            ov[k2] = __builtin_amdgcn_mfma_f32_4x4x1f32(vd, pe, ov[k2], 0, 0, 0);
+          }
+#pragma unroll
+        for (int k2 = 1; k2 < KT; ++k2) ov[0] += ov[k2];
+        o0 = ov[0][0]; o1 = ov[0][1]; o2 = ov[0][2]; o3 = ov[0][3];
+      }
+#endif
       l = xsum(l);
       o0 = xsum(o0); o1 = xsum(o1); o2 = xsum(o2); o3 = xsum(o3);
       const float rl = rcp1(l);
