@@ -109,6 +109,14 @@ template <int V> constexpr int kImgMode = kPrec;
 #define PGRF_TWO_WAVE_MAX_V 4
 #endif
 template <int V> constexpr bool kTwoWave = (V <= PGRF_TWO_WAVE_MAX_V);
+// 4 views at two waves: `nf` (16 registers per view) is not kept from stage A to stage C but rebuilt there from 3
+// registers (one more gather of the prob_embed block of the projection map + 1 MFMA per view): 333 -> 260 spilled
+// registers, 84.7 -> 83.9 ms.  (3 views: 60.2 -> 63.7 ms, so not there.)  -DPGRF_NO_RECOMPUTE_NF disables.
+#ifdef PGRF_NO_RECOMPUTE_NF
+template <int V> constexpr bool kRecomputeNf = false;
+#else
+template <int V> constexpr bool kRecomputeNf = kTwoWave<V> && V > 3;
+#endif
 template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (kTwoWave<V> ? 0 : 2);
 // no image in the split-f16 mode (see above).  (Tried for > 2 views at two waves: image dropped in favour of parking the
 // first view group's prob_embed features through stage B — the register allocator answered with MORE spills, 170 -> 289.)
@@ -383,6 +391,7 @@ struct ViewState {
   float rgb[3];   // gathered source colour (blended at the end)
   float w0;       // sigmoid(neuray_fc) * w
   float v2;       // vis_fc2 output
+  float hv, xn, yn;   // kRecomputeNf: what stage C needs to rebuild `nf` (hit|vis input of prob_embed.0, sampling position)
 };
 
 struct PointGeom {
@@ -556,6 +565,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     for (int t = 0; t < NT; ++t) {
       const f32x16 pe = gather32<kPrjCh>(prj[t] + 3 * 32, brf[t], half);
       const float hv = half ? (vis_s[t] - 0.5f) * 2.f : (hit_s[t] - 0.5f) * 2.f;
+      if constexpr (kRecomputeNf<V>) { vs[V0 + t].hv = hv; vs[V0 + t].xn = pxy[t][0]; vs[V0 + t].yn = pxy[t][1]; }
       a1[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a16, hv, pe, 0, 0, 0);
     }
     float b2[NT][16];
@@ -679,6 +689,19 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const float* LI, co
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
   const float wgt = 1.f / ((float)V + 1e-8f);
+  if constexpr (kRecomputeNf<V>) {
+    const float a16 = kHasImg<V> ? (LI + img_layer_off(L_PE1, kImgMode<V>))[lane * 4]
+                                 : reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int v = V0 + t;
+      const Bilin b = bilin_setup(vs[v].xn, vs[v].yn, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
+      const f32x16 pe = gather32<kPrjCh>(p.prj + (size_t)v * p.hr * p.wr * kPrjCh + 3 * 32, b, half);
+      const f32x16 a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a16, vs[v].hv, pe, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) vs[v].nf[s] = fmaxf(a1[s], 0.f);
+    }
+  }
   f32x16 h[NT][2];
   {
     float b35[NT][35];
