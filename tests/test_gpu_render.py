@@ -420,3 +420,22 @@ def test_nan_in_the_inputs_raises_instead_of_blocking():
                                               # absorbed by v_med3 / v_max, which return the non-NaN operand)
     with pytest.raises(PgrfError, match='NaN'):
         rr.render_rays(_frame(E, bad), coords)
+
+
+@pytest.mark.parametrize('rfn', [3, 4])
+def test_more_views_with_128_sample_fine_pass_vs_oracle(rfn):
+    """3 and 4 source views through the widest kernel shape (fine_depth_use_all: 128 samples per ray, 4 waves per ray)."""
+    from oracle import render_oracle as O
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(16, 32, rfn, 64, seed=20 + rfn, fine=True)
+    case['cfg']['fine_depth_use_all'] = True
+    fr = _frame(E, case['frame'])
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    idx = torch.arange(0, 16 * 32, 7)
+    coords = torch.stack([(idx % 32).float(), (idx // 32).float()], -1)
+    out = rr.render_rays(fr, coords)
+    ref = O.render_rays(case['weights'], case['frame'], coords, case['cfg'])
+    assert out['density_nr_fine'].shape[1] == 128
+    assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 5e-5
+    assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), ref['pixel_colors_nr_fine']) > 60
