@@ -394,6 +394,13 @@ struct ViewState {
   float hv, xn, yn;   // kRecomputeNf: what stage C needs to rebuild `nf` (hit|vis input of prob_embed.0, sampling position)
 };
 
+struct ViewProj {     // projection of one sample point into one source view
+  float px, py, r;    // full-image pixel, distance to the camera
+  float xn, yn;       // normalised sampling position
+  float dd[4];        // [prj_dir - que_dir, <prj_dir, que_dir>]
+  Bilin brf;          // tap setup of the ray_feats / projection map
+};
+
 struct PointGeom {
   float p[3];       // world position
   float qdir[3];    // -d/|d|
@@ -423,12 +430,16 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #else
   constexpr bool kLazyTaps = (kTwoWave<V> && kPrec == 0);
 #endif
+#ifdef PGRF_NO_DEDUPE
+  constexpr bool kDedupe = false;
+#else
+  constexpr bool kDedupe = (NT == 2);
+#endif
   Bilin brf[NT], bfeat_e[NT], bimg_e[NT];
   float pxy[NT][2];
   const float* prj[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int v = V0 + t;
+  auto project_view = [&](int v) {
+    ViewProj o;
     const float* M = p.w2c + v * 12;
     // world -> source camera  (render_ops.py:158-191)
     const float cx = M[0] * g.p[0] + M[1] * g.p[1] + M[2] * g.p[2] + M[3];
@@ -461,7 +472,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
       px = (float)(p.W - 1) * (1.f - th / PGRF_TWO_PI_F);
       py = ph * (float)(p.H - 1) / PGRF_PI_F;
     }
-    dv[t] = r;
+    o.px = px; o.py = py; o.r = r;
     // direction towards the source camera centre  (render_ops.py:195-209): c = -R^T t
     const float ccx = -(M[0] * M[3] + M[4] * M[7] + M[8] * M[11]);
     const float ccy = -(M[1] * M[3] + M[5] * M[7] + M[9] * M[11]);
@@ -469,16 +480,52 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     float dx = g.p[0] - ccx, dy = g.p[1] - ccy, dz = g.p[2] - ccz;
     const float dn_ = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-5f);
     { const float rd = -rcp1(dn_); dx *= rd; dy *= rd; dz *= rd; }
-    vs[v].dd[0] = dx - g.qdir[0];
-    vs[v].dd[1] = dy - g.qdir[1];
-    vs[v].dd[2] = dz - g.qdir[2];
-    vs[v].dd[3] = dx * g.qdir[0] + dy * g.qdir[1] + dz * g.qdir[2];   // aggregate_net.py:8-14
+    o.dd[0] = dx - g.qdir[0];
+    o.dd[1] = dy - g.qdir[1];
+    o.dd[2] = dz - g.qdir[2];
+    o.dd[3] = dx * g.qdir[0] + dy * g.qdir[1] + dz * g.qdir[2];   // aggregate_net.py:8-14
     // bilinear gathers (render_ops.py:243-245, renderer.py:180-188)
     float xn, yn;
     norm_pos(px, py, p.H, p.W, xn, yn);
-    brf[t] = bilin_setup(xn, yn, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
+    o.brf = bilin_setup(xn, yn, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
+    o.xn = xn; o.yn = yn;          // normalised position (bit-identical tap setups later)
+    return o;
+  };
+  ViewProj vp[NT];
+  if constexpr (kDedupe) {
+    // both lane halves hold the same point: half 0 projects it into view V0, half 1 into view V0+1, and one
+    // v_permlane32_swap per value hands each result to the other half (instead of both halves computing both views)
+    const ViewProj mine = project_view(V0 + half);
+    auto both = [&](float x, float& x0, float& x1) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      x0 = __uint_as_float(r[0]); x1 = __uint_as_float(r[1]);
+    };
+    auto bothi = [&](int x, int& x0, int& x1) {
+      const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+      x0 = (int)r[0]; x1 = (int)r[1];
+    };
+    both(mine.px, vp[0].px, vp[1].px); both(mine.py, vp[0].py, vp[1].py); both(mine.r, vp[0].r, vp[1].r);
+    both(mine.xn, vp[0].xn, vp[1].xn); both(mine.yn, vp[0].yn, vp[1].yn);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) both(mine.dd[c], vp[0].dd[c], vp[1].dd[c]);
+    bothi(mine.brf.o00, vp[0].brf.o00, vp[1].brf.o00); bothi(mine.brf.o01, vp[0].brf.o01, vp[1].brf.o01);
+    bothi(mine.brf.o10, vp[0].brf.o10, vp[1].brf.o10); bothi(mine.brf.o11, vp[0].brf.o11, vp[1].brf.o11);
+    both(mine.brf.wnw, vp[0].brf.wnw, vp[1].brf.wnw); both(mine.brf.wne, vp[0].brf.wne, vp[1].brf.wne);
+    both(mine.brf.wsw, vp[0].brf.wsw, vp[1].brf.wsw); both(mine.brf.wse, vp[0].brf.wse, vp[1].brf.wse);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) vp[t] = project_view(V0 + t);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int v = V0 + t;
+    const float px = vp[t].px, py = vp[t].py, r = vp[t].r, xn = vp[t].xn, yn = vp[t].yn;
+    dv[t] = r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vs[v].dd[c] = vp[t].dd[c];
+    brf[t] = vp[t].brf;
     prj[t] = p.prj + (size_t)v * p.hr * p.wr * kPrjCh;
-    pxy[t][0] = xn; pxy[t][1] = yn;       // normalised position (bit-identical tap setups later)
+    pxy[t][0] = xn; pxy[t][1] = yn;
     if constexpr (!kLazyTaps) {
       bfeat_e[t] = bilin_setup(xn, yn, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
       bimg_e[t] = bilin_setup(xn, yn, p.H, p.W, true);
