@@ -288,6 +288,21 @@ __device__ __forceinline__ float head_dot(const float* __restrict__ w, int half,
   return xsum(s);
 }
 
+// partial dot over this lane half's R features (no cross-half sum)
+template <int R>
+__device__ __forceinline__ float head_partial(const float* __restrict__ w, int half, const f32x16& x) {
+  const float* wp = w + half * R;
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s = fmaf(wp[r], x[r], s);
+  return s;
+}
+// s0, s1 = per-half partial sums of view 0 / view 1 -> the full sum of view `half` (one swap + one add for both views)
+__device__ __forceinline__ float pair_mine(float s0, float s1) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 struct Bilin {
   int o00, o01, o10, o11;   // pixel offsets (pixels, not floats) of the 4 taps inside one view's map
   float wnw, wne, wsw, wse;
@@ -420,7 +435,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
                                             ) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
-  float vis_s[NT], hit_s[NT];
+
   float dv[NT];
   // Two-wave kernels (<= 2 views, f32): the tap setup of the two late gathers (img_feats, rgb) is recomputed where they
   // happen instead of living through the whole stage (16 registers per view; 41.5 -> 41.0 ms).  The one-wave kernels
@@ -543,6 +558,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
   // ---- mixture-of-logistics decoder: 3 (4) MLPs 32 -> 32 -> 32 -> head  (dist_decoder.py:53-107)
   // layer 0 of each MLP is read from the per-pixel projection map (pre-activation incl. bias): no MFMA
   float head[NT][6];
+  float hm[6];          // kDedupe: the heads of the view this lane half owns
+  hm[5] = 1.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) head[t][5] = 1.f;
 #pragma unroll
@@ -557,48 +574,81 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
       for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[s]);
     }
     mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2, W + layer_h_off(L_DD2_0 + m), PGRF_LIMG(L_DD2_0 + m));
+    if constexpr (kDedupe) {
+      // heads of the view this lane half owns (half 0: view V0, half 1: view V0+1): activation and everything after it
+      // is computed once per view instead of in both halves
+      elu16(a2[0][0]); elu16(a2[1][0]);
+      auto mine = [&](int k) {
+        return pair_mine(head_partial<16>(PGRF_LHEAD(OFF_DDH_W) + k * 32, half, a2[0][0]),
+                         head_partial<16>(PGRF_LHEAD(OFF_DDH_W) + k * 32, half, a2[1][0])) + W[OFF_DDH_B + k];
+      };
+      if (m == 0) { hm[0] = softplus1(mine(0)); hm[1] = softplus1(mine(1)); }
+      else if (m == 1) { hm[2] = softplus1(mine(2)) + 0.05f; hm[3] = softplus1(mine(3)) + 0.05f; }
+      else if (m == 2) hm[4] = sigmoid1(mine(4));
+      else hm[5] = sigmoid1(mine(5));
+    } else {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      elu16(a2[t][0]);
-      if (m == 0) {
-        head[t][0] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 0 * 32, half, a2[t][0]) + W[OFF_DDH_B + 0]);
-        head[t][1] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 1 * 32, half, a2[t][0]) + W[OFF_DDH_B + 1]);
-      } else if (m == 1) {   // softplus + AddBias(0.05)  (dist_decoder.py:73-81)
-        head[t][2] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 2 * 32, half, a2[t][0]) + W[OFF_DDH_B + 2]) + 0.05f;
-        head[t][3] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 3 * 32, half, a2[t][0]) + W[OFF_DDH_B + 3]) + 0.05f;
-      } else if (m == 2) {
-        head[t][4] = sigmoid1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 4 * 32, half, a2[t][0]) + W[OFF_DDH_B + 4]);
-      } else {
-        head[t][5] = sigmoid1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 5 * 32, half, a2[t][0]) + W[OFF_DDH_B + 5]);
+      for (int t = 0; t < NT; ++t) {
+        elu16(a2[t][0]);
+        if (m == 0) {
+          head[t][0] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 0 * 32, half, a2[t][0]) + W[OFF_DDH_B + 0]);
+          head[t][1] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 1 * 32, half, a2[t][0]) + W[OFF_DDH_B + 1]);
+        } else if (m == 1) {   // softplus + AddBias(0.05)  (dist_decoder.py:73-81)
+          head[t][2] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 2 * 32, half, a2[t][0]) + W[OFF_DDH_B + 2]) + 0.05f;
+          head[t][3] = softplus1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 3 * 32, half, a2[t][0]) + W[OFF_DDH_B + 3]) + 0.05f;
+        } else if (m == 2) {
+          head[t][4] = sigmoid1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 4 * 32, half, a2[t][0]) + W[OFF_DDH_B + 4]);
+        } else {
+          head[t][5] = sigmoid1(head_dot<16>(PGRF_LHEAD(OFF_DDH_W) + 5 * 32, half, a2[t][0]) + W[OFF_DDH_B + 5]);
+        }
       }
     }
   }
   PGRF_TICK(17);  // A: dist decoder MLPs
   // ---- compute_prob (dist_decoder.py:6-51 is_ref branch, :109-140)
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int v = V0 + t;
+  float hvs[NT];         // (hit - 0.5) * 2 in lane half 0, (vis - 0.5) * 2 in lane half 1: the k-step-16 input of prob_embed.0
+  auto prob_of = [&](int v, float depth_v, const float (&hd)[6], float& visib, float& hitp) {
     const float rn_ = -1.f / p.ref_dr[2 * v], rf_ = -1.f / p.ref_dr[2 * v + 1];
-    const float z = (-1.f / fmaxf(dv[t], 1e-5f) - rn_) / (rf_ - rn_);
+    const float z = (-1.f / fmaxf(depth_v, 1e-5f) - rn_) / (rf_ - rn_);
     const float nearp = z - g.near_hw, farp = z + g.far_hw;
-    const float aw = head[t][4];
-    float visib = 0.f, hitp = 0.f;
+    const float aw = hd[4];
+    visib = 0.f; hitp = 0.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const float mean = head[t][k], var = head[t][2 + k];
+      const float mean = hd[k], var = hd[2 + k];
       float c0 = cdf1((nearp - mean) * var);
       float c1 = cdf1((farp - mean) * var);
-      if (p.use_vis) { c0 *= head[t][5]; c1 *= head[t][5]; }
+      if (p.use_vis) { c0 *= hd[5]; c1 *= hd[5]; }
       const float mix = (k == 0) ? aw : 1.f - aw;
       visib += (1.f - c0) * mix;
       hitp += (c1 - c0) * mix;
     }
-    vis_s[t] = visib;
-    hit_s[t] = hitp;
-    if (DBG && store_ok && half == 0) {
-      const size_t o = (size_t)v * npts + pt;
+  };
+  if constexpr (kDedupe) {
+    float visib, hitp;
+    prob_of(V0 + half, half ? dv[1] : dv[0], hm, visib, hitp);
+    // half 0 holds (hit, vis) of view V0, half 1 of view V0+1; one swap puts hit into the lower and vis into the upper
+    // half of each view's register, which is exactly the operand layout prob_embed.0 wants
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint((hitp - 0.5f) * 2.f), __float_as_uint((visib - 0.5f) * 2.f), false, false);
+    hvs[0] = __uint_as_float(r[0]);
+    hvs[1] = __uint_as_float(r[1]);
+    if (DBG && store_ok) {
+      const size_t o = (size_t)(V0 + half) * npts + pt;
       if (sdbg[3]) sdbg[3][o] = visib;
       if (sdbg[4]) sdbg[4][o] = hitp;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int v = V0 + t;
+      float visib, hitp;
+      prob_of(v, dv[t], head[t], visib, hitp);
+      hvs[t] = half ? (visib - 0.5f) * 2.f : (hitp - 0.5f) * 2.f;
+      if (DBG && store_ok && half == 0) {
+        const size_t o = (size_t)v * npts + pt;
+        if (sdbg[3]) sdbg[3][o] = visib;
+        if (sdbg[4]) sdbg[4][o] = hitp;
+      }
     }
   }
   PGRF_TICK(18);  // A: compute_prob
@@ -611,7 +661,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const f32x16 pe = gather32<kPrjCh>(prj[t] + 3 * 32, brf[t], half);
-      const float hv = half ? (vis_s[t] - 0.5f) * 2.f : (hit_s[t] - 0.5f) * 2.f;
+      const float hv = hvs[t];
       if constexpr (kRecomputeNf<V>) { vs[V0 + t].hv = hv; vs[V0 + t].xn = pxy[t][0]; vs[V0 + t].yn = pxy[t][1]; }
       a1[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a16, hv, pe, 0, 0, 0);
     }
