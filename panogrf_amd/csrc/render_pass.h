@@ -930,6 +930,8 @@ template <int V> constexpr int kNT0 = (V >= 2 ? 2 : 1);
 // (at two waves: 3 views in one group 60.1 ms vs 63.5 in groups 2+1; 4 views in one group 88.2 ms vs 85.2 in pairs)
 #ifdef PGRF_NT_ALL
 template <int V> constexpr int kNT0 = V;
+#elif defined(PGRF_NT_PAIRS)
+template <int V> constexpr int kNT0 = V < 2 ? V : 2;
 #else
 template <int V> constexpr int kNT0 = (V <= 3 || !kTwoWave<V>) ? V : 2;
 #endif
