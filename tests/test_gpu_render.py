@@ -439,3 +439,18 @@ def test_more_views_with_128_sample_fine_pass_vs_oracle(rfn):
     assert out['density_nr_fine'].shape[1] == 128
     assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 5e-5
     assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), ref['pixel_colors_nr_fine']) > 60
+
+
+def test_single_source_view_vs_oracle():
+    """rfn = 1 (the reference's ray_mask_view_num default allows it): statistics over one view, softmax over one logit."""
+    from oracle import render_oracle as O
+    from bench import synthetic_case
+    E = _engine()
+    case = synthetic_case(16, 32, 1, 32, seed=31, fine=True)
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    ys, xs = torch.meshgrid(torch.arange(16, dtype=torch.float32), torch.arange(32, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    out = rr.render_rays(_frame(E, case['frame']), coords)
+    ref = O.render_rays(case['weights'], case['frame'], coords, case['cfg'])
+    assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 2e-5
+    assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), ref['pixel_colors_nr_fine']) > 60
