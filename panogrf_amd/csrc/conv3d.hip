@@ -73,6 +73,14 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
     vy[t] = (int)(v % a.Ho); v /= a.Ho;
     vz[t] = (int)(v % a.Do); vb[t] = (int)(v / a.Do);
   }
+  // input-side coordinates and the linear index of the centre tap, once per tile: a tap then costs one wave-uniform
+  // offset, the W wrap and two unsigned range checks (the per-tap index arithmetic was 1.7 VALU per MFMA)
+  int zin[NT], yin[NT], xin[NT], cen[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    zin[t] = vz[t] * a.stride; yin[t] = vy[t] * a.stride; xin[t] = vx[t] * a.stride;
+    cen[t] = ((vb[t] * a.D + zin[t]) * a.H + yin[t]) * a.W;          // row start; + x gives the voxel
+  }
   f32x16 acc[NT][MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -118,16 +126,16 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
     const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
     bool all = true;
     st.c0 = ch * 32 + kk * 16;
+    const int toff = (dz * a.H + dy) * a.W;                             // wave-uniform
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int zi = vz[t] * a.stride + dz, yi = vy[t] * a.stride + dy;
-      int xi = vx[t] * a.stride + dx;
+      int xi = xin[t] + dx;
       xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);          // circular along W
-      st.ok[t] = vok[t] && zi >= 0 && zi < a.D && yi >= 0 && yi < a.H;  // zeros along D, H
-      // always-valid (clamped) address: loads are unconditional and issue back to back; padding and ragged
-      // tiles are applied by a select at use
-      const int zc = min(max(zi, 0), a.D - 1), yc = min(max(yi, 0), a.H - 1);
-      const float* ip = a.in + ((((long long)vb[t] * a.D + zc) * a.H + yc) * a.W + xi) * a.in_cs + a.in_coff;
+      st.ok[t] = vok[t] && (unsigned)(zin[t] + dz) < (unsigned)a.D && (unsigned)(yin[t] + dy) < (unsigned)a.H;  // zeros along D, H
+      // always-valid address (the centre voxel when the tap is padding): loads are unconditional and issue back to
+      // back; padding and ragged tiles are applied by a select at use
+      const int lin = st.ok[t] ? cen[t] + toff + xi : cen[t] + xin[t];
+      const float* ip = a.in + (long long)lin * a.in_cs + a.in_coff;
       all = all && st.ok[t];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -283,6 +291,12 @@ __global__ void __launch_bounds__(256) conv3d_small_kernel(const SmallArgs sa) {
     vy[t] = (int)(v % a.Ho); v /= a.Ho;
     vz[t] = (int)(v % Dq) * NS; vb[t] = (int)(v / Dq);      // first output depth of the group
   }
+  int zin[NT], yin[NT], xin[NT], cen[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    zin[t] = vz[t] * a.stride; yin[t] = vy[t] * a.stride; xin[t] = vx[t] * a.stride;
+    cen[t] = ((vb[t] * a.D + zin[t]) * a.H + yin[t]) * a.W;
+  }
   f32x16 acc[NT];
   {
     f32x16 bv;
@@ -313,15 +327,15 @@ __global__ void __launch_bounds__(256) conv3d_small_kernel(const SmallArgs sa) {
       const int tp = tap_ok ? tap : 0;
       const int dz = tp / 9 - 1, dy = (tp / 3) % 3 - 1, dx = tp % 3 - 1;
       const int c0 = CIN == 32 ? kk * 16 : 0;
+      const int toff = (dz * a.H + dy) * a.W;        // per lane half when taps are packed along K
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int zi = vz[t] * a.stride + dz, yi = vy[t] * a.stride + dy;
-        int xi = vx[t] * a.stride + dx;
+        int xi = xin[t] + dx;
         xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
-        st.ok[t][u] = vok[t] && tap_ok && zi >= 0 && zi < a.D && yi >= 0 && yi < a.H;
+        st.ok[t][u] = vok[t] && tap_ok && (unsigned)(zin[t] + dz) < (unsigned)a.D && (unsigned)(yin[t] + dy) < (unsigned)a.H;
         all = all && st.ok[t][u];
-        const int zc = min(max(zi, 0), a.D - 1), yc = min(max(yi, 0), a.H - 1);
-        const float* ip = a.in + ((((long long)vb[t] * a.D + zc) * a.H + yc) * a.W + xi) * a.in_cs + a.in_coff + c0;
+        const int lin = st.ok[t][u] ? cen[t] + toff + xi : cen[t] + xin[t];
+        const float* ip = a.in + (long long)lin * a.in_cs + a.in_coff + c0;
 #pragma unroll
         for (int q = 0; q < QPT; ++q) st.bv[t][u * QPT + q] = *reinterpret_cast<const float4*>(ip + q * 4);
       }
