@@ -99,16 +99,26 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
 
   const bool full_chunks = (a.Cin & 31) == 0;
   // taps whose whole 32-voxel x NT footprint lies in the zero padding are skipped (wave-uniform bit mask)
+  // (a superset is enough — padding is applied per lane at use — so the 27 taps are the outer product of three
+  // wave-level "some lane has an in-range z" flags and three for y, instead of 27 per-tap reductions)
   unsigned tapmask = 0;
-  for (int tap = 0; tap < 27; ++tap) {
-    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1;
-    bool any = false;
+  {
+    bool zany[3] = {false, false, false}, yany[3] = {false, false, false};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int zi = vz[t] * a.stride + dz, yi = vy[t] * a.stride + dy;
-      any = any || (vok[t] && zi >= 0 && zi < a.D && yi >= 0 && yi < a.H);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        zany[d] = zany[d] || (vok[t] && (unsigned)(zin[t] + d - 1) < (unsigned)a.D);
+        yany[d] = yany[d] || (vok[t] && (unsigned)(yin[t] + d - 1) < (unsigned)a.H);
+      }
+    unsigned zm = 0, ym = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (__any(zany[d])) zm |= 1u << d;
+      if (__any(yany[d])) ym |= 1u << d;
     }
-    if (__any(any)) tapmask |= 1u << tap;
+    for (int tap = 0; tap < 27; ++tap)
+      if (((zm >> (tap / 9)) & 1u) && ((ym >> ((tap / 3) % 3)) & 1u)) tapmask |= 1u << tap;
   }
   if (a.wtaps == 1) tapmask &= 1u << 13;                                // pointwise: centre tap only
 
