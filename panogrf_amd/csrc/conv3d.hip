@@ -40,6 +40,8 @@ struct ConvArgs {
   const float* residual;  // optional tensor added AFTER the activation (CostRegNet skip adds), same slicing as out
   int res_cs, res_coff;
   int wtaps;              // 27, or 1 = pointwise (1x1x1) product with the centre tap only
+  int tapmajor;           // pointwise projection of the Cout == 1 fast path: write out[row][voxel] (row < 27) instead of
+                          // channel-last, so that the 27-tap gather that follows reads consecutive voxels of one row
 };
 
 // packed weight index helpers (shared with the host packer below)
@@ -237,6 +239,19 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
             const float4 v = *reinterpret_cast<const float4*>(&red[(((w * NT + t) * MT + m) * 4 + q) * 256 + lane * 4]);
             acc[t][m][q * 4] += v.x; acc[t][m][q * 4 + 1] += v.y; acc[t][m][q * 4 + 2] += v.z; acc[t][m][q * 4 + 3] += v.w;
           }
+  }
+  if (a.tapmajor) {      // [27][voxels]: 32 consecutive voxels of one row per store instruction and lane half
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!vok[t]) continue;
+      const long long ov = (((long long)vb[t] * a.Do + vz[t]) * a.Ho + vy[t]) * a.Wo + vx[t];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rho_(r, kk);
+        if (row < 27) a.out[(long long)row * nvox + ov] = acc[t][0][r];
+      }
+    }
+    return;
   }
   // epilogue: LeakyReLU, optional residual, 16-byte channel stores
 #pragma unroll
@@ -455,8 +470,9 @@ __global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, con
   }
 }
 
-// Second half of the Cout == 1 convolution: out[p] = act(bias + sum_tap y[p + tap][tap]) where y[q][tap] =
-// <w[:, tap], x[q, :]> was produced by the pointwise MFMA pass (27 of 32 columns used).
+// Second half of the Cout == 1 convolution: out[p] = act(bias + sum_tap y[tap][p + tap]) where y[tap][q] =
+// <w[:, tap], x[q, :]> was produced by the pointwise MFMA pass in tap-major order (so a wave reads 64 consecutive
+// voxels of one row per tap; the channel-last form touched one 128-byte line per lane and tap: 975 -> ~100 us).
 __global__ void __launch_bounds__(256) cout1_gather_kernel(const float* __restrict__ y, const float* __restrict__ bias0, float* __restrict__ out,
                                                            int out_cs, int out_coff, int B, int D, int H, int W, float slope,
                                                            const float* __restrict__ residual, int res_cs, int res_coff) {
@@ -472,7 +488,7 @@ __global__ void __launch_bounds__(256) cout1_gather_kernel(const float* __restri
       const int zi = z + tap / 9 - 1, yi = yy + (tap / 3) % 3 - 1;
       int xi = x + tap % 3 - 1;
       xi = xi < 0 ? xi + W : (xi >= W ? xi - W : xi);
-      if (zi >= 0 && zi < D && yi >= 0 && yi < H) s += y[((((long long)b * D + zi) * H + yi) * W + xi) * 32 + tap];
+      if (zi >= 0 && zi < D && yi >= 0 && yi < H) s += y[(long long)tap * nvox + (((long long)b * D + zi) * H + yi) * W + xi];
     }
     if (bias0) s += bias0[0];
     s = s > 0.f ? s : s * slope;
@@ -610,7 +626,7 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
   a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
   a.chunks = (Cin + 31) / 32; a.cot_total = (Cout + 31) / 32;
-  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0;
   const size_t a_floats = (size_t)a.cot_total * 27 * a.chunks * 1024;
   a.wpk = packed;
   a.bias = has_bias ? packed + a_floats : nullptr;
@@ -707,7 +723,7 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
   a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff;
   a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
   a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
-  a.chunks = 1; a.cot_total = 1; a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27;
+  a.chunks = 1; a.cot_total = 1; a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0;
   if (nshift > 1 && (stride != 1 || a.Do % nshift))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small: nshift %d needs stride 1 and D %% nshift == 0", nshift);
   sa.ns = nshift; sa.nsteps = small_steps(Cin, nshift);
@@ -747,7 +763,7 @@ int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, 
   ConvArgs a;
   a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = y; a.out_cs = 32; a.out_coff = 0; a.Cout = 32;
   a.B = B; a.D = D; a.H = H; a.W = W; a.stride = 1; a.slope = 1.f; a.Do = D; a.Ho = H; a.Wo = W;
-  a.chunks = (Cin + 31) / 32; a.cot_total = 1; a.residual = nullptr; a.res_cs = 0; a.res_coff = 0; a.wtaps = 1;
+  a.chunks = (Cin + 31) / 32; a.cot_total = 1; a.residual = nullptr; a.res_cs = 0; a.res_coff = 0; a.wtaps = 1; a.tapmajor = 1;
   const size_t a_floats = (size_t)27 * a.chunks * 1024;
   a.wpk = packed + a_floats + 32 + (((size_t)27 * Cin + 1 + 3) & ~(size_t)3);
   a.bias = nullptr;
