@@ -644,7 +644,11 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   // tile shape per wave: more voxel tiles per wave when the layer is large enough to still fill 256 CUs
   const int mt = (a.cot_total % 2 == 0) ? 2 : 1;
   const long long waves_nt4 = (tiles + 3) / 4 * (a.cot_total / mt);
-  int nt = waves_nt4 >= 2048 ? 4 : ((tiles + 1) / 2 * (a.cot_total / mt) >= 2048 ? 2 : 1);
+  // one wave per SIMD with 4 voxel tiles beats two waves with 2 (each weight operand then feeds twice the MFMAs:
+  // measured 256->256 at 32x64x16: 908 vs 1312 us), so the thresholds are "every SIMD gets a wave", not two
+  int thr = 1024;
+  if (const char* e = getenv("PGRF_CONV_THR")) thr = atoi(e);                                              // tuning knob
+  int nt = waves_nt4 >= thr ? 4 : ((tiles + 1) / 2 * (a.cot_total / mt) >= thr ? 2 : 1);
   if (const char* e = getenv("PGRF_CONV_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nt = v; }   // tuning knob
   const long long waves_plain = (tiles + nt - 1) / nt * (a.cot_total / mt);
   bool split = (nt == 1) && waves_plain < 1536 && (long long)27 * a.chunks >= 16;
