@@ -735,7 +735,9 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
   a.bias = has_bias ? packed + (size_t)sa.nsteps * 1024 : nullptr;
   const long long nbase = (long long)B * (a.Do / nshift) * a.Ho * a.Wo;
   const long long tiles = (nbase + 31) / 32;
-  const int nt = tiles >= 4 * 2048 ? 4 : (tiles >= 2 * 2048 ? 2 : 1);
+  int sthr = 256;                                   // workgroups (4 waves each) wanted before a wave takes more tiles
+  if (const char* e = getenv("PGRF_CONV_STHR")) sthr = atoi(e);                                            // tuning knob
+  const int nt = tiles >= 16LL * sthr ? 4 : (tiles >= 8LL * sthr ? 2 : 1);
   dim3 grid((unsigned)((tiles + 4 * nt - 1) / (4 * nt)));
 #define PGRF_LS(CIN_, NS_)                                                                                         \
   do {                                                                                                             \
