@@ -443,7 +443,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #ifdef PGRF_NO_LAZY_TAPS
   constexpr bool kLazyTaps = false;
 #else
-  constexpr bool kLazyTaps = (kTwoWave<V> && kPrec == 0);
+  constexpr bool kLazyTaps = (kTwoWave<V> && kPrec == 0 && V != 3);   // 3 views in one group: 118 -> 6 spilled registers and
+                                                                       // 60.1 -> 55.3 ms WITHOUT it (allocator behaviour, measured)
 #endif
 #ifdef PGRF_NO_DEDUPE
   constexpr bool kDedupe = false;
