@@ -397,7 +397,10 @@ __device__ unsigned long long g_stage_cycles[32];
 #define PGRF_TICK(i) do {} while (0)
 #else
 // stage boundaries are scheduling fences: measured 47.5 -> 46.3 ms/frame (fewer live ranges crossing stages)
-#define PGRF_TICK(i) __builtin_amdgcn_sched_barrier(0)
+#ifndef PGRF_FENCE_MASK
+#define PGRF_FENCE_MASK 0xffffffffu      // bit i = stage boundary i is a fence (tuning knob)
+#endif
+#define PGRF_TICK(i) do { if ((PGRF_FENCE_MASK >> (i)) & 1u) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
 struct ViewState {
