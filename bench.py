@@ -192,6 +192,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        # never re-exec from here (a process that touched the GPU must not exec): tell the caller how to launch
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 as  python -m torch.distributed.run '
+                         f'--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the HIP renderer has no CPU fallback')
     backend = os.environ.get('PGRF_BENCH_BACKEND', 'nccl')      # 'gloo' = test-only: ranks may then share one GPU

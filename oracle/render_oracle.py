@@ -265,14 +265,20 @@ def _wmean_var(x, wgt):
     return mean, var
 
 
-def ray_attention(w, pre, g):
+def ray_attention(w, pre, g, masked=False):
     """4-head self attention over the samples of each ray + residual + LayerNorm.
-    g [rn,dn,16]. ibrnet.py:52-102, :7-27 (temperature 2, no mask effect: all valid)."""
+    g [rn,dn,16]. ibrnet.py:52-102, :7-27 (temperature 2).
+    The reference passes mask=(num_valid_obs > 1) (ibrnet.py:358-360) and every projection counts as valid, so the
+    mask is all ones for rfn >= 2 and all ZERO for a single source view: `masked_fill(mask == 0, -1e9)` (ibrnet.py:20)
+    then sets every logit to -1e9 and the softmax is uniform -> `masked=True` gives the mean of V over the ray."""
     rn, dn, _ = g.shape
     q = F.linear(g, w[pre + '.w_qs.weight']).view(rn, dn, 4, 4).transpose(1, 2)
     k = F.linear(g, w[pre + '.w_ks.weight']).view(rn, dn, 4, 4).transpose(1, 2)
     v = F.linear(g, w[pre + '.w_vs.weight']).view(rn, dn, 4, 4).transpose(1, 2)
-    attn = F.softmax(torch.matmul(q / 2.0, k.transpose(2, 3)), dim=-1)
+    attn = torch.matmul(q / 2.0, k.transpose(2, 3))
+    if masked:
+        attn = torch.full_like(attn, -1e9)
+    attn = F.softmax(attn, dim=-1)
     o = torch.matmul(attn, v).transpose(1, 2).reshape(rn, dn, 16)
     o = F.linear(o, w[pre + '.fc.weight']) + g
     return F.layer_norm(o, (16,), w[pre + '.layer_norm.weight'], w[pre + '.layer_norm.bias'], 1e-6)
@@ -315,7 +321,7 @@ def aggregate(w, pre, rgb, img_feats, ray_feats, hit_prob, vis, ddiff, want_debu
     g = F.elu(_lin(w, ag + '.geometry_fc.2', F.elu(_lin(w, ag + '.geometry_fc.0', g))))
     dbg['geo'] = g
     g = g + pos_encoding(dn).unsqueeze(0).to(g.device)
-    g = ray_attention(w, ag + '.ray_attention', g)
+    g = ray_attention(w, ag + '.ray_attention', g, masked=(rfn <= 1))
     dbg['attn'] = g
     sigma = F.relu(_lin(w, ag + '.out_geometry_fc.2', F.elu(_lin(w, ag + '.out_geometry_fc.0', g))))
     xr = torch.cat([x, v2, rdiff], -1)

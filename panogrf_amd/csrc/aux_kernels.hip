@@ -120,6 +120,15 @@ int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, flo
 // the CPU path the golden vectors come from), searchsorted(right=True) is a count of cdf <= u.
 constexpr int kMaxS = 128;   // max dn, max fdn
 
+// Total order for the rank sorts below: "element (o, index k) comes before element (v, index j)".  NaNs sort last
+// (as in torch.sort) and ties go to the lower index, so every rank 0..n-1 is written exactly once even when a NaN
+// reaches the sampler (a partial order would leave output slots of the caller's uninitialised buffer unwritten).
+__device__ __forceinline__ bool sorts_before(float o, int k, float v, int j) {
+  const bool on = (o != o), vn = (v != v);
+  if (on || vn) return (!on && vn) || (on == vn && k < j);
+  return o < v || (o == v && k < j);
+}
+
 __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict__ depth, const float* __restrict__ hit,
                                                          float qnear, float qfar, int use_disp, int use_all, int rn,
                                                          int dn, int fdn, float* __restrict__ out) {
@@ -187,7 +196,7 @@ __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict
     int rank = 0;
     for (int k = 0; k < total; ++k) {
       const float o = s_val[wv][k];
-      rank += (o < v || (o == v && k < j)) ? 1 : 0;
+      rank += sorts_before(o, k, v, j) ? 1 : 0;
     }
     if (ok) out[(size_t)ray * total + rank] = v;
   }
@@ -227,7 +236,7 @@ __global__ void __launch_bounds__(256) merge_c2f_kernel(const float* __restrict_
     int rank = 0;
     for (int k = 0; k < total; ++k) {
       const float w = s_z[wv][k];
-      rank += (w < v || (w == v && k < j)) ? 1 : 0;
+      rank += sorts_before(w, k, v, j) ? 1 : 0;
     }
     const float den = (j < dnc) ? denc[(size_t)rayc * dnc + j] : denf[(size_t)rayc * dnf + (j - dnc)];
     const float* cp = (j < dnc) ? colc + ((size_t)rayc * dnc + j) * 3 : colf + ((size_t)rayc * dnf + (j - dnc)) * 3;

@@ -1170,6 +1170,10 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
       for (int k2 = 0; k2 < KT; ++k2) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[k2][r] = 0.f;
+        // One source view: the reference masks the attention with (num_valid_obs > 1), which is false everywhere, and
+        // masked_fill(mask == 0, -1e9) makes every logit equal (ibrnet.py:20,358-360): uniform weights, the output is
+        // the mean of V over the ray's samples.  Equal logits = the zero-initialised S, so the products are skipped.
+        if constexpr (V > 1)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const float a = lds_k[(key_base + k2 * 32 + pl) * kKStride + hd * 4 + 2 * s + half];

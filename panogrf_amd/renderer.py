@@ -26,6 +26,15 @@ def _mlp(dims, acts):
     return nn.Sequential(*layers)
 
 
+def _interpolate_feats(feats, points):
+    """interpolate_feats(feats [b,f,h,w], points [b,n,2] in pixels, align_corners=True) -> [b,n,f]: bilinear,
+    zeros padding (network/ops.py:32-52).  Per-frame ground-truth lookup only, not on the per-ray path."""
+    h, w = feats.shape[-2:]
+    grid = torch.stack([points[..., 0] / (w - 1) * 2 - 1, points[..., 1] / (h - 1) * 2 - 1], -1).unsqueeze(1)
+    out = torch.nn.functional.grid_sample(feats, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+    return out.squeeze(2).permute(0, 2, 1)
+
+
 class _AddBias(nn.Module):            # index placeholder for network/ops.py:119-125 (no parameters)
     def __init__(self, val=0.05):
         super().__init__()
@@ -190,9 +199,9 @@ class NeuralRayBaseRenderer(nn.Module):
             dn = out['density_nr' + suffix].shape[1]
             for k in ('pixel_colors_nr', 'hit_prob_nr', 'colors_nr', 'density_nr'):
                 res[k + suffix] = out[k + suffix].unsqueeze(0)
-            if 'imgs' in que_imgs_info:
-                xy = que_imgs_info['coords'][0].long()
-                res['pixel_colors_gt' + suffix] = que_imgs_info['imgs'][:, :, xy[:, 1], xy[:, 0]].permute(0, 2, 1)
+            gt_key = 'imgs' if 'imgs' in que_imgs_info else ('cube_imgs' if 'cube_imgs' in que_imgs_info else None)
+            if gt_key is not None:      # ground-truth colours of the query pixels (renderer.py:277-288)
+                res['pixel_colors_gt' + suffix] = _interpolate_feats(que_imgs_info[gt_key], que_imgs_info['coords'])
             if c['use_ray_mask']:
                 ok = (imgs.shape[0] >= c['ray_mask_view_num']) and (dn > c['ray_mask_point_num'])
                 res['ray_mask' + suffix] = torch.full((1, rn), bool(ok), dtype=torch.bool, device=dev)

@@ -29,6 +29,18 @@ def save_ppm(path, rgb):                      # rgb uint8 [h,w,3]; no image libr
         f.write(rgb.tobytes())
 
 
+def check_loaded(result):
+    """A reference checkpoint must fill every parameter of the render path; only the init net (MVS stage, passed to the
+    renderer separately) and the direct-rendering solver may be left over (render.py:150-153 of the reference loads
+    strictly)."""
+    need = ('dist_decoder.', 'agg_net.', 'fine_dist_decoder.', 'fine_agg_net.', 'image_encoder.', 'vis_encoder.')
+    missing = [k for k in result.missing_keys if k.startswith(need)]
+    extra = [k for k in result.unexpected_keys if not k.startswith(('init_net.', 'sph_fitter.'))]
+    if missing or extra:
+        raise SystemExit(f'checkpoint does not match the renderer configuration: {len(missing)} missing '
+                         f'(e.g. {missing[:3]}), {len(extra)} unexpected (e.g. {extra[:3]})')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--height', type=int, default=256)
@@ -46,7 +58,7 @@ def main():
     renderer = name2network[cfg['network']](cfg)
     if args.ckpt:
         ckpt = torch.load(args.ckpt, map_location='cpu')
-        renderer.load_state_dict(ckpt['network_state_dict'], strict=False)
+        check_loaded(renderer.load_state_dict(ckpt['network_state_dict'], strict=False))
     else:   # random-init encoders + seeded per-ray nets with a density boost (no pretrained files offline)
         renderer.load_state_dict(synthetic_weights(0), strict=False)
     renderer = renderer.cuda().eval()

@@ -275,6 +275,9 @@ def main():
     if '--full-only' in sys.argv:
         full_render_fixture('render_full_v2_dn32', seed=800, rfn=2, H=32, W=64, dn=32)
         return
+    if '--v1-only' in sys.argv:     # added in round 2: the other fixtures are not regenerated
+        stage_fixture('render_stages_v1_dn32', seed=900, rfn=1, H=32, W=64, rn=12, dn=32, keep_big=False)
+        return
     stage_fixture('render_stages_v2_dn32', seed=100, rfn=2, H=32, W=64, rn=24, dn=32)
     stage_fixture('render_stages_v2_dn64', seed=200, rfn=2, H=32, W=64, rn=12, dn=64, keep_big=False)
     stage_fixture('render_stages_v4_dn32', seed=300, rfn=4, H=32, W=64, rn=12, dn=32, keep_big=False)
@@ -283,6 +286,8 @@ def main():
     frame_fixture('render_frame_v2_dn32', seed=600, rfn=2, H=32, W=64, dn=32)
     frame_fixture('render_frame_v2_c2fall', seed=700, rfn=2, H=16, W=32, dn=32, c2f_all=True)
     full_render_fixture('render_full_v2_dn32', seed=800, rfn=2, H=32, W=64, dn=32)
+    # single source view: ray attention is fully masked there (ibrnet.py:358-360) -> uniform weights
+    stage_fixture('render_stages_v1_dn32', seed=900, rfn=1, H=32, W=64, rn=12, dn=32, keep_big=False)
 
 
 if __name__ == '__main__':

@@ -11,7 +11,7 @@ from tests import fixtures as FX
 pytestmark = pytest.mark.gpu
 
 STAGE_FIXTURES = ['render_stages_v2_dn32', 'render_stages_v2_dn64', 'render_stages_v4_dn32',
-                  'render_stages_v3_vis', 'render_stages_v2_randinit']
+                  'render_stages_v3_vis', 'render_stages_v2_randinit', 'render_stages_v1_dn32']
 # absolute tolerances (scaled by max|ref| when that is > 1).  fp32 round-off only: the reference
 # differs from itself by ~4e-7 (coarse) between CPU thread counts.
 TOL = dict(px=2e-3, depth_v=2e-5, ddiff=5e-6, vis=5e-6, hit=5e-6, ray_feats=5e-5, rgb=1e-5, img_feats=5e-5,
@@ -454,3 +454,25 @@ def test_single_source_view_vs_oracle():
     ref = O.render_rays(case['weights'], case['frame'], coords, case['cfg'])
     assert FX.max_abs(out['pixel_colors_nr'].cpu(), ref['pixel_colors_nr']) < 2e-5
     assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), ref['pixel_colors_nr_fine']) > 60
+
+
+def test_sampler_writes_every_slot_with_nan_inputs():
+    """A NaN in the coarse hit probabilities / depths must not leave output slots of the (uninitialised) fine-depth
+    buffer unwritten: the rank sort uses a NaN-total order (NaNs last, like torch.sort)."""
+    E = _engine()
+    rn, dn = 6, 64
+    depth = E.sample_coarse_depth(0.5, 15.0, rn, dn)
+    hit = torch.rand(rn, dn, generator=torch.Generator().manual_seed(1)).cuda()
+    hit[1, 10] = float('nan')                 # poisons the whole pdf of ray 1 -> every fine depth of that ray is NaN
+    d2 = depth.clone()
+    d2[3, 5] = float('nan')                   # one NaN depth among the coarse samples of ray 3
+    for use_all in (False, True):
+        for _ in range(3):                    # fresh torch.empty buffers; a stale slot would show up as a finite outlier
+            fd = E.sample_fine_depth(d2, hit, (0.5, 15.0), dn, use_all=use_all).cpu()
+            ok = [0, 2, 4, 5]
+            assert torch.isfinite(fd[ok]).all() and bool((fd[ok][:, 1:] >= fd[ok][:, :-1]).all())
+            assert torch.isnan(fd[1, -dn:]).all()             # every fine sample of ray 1 is NaN and sorts last
+            if use_all:
+                assert torch.isfinite(fd[1, :dn]).all() and int(torch.isnan(fd[3]).sum()) >= 1
+                fin = fd[3][torch.isfinite(fd[3])]
+                assert bool((fin[1:] >= fin[:-1]).all()) and torch.isnan(fd[3, fin.numel():]).all()

@@ -7,7 +7,7 @@ from oracle import render_oracle as O
 from tests import fixtures as FX
 
 STAGE_FIXTURES = ['render_stages_v2_dn32', 'render_stages_v2_dn64', 'render_stages_v4_dn32',
-                  'render_stages_v3_vis', 'render_stages_v2_randinit']
+                  'render_stages_v3_vis', 'render_stages_v2_randinit', 'render_stages_v1_dn32']
 
 # tolerances: the reference differs from itself by ~4e-7 (coarse) between thread counts
 TOL = dict(px=2e-3, depth_v=2e-5, ddiff=2e-6, vis=2e-5, hit=2e-5, ray_feats=2e-5, rgb=2e-5, img_feats=2e-5,

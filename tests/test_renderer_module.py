@@ -136,3 +136,45 @@ def test_encoder_graph_replay_equals_eager():
                 assert float((a_f - e_f).abs().max()) <= 4 * noise + 1e-5 * float(e_f.abs().max())
                 assert float((a_r - e_r).abs().max()) <= 1e-4 * max(1.0, float(e_r.abs().max()))
     assert len(net._enc_graphs) == 2
+
+
+def test_pixel_colors_gt_is_bilinear_with_zero_padding():
+    """CPU: ground-truth lookup = interpolate_feats(..., align_corners=True), zeros padding (renderer.py:277-288,
+    ops.py:32-52), for 'imgs' and for 'cube_imgs' queries; integer coords reproduce the pixel, fractional ones blend."""
+    from panogrf_amd.renderer import _interpolate_feats
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 5, 7, generator=g)
+    pts = torch.tensor([[[0.0, 0.0], [6.0, 4.0], [2.0, 3.0], [2.5, 3.0], [1.25, 0.5], [-0.5, 0.0], [6.5, 4.0]]])
+    out = _interpolate_feats(img, pts)
+    assert out.shape == (1, 7, 3)
+    assert torch.allclose(out[0, 0], img[0, :, 0, 0], atol=1e-6) and torch.allclose(out[0, 1], img[0, :, 4, 6], atol=1e-6)
+    assert torch.allclose(out[0, 2], img[0, :, 3, 2], atol=1e-6)
+    assert torch.allclose(out[0, 3], 0.5 * (img[0, :, 3, 2] + img[0, :, 3, 3]), atol=1e-6)
+    want = 0.5 * (0.75 * img[0, :, 0, 1] + 0.25 * img[0, :, 0, 2]) + 0.5 * (0.75 * img[0, :, 1, 1] + 0.25 * img[0, :, 1, 2])
+    assert torch.allclose(out[0, 4], want, atol=1e-6)
+    assert torch.allclose(out[0, 5], 0.5 * img[0, :, 0, 0], atol=1e-6)       # half outside: zeros padding
+    assert torch.allclose(out[0, 6], 0.5 * img[0, :, 4, 6], atol=1e-6)
+
+
+def test_render_script_rejects_mismatched_checkpoint():
+    import importlib, sys, os
+    from collections import namedtuple
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    R = importlib.import_module('render')
+    Res = namedtuple('Res', 'missing_keys unexpected_keys')
+    R.check_loaded(Res([], ['init_net.depth_conv.0.weight', 'sph_fitter.regs']))        # tolerated
+    with pytest.raises(SystemExit):
+        R.check_loaded(Res(['fine_agg_net.agg_impl.base_fc.0.weight'], []))
+    with pytest.raises(SystemExit):
+        R.check_loaded(Res([], ['module.agg_net.prob_embed.0.weight']))
+
+
+def test_bench_refuses_gpu_count_mismatch():
+    """`python bench.py --gpus 8` without torchrun must not silently run (and report) a 1-GPU number."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], capture_output=True, text=True,
+                       timeout=300, cwd=root, env=env)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
