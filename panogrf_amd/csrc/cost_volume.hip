@@ -8,6 +8,8 @@
 // instead of being recomputed per channel group.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "pgrf_internal.h"
 
 namespace pgrf {
@@ -28,47 +30,79 @@ struct HypArgs {
   float lo, hi;
 };
 
-// pipeline3_model.py:723-733 (clamp(ref_mu + k*fixed_sigma)), :774-815 (linspace planes, concat, sort)
-__global__ void depth_hypotheses_kernel(const HypArgs a) {
-  const size_t total = (size_t)a.B * a.hw;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t b = i / a.hw, pix = i % a.hw;
-    const float mu = a.ref_mu[i];
-    float gv[kMaxGuided];
+// pipeline3_model.py:723-733 (clamp(ref_mu + k*fixed_sigma)), :774-815 (linspace planes, concat, sort).
+// The sorted sequence of a pixel is the merge of its sorted guided planes g[0..n_g) with the ascending uniform planes
+// u[0..n_u) shared by all pixels: guided plane k lands in slot  k + #{u < g_k}  (ties: guided first; equal values are
+// interchangeable), every other slot d holds the uniform plane  d - #{guided slots < d}.
+// One thread = one pixel x kHypSlice consecutive slots (consecutive threads = consecutive pixels: coalesced loads and
+// stores); the pixel's guided slots are found once per thread by branch-free binary search over the uniform planes in LDS.
+// NG = compile-time bound on n_guided (the sort and the searches are unrolled over it).
+constexpr int kHypSlice = 16;
+template <int NG>
+__global__ void __launch_bounds__(256) depth_hypotheses_kernel(const HypArgs a, int nslice) {
+  __shared__ float s_uni[256];
+  const int D = a.n_guided + a.n_uniform;
+  for (int i = threadIdx.x; i < a.n_uniform && i < 256; i += 256) s_uni[i] = a.uniform[i];
+  __syncthreads();
+  // 32-bit index arithmetic (the launcher checks the sizes): 64-bit div/mod costs ~100 instructions each
+  const unsigned total = (unsigned)a.B * nslice * a.hw;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned row = i / (unsigned)a.hw;
+    const unsigned pix = i - row * a.hw;
+    const unsigned b = row / (unsigned)nslice;
+    const int d0 = (int)(row - b * nslice) * kHypSlice;
+    const float mu = a.ref_mu[b * a.hw + pix];
+    float gv[NG];
 #pragma unroll
-    for (int k = 0; k < kMaxGuided; ++k) gv[k] = (k < a.n_guided) ? fminf(fmaxf(mu + a.offs[k], a.lo), a.hi) : 3.0e38f;
-    // insertion sort of the (few) guided planes
+    for (int k = 0; k < NG; ++k) gv[k] = (k < a.n_guided) ? fminf(fmaxf(mu + a.offs[k], a.lo), a.hi) : 3.0e38f;
 #pragma unroll
-    for (int k = 1; k < kMaxGuided; ++k)
+    for (int k = 1; k < NG; ++k)         // insertion sort of the (few) guided planes
 #pragma unroll
       for (int j = k; j > 0; --j)
         if (gv[j] < gv[j - 1]) { const float t = gv[j]; gv[j] = gv[j - 1]; gv[j - 1] = t; }
-    // merge with the ascending uniform planes
-    float* o = a.out + b * (size_t)(a.n_guided + a.n_uniform) * a.hw + pix;
-    int gi = 0, ui = 0;
-    const int D = a.n_guided + a.n_uniform;
-    for (int d = 0; d < D; ++d) {
-      float gcur = 3.0e38f;
+    int pos[NG];
 #pragma unroll
-      for (int k = 0; k < kMaxGuided; ++k) gcur = (k == gi) ? gv[k] : gcur;
-      const float ucur = (ui < a.n_uniform) ? a.uniform[ui] : 3.0e38f;
-      const bool take_g = (gi < a.n_guided) && (gcur <= ucur);
-      o[(size_t)d * a.hw] = take_g ? gcur : ucur;
-      gi += take_g ? 1 : 0;
-      ui += take_g ? 0 : 1;
+    for (int k = 0; k < NG; ++k) {
+      int lo = 0;
+#pragma unroll
+      for (int step = 256; step >= 1; step >>= 1)
+        if (lo + step <= a.n_uniform && s_uni[lo + step - 1] < gv[k]) lo += step;
+      pos[k] = (k < a.n_guided) ? k + lo : 0x7fffffff;
+    }
+    int cnt = 0;                         // guided slots before d0
+#pragma unroll
+    for (int k = 0; k < NG; ++k) cnt += (pos[k] < d0) ? 1 : 0;
+    float* o = a.out + ((size_t)b * D + d0) * a.hw + pix;
+    for (int d = d0; d < d0 + kHypSlice && d < D; ++d) {
+      float val = 0.f;
+      bool hit = false;
+#pragma unroll
+      for (int k = 0; k < NG; ++k)
+        if (pos[k] == d) { val = gv[k]; hit = true; }
+      if (!hit) val = s_uni[d - cnt];
+      cnt += hit ? 1 : 0;
+      *o = val;
+      o += a.hw;
     }
   }
 }
 
 int launch_depth_hypotheses(const float* ref_mu, int B, int hw, const float* offs_host, int n_guided, float lo, float hi,
                             const float* uniform_dev, int n_uniform, float* out, void* stream) {
+  if (n_uniform > 256) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_depth_hypotheses: n_uniform=%d > 256", n_uniform);
+  const int D = n_guided + n_uniform;
+  const int nslice = (D + kHypSlice - 1) / kHypSlice;
+  if ((double)B * hw * nslice >= 2147483648.0) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_depth_hypotheses: >= 2^31 work items");
   HypArgs a;
   a.ref_mu = ref_mu; a.uniform = uniform_dev; a.out = out; a.n_guided = n_guided; a.n_uniform = n_uniform;
   a.B = B; a.hw = hw; a.lo = lo; a.hi = hi;
   for (int k = 0; k < kMaxGuided; ++k) a.offs[k] = (k < n_guided) ? offs_host[k] : 0.f;
-  const size_t total = (size_t)B * hw;
-  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(depth_hypotheses_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a);
+  const size_t total = (size_t)B * hw * nslice;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (n_guided <= 8)
+    hipLaunchKernelGGL(depth_hypotheses_kernel<8>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a, nslice);
+  else
+    hipLaunchKernelGGL(depth_hypotheses_kernel<kMaxGuided>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a, nslice);
   PGRF_CHECK_LAUNCH("depth_hypotheses");
   return PGRF_OK;
 }
@@ -101,14 +135,19 @@ __device__ __forceinline__ void inv3(const float* m, float* o) {   // adjugate /
   o[6] = Cc * r; o[7] = -(a * h - b * g) * r; o[8] = (a * e - b * d) * r;
 }
 
-// spherical_cost_volume.py:135-198 + my_torch_helpers.py:34-38,62-96 for one (voxel, source view)
+// Per-wave constants of one batch element: inverse reference rotation and the poses involved
+// (spherical_cost_volume.py:143-150: P_w = R_ref^-1 (z*dir - t_ref), P_s = R_src P_w + t_src)
+struct BatchPose {
+  float Ri[9], tr[3];
+};
+
+// unit direction of a reference pixel in the dataset's convention (spherical_cost_volume.py:281-296,
+// my_torch_helpers.py:34-56); Python folds the scalar factors in double before they meet the float tensors.
+// Depends on the pixel only: computed once per wave and reused for every depth plane of the wave's chunk.
 template <bool GEN>
-__device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y, int x, float depth) {
+__device__ __forceinline__ void pixel_dir(const CvArgs& a, int y, int x, float& ux, float& uy, float& uz) {
   const float PI_F = 3.14159265358979323846f, HALF_PI_F = 1.57079632679489661923f, TWO_PI_F = 6.28318530717958647692f;
   const double PI_D = 3.14159265358979323846;
-  // pixel centre -> angles -> unit direction, per dataset (spherical_cost_volume.py:281-296, my_torch_helpers.py:34-56);
-  // Python folds the scalar factors in double before they meet the float tensors
-  float ux, uy, uz;
   const float fx = (float)x, fy = (float)y;
   if (!GEN || a.dataset == PGRF_DATASET_M3D) {
     const float phi = (fy + 0.5f) * (float)(PI_D / (double)a.h);
@@ -131,23 +170,25 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
     const float sp = sinf(phi);
     ux = sp * cosf(theta); uy = sp * sinf(theta); uz = cosf(phi);
   }
+}
+
+// spherical_cost_volume.py:135-198 + my_torch_helpers.py:62-96 for one (voxel, source view): back-project, move to the
+// source frame, cartesian -> sphere -> grid, bilinear tap setup (zeros padding, align_corners=True)
+template <bool GEN>
+__device__ __forceinline__ Taps warp_taps(const CvArgs& a, const BatchPose& bp, const float* __restrict__ Rs,
+                                          const float* __restrict__ ts, float ux, float uy, float uz, float depth) {
+  const float PI_F = 3.14159265358979323846f, HALF_PI_F = 1.57079632679489661923f, TWO_PI_F = 6.28318530717958647692f;
   const float mx = depth * ux, my = depth * uy, mz = depth * uz;
-  const float* Rr = a.rots + ((size_t)b * a.S + a.ref_idx) * 9;
-  const float* tr = a.trans + ((size_t)b * a.S + a.ref_idx) * 3;
-  float Ri[9];
-  inv3(Rr, Ri);
-  const float dx = mx - tr[0], dy = my - tr[1], dz = mz - tr[2];
-  const float wx = Ri[0] * dx + Ri[1] * dy + Ri[2] * dz;
-  const float wy = Ri[3] * dx + Ri[4] * dy + Ri[5] * dz;
-  const float wz = Ri[6] * dx + Ri[7] * dy + Ri[8] * dz;
-  const float* Rs = a.rots + ((size_t)b * a.S + src) * 9;
-  const float* ts = a.trans + ((size_t)b * a.S + src) * 3;
+  const float dx = mx - bp.tr[0], dy = my - bp.tr[1], dz = mz - bp.tr[2];
+  const float wx = bp.Ri[0] * dx + bp.Ri[1] * dy + bp.Ri[2] * dz;
+  const float wy = bp.Ri[3] * dx + bp.Ri[4] * dy + bp.Ri[5] * dz;
+  const float wz = bp.Ri[6] * dx + bp.Ri[7] * dy + bp.Ri[8] * dz;
   const float cx = Rs[0] * wx + Rs[1] * wy + Rs[2] * wz + ts[0];
   const float cy = Rs[3] * wx + Rs[4] * wy + Rs[5] * wz + ts[1];
   const float cz = Rs[6] * wx + Rs[7] * wy + Rs[8] * wz + ts[2];
   const float radius = sqrtf(cx * cx + cy * cy + cz * cz);
-  // cartesian -> (theta, phi) -> grid coordinates u, v in [-1,1] (my_torch_helpers.py:62-120,
-  // spherical_cost_volume.py:153-190)
+  // x mod 2pi for x in [0, 4pi): fmodf is exact, and so is this subtraction (Sterbenz) -> bit-identical, no libm call
+  auto wrap2pi = [&](float x) { return x >= TWO_PI_F ? x - TWO_PI_F : x; };
   float u, v;
   if (!GEN || a.dataset == PGRF_DATASET_M3D) {
     const float th = atan2f(cz, cx);
@@ -157,12 +198,12 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
     if (fabsf(yor) < COSD) ph = acosf(yor);
     else if (cy >= 0.f) ph = LIN * (1.f - yor) / ONE_M_COSD;
     else ph = PI_F - LIN * (yor + 1.f) / ONE_M_COSD;
-    u = fmodf(th + HALF_PI_F + TWO_PI_F, TWO_PI_F) / PI_F - 1.f;
+    u = wrap2pi(th + HALF_PI_F + TWO_PI_F) / PI_F - 1.f;
     v = 2.f * ph / PI_F - 1.f;
   } else if (a.dataset == PGRF_DATASET_REPLICA_TEST) {
     const float th = atan2f(cx, cz);
     const float ph = -asinf(cz / radius);          // the reference takes z here (my_torch_helpers.py:99)
-    u = fmodf(th + PI_F + TWO_PI_F, TWO_PI_F) / PI_F - 1.f;
+    u = wrap2pi(th + PI_F + TWO_PI_F) / PI_F - 1.f;
     v = 2.f * (-ph + HALF_PI_F) / PI_F - 1.f;
   } else if (a.dataset == PGRF_DATASET_RESIDENTIAL) {
     float th = -atan2f(-cz, cx);
@@ -187,7 +228,8 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
   const int cx0 = min(max(x0, 0), a.w - 1), cx1 = min(max(x1, 0), a.w - 1);
   const int cy0 = min(max(y0, 0), a.h - 1), cy1 = min(max(y1, 0), a.h - 1);
   Taps t;
-  t.o00 = cy0 * a.w + cx0; t.o01 = cy0 * a.w + cx1; t.o10 = cy1 * a.w + cx0; t.o11 = cy1 * a.w + cx1;
+  // element offsets of the 4 taps inside one view's [h,w,C] map
+  t.o00 = (cy0 * a.w + cx0) * a.C; t.o01 = (cy0 * a.w + cx1) * a.C; t.o10 = (cy1 * a.w + cx0) * a.C; t.o11 = (cy1 * a.w + cx1) * a.C;
   t.w00 = (vx0 && vy0) ? (1.f - ax) * (1.f - ay) : 0.f;
   t.w01 = (vx1 && vy0) ? ax * (1.f - ay) : 0.f;
   t.w10 = (vx0 && vy1) ? (1.f - ax) * ay : 0.f;
@@ -195,76 +237,191 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, int b, int src, int y
   return t;
 }
 
-// GEN = false: m3d convention only (the other conventions compiled in cost 113 -> 176 us at 128x256x64)
-template <bool GEN, int NSRC>      // NSRC: source views accumulated (tap setups kept in registers: 8 per view)
-__global__ void __launch_bounds__(256) cost_volume_kernel(const CvArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int lpv = a.C / 4;                  // lanes per voxel (power of two <= 64)
-  const int vpi = 64 / lpv;                 // voxels per inner iteration
-  const size_t hw = (size_t)a.h * a.w;
-  const size_t nvox = (size_t)a.B * a.D * hw;
-  const size_t wave_global = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-  for (size_t base = wave_global * 64; base < nvox; base += nwaves * 64) {
-    // lane i owns the geometry of voxel base+i
-    const size_t vox = base + lane < nvox ? base + lane : nvox - 1;
-    const int x = (int)(vox % a.w);
-    const int y = (int)((vox / a.w) % a.h);
-    const int b = (int)(vox / (hw * a.D));
-    const float depth = a.depth[vox];          // [B,D,h,w] has the same linear voxel order as the output
-    const int sub = lane / lpv, cg = lane % lpv;
-    // tap setup once per (voxel, source view), kept in registers (static indexing only)
-    Taps tp[NSRC];
+// One wave = 64 consecutive pixels of one batch element x DCH consecutive depth planes.
+//   * per wave, once: the pixels' unit directions (4 libm sin/cos), the inverse reference rotation, the reference
+//     features of the pixels each lane will write (they do not depend on the plane);
+//   * per plane: lane i computes the warp of voxel (plane, pixel i) into every source view (atan2/acos + tap setup, the
+//     part that cannot be shared) and parks the 8 tap fields in LDS; then the wave streams the 64 voxels out, C/CPL
+//     lanes per voxel, each lane blending CPL channels from 4 taps (16-byte loads) and writing CPL*4 contiguous
+//     bytes: a wave instruction writes 1 KiB of consecutive addresses.
+// Template switches keep run-time branches out of the streaming loop:
+//   GEN   false = m3d convention only;  C32 true = C == 32 with 8 channels per lane and the 4 inner iterations
+//   unrolled (reference features hoisted out of the plane loop), false = any power-of-two C, 4 channels per lane;
+//   ABS   true = abs_diff cost (the only type the reference uses), false = run-time cost type;
+//   DIVIDE false = scale by 1/div, exact because div is a power of two (1 for two views, 2 for S = 4), true = IEEE division.
+#ifndef PGRF_CV_WAVES
+#define PGRF_CV_WAVES 1          // minimum waves per SIMD the register allocation must allow (tuning knob)
+#endif
+#ifndef PGRF_CV_MINITEMS
+#define PGRF_CV_MINITEMS 4096    // planes per wave are halved until the launch has this many waves (tuning knob;
+                                 // measured at 128x256x64: 4096 -> 74 us, 8192 -> 85, 16384 -> 76, 32768 -> 82)
+#endif
+template <bool GEN, int NSRC, bool C32, bool ABS, bool DIVIDE>
+__global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const CvArgs a, int dch, int nchunk, int tiles_per_img) {
+  // A lane always moves 4 channels (16 B) of a voxel and C/4 consecutive lanes cover the voxel's contiguous C*4 bytes, so
+  // every wave load instruction reads whole 128-byte lines and every wave store instruction writes 1 KiB of
+  // consecutive addresses.  C32: 8 lanes per voxel, and a lane handles G = 2 voxels (8 apart) per inner iteration for
+  // twice the loads in flight; generic C: one voxel per lane and iteration.
+  constexpr int G = C32 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds_taps[4][NSRC][64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = C32 ? 32 : a.C;
+  const int lpv = C / 4;                           // lanes per voxel (power of two, <= 64)
+  const int vpg = 64 / lpv;                        // voxels per group (one wave instruction)
+  constexpr int NIT_STATIC = C32 ? 4 : 1;
+  const int nit = C32 ? 4 : lpv;                   // inner iterations per 64 voxels (G * vpg voxels each)
+  const int hw = a.h * a.w;
+  const long item = (long)blockIdx.x * 4 + wave;
+  const long nitems = (long)a.B * tiles_per_img * nchunk;
+  if (item >= nitems) return;
+  const int chunk = __builtin_amdgcn_readfirstlane((int)(item % nchunk));
+  const int tile = __builtin_amdgcn_readfirstlane((int)(item / nchunk));
+  const int b = tile / tiles_per_img;
+  const int pix0 = (tile % tiles_per_img) * 64;
+  const int pix = min(pix0 + lane, hw - 1);
+  float ux, uy, uz;
+  pixel_dir<GEN>(a, pix / a.w, pix % a.w, ux, uy, uz);
+  BatchPose bp;
+  {
+    const float* Rr = a.rots + ((size_t)b * a.S + a.ref_idx) * 9;
+    const float* tr = a.trans + ((size_t)b * a.S + a.ref_idx) * 3;
+    inv3(Rr, bp.Ri);
+    bp.tr[0] = tr[0]; bp.tr[1] = tr[1]; bp.tr[2] = tr[2];
+  }
+  const int sub = lane / lpv, cg = lane % lpv;
+  const float* __restrict__ fb = a.feats + (size_t)b * a.S * hw * C;      // this batch element's views
+  const float rdiv = 1.f / a.div;
+
+  // reference features of the voxels this lane writes: plane-independent, so loaded once when the iteration count is static
+  float4 rvs[NIT_STATIC][G];
+  if constexpr (C32) {
 #pragma unroll
-    for (int s = 0; s < NSRC; ++s) tp[s] = warp_taps<GEN>(a, b, a.src_idx[s], y, x, depth);
-    const int mypix = (int)(vox % hw);
-    for (int it = 0; it < 64 / vpi; ++it) {
-      const int owner = it * vpi + sub;        // lane holding this voxel's geometry
-      const size_t myvox = base + owner;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int ob = __shfl(b, owner, 64);
-      const int pix = __shfl(mypix, owner, 64);
-      const float4 rv = *reinterpret_cast<const float4*>(a.feats + (((size_t)ob * a.S + a.ref_idx) * hw + pix) * a.C + cg * 4);
+    for (int it = 0; it < 4; ++it)
 #pragma unroll
-      for (int s = 0; s < NSRC; ++s) {
-        const Taps& t = tp[s];
-        const int o00 = __shfl(t.o00, owner, 64), o01 = __shfl(t.o01, owner, 64);
-        const int o10 = __shfl(t.o10, owner, 64), o11 = __shfl(t.o11, owner, 64);
-        const float w00 = __shfl(t.w00, owner, 64), w01 = __shfl(t.w01, owner, 64);
-        const float w10 = __shfl(t.w10, owner, 64), w11 = __shfl(t.w11, owner, 64);
-        const float* sb = a.feats + ((size_t)ob * a.S + a.src_idx[s]) * hw * a.C + cg * 4;
-        const float4 p00 = *reinterpret_cast<const float4*>(sb + (size_t)o00 * a.C);
-        const float4 p01 = *reinterpret_cast<const float4*>(sb + (size_t)o01 * a.C);
-        const float4 p10 = *reinterpret_cast<const float4*>(sb + (size_t)o10 * a.C);
-        const float4 p11 = *reinterpret_cast<const float4*>(sb + (size_t)o11 * a.C);
-        float4 wv;
-        wv.x = p00.x * w00 + p01.x * w01 + p10.x * w10 + p11.x * w11;
-        wv.y = p00.y * w00 + p01.y * w01 + p10.y * w10 + p11.y * w11;
-        wv.z = p00.z * w00 + p01.z * w01 + p10.z * w10 + p11.z * w11;
-        wv.w = p00.w * w00 + p01.w * w01 + p10.w * w10 + p11.w * w11;
-        float4 c;
-        if (a.cost_type == 0) { c.x = fabsf(wv.x - rv.x); c.y = fabsf(wv.y - rv.y); c.z = fabsf(wv.z - rv.z); c.w = fabsf(wv.w - rv.w); }
-        else if (a.cost_type == 1) { c.x = wv.x * rv.x; c.y = wv.y * rv.y; c.z = wv.z * rv.z; c.w = wv.w * rv.w; }
-        else c = wv;
-        acc.x += c.x / a.div; acc.y += c.y / a.div; acc.z += c.z / a.div; acc.w += c.w / a.div;
+      for (int g = 0; g < G; ++g) {
+        const int rpix = min(pix0 + (it * G + g) * vpg + sub, hw - 1);
+        rvs[it][g] = *reinterpret_cast<const float4*>(fb + ((size_t)a.ref_idx * hw + rpix) * C + cg * 4);
       }
-      if (myvox < nvox) *reinterpret_cast<float4*>(a.out + myvox * a.C + cg * 4) = acc;
+  }
+
+  auto cost_of = [&](const float4& wv, const float4& rv) {
+    float4 c;
+    if (ABS || a.cost_type == 0) { c.x = fabsf(wv.x - rv.x); c.y = fabsf(wv.y - rv.y); c.z = fabsf(wv.z - rv.z); c.w = fabsf(wv.w - rv.w); }
+    else if (a.cost_type == 1) { c.x = wv.x * rv.x; c.y = wv.y * rv.y; c.z = wv.z * rv.z; c.w = wv.w * rv.w; }
+    else c = wv;
+    if (DIVIDE) { c.x /= a.div; c.y /= a.div; c.z /= a.div; c.w /= a.div; }
+    else { c.x *= rdiv; c.y *= rdiv; c.z *= rdiv; c.w *= rdiv; }
+    return c;
+  };
+  auto stream_voxels = [&](int it, const float4 (&rv)[G], float* __restrict__ op) {
+    float4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      const float* sb = fb + (size_t)a.src_idx[s] * hw * C + cg * 4;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int owner = (it * G + g) * vpg + sub;          // lane that computed this voxel's taps
+        const float4* tpv = reinterpret_cast<const float4*>(&lds_taps[wave][s][owner][0]);
+        const float4 to = tpv[0], tw = tpv[1];
+#ifdef PGRF_CV_ABL_GATHER   // timing experiment: every tap reads element 0 of the source map
+        const unsigned o00 = 0, o01 = 0, o10 = 0, o11 = 0;
+#else
+        const unsigned o00 = (unsigned)__float_as_int(to.x), o01 = (unsigned)__float_as_int(to.y);
+        const unsigned o10 = (unsigned)__float_as_int(to.z), o11 = (unsigned)__float_as_int(to.w);
+#endif
+        const float4 p00 = *reinterpret_cast<const float4*>(sb + o00);
+        const float4 p01 = *reinterpret_cast<const float4*>(sb + o01);
+        const float4 p10 = *reinterpret_cast<const float4*>(sb + o10);
+        const float4 p11 = *reinterpret_cast<const float4*>(sb + o11);
+        float4 wv;
+        wv.x = p00.x * tw.x + p01.x * tw.y + p10.x * tw.z + p11.x * tw.w;
+        wv.y = p00.y * tw.x + p01.y * tw.y + p10.y * tw.z + p11.y * tw.w;
+        wv.z = p00.z * tw.x + p01.z * tw.y + p10.z * tw.z + p11.z * tw.w;
+        wv.w = p00.w * tw.x + p01.w * tw.y + p10.w * tw.z + p11.w * tw.w;
+        const float4 c = cost_of(wv, rv[g]);
+        acc[g].x += c.x; acc[g].y += c.y; acc[g].z += c.z; acc[g].w += c.w;
+      }
     }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int opix = pix0 + (it * G + g) * vpg + sub;
+#ifdef PGRF_CV_ABL_STORE    // timing experiment: only values that can never occur are stored
+      if (opix < hw && acc[g].x == -12345.f)
+#else
+      if (opix < hw)
+#endif
+        *reinterpret_cast<float4*>(op + (size_t)opix * C + cg * 4) = acc[g];
+    }
+  };
+
+  const int d0 = chunk * dch, d1 = min(d0 + dch, a.D);
+  const float* __restrict__ dp = a.depth + (size_t)b * a.D * hw + pix;
+  float depth = dp[(size_t)d0 * hw];
+  for (int d = d0; d < d1; ++d) {
+    const float depth_next = dp[(size_t)min(d + 1, d1 - 1) * hw];     // in flight while this plane is processed
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      const float* Rs = a.rots + ((size_t)b * a.S + a.src_idx[s]) * 9;
+      const float* ts = a.trans + ((size_t)b * a.S + a.src_idx[s]) * 3;
+#ifdef PGRF_CV_ABL_GEOM     // timing experiment: no warp geometry
+      Taps t; t.o00 = lane * 32; t.o01 = lane * 32 + 32; t.o10 = lane * 32 + 8192; t.o11 = lane * 32 + 8224; t.w00 = depth; t.w01 = ux; t.w10 = uy; t.w11 = uz;
+#else
+      const Taps t = warp_taps<GEN>(a, bp, Rs, ts, ux, uy, uz, depth);
+#endif
+      float4* dst = reinterpret_cast<float4*>(&lds_taps[wave][s][lane][0]);
+      dst[0] = make_float4(__int_as_float(t.o00), __int_as_float(t.o01), __int_as_float(t.o10), __int_as_float(t.o11));
+      dst[1] = make_float4(t.w00, t.w01, t.w10, t.w11);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* __restrict__ op = a.out + ((size_t)b * a.D + d) * hw * C;
+    if constexpr (C32) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) stream_voxels(it, rvs[it], op);
+    } else {
+      for (int it = 0; it < nit; ++it) {
+        const int rpix = min(pix0 + it * vpg + sub, hw - 1);
+        float4 rv[G];
+        rv[0] = *reinterpret_cast<const float4*>(fb + ((size_t)a.ref_idx * hw + rpix) * C + cg * 4);
+        stream_voxels(it, rv, op);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();     // the next plane's tap stores must not pass this plane's tap loads
+    depth = depth_next;
   }
 }
 
 int launch_cost_volume(const CvArgs& a, void* stream) {
-  const size_t nvox = (size_t)a.B * a.D * a.h * a.w;
-  const size_t waves = (nvox + 63) / 64;
-  size_t blocks = (waves + 3) / 4;
-  if (blocks > 256 * 16) blocks = 256 * 16;
-#define PGRF_CV(GEN_, N_) hipLaunchKernelGGL((cost_volume_kernel<GEN_, N_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a)
+  const int hw = a.h * a.w;
+  const int tiles_per_img = (hw + 63) / 64;
+  // planes per wave: amortises the per-pixel prologue; keep >= ~32 waves per CU when the volume allows it
+  int dch = 8;
+  while (dch > 1 && (long)a.B * tiles_per_img * ((a.D + dch - 1) / dch) < PGRF_CV_MINITEMS) dch >>= 1;
+  const int nchunk = (a.D + dch - 1) / dch;
+  const long nitems = (long)a.B * tiles_per_img * nchunk;
+  const unsigned blocks = (unsigned)((nitems + 3) / 4);
+  int ex = 0;
+  const bool divide = std::frexp(a.div, &ex) != 0.5f;      // not a power of two: 1/div is not exact
+  const bool c32 = (a.C == 32), abs_ = (a.cost_type == 0);
+#define PGRF_CV5(GEN_, N_, C32_, ABS_, DIV_) \
+  hipLaunchKernelGGL((cost_volume_kernel<GEN_, N_, C32_, ABS_, DIV_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dch, nchunk, tiles_per_img)
+  // the shipped convention gets every specialisation; the other conventions share the run-time-switched kernel
+#define PGRF_CV_M3D(N_) do { \
+    if (c32 && abs_ && !divide) PGRF_CV5(false, N_, true, true, false); \
+    else if (c32 && !divide) PGRF_CV5(false, N_, true, false, false); \
+    else if (!divide) PGRF_CV5(false, N_, false, false, false); \
+    else PGRF_CV5(false, N_, false, false, true); } while (0)
+#define PGRF_CV_GEN(N_) do { if (!divide) PGRF_CV5(true, N_, false, false, false); else PGRF_CV5(true, N_, false, false, true); } while (0)
   if (a.dataset == PGRF_DATASET_M3D) {
-    if (a.n_src == 1) PGRF_CV(false, 1); else if (a.n_src == 2) PGRF_CV(false, 2); else if (a.n_src == 3) PGRF_CV(false, 3); else PGRF_CV(false, 4);
+    if (a.n_src == 1) PGRF_CV_M3D(1); else if (a.n_src == 2) PGRF_CV_M3D(2); else if (a.n_src == 3) PGRF_CV_M3D(3); else PGRF_CV_M3D(4);
   } else {
-    if (a.n_src == 1) PGRF_CV(true, 1); else if (a.n_src == 2) PGRF_CV(true, 2); else if (a.n_src == 3) PGRF_CV(true, 3); else PGRF_CV(true, 4);
+    if (a.n_src == 1) PGRF_CV_GEN(1); else if (a.n_src == 2) PGRF_CV_GEN(2); else if (a.n_src == 3) PGRF_CV_GEN(3); else PGRF_CV_GEN(4);
   }
-#undef PGRF_CV
+#undef PGRF_CV5
+#undef PGRF_CV_M3D
+#undef PGRF_CV_GEN
   PGRF_CHECK_LAUNCH("cost_volume");
   return PGRF_OK;
 }
@@ -302,6 +459,7 @@ int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const fl
   if (ref_idx < 0 || ref_idx >= S) return set_error(PGRF_ERR_ARG, "pgrf_cost_volume_erp: ref_idx out of range");
   if (cost_type < 0 || cost_type > 2) return set_error(PGRF_ERR_ARG, "pgrf_cost_volume_erp: unknown cost type %d", cost_type);
   if (!(src_div > 0.f)) return set_error(PGRF_ERR_ARG, "pgrf_cost_volume_erp: src_div must be > 0");
+  if ((double)h * w * C >= 2147483648.0) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_cost_volume_erp: a view of >= 2^31 elements");
   if (B == 0) return PGRF_OK;
   CvArgs a;
   a.feats = feats; a.depth = depth_volume; a.rots = rots; a.trans = trans; a.out = out;
