@@ -12,6 +12,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "pgrf_internal.h"
 
@@ -52,8 +53,11 @@ __host__ __device__ inline size_t wpk_index(int cot, int tap, int chunk, int chu
 // SPLIT: the 4 waves of the workgroup share ONE output tile and split the (tap, chunk) reduction 4 ways
 // (partials combined through LDS) — for the deep, low-resolution layers whose plain decomposition yields
 // fewer waves than the chip has SIMDs.
+#ifndef PGRF_CONV_WAVES
+#define PGRF_CONV_WAVES 1        // minimum waves per SIMD the register allocation must allow (tuning knob)
+#endif
 template <int MT, int NT, bool SPLIT>
-__global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float red[SPLIT ? 3 * MT * NT * 16 * 64 : 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -100,29 +104,54 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
   }
 
   const bool full_chunks = (a.Cin & 31) == 0;
-  // taps whose whole 32-voxel x NT footprint lies in the zero padding are skipped (wave-uniform bit mask)
-  // (a superset is enough — padding is applied per lane at use — so the 27 taps are the outer product of three
-  // wave-level "some lane has an in-range z" flags and three for y, instead of 27 per-tap reductions)
-  unsigned tapmask = 0;
+  // Byte offsets (32-bit; the launcher checks the buffer is < 4 GiB) of the three W-neighbours of every tile voxel,
+  // circular wrap applied, lane half's channel offset included.  A tap's operand address is then
+  //   (a.in + wave-uniform offset of (dz, dy, chunk))  +  voff[t][dx]
+  // i.e. a scalar base plus a per-lane offset that does not change over the whole reduction: no per-tap index
+  // arithmetic, range checks or selects on the vector ALU (they were 2 VALU instructions per MFMA, and the f32 MFMA
+  // shares its pipe with the VALU).
+  unsigned voff[NT][3];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      int xi = xin[t] + dxi - 1;
+      xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);          // circular along W
+      voff[t][dxi] = ((unsigned)(cen[t] + xi) * (unsigned)a.in_cs + (unsigned)(a.in_coff + kk * 16)) * 4u;
+    }
+  // Wave-level classification of the three depth and the three height offsets:
+  //   zm/ym  : SOME lane has an in-range source for this offset (otherwise the tap is skipped: whole footprint in the
+  //            zero padding; a superset is enough, so the 27 taps are the outer product of 3 + 3 flags);
+  //   zam/yam: EVERY lane of every tile has one -> the tap's loads need no mask at all (fast path, > 95 % of the
+  //            tiles of a volume); the others (volume faces, ragged last tile) take the masked path.
+  unsigned tapmask = 0, zam = 0, yam = 0;
   {
     bool zany[3] = {false, false, false}, yany[3] = {false, false, false};
+    bool zall[3] = {true, true, true}, yall[3] = {true, true, true};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        zany[d] = zany[d] || (vok[t] && (unsigned)(zin[t] + d - 1) < (unsigned)a.D);
-        yany[d] = yany[d] || (vok[t] && (unsigned)(yin[t] + d - 1) < (unsigned)a.H);
+        const bool zr = vok[t] && (unsigned)(zin[t] + d - 1) < (unsigned)a.D;
+        const bool yr = vok[t] && (unsigned)(yin[t] + d - 1) < (unsigned)a.H;
+        zany[d] = zany[d] || zr; yany[d] = yany[d] || yr;
+        zall[d] = zall[d] && zr; yall[d] = yall[d] && yr;
       }
     unsigned zm = 0, ym = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       if (__any(zany[d])) zm |= 1u << d;
       if (__any(yany[d])) ym |= 1u << d;
+      if (__all(zall[d])) zam |= 1u << d;
+      if (__all(yall[d])) yam |= 1u << d;
     }
-    for (int tap = 0; tap < 27; ++tap)
-      if (((zm >> (tap / 9)) & 1u) && ((ym >> ((tap / 3) % 3)) & 1u)) tapmask |= 1u << tap;
+    for (int r = 0; r < 9; ++r)
+      if (((zm >> (r / 3)) & 1u) && ((ym >> (r % 3)) & 1u)) tapmask |= 1u << r;     // bit r = tap row (dz, dy) = (r/3, r%3)
   }
-  if (a.wtaps == 1) tapmask &= 1u << 13;                                // pointwise: centre tap only
+  if (a.wtaps == 1) tapmask &= 1u << 4;                                 // pointwise: centre tap only
+#ifdef PGRF_CONV_NO_FAST   // experiment: every tap through the masked path
+  zam = yam = 0;
+#endif
 
   // Operand buffers of one (tap, 32-channel chunk) step.  Two of them ping-pong: the loads of step i+1 are
   // issued before the MFMAs of step i, so the L2/L1 round trip hides under 16*MT*NT MFMAs (the kernel runs at
@@ -134,28 +163,36 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
     bool need_mask;
     int c0;
   };
-  auto issue = [&](Step& st, int tap, int ch) {
-    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-    bool all = true;
+  // row = tap row index dz*3 + dy; DXI = the W offset + 1 as a compile-time constant (a run-time dx made the compiler
+  // index voff[][] through scratch memory)
+  auto issue = [&](Step& st, int row, int ch, auto dx_tag) {
+    constexpr int dxi = decltype(dx_tag)::value;
+    const int dzi = row / 3, dyi = row % 3, tap = row * 3 + dxi;
     st.c0 = ch * 32 + kk * 16;
-    const int toff = (dz * a.H + dy) * a.W;                             // wave-uniform
+    // wave-uniform part of the address: the tap's row offset and the channel chunk
+    const char* sb = reinterpret_cast<const char*>(a.in) + ((long long)((dzi - 1) * a.H + (dyi - 1)) * a.W * a.in_cs + ch * 32) * 4;
+    const bool fast = full_chunks && ((zam >> dzi) & (yam >> dyi) & 1u);
+    st.need_mask = !fast;
+    if (fast) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      int xi = xin[t] + dx;
-      xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);          // circular along W
-      st.ok[t] = vok[t] && (unsigned)(zin[t] + dz) < (unsigned)a.D && (unsigned)(yin[t] + dy) < (unsigned)a.H;  // zeros along D, H
-      // always-valid address (the centre voxel when the tap is padding): loads are unconditional and issue back to
-      // back; padding and ragged tiles are applied by a select at use
-      const int lin = st.ok[t] ? cen[t] + toff + xi : cen[t] + xin[t];
-      const float* ip = a.in + (long long)lin * a.in_cs + a.in_coff;
-      all = all && st.ok[t];
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cq = (st.c0 + q * 4 + 4 <= a.Cin) ? st.c0 + q * 4 : 0;
-        st.bv[t][q] = *reinterpret_cast<const float4*>(ip + cq);
+        for (int q = 0; q < 4; ++q) st.bv[t][q] = *reinterpret_cast<const float4*>(sb + voff[t][dxi] + q * 16);
+    } else {
+      const char* cb = reinterpret_cast<const char*>(a.in) + (long long)ch * 128;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        st.ok[t] = vok[t] && (unsigned)(zin[t] + dzi - 1) < (unsigned)a.D && (unsigned)(yin[t] + dyi - 1) < (unsigned)a.H;  // zeros along D, H
+        // always-valid address (the centre voxel when the tap is padding): loads are unconditional and issue back to
+        // back; padding, ragged tiles and the channel tail are applied by a select at use
+        const char* ip = st.ok[t] ? sb + voff[t][dxi] : cb + voff[t][1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long long qo = (st.c0 + q * 4 + 4 <= a.Cin) ? q * 16 : -(long long)st.c0 * 4;      // tail: channel 0
+          st.bv[t][q] = *reinterpret_cast<const float4*>(ip + qo);
+        }
       }
     }
-    st.need_mask = !__all(all) || !full_chunks;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const float4* ap = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, a.wtaps == 1 ? 0 : tap, ch, a.chunks, 0, 0, a.wtaps)) + lane;
@@ -189,30 +226,54 @@ __global__ void __launch_bounds__(256) conv3d_wrap_kernel(const ConvArgs a) {
       }
     }
   };
-  // wave-uniform iterator over (valid tap, chunk)
+  // Wave-uniform iterator over macro steps = (valid tap row, chunk); a macro step is the three W taps dx = -1, 0, +1.
+  // Steps alternate between the two operand buffers, so the pattern (buffer, dx) repeats every 6 steps = 2 macro
+  // steps: the loop body below is that period, with dx a compile-time constant in every issue.
+  // SPLIT: wave w takes the macro steps whose running index is w modulo 4.
   unsigned rem = tapmask;
-  int tap = rem ? __ffs(rem) - 1 : -1, ch = 0, sidx = 0;
+  int row = rem ? __ffs(rem) - 1 : -1, ch = 0, midx = 0;
   auto next1 = [&]() {
-    if (++ch == a.chunks) { ch = 0; rem &= rem - 1; tap = rem ? __ffs(rem) - 1 : -1; }
-    ++sidx;
+    if (++ch == a.chunks) { ch = 0; rem &= rem - 1; row = rem ? __ffs(rem) - 1 : -1; }
+    ++midx;
   };
   auto advance = [&]() {
     next1();
-    if (SPLIT) while (tap >= 0 && (sidx & 3) != wave) next1();       // this wave's quarter of the steps
+    if (SPLIT) while (row >= 0 && (midx & 3) != wave) next1();       // this wave's quarter of the macro steps
   };
-  if (SPLIT) while (tap >= 0 && (sidx & 3) != wave) next1();
+  if (SPLIT) while (row >= 0 && (midx & 3) != wave) next1();
+  typedef std::integral_constant<int, 0> DX0;
+  typedef std::integral_constant<int, 1> DX1;
+  typedef std::integral_constant<int, 2> DX2;
   Step P, Q;
-  if (tap >= 0) {
-    issue(P, tap, ch); advance();
+  if (row >= 0 && a.wtaps == 1) {          // pointwise product: the centre tap of every chunk
+    issue(P, row, ch, DX1()); advance();
     while (true) {
-      const bool hasQ = tap >= 0;
-      if (hasQ) { issue(Q, tap, ch); advance(); }
+      const bool hasQ = row >= 0;
+      if (hasQ) { issue(Q, row, ch, DX1()); advance(); }
       compute(P);
       if (!hasQ) break;
-      const bool hasP = tap >= 0;
-      if (hasP) { issue(P, tap, ch); advance(); }
+      const bool hasP = row >= 0;
+      if (hasP) { issue(P, row, ch, DX1()); advance(); }
       compute(Q);
       if (!hasP) break;
+    }
+  } else if (row >= 0) {
+    issue(P, row, ch, DX0());
+    while (true) {
+      issue(Q, row, ch, DX1()); compute(P);
+      issue(P, row, ch, DX2()); compute(Q);
+      advance();
+      const bool more1 = row >= 0;
+      if (more1) issue(Q, row, ch, DX0());
+      compute(P);
+      if (!more1) break;
+      issue(P, row, ch, DX1()); compute(Q);
+      issue(Q, row, ch, DX2()); compute(P);
+      advance();
+      const bool more2 = row >= 0;
+      if (more2) issue(P, row, ch, DX0());
+      compute(Q);
+      if (!more2) break;
     }
   }
   if (SPLIT) {
@@ -617,6 +678,8 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wrap: null pointer");
   if (stride != 1 && stride != 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wrap: stride %d", stride);
   if (B < 1 || D < 1 || H < 1 || W < 2) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wrap: bad dims");
+  if ((double)B * D * H * W * in_cs * 4.0 >= 4294967296.0)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wrap: input buffer of >= 4 GiB (32-bit byte offsets)");
   if (((Cin & 3) == 0 || Cout != 1) && ((in_cs & 3) || (in_coff & 3)))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wrap: input channel stride/offset must be multiples of 4");
   if (Cout != 1 && ((Cin & 3) || (Cout & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3)))
@@ -766,6 +829,8 @@ int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, 
                               int D, int H, int W, void* stream) {
   if (!in || !packed || !y) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_cout1_project: null pointer");
   if ((Cin & 3) || (in_cs & 3) || (in_coff & 3)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_cout1_project: channels/strides must be multiples of 4");
+  if ((double)B * D * H * W * in_cs * 4.0 >= 4294967296.0)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_cout1_project: input buffer of >= 4 GiB (32-bit byte offsets)");
   ConvArgs a;
   a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = y; a.out_cs = 32; a.out_coff = 0; a.Cout = 32;
   a.B = B; a.D = D; a.H = H; a.W = W; a.stride = 1; a.slope = 1.f; a.Do = D; a.Ho = H; a.Wo = W;
