@@ -167,6 +167,9 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
   // index voff[][] through scratch memory)
   auto issue = [&](Step& st, int row, int ch, auto dx_tag) {
     constexpr int dxi = decltype(dx_tag)::value;
+#ifdef PGRF_CONV_ABL_NOISSUE   // timing experiment: operands are loaded once, every later step reuses the registers
+    if (!(row == __ffs(tapmask) - 1 && ch == 0 && dxi < 2)) { st.need_mask = false; return; }
+#endif
     const int dzi = row / 3, dyi = row % 3, tap = row * 3 + dxi;
     st.c0 = ch * 32 + kk * 16;
     // wave-uniform part of the address: the tap's row offset and the channel chunk
@@ -177,7 +180,11 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
+#ifdef PGRF_CONV_ABL_B      // timing experiment: every tap reads the centre voxel of chunk 0 (L1 resident)
+        for (int q = 0; q < 4; ++q) st.bv[t][q] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.in) + voff[t][1] + q * 16);
+#else
         for (int q = 0; q < 4; ++q) st.bv[t][q] = *reinterpret_cast<const float4*>(sb + voff[t][dxi] + q * 16);
+#endif
     } else {
       const char* cb = reinterpret_cast<const char*>(a.in) + (long long)ch * 128;
 #pragma unroll
@@ -195,36 +202,86 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+#ifdef PGRF_CONV_ABL_A      // timing experiment: every step reads the weights of tap 0, chunk 0
+      const float4* ap = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, 0, 0, a.chunks, 0, 0, a.wtaps)) + lane;
+#else
       const float4* ap = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, a.wtaps == 1 ? 0 : tap, ch, a.chunks, 0, 0, a.wtaps)) + lane;
+#endif
       st.av[m][0] = ap[0]; st.av[m][1] = ap[64]; st.av[m][2] = ap[128]; st.av[m][3] = ap[192];
     }
   };
+  auto apply_mask = [&](Step& st) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = st.ok[t] && (st.c0 + q * 4 + 4 <= a.Cin);
+        st.bv[t][q].x = ok ? st.bv[t][q].x : 0.f; st.bv[t][q].y = ok ? st.bv[t][q].y : 0.f;
+        st.bv[t][q].z = ok ? st.bv[t][q].z : 0.f; st.bv[t][q].w = ok ? st.bv[t][q].w : 0.f;
+      }
+  };
+  auto mfma_group = [&](const Step& st, int m, int s4) {       // 4 k-steps x NT voxel tiles of one A float4
+    const float av[4] = {st.av[m][s4].x, st.av[m][s4].y, st.av[m][s4].z, st.av[m][s4].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 bq = st.bv[t][s4];
+        const float bs = (j == 0) ? bq.x : (j == 1) ? bq.y : (j == 2) ? bq.z : bq.w;
+        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bs, acc[t][m], 0, 0, 0);
+      }
+  };
   auto compute = [&](Step& st) {
-    if (st.need_mask) {
+    if (st.need_mask) apply_mask(st);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool ok = st.ok[t] && (st.c0 + q * 4 + 4 <= a.Cin);
-          st.bv[t][q].x = ok ? st.bv[t][q].x : 0.f; st.bv[t][q].y = ok ? st.bv[t][q].y : 0.f;
-          st.bv[t][q].z = ok ? st.bv[t][q].z : 0.f; st.bv[t][q].w = ok ? st.bv[t][q].w : 0.f;
-        }
-    }
+      for (int s4 = 0; s4 < 4; ++s4) mfma_group(st, m, s4);
+  };
+  // One pipeline step: the MFMAs of `cur` while the operands of the next step (row, ch, dx) are requested into `nxt`.
+  // With one wave per SIMD nothing else keeps the matrix pipe busy while ~24 loads and their addresses are issued
+  // (measured: 13 % of the kernel), so when the next step needs no padding mask its loads are spread between the MFMA
+  // groups of this one — a single basic block, pinned with sched_group_barrier (the scheduler otherwise hoists every
+  // load in front of the first MFMA).  A masked next step keeps the plain issue-then-compute order.
+#ifdef PGRF_CONV_NO_FUSE
+  constexpr bool kFuse = false;
+#else
+  constexpr bool kFuse = true;
+#endif
+  // In-place pipeline step: the MFMAs of the step held in `st`, and behind each MFMA group the loads that refill exactly
+  // the registers that group was the last to read with the operands of the NEXT step (row, ch, dx): the A float4 of
+  // group (m, s4) right after it, the B float4s of k-quad s4 after the last cout tile has used them.  One operand
+  // buffer instead of two (96 registers fewer than ping-pong), and the ~24 loads of a step are spread between its
+  // MFMA groups instead of draining the matrix pipe in front of them (one wave per SIMD: nobody else fills it;
+  // measured 13 % of the kernel).  A refilled register is next read >= 4 groups (4096 cycles) later.
+  auto step_fast = [&](Step& st, int row, int ch, auto dx_tag) {
+    constexpr int dxi = decltype(dx_tag)::value;
+    const int dzi = row / 3, dyi = row % 3, tap = row * 3 + dxi;
+    const char* sb = reinterpret_cast<const char*>(a.in) + ((long long)((dzi - 1) * a.H + (dyi - 1)) * a.W * a.in_cs + ch * 32) * 4;
+    const float4* ap[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m)
+      ap[m] = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, tap, ch, a.chunks, 0, 0, 27)) + lane;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const float av[4] = {st.av[m][s4].x, st.av[m][s4].y, st.av[m][s4].z, st.av[m][s4].w};
+        mfma_group(st, m, s4);
+        st.av[m][s4] = ap[m][s4 * 64];
+        if (m == MT - 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const float4 bq = st.bv[t][s4];
-            const float bs = (j == 0) ? bq.x : (j == 1) ? bq.y : (j == 2) ? bq.z : bq.w;
-            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bs, acc[t][m], 0, 0, 0);
-          }
+          for (int t = 0; t < NT; ++t) st.bv[t][s4] = *reinterpret_cast<const float4*>(sb + voff[t][dxi] + s4 * 16);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                       // the group's MFMAs ...
+        if (m == MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1 + NT, 0);      // ... then the refills
+        else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
-    }
+  };
+  auto mfma_all = [&](const Step& st) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) mfma_group(st, m, s4);
   };
   // Wave-uniform iterator over macro steps = (valid tap row, chunk); a macro step is the three W taps dx = -1, 0, +1.
   // Steps alternate between the two operand buffers, so the pattern (buffer, dx) repeats every 6 steps = 2 macro
@@ -244,8 +301,24 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
   typedef std::integral_constant<int, 0> DX0;
   typedef std::integral_constant<int, 1> DX1;
   typedef std::integral_constant<int, 2> DX2;
-  Step P, Q;
-  if (row >= 0 && a.wtaps == 1) {          // pointwise product: the centre tap of every chunk
+  // Interior waves (every lane of every tile has all 27 taps in range; > 90 % of a volume): a loop of fused steps with
+  // no padding logic at all.  Everything else (volume faces, ragged last tile, channel tails, pointwise mode): the
+  // generic loop with masked loads.
+  const bool interior = kFuse && full_chunks && zam == 7u && yam == 7u && a.wtaps == 27 && tapmask == 0x1ffu;
+  if (interior) {
+    Step P;
+    P.need_mask = false;
+    issue(P, row, ch, DX0());                  // fast path of issue(): plain loads
+    while (true) {
+      step_fast(P, row, ch, DX1());
+      step_fast(P, row, ch, DX2());
+      advance();
+      if (row < 0) break;
+      step_fast(P, row, ch, DX0());
+    }
+    mfma_all(P);
+  } else if (row >= 0 && a.wtaps == 1) {          // pointwise product: the centre tap of every chunk
+    Step P, Q;
     issue(P, row, ch, DX1()); advance();
     while (true) {
       const bool hasQ = row >= 0;
@@ -258,6 +331,7 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
       if (!hasP) break;
     }
   } else if (row >= 0) {
+    Step P, Q;
     issue(P, row, ch, DX0());
     while (true) {
       issue(Q, row, ch, DX1()); compute(P);
