@@ -90,6 +90,15 @@ int pgrf_sample_coarse_depth(float min_depth, float max_depth, int use_disp, int
  * network/render_ops.py:413-473 sample_fine_depth + network/renderer.py:469-472. */
 int pgrf_sample_fine_depth(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
                            int use_all, int rn, int dn, int fdn, float* out, void* stream);
+/* Training-mode forms of the two samplers (is_train=True in network/renderer.py:607,437): the caller supplies the uniform
+ * draws the reference takes from torch.rand, so that a seeded run reproduces the reference's sample positions.
+ *   jitter [rn, dn-2] in [0,1): interior coarse samples move by (r - 0.5) * 0.999 bins (render_ops.py:310-311,329-330);
+ *   u      [rn, fdn]  in [0,1): inverse-CDF positions replacing the bin centres (render_ops.py:443-449).
+ * NULL = the deterministic eval behaviour of the functions above. */
+int pgrf_sample_coarse_depth_train(float min_depth, float max_depth, int use_disp, int rn, int dn, const float* jitter,
+                                   float* depth, void* stream);
+int pgrf_sample_fine_depth_train(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
+                                 int use_all, int rn, int dn, int fdn, const float* u, float* out, void* stream);
 
 /* ------------------------------------------------------------------ one network pass ------- */
 typedef struct PgrfPassOut {   /* any pointer may be NULL = not wanted */
@@ -170,6 +179,14 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
                      const PgrfRenderCfg* cfg, const float* coords, int rn, const PgrfPassOut* coarse,
                      const PgrfPassOut* fine, float* fine_depth_out, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* The same per-batch path in training mode (is_train=True: render_impl passes random_sample=True to both samplers,
+ * network/renderer.py:607,437-438).  coarse_jitter [rn, dn-2] / fine_u [rn, fdn] as in the *_train samplers (NULL = eval
+ * behaviour); coarse_depth_out [rn, dn] (optional) returns the jittered coarse depths.  Forward only. */
+int pgrf_render_rays_train(const PgrfFrame* frame, const float* blob_coarse, const float* blob_fine,
+                           const PgrfRenderCfg* cfg, const float* coords, int rn, const float* coarse_jitter,
+                           const float* fine_u, const PgrfPassOut* coarse, const PgrfPassOut* fine,
+                           float* coarse_depth_out, float* fine_depth_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 
 /* ------------------------------------------------------------------ spherical cost volume -- */

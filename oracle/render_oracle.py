@@ -43,20 +43,24 @@ def erp_ray_directions(H, W, dataset='m3d'):
     return d / torch.norm(d, p=2, dim=-1, keepdim=True)
 
 
-def sample_coarse_depth(min_depth, max_depth, rn, dn, use_disp=True, device='cpu'):
-    """Deterministic (eval) stratified depths, [rn,dn]. network/render_ops.py:292-339."""
+def sample_coarse_depth(min_depth, max_depth, rn, dn, use_disp=True, device='cpu', jitter=None):
+    """Stratified depths, [rn,dn]. network/render_ops.py:292-339.  Eval: deterministic; training: `jitter` [rn,dn-2]
+    uniform draws move the interior samples by (r - 0.5) * 0.999 bins (:310-311, :329-330)."""
     near = torch.tensor(float(min_depth), device=device)
     far = torch.tensor(float(max_depth), device=device)
-    val = torch.arange(1, dn - 1, dtype=torch.float32, device=device)
+    val = torch.arange(1, dn - 1, dtype=torch.float32, device=device).view(1, dn - 2).expand(rn, dn - 2)
+    if jitter is not None:
+        val = val + (jitter.to(device) - 0.5) * 0.999
+    zero = torch.zeros(rn, 1, device=device)
     if use_disp:
         interval = (1 / far - 1 / near) / (dn - 1)
-        ticks = torch.cat([torch.zeros(1, device=device), interval * val, (1 / far - 1 / near).view(1)])
+        ticks = torch.cat([zero, interval * val, (1 / far - 1 / near).view(1, 1).expand(rn, 1)], -1)
         depth = 1 / (1 / near + ticks)
     else:
         interval = (far - near) / (dn - 1)
-        ticks = torch.cat([torch.zeros(1, device=device), interval * val, (far - near).view(1)])
+        ticks = torch.cat([zero, interval * val, (far - near).view(1, 1).expand(rn, 1)], -1)
         depth = near + ticks
-    return depth.view(1, dn).expand(rn, dn).contiguous()
+    return depth.contiguous()
 
 
 def normalized_inverse_depth(depth, near, far):
@@ -349,8 +353,9 @@ def composite(density, colors, depth):
 
 
 # --------------------------------------------------------------------------- importance sampling (a-10)
-def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True):
-    """Deterministic inverse-CDF resampling in normalised inverse depth, then sort.
+def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True, u=None):
+    """Inverse-CDF resampling in normalised inverse depth, then sort.  Eval: bin-centre positions; training: `u`
+    [rn,fdn] uniform draws (render_ops.py:449).
     depth, hit_prob [rn,dn] -> [rn,fdn].  render_ops.py:413-473, renderer.py:469-472."""
     near, far = que_depth_range[0], que_depth_range[1]
     if use_disp:
@@ -362,7 +367,10 @@ def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True):
     pdf = hp / torch.sum(hp, -1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)         # dn+1
     interval = 1 / fdn
-    u = (0.5 * interval + torch.arange(fdn) * interval).to(cdf.device).expand(*cdf.shape[:-1], fdn).contiguous()
+    if u is None:
+        u = (0.5 * interval + torch.arange(fdn) * interval).to(cdf.device).expand(*cdf.shape[:-1], fdn).contiguous()
+    else:
+        u = u.to(cdf.device).contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = torch.clamp(inds - 1, min=0)
     above = torch.clamp(inds, max=cdf.shape[-1] - 1)
@@ -434,18 +442,18 @@ def merge_c2f_all(coarse_depth, coarse, fine_depth, fine):
             'render_depth': rdepth}
 
 
-def render_rays(weights, frame, coords, cfg, want_debug=False):
+def render_rays(weights, frame, coords, cfg, want_debug=False, jitter=None, u=None):
     """Coarse (+ fine) render of rays `coords` [rn,2]; keys follow renderer.py:567-633 with the
-    leading qn=1 axis dropped."""
+    leading qn=1 axis dropped.  jitter / u: the uniform draws of a training-mode forward (is_train=True)."""
     rn = coords.shape[0]
     dn = cfg['depth_sample_num']
-    depth = sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn, cfg.get('use_disp', True), coords.device)
+    depth = sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn, cfg.get('use_disp', True), coords.device, jitter)
     ccfg = {'use_vis': cfg.get('dist_decoder_cfg', {}).get('use_vis', True)}
     out = render_pass(weights, 'dist_decoder', 'agg_net', frame, coords, depth, ccfg, want_debug)
     out['depth'] = depth
     if cfg.get('use_hierarchical_sampling', False):
         fdn = cfg['fine_depth_sample_num']
-        fd = sample_fine_depth(depth, out['hit_prob_nr'], frame['que_depth_range'], fdn, cfg.get('use_disp', True))
+        fd = sample_fine_depth(depth, out['hit_prob_nr'], frame['que_depth_range'], fdn, cfg.get('use_disp', True), u)
         if cfg.get('fine_depth_use_all', False):
             fd = torch.sort(torch.cat([depth, fd], -1), -1)[0]
         fcfg = {'use_vis': cfg.get('fine_dist_decoder_cfg', {}).get('use_vis', True)}

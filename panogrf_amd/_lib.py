@@ -59,6 +59,8 @@ SYMBOLS = {
     "pgrf_pack_weights": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_sample_coarse_depth": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P]),
     "pgrf_sample_fine_depth": (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "pgrf_sample_coarse_depth_train": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "pgrf_sample_fine_depth_train": (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "pgrf_render_pass_workspace_bytes": (C.c_size_t, [C.POINTER(PgrfFrame)]),
     "pgrf_render_pass": (C.c_int, [C.POINTER(PgrfFrame), _P, C.c_int, _P, _P, C.c_int, C.c_int,
                                    C.POINTER(PgrfPassOut), C.POINTER(PgrfPassDebug), _P, C.c_size_t, _P]),
@@ -83,6 +85,8 @@ SYMBOLS = {
     "pgrf_render_workspace_bytes": (C.c_size_t, [C.POINTER(PgrfFrame), C.POINTER(PgrfRenderCfg), C.c_int]),
     "pgrf_render_rays": (C.c_int, [C.POINTER(PgrfFrame), _P, _P, C.POINTER(PgrfRenderCfg), _P, C.c_int,
                                    C.POINTER(PgrfPassOut), C.POINTER(PgrfPassOut), _P, _P, C.c_size_t, _P]),
+    "pgrf_render_rays_train": (C.c_int, [C.POINTER(PgrfFrame), _P, _P, C.POINTER(PgrfRenderCfg), _P, C.c_int, _P, _P,
+                                         C.POINTER(PgrfPassOut), C.POINTER(PgrfPassOut), _P, _P, _P, C.c_size_t, _P]),
 }
 
 

@@ -85,31 +85,36 @@ int launch_project_ray_feats(const float* rf, const float* blob, int npix, int u
 }
 
 // ------------------------------------------------------------------------------------------
-// sample_depth, eval mode (network/render_ops.py:292-339): identical for every ray.
-__global__ void coarse_depth_kernel(float near, float far, int use_disp, int rn, int dn, float* __restrict__ depth) {
+// sample_depth (network/render_ops.py:292-339).  Eval: identical for every ray.  Training (jitter != null): the interior
+// samples are moved by (r - 0.5) * 0.999 bins, r = the caller's uniform draws [rn, dn-2] (render_ops.py:310-311,329-330);
+// the end points stay exact.
+__global__ void coarse_depth_kernel(float near, float far, int use_disp, int rn, int dn, const float* __restrict__ jitter,
+                                    float* __restrict__ depth) {
   const size_t total = (size_t)rn * dn;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % dn);
+    float val = (float)k;
+    if (jitter && k > 0 && k < dn - 1) val = val + (jitter[(i / dn) * (size_t)(dn - 2) + (k - 1)] - 0.5f) * 0.999f;
     float d;
     if (use_disp) {
       const float diff = 1.f / far - 1.f / near;
       const float interval = diff / (float)(dn - 1);
-      const float tick = (k == 0) ? 0.f : (k == dn - 1 ? diff : interval * (float)k);
+      const float tick = (k == 0) ? 0.f : (k == dn - 1 ? diff : interval * val);
       d = 1.f / (1.f / near + tick);
     } else {
       const float diff = far - near;
       const float interval = diff / (float)(dn - 1);
-      const float tick = (k == 0) ? 0.f : (k == dn - 1 ? diff : interval * (float)k);
+      const float tick = (k == 0) ? 0.f : (k == dn - 1 ? diff : interval * val);
       d = near + tick;
     }
     depth[i] = d;
   }
 }
 
-int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, float* depth, void* stream) {
+int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, const float* jitter, float* depth, void* stream) {
   const size_t total = (size_t)rn * dn;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(coarse_depth_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, near, far, use_disp, rn, dn, depth);
+  hipLaunchKernelGGL(coarse_depth_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, near, far, use_disp, rn, dn, jitter, depth);
   PGRF_CHECK_LAUNCH("coarse_depth");
   return PGRF_OK;
 }
@@ -131,7 +136,8 @@ __device__ __forceinline__ bool sorts_before(float o, int k, float v, int j) {
 
 __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict__ depth, const float* __restrict__ hit,
                                                          float qnear, float qfar, int use_disp, int use_all, int rn,
-                                                         int dn, int fdn, float* __restrict__ out) {
+                                                         int dn, int fdn, const float* __restrict__ urand,
+                                                         float* __restrict__ out) {
   __shared__ float s_pdf[4][kMaxS];
   __shared__ float s_cdf[4][kMaxS + 1];
   __shared__ float s_ctr[4][kMaxS + 1];
@@ -172,7 +178,8 @@ __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict
   const float half_iv = (float)(0.5 * (1.0 / (double)fdn));
   const int base = use_all ? dn : 0;
   for (int j = lane; j < fdn; j += 64) {
-    const float u = half_iv + (float)j * interval;
+    // eval: bin centres of [0,1); training: the caller's uniform draws [rn, fdn] (render_ops.py:443-449)
+    const float u = urand ? urand[(size_t)rayc * fdn + j] : half_iv + (float)j * interval;
     int inds = 0;
     for (int k = 0; k <= dn; ++k) inds += (s_cdf[wv][k] <= u) ? 1 : 0;
     const int below = max(inds - 1, 0), above = min(inds, dn);
@@ -203,10 +210,10 @@ __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict
 }
 
 int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
-                      int dn, int fdn, float* out, void* stream) {
+                      int dn, int fdn, const float* urand, float* out, void* stream) {
   const int blocks = (rn + 3) / 4;
   hipLaunchKernelGGL(fine_depth_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, hit, qnear, qfar, use_disp,
-                     use_all, rn, dn, fdn, out);
+                     use_all, rn, dn, fdn, urand, out);
   PGRF_CHECK_LAUNCH("fine_depth");
   return PGRF_OK;
 }

@@ -23,9 +23,9 @@ int set_error(int code, const char* fmt, ...) {
 
 int launch_project_ray_feats(const float* rf, const float* blob, int npix, int use_vis, float* out, void* stream);
 int launch_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream);
-int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, float* depth, void* stream);
+int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, const float* jitter, float* depth, void* stream);
 int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
-                      int dn, int fdn, float* out, void* stream);
+                      int dn, int fdn, const float* urand, float* out, void* stream);
 int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
                      const float* denf, int dnf, int rn, const PgrfPassOut& o, void* stream);
 
@@ -127,7 +127,7 @@ using namespace pgrf;
 extern "C" {
 
 const char* pgrf_last_error(void) { return g_err; }
-int pgrf_abi_version(void) { return 3; }
+int pgrf_abi_version(void) { return 4; }
 
 int pgrf_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream) {
   if (!src || !dst) return set_error(PGRF_ERR_ARG, "pgrf_pack_map: null pointer");
@@ -143,22 +143,32 @@ int pgrf_pack_weights(const float* const* raw_host, int n_raw, int use_vis, int 
   return pack_weights_host(raw_host, n_raw, use_vis, max_dn, blob_host);
 }
 
-int pgrf_sample_coarse_depth(float min_depth, float max_depth, int use_disp, int rn, int dn, float* depth, void* stream) {
+int pgrf_sample_coarse_depth_train(float min_depth, float max_depth, int use_disp, int rn, int dn, const float* jitter,
+                                   float* depth, void* stream) {
   if (!depth) return set_error(PGRF_ERR_ARG, "pgrf_sample_coarse_depth: null output");
   if (dn < 3 || rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_sample_coarse_depth: need dn > 2 (got %d), rn >= 0 (got %d)", dn, rn);
   if (!(min_depth > 0.f) || !(max_depth > min_depth)) return set_error(PGRF_ERR_ARG, "pgrf_sample_coarse_depth: bad depth range");
   if (rn == 0) return PGRF_OK;
-  return launch_coarse_depth(min_depth, max_depth, use_disp, rn, dn, depth, stream);
+  return launch_coarse_depth(min_depth, max_depth, use_disp, rn, dn, jitter, depth, stream);
 }
 
-int pgrf_sample_fine_depth(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
-                           int use_all, int rn, int dn, int fdn, float* out, void* stream) {
+int pgrf_sample_coarse_depth(float min_depth, float max_depth, int use_disp, int rn, int dn, float* depth, void* stream) {
+  return pgrf_sample_coarse_depth_train(min_depth, max_depth, use_disp, rn, dn, nullptr, depth, stream);
+}
+
+int pgrf_sample_fine_depth_train(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
+                                 int use_all, int rn, int dn, int fdn, const float* u, float* out, void* stream) {
   if (!depth || !hit_prob || !out) return set_error(PGRF_ERR_ARG, "pgrf_sample_fine_depth: null pointer");
   if (dn < 2 || dn > PGRF_MAX_DN || fdn < 1 || fdn > PGRF_MAX_DN)
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_sample_fine_depth: dn=%d fdn=%d outside [2,%d]/[1,%d]", dn, fdn, PGRF_MAX_DN, PGRF_MAX_DN);
   if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_sample_fine_depth: rn < 0");
   if (rn == 0) return PGRF_OK;
-  return launch_fine_depth(depth, hit_prob, que_near, que_far, use_disp, use_all, rn, dn, fdn, out, stream);
+  return launch_fine_depth(depth, hit_prob, que_near, que_far, use_disp, use_all, rn, dn, fdn, u, out, stream);
+}
+
+int pgrf_sample_fine_depth(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
+                           int use_all, int rn, int dn, int fdn, float* out, void* stream) {
+  return pgrf_sample_fine_depth_train(depth, hit_prob, que_near, que_far, use_disp, use_all, rn, dn, fdn, nullptr, out, stream);
 }
 
 size_t pgrf_render_pass_workspace_bytes(const PgrfFrame* frame) {
@@ -201,9 +211,10 @@ size_t pgrf_render_workspace_bytes(const PgrfFrame* frame, const PgrfRenderCfg* 
   return b;
 }
 
-int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const float* blob_fine, const PgrfRenderCfg* cfg,
-                     const float* coords, int rn, const PgrfPassOut* coarse, const PgrfPassOut* fine, float* fine_depth_out,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+int pgrf_render_rays_train(const PgrfFrame* frame, const float* blob_coarse, const float* blob_fine, const PgrfRenderCfg* cfg,
+                           const float* coords, int rn, const float* coarse_jitter, const float* fine_u,
+                           const PgrfPassOut* coarse, const PgrfPassOut* fine, float* coarse_depth_out, float* fine_depth_out,
+                           void* workspace, size_t workspace_bytes, void* stream) {
   if (!cfg || !coarse) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: null cfg/coarse");
   if (cfg->hierarchical && (!fine || !blob_fine)) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: hierarchical render needs fine outputs and weights");
   if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: rn < 0");
@@ -241,15 +252,16 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
     if (!oc.colors) oc.colors = col_c; else col_c = oc.colors;
     if (!oc.density) oc.density = den_c; else den_c = oc.density;
   }
-  int rc = pgrf_sample_coarse_depth(cfg->min_depth, cfg->max_depth, cfg->use_disp, rn, cfg->dn, depth_c, stream);
+  if (coarse_depth_out) depth_c = coarse_depth_out;
+  int rc = pgrf_sample_coarse_depth_train(cfg->min_depth, cfg->max_depth, cfg->use_disp, rn, cfg->dn, coarse_jitter, depth_c, stream);
   if (rc) return rc;
   const int pf = cfg->precision == 1 ? PGRF_PASS_F16X3 : 0;
   if (cfg->precision != 0 && cfg->precision != 1) return set_error(PGRF_ERR_ARG, "pgrf_render_rays: precision must be 0 (f32) or 1 (f16x3)");
   rc = do_render_pass(frame, blob_coarse, (cfg->use_vis_coarse ? PGRF_PASS_USE_VIS : 0) | pf, coords, depth_c, rn, cfg->dn, &oc, nullptr, prj_ws, prj_bytes, stream, raytab);
   if (rc || !cfg->hierarchical) return rc;
   float* fd = fine_depth_out ? fine_depth_out : depth_f;
-  rc = pgrf_sample_fine_depth(depth_c, oc.hit_prob, frame->que_depth_range[0], frame->que_depth_range[1], cfg->use_disp,
-                              cfg->fine_use_all, rn, cfg->dn, cfg->fdn, fd, stream);
+  rc = pgrf_sample_fine_depth_train(depth_c, oc.hit_prob, frame->que_depth_range[0], frame->que_depth_range[1], cfg->use_disp,
+                                    cfg->fine_use_all, rn, cfg->dn, cfg->fdn, fine_u, fd, stream);
   if (rc) return rc;
   if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &of, nullptr, prj_ws, prj_bytes, stream, raytab);
   // fine pass into scratch, then one composite over the union (renderer.py:484-518)
@@ -259,6 +271,13 @@ int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const flo
   rc = do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &tmp, nullptr, prj_ws, prj_bytes, stream, raytab);
   if (rc) return rc;
   return pgrf_merge_c2f(depth_c, col_c, den_c, cfg->dn, fd, col_f, den_f, fdn_eff, rn, &of, stream);
+}
+
+int pgrf_render_rays(const PgrfFrame* frame, const float* blob_coarse, const float* blob_fine, const PgrfRenderCfg* cfg,
+                     const float* coords, int rn, const PgrfPassOut* coarse, const PgrfPassOut* fine, float* fine_depth_out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+  return pgrf_render_rays_train(frame, blob_coarse, blob_fine, cfg, coords, rn, nullptr, nullptr, coarse, fine, nullptr,
+                                fine_depth_out, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

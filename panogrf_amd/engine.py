@@ -128,20 +128,31 @@ _DEBUG_SHAPES = {
 }
 
 
-def sample_coarse_depth(min_depth, max_depth, rn, dn, use_disp=True, device='cuda'):
+def sample_coarse_depth(min_depth, max_depth, rn, dn, use_disp=True, device='cuda', jitter=None):
+    """sample_depth (render_ops.py:292-339).  jitter [rn,dn-2] uniform draws = training mode (random_sample=True)."""
     _require_gpu()
     out = torch.empty(rn, dn, dtype=torch.float32, device=device)
-    lib.check(lib.pgrf_sample_coarse_depth(float(min_depth), float(max_depth), int(use_disp), rn, dn, _ptr(out), _stream()))
+    if jitter is not None:
+        jitter = _f32c(jitter, device)
+        if tuple(jitter.shape) != (rn, dn - 2):
+            raise PgrfError(f'jitter must be [rn, dn-2] = [{rn}, {dn - 2}], got {tuple(jitter.shape)}')
+    lib.check(lib.pgrf_sample_coarse_depth_train(float(min_depth), float(max_depth), int(use_disp), rn, dn, _ptr(jitter),
+                                                 _ptr(out), _stream()))
     return out
 
 
-def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True, use_all=False):
+def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True, use_all=False, u=None):
+    """sample_fine_depth + sort (render_ops.py:413-473, renderer.py:469-472).  u [rn,fdn] uniform draws = training mode."""
     _require_gpu()
     depth, hit_prob = _f32c(depth), _f32c(hit_prob)
     rn, dn = depth.shape
     out = torch.empty(rn, (dn + fdn) if use_all else fdn, dtype=torch.float32, device=depth.device)
-    lib.check(lib.pgrf_sample_fine_depth(_ptr(depth), _ptr(hit_prob), float(que_depth_range[0]), float(que_depth_range[1]),
-                                         int(use_disp), int(use_all), rn, dn, fdn, _ptr(out), _stream()))
+    if u is not None:
+        u = _f32c(u, depth.device)
+        if tuple(u.shape) != (rn, fdn):
+            raise PgrfError(f'u must be [rn, fdn] = [{rn}, {fdn}], got {tuple(u.shape)}')
+    lib.check(lib.pgrf_sample_fine_depth_train(_ptr(depth), _ptr(hit_prob), float(que_depth_range[0]), float(que_depth_range[1]),
+                                               int(use_disp), int(use_all), rn, dn, fdn, _ptr(u), _ptr(out), _stream()))
     return out
 
 
@@ -225,12 +236,21 @@ class RayRenderer:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws, need
 
-    def render_rays(self, frame, coords, want=('pixel', 'depth', 'density', 'colors')):
-        """coords [rn,2] -> dict with the reference's key names (no qn axis).  hit_prob_* are
-        dropped like the reference does in eval (renderer.py:675)."""
+    def render_rays(self, frame, coords, want=('pixel', 'depth', 'density', 'colors'), is_train=False, jitter=None):
+        """coords [rn,2] -> dict with the reference's key names (no qn axis).  The caller drops hit_prob_* in eval like
+        the reference does (renderer.py:675).  is_train: as in the reference's render_impl, the COARSE depths stay
+        deterministic (renderer.py:607 passes random_sample=False even when training) and the importance sampler takes
+        uniform draws (renderer.py:437-438 -> render_ops.py:449), made here exactly where the reference makes them
+        (torch.rand([1, rn, fdn]) on the CPU generator), so a seeded run reproduces its sample positions.  `jitter`
+        ([rn, dn-2] uniform draws) additionally moves the coarse samples like sample_depth(random_sample=True) would.
+        Forward only."""
         coords = _f32c(coords, self.device)
         rn = coords.shape[0]
         c = self.ccfg
+        jit = None if jitter is None else _f32c(jitter, self.device)
+        u_fine = None
+        if is_train and rn > 0 and c.hierarchical:
+            u_fine = torch.rand([1, rn, c.fdn])[0].to(self.device).contiguous()
         fdn_eff = c.dn + c.fdn if c.fine_use_all else c.fdn
         dn_f_out = c.dn + fdn_eff if c.c2f_all else fdn_eff
         # cfg['hip_check_nan']: the reference drops into ipdb when a NaN shows up (renderer.py:264-265,459-462); here the
@@ -248,9 +268,12 @@ class RayRenderer:
             out['depth_fine'] = fd
         fs = frame.c_struct()
         ws, nbytes = self._workspace(fs, rn)
-        lib.check(lib.pgrf_render_rays(C.byref(fs), _ptr(self.blob_c), _ptr(self.blob_f), C.byref(c), _ptr(coords), rn,
-                                       C.byref(oc), C.byref(of) if of is not None else None, _ptr(fd), _ptr(ws),
-                                       C.c_size_t(nbytes), _stream()))
+        cd = torch.empty(rn, c.dn, device=self.device) if (is_train or jit is not None) else None
+        if cd is not None:
+            out['depth'] = cd
+        lib.check(lib.pgrf_render_rays_train(C.byref(fs), _ptr(self.blob_c), _ptr(self.blob_f), C.byref(c), _ptr(coords), rn,
+                                             _ptr(jit), _ptr(u_fine), C.byref(oc), C.byref(of) if of is not None else None,
+                                             _ptr(cd), _ptr(fd), _ptr(ws), C.c_size_t(nbytes), _stream()))
         if flag is not None and int(flag.item()):
             raise PgrfError('NaN in the rendered samples (density / colour / hit probability)')
         return out

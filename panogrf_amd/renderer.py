@@ -6,7 +6,8 @@ parameter names (`image_encoder`, `vis_encoder`, `dist_decoder`, `agg_net.agg_im
 works unchanged, and `renderer(data)` / `render(que_imgs_info, ref_imgs_info, is_train)` return the same
 dict keys and shapes (network/renderer.py:635-686, 777-786).  The per-frame 2-D encoders run on stock
 PyTorch-ROCm; everything per ray goes to the HIP library.  The Linear layers below are parameter HOLDERS:
-their forward is never called.  Eval only: training is out of scope.
+their forward is never called.  Inference; training mode (`'eval' not in data`) is forward-only: the reference's
+random sampling and extra outputs, no backward pass.
 """
 import math
 
@@ -179,19 +180,25 @@ class NeuralRayBaseRenderer(nn.Module):
             self._rr_key = key
         return self._rr
 
+    @staticmethod
+    def _check_train(is_train):
+        """Training mode is FORWARD ONLY: jittered stratified sampling, random importance samples and
+        the hit_prob_* outputs as in the reference; the HIP kernels have no backward pass, so autograd must be off."""
+        if is_train and torch.is_grad_enabled():
+            raise NotImplementedError('training-mode forward runs under torch.no_grad() only: the HIP path has no backward pass')
+
     # ------------------------------------------------------------------ reference interface
     def render_impl(self, que_imgs_info, ref_imgs_info, is_train, is_perspec=False):
         """One ray batch (network/renderer.py:567-633).  `ref_imgs_info` must carry 'img_feats' and
         (vis-encoded) 'ray_feats' like after lines 641-642 of the reference."""
-        if is_train:
-            raise NotImplementedError('training is out of scope: eval only')
+        self._check_train(is_train)
         imgs = ref_imgs_info['imgs']
         dev = imgs.device
         rr = self._engine(dev)
         frame = ref_imgs_info.get('_pgrf_frame')
         if frame is None:
             frame = self._make_frame(que_imgs_info, ref_imgs_info, is_perspec)
-        out = rr.render_rays(frame, que_imgs_info['coords'][0])
+        out = rr.render_rays(frame, que_imgs_info['coords'][0], is_train=bool(is_train))
         c = self.cfg
         res = {}
         rn = que_imgs_info['coords'].shape[1]
@@ -256,8 +263,7 @@ class NeuralRayBaseRenderer(nn.Module):
     def render(self, que_imgs_info, ref_imgs_info, is_train, is_perspec=False):
         """Whole query view (network/renderer.py:635-686).  Mutates ref_imgs_info['img_feats'/'ray_feats'] and
         que_imgs_info['coords'] like the reference does."""
-        if is_train:
-            raise NotImplementedError('training is out of scope: eval only')
+        self._check_train(is_train)
         ref_img_feats, ray_feats = self._encode(ref_imgs_info['imgs'], ref_imgs_info['ray_feats'])
         ref_imgs_info['img_feats'] = ref_img_feats
         ref_imgs_info['ray_feats'] = ray_feats
@@ -273,7 +279,7 @@ class NeuralRayBaseRenderer(nn.Module):
             que_imgs_info['coords'] = coords[:, s:s + rb]
             info = self.render_impl(que_imgs_info, ref, is_train, is_perspec)
             for k, v in info.items():
-                if k.startswith('hit_prob'):
+                if k.startswith('hit_prob') and not is_train:        # kept in training mode only (renderer.py:675)
                     continue
                 parts.setdefault(k, []).append(v)
         return {k: torch.cat(v, 1) if len(v) > 1 else v[0] for k, v in parts.items()}

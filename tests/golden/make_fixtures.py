@@ -269,9 +269,57 @@ def full_render_fixture(name, seed, rfn, H, W, dn):
           sorted(out.keys()))
 
 
+def train_fixture(name, seed, rfn, H, W, rn, dn):
+    """Training-mode forward (is_train=True) of the reference's render_impl: deterministic coarse depths
+    (renderer.py:607 passes random_sample=False) and random importance samples (renderer.py:437-438).  The uniform
+    draws are reproduced by re-seeding (render_ops.py:449 draws [1,rn,fdn] on the CPU generator; nothing else consumes
+    it) and stored with the outputs; the fixture also holds sample_depth(random_sample=True) for the jitter path."""
+    from network.renderer import NeuralRayBaseRenderer
+    cfg = base_cfg(H, W, dn)
+    torch.manual_seed(seed)
+    r = NeuralRayBaseRenderer(dict(cfg)).eval()
+    boost_density(r, seed + 1)
+    frame = make_frame(seed + 2, rfn, H, W)
+    g = torch.Generator().manual_seed(seed + 3)
+    idx = torch.randperm(H * W, generator=g)[:rn]
+    coords = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+    que = {'c2w': frame['que_c2w'][None], 'w2c': frame['que_w2c'][None], 'coords': coords[None],
+           'depth_range': frame['que_depth_range'][None]}
+    ref = {'imgs': frame['imgs'], 'w2c': frame['w2c'], 'depth_range': frame['ref_depth_range'],
+           'ray_feats': frame['ray_feats'], 'img_feats': frame['img_feats']}
+    from network import render_ops as ro
+    torch.manual_seed(seed + 4)
+    u = torch.rand([1, rn, dn])[0]
+    torch.manual_seed(seed + 4)
+    with torch.no_grad():
+        top = r.render_impl(que, ref, True)
+    torch.manual_seed(seed + 5)
+    jitter = torch.rand(1, rn, dn - 2, dtype=torch.float32)[0]
+    torch.manual_seed(seed + 5)
+    jit_depth = ro.sample_depth(r.cfg, coords[None], dn, True, use_disp=True)[0][0]
+    keep = ['pixel_colors_nr', 'pixel_colors_nr_fine', 'render_depth', 'render_depth_fine', 'density_nr', 'density_nr_fine',
+            'hit_prob_nr', 'hit_prob_nr_fine']
+    arrs = {}
+    arrs.update(to_np(frame, 'in.'))
+    arrs['in.coords'] = coords.numpy()
+    arrs['in.jitter'] = jitter.numpy()
+    arrs['in.u'] = u.numpy()
+    arrs['out.jittered_depth'] = jit_depth.numpy()
+    arrs.update(to_np(per_ray_weights(r), 'w.'))
+    arrs.update(to_np({k: top[k][0] for k in keep}, 'out.'))
+    arrs['out.keys'] = np.frombuffer('\n'.join(sorted(top.keys())).encode(), np.uint8)
+    arrs['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print(name, os.path.getsize(path) // 1024, 'KiB', sorted(top.keys()))
+
+
 def main():
     torch.set_num_threads(1)
     R.setup()
+    if '--train-only' in sys.argv:  # added in round 2: the other fixtures are not regenerated
+        train_fixture('render_train_v2_dn32', seed=1000, rfn=2, H=32, W=64, rn=48, dn=32)
+        return
     if '--full-only' in sys.argv:
         full_render_fixture('render_full_v2_dn32', seed=800, rfn=2, H=32, W=64, dn=32)
         return
@@ -288,6 +336,7 @@ def main():
     full_render_fixture('render_full_v2_dn32', seed=800, rfn=2, H=32, W=64, dn=32)
     # single source view: ray attention is fully masked there (ibrnet.py:358-360) -> uniform weights
     stage_fixture('render_stages_v1_dn32', seed=900, rfn=1, H=32, W=64, rn=12, dn=32, keep_big=False)
+    train_fixture('render_train_v2_dn32', seed=1000, rfn=2, H=32, W=64, rn=48, dn=32)
 
 
 if __name__ == '__main__':

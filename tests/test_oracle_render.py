@@ -101,3 +101,23 @@ def test_oracle_perspective_rays_vs_reference():
     pts, qdir = O.ray_points_perspective(g['persp.coords'], g['persp.pose'], g['persp.K'], g['depth'])
     assert float((pts - g['persp.pts']).abs().max()) < 2e-6
     assert float((qdir - g['persp.que_dir']).abs().max()) < 1e-6
+
+
+def test_training_mode_forward_vs_reference():
+    """is_train=True: deterministic coarse depths + random importance samples, fed with the reference's own uniform
+    draws (tests/golden/make_fixtures.py train_fixture); and sample_depth(random_sample=True) for the jitter path."""
+    torch.set_num_threads(1)
+    frame, w, cfg, g = FX.load('render_train_v2_dn32')
+    gold = g['out']
+    out = O.render_rays(w, frame, frame['coords'], cfg, u=frame['u'])
+    assert FX.max_abs(out['pixel_colors_nr'], gold['pixel_colors_nr']) < 2e-5
+    assert FX.max_abs(out['hit_prob_nr'], gold['hit_prob_nr']) < 2e-5
+    assert FX.max_abs(out['render_depth'], gold['render_depth']) < 2e-4
+    assert FX.psnr(out['pixel_colors_nr_fine'], gold['pixel_colors_nr_fine']) > 80.0
+    assert FX.max_abs(out['render_depth_fine'], gold['render_depth_fine']) < 5e-3
+    rn, dn = frame['coords'].shape[0], cfg['depth_sample_num']
+    d0 = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn)
+    dj = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn, jitter=frame['jitter'])
+    assert FX.max_abs(dj, gold['jittered_depth']) < 2e-6
+    # the jitter really moved the samples, and never past the neighbouring bin
+    assert float((dj - d0).abs().max()) > 1e-3 and bool((dj[:, 1:] > dj[:, :-1]).all())

@@ -51,9 +51,18 @@ def test_render_end_to_end_vs_reference():
     assert FX.psnr(out['pixel_colors_nr'].cpu(), gold['pixel_colors_nr']) > 80
     assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), gold['pixel_colors_nr_fine']) > 60
     assert torch.equal(out['ray_mask_fine'].cpu(), gold['ray_mask_fine'])
-    # training mode is refused, not silently approximated
+    # training mode is forward-only: refused while autograd is on (there is no backward pass) ...
     with pytest.raises(NotImplementedError):
         net({'que_imgs_info': que, 'ref_imgs_info': ref})
+    # ... and under no_grad it returns the reference's training outputs: hit_prob_* kept (renderer.py:675), random
+    # importance samples -> a different fine image, the same deterministic coarse image
+    ref2 = {'imgs': frame['imgs'].cuda(), 'w2c': frame['w2c'].cuda(), 'depth_range': frame['ref_depth_range'].cuda(),
+            'ray_feats': frame['ray_feats'].cuda()}
+    with torch.no_grad():
+        tr = net({'que_imgs_info': que, 'ref_imgs_info': ref2})
+    assert sorted(tr.keys()) == sorted(out_keys + ['hit_prob_nr', 'hit_prob_nr_fine'])
+    assert FX.max_abs(tr['pixel_colors_nr'], out['pixel_colors_nr']) < 1e-6
+    assert FX.max_abs(tr['pixel_colors_nr_fine'], out['pixel_colors_nr_fine']) > 1e-5
 
 
 def test_imgs_info_builders_shapes():
