@@ -165,18 +165,25 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
              [](int m, int r) { return m == 0 ? 3 + r : (r < 3 ? r : -1); });
   // ---- base_fc ----------------------------------------------------------------------
   // columns of base_fc.0: [mean0(35) var0(35) mean1(35) var1(35) | rgb_feat(35) neuray(32)]
+  // k-steps of the view-shared block: the 32 image-feature columns of the four statistics (4 x 16 steps), then the
+  // 3 colour columns of each, packed two per step with no empty slot (6 steps, 70 in all instead of 4 x 19 = 76):
+  //   64: (mean0.r | mean0.g)  65: (var0.r | var0.g)  66: (mean1.r | mean1.g)  67: (var1.r | var1.g)
+  //   68: (mean0.b | mean1.b)  69: (var0.b  | var1.b)         (lane half 0 | lane half 1)
   pack_layer(blob, L_BG, base_fused.data(), 207, base_bias.data(),
              [](int s, int h) {
-               const int stat = s / 19, j = s % 19;
-               if (j < 16) return 35 * stat + 3 + rho(j, h);
-               return h == 0 ? 35 * stat + (j - 16) : -1;
+               if (s < 64) return 35 * (s / 16) + 3 + rho(s % 16, h);
+               const int t = s - 64;
+               if (t < 4) return 35 * t + h;
+               return 35 * ((t - 4) + 2 * h) + 2;
              },
              [](int m, int r) { return 32 * m + r; });
+  // per-view block: image features (16 steps), colour (r | g), (b | -), prob_embed features (16 steps): 34 steps
   pack_layer(blob, L_BV, base_fused.data(), 207, nullptr,
              [](int s, int h) {
                if (s < 16) return 140 + 3 + rho(s, h);
-               if (s < 19) return h == 0 ? 140 + (s - 16) : -1;
-               return 175 + rho(s - 19, h);
+               if (s == 16) return 140 + h;
+               if (s == 17) return h == 0 ? 140 + 2 : -1;
+               return 175 + rho(s - 18, h);
              },
              [](int m, int r) { return 32 * m + r; });
   pack_layer(blob, L_B2, raw[R_BASE_2_W], 64, raw[R_BASE_2_B],

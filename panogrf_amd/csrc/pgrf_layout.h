@@ -56,7 +56,7 @@ enum LayerId {
   L_COUNT
 };
 
-constexpr int kKS[L_COUNT] = {16, 16, 16, 16, 16, 17, 16, 16, 2, 8, 76, 35, 32, 16, 16, 16, 33, 32, 8, 8, 8, 19, 8};
+constexpr int kKS[L_COUNT] = {16, 16, 16, 16, 16, 17, 16, 16, 2, 8, 70, 34, 32, 16, 16, 16, 33, 32, 8, 8, 8, 19, 8};
 constexpr int kMT[L_COUNT] = {4, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 2, 1, 2, 1, 1, 1, 1};
 constexpr bool kHasBias[L_COUNT] = {true, true, true, true, true, true, true, true, true, true, true, false, true,
                                     true, true, true, true, true, false, false, true, true, true};

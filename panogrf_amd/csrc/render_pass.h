@@ -405,7 +405,7 @@ __device__ unsigned long long g_stage_cycles[32];
 
 struct ViewState {
   f32x16 fa;      // rgb_feat tile A (img-feat part, + dir feat); later: x (base_fc output, 32)
-  float fb[3];    // rgb_feat tile B (rgb part + dir feat), meaningful in lanes 0..31
+  float fb[3];    // rgb_feat tile B (rgb part + dir feat), the same value in both lane halves
   f32x16 nf;      // relu(prob_embed.0): prob_embed.2 ("neuray feat") is folded into its consumers' weights
   float dd[4];    // [prj_dir - que_dir, <prj_dir,que_dir>]
   float rgb[3];   // gathered source colour (blended at the end)
@@ -746,10 +746,14 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
       for (int t = 0; t < NT; ++t) a2[t][0] = a2m[t][0];
     } else {
       mfma_layer<8, 2, NT, true>(W + layer_a_off(L_RD2), W + layer_b_off(L_RD2), lane, b8, a2, W + layer_h_off(L_RD2), PGRF_LIMG(L_RD2));
+      // rows 0..2 of tile 1 sit in lane half 0 only; the packed base_fc operands want the colour part in both halves
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgbdir[t][c] = a2[t][1][c];
+        for (int c = 0; c < 3; ++c) {
+          const unsigned x = __float_as_uint(a2[t][1][c]);
+          rgbdir[t][c] = __uint_as_float(__builtin_amdgcn_permlane32_swap(x, x, false, false)[0]);
+        }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -807,20 +811,20 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const float* LI, co
   }
   f32x16 h[NT][2];
   {
-    float b35[NT][35];
+    float b34[NT][34];      // [img feats 16 | (r|g) (b|-) | prob_embed feats 16]: pgrf_layout.h / pack_weights.cpp L_BV
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int v = V0 + t;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) b35[t][s] = vs[v].fa[s];
+      for (int s = 0; s < 16; ++s) b34[t][s] = vs[v].fa[s];
+      b34[t][16] = half ? vs[v].fb[1] : vs[v].fb[0];
+      b34[t][17] = half ? 0.f : vs[v].fb[2];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) b35[t][16 + c] = vs[v].fb[c];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) b35[t][19 + s] = vs[v].nf[s];
+      for (int s = 0; s < 16; ++s) b34[t][18 + s] = vs[v].nf[s];
       h[t][0] = G[0];
       h[t][1] = G[1];
     }
-    mfma_layer<35, 2, NT, false>(W + layer_a_off(L_BV), nullptr, lane, b35, h, W + layer_h_off(L_BV), PGRF_LIMG(L_BV));
+    mfma_layer<34, 2, NT, false>(W + layer_a_off(L_BV), nullptr, lane, b34, h, W + layer_h_off(L_BV), PGRF_LIMG(L_BV));
   }
   f32x16 x[NT][1];
   {
@@ -1073,25 +1077,39 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
   f32x16 G[1][2];
   {
     const float wgt = 1.f / ((float)V + 1e-8f);
-    float b76[1][76];
+    // k-step order of the shared block (pack_weights.cpp L_BG): the four statistics of the 32 image-feature channels
+    // (16 registers each), then the colour channels two per register: (r|g) of each statistic and (b of the w0
+    // statistics | b of the w statistics) — 70 k-steps, no empty lane-half slots
+    float b70[1][70];
+    auto stats = [&](const float (&xv)[V], const float (&wa)[V], float& m, float& var) {
+      m = 0.f;
 #pragma unroll
-    for (int j = 0; j < 19; ++j) {
+      for (int v = 0; v < V; ++v) m += xv[v] * wa[v];
+      var = 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) { const float d = xv[v] - m; var += wa[v] * (d * d); }
+    };
+    float w0a[V], w1a[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { w0a[v] = vs[v].w0; w1a[v] = wgt; }
+#pragma unroll
+    for (int j = 0; j < 17; ++j) {
       float xv[V];
 #pragma unroll
-      for (int v = 0; v < V; ++v) xv[v] = (j < 16) ? vs[v].fa[j < 16 ? j : 0] : vs[v].fb[j >= 16 ? j - 16 : 0];
-      float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-      for (int v = 0; v < V; ++v) { m0 += xv[v] * vs[v].w0; m1 += xv[v] * wgt; }
-      float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-      for (int v = 0; v < V; ++v) {
-        const float d0 = xv[v] - m0, d1 = xv[v] - m1;
-        v0 += vs[v].w0 * (d0 * d0);
-        v1 += wgt * (d1 * d1);
-      }
-      b76[0][j] = m0; b76[0][19 + j] = v0; b76[0][38 + j] = m1; b76[0][57 + j] = v1;
+      for (int v = 0; v < V; ++v) xv[v] = (j < 16) ? vs[v].fa[j < 16 ? j : 0] : (half ? vs[v].fb[1] : vs[v].fb[0]);
+      float m0, v0, m1, v1;
+      stats(xv, w0a, m0, v0);
+      stats(xv, w1a, m1, v1);
+      if (j < 16) { b70[0][j] = m0; b70[0][16 + j] = v0; b70[0][32 + j] = m1; b70[0][48 + j] = v1; }
+      else { b70[0][64] = m0; b70[0][65] = v0; b70[0][66] = m1; b70[0][67] = v1; }
     }
-    mfma_layer<76, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b76, G, W + layer_h_off(L_BG), PGRF_LIMG(L_BG));
+    {
+      float xv[V], wsel[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) { xv[v] = vs[v].fb[2]; wsel[v] = half ? wgt : vs[v].w0; }
+      stats(xv, wsel, b70[0][68], b70[0][69]);
+    }
+    mfma_layer<70, 2, 1, true>(W + layer_a_off(L_BG), W + layer_b_off(L_BG), lane, b70, G, W + layer_h_off(L_BG), PGRF_LIMG(L_BG));
   }
   PGRF_TICK(2);   // stage B
 
