@@ -256,6 +256,36 @@ int pgrf_avgpool3d_2(const float* in, int in_cs, int in_coff, float* out, int ou
 int pgrf_upsample3d_2(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff, int B, int D, int H,
                       int W, int C, void* stream);
 
+/* ------------------------------------------------------------------ per-frame 2-D encoders --- */
+/* ResUNetLight image encoder (network/ops.py:235-455) and DefaultVisEncoder
+ * (network/vis_encoder.py:6-32) on channel-last maps [N,H,W,Cs] with (cs, coff) channel slices (U-Net concatenations
+ * are slices of one buffer).  They run once per frame; `panogrf_amd/encoders_hip.py` is the layer sequence. */
+/* 3x3 (pad 1) or 1x1 convolution, stride 1|2, + bias, + optional residual; padding: zeros along H, circular along W
+ * when wrap_w != 0 (WrapPadding, models/common_blocks.py:258-292) or zeros (the `upconv` blocks, network/ops.py:226-233).
+ * Weights [Cout,Cin,k,k] as in nn.Conv2d, packed once by pgrf_pack_conv2d.  Runs on the implicit-GEMM MFMA kernel of
+ * pgrf_conv3d_wrap on a depth-1 volume.  Cin, Cout multiples of 4. */
+size_t pgrf_conv2d_packed_floats(int Cout, int Cin);
+int pgrf_pack_conv2d(const float* w_host, const float* bias_host, int Cout, int Cin, int ksize, float* packed_host);
+int pgrf_conv2d(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                const float* packed, int has_bias, int wrap_w, int N, int H, int W, int stride, const float* residual,
+                int res_cs, int res_coff, void* stream);
+/* Stem: direct k x k convolution (k odd <= 7, stride 1|2, pad k/2, no bias) of an NCHW input with Cin <= 4 into a
+ * channel-last map; w_dev [Cout,Cin,k,k] DEVICE pointer, Cout 16|32.  ResUNetLight.conv1 (network/ops.py:262-268). */
+int pgrf_conv2d_direct(const float* in_nchw, int N, int Cin, int H, int W, const float* w_dev, int Cout, int ksize, int stride,
+                       int wrap_w, float* out, int out_cs, int out_coff, void* stream);
+/* nn.InstanceNorm2d(C, affine=True, track_running_stats=False) + activation (0 none, 1 ReLU, 2 ELU), with an optional
+ * residual added BEFORE the activation (BasicBlock: relu(bn2(conv2) + shortcut), network/ops.py:127-196).  gamma/beta
+ * may be NULL.  `partial`: caller-owned scratch of N * pgrf_instnorm_chunks(HW) * C * 2 floats.  In place is allowed
+ * (out == x). */
+int pgrf_instnorm_chunks(int HW);
+int pgrf_instnorm(const float* x, int cs, int coff, int C, int N, int HW, const float* gamma, const float* beta, float eps,
+                  int act, const float* residual, int res_cs, int res_coff, float* out, int out_cs, int out_coff,
+                  float* partial, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=...) between channel-last maps (network/ops.py:226-233 upconv x2 with
+ * align_corners=True; network/vis_encoder.py:27-29 resize to the ray-feature resolution with align_corners=False). */
+int pgrf_resize_bilinear(const float* in, int in_cs, int in_coff, int C, int N, int H, int W, float* out, int out_cs, int out_coff,
+                         int Ho, int Wo, int align_corners, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

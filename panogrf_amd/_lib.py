@@ -85,6 +85,17 @@ SYMBOLS = {
     "pgrf_render_workspace_bytes": (C.c_size_t, [C.POINTER(PgrfFrame), C.POINTER(PgrfRenderCfg), C.c_int]),
     "pgrf_render_rays": (C.c_int, [C.POINTER(PgrfFrame), _P, _P, C.POINTER(PgrfRenderCfg), _P, C.c_int,
                                    C.POINTER(PgrfPassOut), C.POINTER(PgrfPassOut), _P, _P, C.c_size_t, _P]),
+    "pgrf_conv2d_packed_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "pgrf_pack_conv2d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "pgrf_conv2d": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "pgrf_conv2d_direct": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
+                                     C.c_int, C.c_int, _P]),
+    "pgrf_instnorm_chunks": (C.c_int, [C.c_int]),
+    "pgrf_instnorm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P, C.c_int,
+                                C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    "pgrf_resize_bilinear": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_render_rays_train": (C.c_int, [C.POINTER(PgrfFrame), _P, _P, C.POINTER(PgrfRenderCfg), _P, C.c_int, _P, _P,
                                          C.POINTER(PgrfPassOut), C.POINTER(PgrfPassOut), _P, _P, _P, C.c_size_t, _P]),
 }

@@ -43,6 +43,7 @@ struct ConvArgs {
   int wtaps;              // 27, or 1 = pointwise (1x1x1) product with the centre tap only
   int tapmajor;           // pointwise projection of the Cout == 1 fast path: write out[row][voxel] (row < 27) instead of
                           // channel-last, so that the 27-tap gather that follows reads consecutive voxels of one row
+  int wrap_w;             // 1: circular padding along W (ERP wrap); 0: zeros (the 2-D `upconv` blocks, network/ops.py:226-233)
 };
 
 // packed weight index helpers (shared with the host packer below)
@@ -111,20 +112,24 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
   // arithmetic, range checks or selects on the vector ALU (they were 2 VALU instructions per MFMA, and the f32 MFMA
   // shares its pipe with the VALU).
   unsigned voff[NT][3];
+  unsigned xbad[NT];          // bit dx: the W neighbour is outside the map and the padding is zeros (wrap_w == 0)
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    xbad[t] = 0;
 #pragma unroll
     for (int dxi = 0; dxi < 3; ++dxi) {
       int xi = xin[t] + dxi - 1;
+      if (!a.wrap_w && (xi < 0 || xi >= a.W)) xbad[t] |= 1u << dxi;
       xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);          // circular along W
       voff[t][dxi] = ((unsigned)(cen[t] + xi) * (unsigned)a.in_cs + (unsigned)(a.in_coff + kk * 16)) * 4u;
     }
+  }
   // Wave-level classification of the three depth and the three height offsets:
   //   zm/ym  : SOME lane has an in-range source for this offset (otherwise the tap is skipped: whole footprint in the
   //            zero padding; a superset is enough, so the 27 taps are the outer product of 3 + 3 flags);
   //   zam/yam: EVERY lane of every tile has one -> the tap's loads need no mask at all (fast path, > 95 % of the
   //            tiles of a volume); the others (volume faces, ragged last tile) take the masked path.
-  unsigned tapmask = 0, zam = 0, yam = 0;
+  unsigned tapmask = 0, zam = 0, yam = 0, zm_ = 0, ym_ = 0;
   {
     bool zany[3] = {false, false, false}, yany[3] = {false, false, false};
     bool zall[3] = {true, true, true}, yall[3] = {true, true, true};
@@ -147,6 +152,7 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
     }
     for (int r = 0; r < 9; ++r)
       if (((zm >> (r / 3)) & 1u) && ((ym >> (r % 3)) & 1u)) tapmask |= 1u << r;     // bit r = tap row (dz, dy) = (r/3, r%3)
+    zm_ = zm; ym_ = ym;
   }
   if (a.wtaps == 1) tapmask &= 1u << 4;                                 // pointwise: centre tap only
 #ifdef PGRF_CONV_NO_FAST   // experiment: every tap through the masked path
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
     st.c0 = ch * 32 + kk * 16;
     // wave-uniform part of the address: the tap's row offset and the channel chunk
     const char* sb = reinterpret_cast<const char*>(a.in) + ((long long)((dzi - 1) * a.H + (dyi - 1)) * a.W * a.in_cs + ch * 32) * 4;
-    const bool fast = full_chunks && ((zam >> dzi) & (yam >> dyi) & 1u);
+    const bool fast = full_chunks && a.wrap_w && ((zam >> dzi) & (yam >> dyi) & 1u);
     st.need_mask = !fast;
     if (fast) {
 #pragma unroll
@@ -189,7 +195,8 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
       const char* cb = reinterpret_cast<const char*>(a.in) + (long long)ch * 128;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        st.ok[t] = vok[t] && (unsigned)(zin[t] + dzi - 1) < (unsigned)a.D && (unsigned)(yin[t] + dyi - 1) < (unsigned)a.H;  // zeros along D, H
+        st.ok[t] = vok[t] && (unsigned)(zin[t] + dzi - 1) < (unsigned)a.D && (unsigned)(yin[t] + dyi - 1) < (unsigned)a.H &&
+                   !((xbad[t] >> dxi) & 1u);                                                              // zeros along D, H (and W)
         // always-valid address (the centre voxel when the tap is padding): loads are unconditional and issue back to
         // back; padding, ragged tiles and the channel tail are applied by a select at use
         const char* ip = st.ok[t] ? sb + voff[t][dxi] : cb + voff[t][1];
@@ -301,11 +308,13 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
   typedef std::integral_constant<int, 0> DX0;
   typedef std::integral_constant<int, 1> DX1;
   typedef std::integral_constant<int, 2> DX2;
-  // Interior waves (every lane of every tile has all 27 taps in range; > 90 % of a volume): a loop of fused steps with
+  // Interior waves (every lane of every tile has all its taps in range; > 90 % of a volume): a loop of fused steps with
   // no padding logic at all.  Everything else (volume faces, ragged last tile, channel tails, pointwise mode): the
   // generic loop with masked loads.
-  const bool interior = kFuse && full_chunks && zam == 7u && yam == 7u && a.wtaps == 27 && tapmask == 0x1ffu;
-  if (interior) {
+  // (every tap row that is needed at all is in range for every lane: also the depth-1 volumes of the 2-D encoders, whose
+  // dz = +-1 rows are skipped as a whole)
+  const bool interior = kFuse && full_chunks && a.wrap_w && zam == zm_ && yam == ym_ && a.wtaps == 27 && tapmask != 0u;
+  if (interior && row >= 0) {              // (row < 0: a split-K wave that got no macro step)
     Step P;
     P.need_mask = false;
     issue(P, row, ch, DX0());                  // fast path of issue(): plain loads
@@ -746,9 +755,9 @@ int pgrf_pack_conv3d(const float* w_host, const float* bias_host, int Cout, int 
   return PGRF_OK;
 }
 
-int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
-                     const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
-                     const float* residual, int res_cs, int res_coff, void* stream) {
+static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                            const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
+                            const float* residual, int res_cs, int res_coff, int wrap_w, void* stream) {
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wrap: null pointer");
   if (stride != 1 && stride != 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wrap: stride %d", stride);
   if (B < 1 || D < 1 || H < 1 || W < 2) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wrap: bad dims");
@@ -763,7 +772,7 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
   a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
   a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
   a.chunks = (Cin + 31) / 32; a.cot_total = (Cout + 31) / 32;
-  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0; a.wrap_w = wrap_w;
   const size_t a_floats = (size_t)a.cot_total * 27 * a.chunks * 1024;
   a.wpk = packed;
   a.bias = has_bias ? packed + a_floats : nullptr;
@@ -808,6 +817,41 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
 #undef PGRF_LAUNCH
   PGRF_CHECK_LAUNCH("conv3d_wrap");
   return PGRF_OK;
+}
+
+int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                     const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
+                     const float* residual, int res_cs, int res_coff, void* stream) {
+  return conv3d_wrap_impl(in, in_cs, in_coff, Cin, out, out_cs, out_coff, Cout, packed, has_bias, B, D, H, W, stride,
+                          lrelu_slope, residual, res_cs, res_coff, 1, stream);
+}
+
+// ---- 2-D convolutions of the per-frame encoders: the same kernel on a depth-1 volume ------------------------------
+// (the depth taps dz = +-1 fall into the zero padding for every lane and are skipped by the wave-level tap mask, so a
+// 3x3 conv costs 9 taps; a 1x1 conv is packed as a 3x3 kernel whose only non-zero tap is the centre)
+size_t pgrf_conv2d_packed_floats(int Cout, int Cin) { return pgrf_conv3d_packed_floats(Cout, Cin); }
+
+int pgrf_pack_conv2d(const float* w_host, const float* bias_host, int Cout, int Cin, int ksize, float* packed_host) {
+  if (!w_host || !packed_host) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv2d: null pointer");
+  if (ksize != 1 && ksize != 3) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv2d: kernel size %d (1 or 3)", ksize);
+  if (Cout < 1 || Cin < 1) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv2d: bad channels");
+  float* w3 = (float*)std::calloc((size_t)Cout * Cin * 27, sizeof(float));
+  if (!w3) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv2d: out of host memory");
+  for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc) {
+    if (ksize == 3) for (int t = 0; t < 9; ++t) w3[oc * 27 + 9 + t] = w_host[oc * 9 + t];
+    else w3[oc * 27 + 13] = w_host[oc];
+  }
+  const int rc = pgrf_pack_conv3d(w3, bias_host, Cout, Cin, packed_host);
+  std::free(w3);
+  return rc;
+}
+
+int pgrf_conv2d(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                const float* packed, int has_bias, int wrap_w, int N, int H, int W, int stride, const float* residual,
+                int res_cs, int res_coff, void* stream) {
+  if (Cout == 1) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv2d: Cout == 1");
+  return conv3d_wrap_impl(in, in_cs, in_coff, Cin, out, out_cs, out_coff, Cout, packed, has_bias, N, 1, H, W, stride, 1.f,
+                          residual, res_cs, res_coff, wrap_w ? 1 : 0, stream);
 }
 
 // ---- narrow layers (conv3d_small_kernel) -------------------------------------------------------------------------
@@ -864,7 +908,7 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
   a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff;
   a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
   a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
-  a.chunks = 1; a.cot_total = 1; a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0;
+  a.chunks = 1; a.cot_total = 1; a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0; a.wrap_w = 1;
   if (nshift > 1 && (stride != 1 || a.Do % nshift))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small: nshift %d needs stride 1 and D %% nshift == 0", nshift);
   sa.ns = nshift; sa.nsteps = small_steps(Cin, nshift);
@@ -908,7 +952,7 @@ int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, 
   ConvArgs a;
   a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = y; a.out_cs = 32; a.out_coff = 0; a.Cout = 32;
   a.B = B; a.D = D; a.H = H; a.W = W; a.stride = 1; a.slope = 1.f; a.Do = D; a.Ho = H; a.Wo = W;
-  a.chunks = (Cin + 31) / 32; a.cot_total = 1; a.residual = nullptr; a.res_cs = 0; a.res_coff = 0; a.wtaps = 1; a.tapmajor = 1;
+  a.chunks = (Cin + 31) / 32; a.cot_total = 1; a.residual = nullptr; a.res_cs = 0; a.res_coff = 0; a.wtaps = 1; a.tapmajor = 1; a.wrap_w = 1;
   const size_t a_floats = (size_t)27 * a.chunks * 1024;
   a.wpk = packed + a_floats + 32 + (((size_t)27 * Cin + 1 + 3) & ~(size_t)3);
   a.bias = nullptr;

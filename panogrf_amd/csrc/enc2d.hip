@@ -1,0 +1,285 @@
+// Per-frame 2-D encoder primitives for gfx950: what ResUNetLight (network/ops.py:235-455)
+// and DefaultVisEncoder (network/vis_encoder.py:6-32) need besides the 3x3 / 1x1 convolutions, which run on the
+// implicit-GEMM MFMA kernel of conv3d.hip (pgrf_conv2d):
+//   * the stem: 7x7 stride-2 convolution of the NCHW input image (3 channels) with ERP wrap padding -> channel-last map
+//   * InstanceNorm2d(affine) in two launches: per-chunk partial sums, then normalise + activation (+ residual)
+//   * bilinear resize (align_corners on/off) between channel-last maps, writing into a channel slice (U-Net concats)
+// All maps are channel-last [N,H,W,Cs] with (cs, coff) slices like the 3-D volumes.  These layers run once per frame
+// on a few MB: they are launch/latency bound, so the point is few, fused launches (MIOpen + torch elementwise needs
+// ~250 launches per frame for the same work), not roofline.
+#include <hip/hip_runtime.h>
+
+#include "pgrf_internal.h"
+
+namespace pgrf {
+
+#define PGRF_CHECK_LAUNCH(what)                                                                       \
+  do {                                                                                                \
+    const hipError_t e__ = hipGetLastError();                                                         \
+    if (e__ != hipSuccess) return set_error(PGRF_ERR_LAUNCH, what " launch failed: %s", hipGetErrorString(e__)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Direct KxK convolution of a narrow NCHW input (Cin <= 4): the stem conv1 = WrapPadding(3) + Conv2d(3, 16, 7, 2)
+// (network/ops.py:262-268, models/common_blocks.py:258-292: zeros along H, circular along W).  One thread = PX
+// consecutive output pixels of a row x COUT channels: the weights sit in LDS as [cin][ky][kx][COUT] and every
+// broadcast float4 read of them feeds PX pixels.  Measured for 2 x 512 x 1024 -> 16 channels: PX = 1 58 us, PX = 2 62 us,
+// PX = 4 82 us (fewer waves left to hide the strided input loads), so the launcher uses PX = 1.
+template <int COUT, int PX>
+__global__ void __launch_bounds__(256) conv2d_direct_kernel(const float* __restrict__ in, int N, int Cin, int H, int W,
+                                                            const float* __restrict__ wgt /* [COUT][Cin][K][K] */, int K,
+                                                            int stride, int wrap_w, float* __restrict__ out, int out_cs,
+                                                            int out_coff, int Ho, int Wo) {
+  extern __shared__ float s_w[];          // [Cin*K*K][COUT]
+  const int taps = Cin * K * K;
+  for (int i = threadIdx.x; i < taps * COUT; i += blockDim.x) {
+    const int co = i % COUT, t = i / COUT;
+    s_w[i] = wgt[(size_t)co * taps + t];
+  }
+  __syncthreads();
+  const int Wg = (Wo + PX - 1) / PX;                      // pixel groups per row
+  const long long total = (long long)N * Ho * Wg;
+  const int pad = K / 2;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+    const int xg = (int)(p % Wg);
+    const int yo = (int)((p / Wg) % Ho);
+    const int n = (int)(p / ((long long)Wg * Ho));
+    const int xo0 = xg * PX;
+    float acc[PX][COUT];
+#pragma unroll
+    for (int j = 0; j < PX; ++j)
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc[j][c] = 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* ip = in + ((size_t)n * Cin + ci) * H * W;
+      for (int ky = 0; ky < K; ++ky) {
+        const int yi = yo * stride + ky - pad;
+        if (yi < 0 || yi >= H) continue;                       // zeros along H
+        const float* rowp = ip + (size_t)yi * W;
+        for (int kx = 0; kx < K; ++kx) {
+          float v[PX];
+#pragma unroll
+          for (int j = 0; j < PX; ++j) {
+            int xi = (xo0 + j) * stride + kx - pad;
+            bool ok = true;
+            if (xi < 0 || xi >= W) {
+              if (wrap_w) xi = xi < 0 ? xi + W : (xi >= W ? xi - W : xi);     // circular along W
+              else ok = false;
+              if (xi >= W) { xi = W - 1; ok = false; }          // ragged last group: pixel beyond the row
+            }
+            v[j] = ok ? rowp[xi] : 0.f;
+          }
+          const float4* wp = reinterpret_cast<const float4*>(s_w + ((ci * K + ky) * K + kx) * COUT);
+#pragma unroll
+          for (int q = 0; q < COUT / 4; ++q) {
+            const float4 w4 = wp[q];
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+              acc[j][4 * q] = fmaf(v[j], w4.x, acc[j][4 * q]); acc[j][4 * q + 1] = fmaf(v[j], w4.y, acc[j][4 * q + 1]);
+              acc[j][4 * q + 2] = fmaf(v[j], w4.z, acc[j][4 * q + 2]); acc[j][4 * q + 3] = fmaf(v[j], w4.w, acc[j][4 * q + 3]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      if (xo0 + j >= Wo) continue;
+      float* op = out + ((((size_t)n * Ho + yo) * Wo) + xo0 + j) * out_cs + out_coff;
+#pragma unroll
+      for (int q = 0; q < COUT / 4; ++q)
+        *reinterpret_cast<float4*>(op + 4 * q) = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// InstanceNorm2d statistics: block (n, chunk) sums x and x^2 of its pixel range for every channel.
+// Thread layout: C/4 channel quads x 256/(C/4) pixel lanes; pixel lanes are combined through LDS.
+__global__ void __launch_bounds__(256) instnorm_stats_kernel(const float* __restrict__ x, int cs, int coff, int C, int HW,
+                                                             int nchunk, float* __restrict__ partial /* [N][nchunk][C][2] */) {
+  __shared__ float s_red[256 * 8];
+  const int quads = C / 4, plan = 256 / quads;             // C <= 256, a multiple of 4 and dividing 1024
+  const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * per, p1 = min(p0 + per, HW);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pl < plan) {
+    const float* xp = x + (size_t)n * HW * cs + coff + q * 4;
+    for (int p = p0 + pl; p < p1; p += plan) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + (size_t)p * cs);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      ss[0] = fmaf(v.x, v.x, ss[0]); ss[1] = fmaf(v.y, v.y, ss[1]); ss[2] = fmaf(v.z, v.z, ss[2]); ss[3] = fmaf(v.w, v.w, ss[3]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s_red[threadIdx.x * 8 + i] = s[i]; s_red[threadIdx.x * 8 + 4 + i] = ss[i]; }
+  __syncthreads();
+  if (threadIdx.x < quads) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < plan; ++l)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += s_red[(l * quads + threadIdx.x) * 8 + i];
+    float* pp = partial + (((size_t)n * nchunk + chunk) * C + threadIdx.x * 4) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pp[2 * i] = a[i]; pp[2 * i + 1] = a[4 + i]; }
+  }
+}
+
+// y = act((x - mean) * rstd * gamma + beta [+ residual]); act: 0 none, 1 ReLU, 2 ELU.  Biased variance, as
+// nn.InstanceNorm2d(track_running_stats=False) computes it; the partial sums are combined in double.
+__global__ void __launch_bounds__(256) instnorm_apply_kernel(const float* __restrict__ x, int cs, int coff, int C, int N, int HW,
+                                                             const float* __restrict__ partial, int nchunk,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int act, const float* __restrict__ residual, int res_cs,
+                                                             int res_coff, float* __restrict__ out, int out_cs, int out_coff) {
+  __shared__ float s_scale[256], s_shift[256];
+  const int n = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s = 0.0, ss = 0.0;
+    const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)n * nchunk * C + c;
+#pragma unroll 8
+    for (int k = 0; k < nchunk; ++k) {           // independent loads, issued together
+      const float2 v = pp[(size_t)k * C];
+      s += (double)v.x; ss += (double)v.y;
+    }
+    const double mean = s / (double)HW;
+    double var = ss / (double)HW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    s_scale[c] = rstd * g;
+    s_shift[c] = b - (float)mean * rstd * g;
+  }
+  __syncthreads();
+  const int quads = C / 4;
+  const long long total = (long long)HW * quads;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % quads);
+    const size_t p = (size_t)(i / quads) + (size_t)n * HW;
+    const float4 v = *reinterpret_cast<const float4*>(x + p * cs + coff + q * 4);
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = fmaf(r[k], s_scale[q * 4 + k], s_shift[q * 4 + k]);
+    if (residual) {
+      const float4 rv = *reinterpret_cast<const float4*>(residual + p * res_cs + res_coff + q * 4);
+      r[0] += rv.x; r[1] += rv.y; r[2] += rv.z; r[3] += rv.w;
+    }
+    if (act == 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = fmaxf(r[k], 0.f);
+    } else if (act == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = r[k] > 0.f ? r[k] : expm1f(r[k]);
+    }
+    *reinterpret_cast<float4*>(out + p * out_cs + out_coff + q * 4) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// F.interpolate(mode='bilinear') between channel-last maps, align_corners on or off (PyTorch's source-index rules:
+// aten/src/ATen/native/UpSample.h area_pixel_compute_source_index); thread per (output pixel, 4-channel group).
+__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __restrict__ in, int in_cs, int in_coff, int C, int N,
+                                                              int H, int W, float* __restrict__ out, int out_cs, int out_coff,
+                                                              int Ho, int Wo, int align) {
+  const int quads = C / 4;
+  const long long total = (long long)N * Ho * Wo * quads;
+  const float sy = align ? (Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f) : (float)H / (float)Ho;
+  const float sx = align ? (Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f) : (float)W / (float)Wo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % quads);
+    long long p = i / quads;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float fy = align ? sy * (float)yo : fmaxf(sy * ((float)yo + 0.5f) - 0.5f, 0.f);
+    float fx = align ? sx * (float)xo : fmaxf(sx * ((float)xo + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* bp = in + (size_t)n * H * W * in_cs + in_coff + q * 4;
+    const float4 a = *reinterpret_cast<const float4*>(bp + ((size_t)y0 * W + x0) * in_cs);
+    const float4 b = *reinterpret_cast<const float4*>(bp + ((size_t)y0 * W + x1) * in_cs);
+    const float4 c = *reinterpret_cast<const float4*>(bp + ((size_t)y1 * W + x0) * in_cs);
+    const float4 d = *reinterpret_cast<const float4*>(bp + ((size_t)y1 * W + x1) * in_cs);
+    float4 r;
+    r.x = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+    r.y = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+    r.z = hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
+    r.w = hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
+    *reinterpret_cast<float4*>(out + (((size_t)n * Ho + yo) * Wo + xo) * out_cs + out_coff + q * 4) = r;
+  }
+}
+
+static int grid_for(long long total, int cap = 8192) {
+  long long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace pgrf
+
+using namespace pgrf;
+
+extern "C" {
+
+int pgrf_conv2d_direct(const float* in_nchw, int N, int Cin, int H, int W, const float* w_dev, int Cout, int ksize, int stride,
+                       int wrap_w, float* out, int out_cs, int out_coff, void* stream) {
+  if (!in_nchw || !w_dev || !out) return set_error(PGRF_ERR_ARG, "pgrf_conv2d_direct: null pointer");
+  if (Cin < 1 || Cin > 4 || (ksize & 1) == 0 || ksize < 1 || ksize > 7 || (stride != 1 && stride != 2))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv2d_direct: Cin %d (1..4), ksize %d (odd <= 7), stride %d (1|2)", Cin, ksize, stride);
+  if (!(Cout == 16 || Cout == 32) || (out_cs & 3) || (out_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv2d_direct: Cout %d (16|32), channel stride/offset multiples of 4", Cout);
+  if (N < 1 || H < 1 || W < 1) return set_error(PGRF_ERR_ARG, "pgrf_conv2d_direct: bad dims");
+  const int pad = ksize / 2;
+  const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  const size_t shmem = (size_t)Cin * ksize * ksize * Cout * sizeof(float);
+  if (Cout == 16) {
+    const long long total = (long long)N * Ho * Wo;
+    hipLaunchKernelGGL((conv2d_direct_kernel<16, 1>), dim3(grid_for(total)), dim3(256), shmem, (hipStream_t)stream, in_nchw, N, Cin, H, W,
+                       w_dev, ksize, stride, wrap_w, out, out_cs, out_coff, Ho, Wo);
+  } else {
+    const long long total = (long long)N * Ho * Wo;
+    hipLaunchKernelGGL((conv2d_direct_kernel<32, 1>), dim3(grid_for(total)), dim3(256), shmem, (hipStream_t)stream, in_nchw, N, Cin, H, W,
+                       w_dev, ksize, stride, wrap_w, out, out_cs, out_coff, Ho, Wo);
+  }
+  PGRF_CHECK_LAUNCH("conv2d_direct");
+  return PGRF_OK;
+}
+
+int pgrf_instnorm_chunks(int HW) {               // pixel chunks (= workgroups) per image: ~512 pixels each, at most 32
+  int n = (HW + 511) / 512;                      // (few partials: the apply kernel sums them per channel before it starts)
+  return n < 1 ? 1 : (n > 32 ? 32 : n);
+}
+
+int pgrf_instnorm(const float* x, int cs, int coff, int C, int N, int HW, const float* gamma, const float* beta, float eps,
+                  int act, const float* residual, int res_cs, int res_coff, float* out, int out_cs, int out_coff,
+                  float* partial, void* stream) {
+  if (!x || !out || !partial) return set_error(PGRF_ERR_ARG, "pgrf_instnorm: null pointer");
+  if (C < 4 || C > 256 || (C & 3) || 1024 % C != 0 || (cs & 3) || (coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_instnorm: C %d (power of two in [4,256]); strides/offsets multiples of 4", C);
+  if (N < 1 || HW < 1 || act < 0 || act > 2) return set_error(PGRF_ERR_ARG, "pgrf_instnorm: bad arguments");
+  const int nchunk = pgrf_instnorm_chunks(HW);
+  hipLaunchKernelGGL(instnorm_stats_kernel, dim3(nchunk, N), dim3(256), 0, (hipStream_t)stream, x, cs, coff, C, HW, nchunk, partial);
+  PGRF_CHECK_LAUNCH("instnorm_stats");
+  const long long total = (long long)HW * (C / 4);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total, 1024), N), dim3(256), 0, (hipStream_t)stream, x, cs, coff, C, N, HW,
+                     partial, nchunk, gamma, beta, eps, act, residual, res_cs, res_coff, out, out_cs, out_coff);
+  PGRF_CHECK_LAUNCH("instnorm_apply");
+  return PGRF_OK;
+}
+
+int pgrf_resize_bilinear(const float* in, int in_cs, int in_coff, int C, int N, int H, int W, float* out, int out_cs, int out_coff,
+                         int Ho, int Wo, int align_corners, void* stream) {
+  if (!in || !out) return set_error(PGRF_ERR_ARG, "pgrf_resize_bilinear: null pointer");
+  if ((C & 3) || C < 4 || (in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_resize_bilinear: C and strides/offsets must be multiples of 4");
+  if (N < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return set_error(PGRF_ERR_ARG, "pgrf_resize_bilinear: bad dims");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_cs, in_coff, C, N, H, W,
+                     out, out_cs, out_coff, Ho, Wo, align_corners ? 1 : 0);
+  PGRF_CHECK_LAUNCH("resize_bilinear");
+  return PGRF_OK;
+}
+
+}  // extern "C"

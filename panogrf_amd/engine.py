@@ -71,6 +71,17 @@ def pack_map(t):
     return out
 
 
+def _channel_last(t, dev):
+    """[n,C,h,w] -> channel-last [n,h,w,C].  A tensor that already is an NCHW-shaped view of channel-last memory (what the
+    HIP encoders return, or torch.channels_last) is taken as it is; anything else goes through pgrf_pack_map."""
+    t = t.detach()
+    if t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.dim() == 4 and t.shape[1] % 4 == 0:
+        v = t.permute(0, 2, 3, 1)
+        if v.is_contiguous():
+            return v
+    return pack_map(_f32c(t, dev))
+
+
 class Frame:
     """Source-view data of one frame in the layout the kernels read (PgrfFrame)."""
 
@@ -92,13 +103,12 @@ class Frame:
             que_c2w = torch.cat([rot, trans], 1)
             self.que_kinv = [float(x) for x in torch.inverse(_f32c(que_K, 'cpu').reshape(3, 3)).reshape(-1)]
         dev = torch.device(device)
-        imgs, img_feats, ray_feats = _f32c(imgs, dev), _f32c(img_feats, dev), _f32c(ray_feats, dev)
         if img_feats.shape[1] != FEAT_CH or ray_feats.shape[1] != FEAT_CH or imgs.shape[1] != 3:
             raise PgrfError(f"expected imgs [rfn,3,H,W], img_feats/ray_feats [rfn,{FEAT_CH},h,w]")
         self.rfn, _, self.H, self.W = imgs.shape
-        self.imgs = pack_map(imgs)
-        self.img_feats = pack_map(img_feats)
-        self.ray_feats = pack_map(ray_feats)
+        self.imgs = pack_map(_f32c(imgs, dev))
+        self.img_feats = _channel_last(img_feats, dev)
+        self.ray_feats = _channel_last(ray_feats, dev)
         self.w2c = _f32c(w2c, dev).reshape(self.rfn, 12)
         self.ref_dr = _f32c(ref_depth_range, dev).reshape(self.rfn, 2)
         self.que_c2w = [float(x) for x in _f32c(que_c2w, 'cpu').reshape(-1)[:12]]

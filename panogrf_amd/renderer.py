@@ -216,14 +216,31 @@ class NeuralRayBaseRenderer(nn.Module):
                 res['render_depth' + suffix] = out['render_depth' + suffix].unsqueeze(0)
         return res
 
+    def _torch_encoders(self, imgs, ray_feats):
+        feats = self.image_encoder(imgs)
+        return feats, self.vis_encoder(ray_feats, feats)
+
+    def _encoder_fn(self, imgs):
+        """The per-frame encoders run on the HIP library (panogrf_amd/encoders_hip.py) when the input is
+        on the GPU, autograd is off and the frame size allows it (H, W multiples of 16); cfg['hip_encoders']=False, or
+        any other case, keeps the same modules on PyTorch-ROCm / MIOpen."""
+        h, w = imgs.shape[-2:]
+        if not (imgs.is_cuda and self.cfg.get('hip_encoders', True)) or torch.is_grad_enabled() or h % 16 or w % 16:
+            return self._torch_encoders
+        he = self.__dict__.get('_hip_enc')
+        if he is None or he.device != imgs.device:
+            from .encoders_hip import HipEncoders
+            he = self.__dict__['_hip_enc'] = HipEncoders(self.image_encoder, self.vis_encoder, imgs.device)
+        return he
+
     def _encode(self, imgs, ray_feats):
         """The two per-frame 2-D encoders (network/renderer.py:639-642).  On a GPU their ~70 small kernels are
         launch-bound (3.4 ms eager for 2x512x1024), so the launch sequence is captured once per input shape into a
         hipGraph and replayed (1.9 ms); cfg['hip_graph_encoders']=False keeps eager launches."""
+        enc = self._encoder_fn(imgs)
         if not (imgs.is_cuda and self.cfg.get('hip_graph_encoders', True)) or torch.is_grad_enabled():
-            feats = self.image_encoder(imgs)
-            return feats, self.vis_encoder(ray_feats, feats)
-        key = (tuple(imgs.shape), tuple(ray_feats.shape), imgs.device, imgs.dtype, ray_feats.dtype)
+            return enc(imgs, ray_feats)
+        key = (tuple(imgs.shape), tuple(ray_feats.shape), imgs.device, imgs.dtype, ray_feats.dtype, enc is self._torch_encoders)
         graphs = self.__dict__.setdefault('_enc_graphs', {})
         ent = graphs.get(key)
         if ent is None:
@@ -231,14 +248,12 @@ class NeuralRayBaseRenderer(nn.Module):
             side = torch.cuda.Stream(device=imgs.device)
             side.wait_stream(torch.cuda.current_stream(imgs.device))
             with torch.cuda.stream(side):
-                for _ in range(2):                      # warm-up outside capture (MIOpen find, workspace allocations)
-                    f = self.image_encoder(s_imgs)
-                    self.vis_encoder(s_rf, f)
+                for _ in range(2):                      # warm-up outside capture (weight packing, MIOpen find, allocations)
+                    enc(s_imgs, s_rf)
             torch.cuda.current_stream(imgs.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
-                o_feats = self.image_encoder(s_imgs)
-                o_rf = self.vis_encoder(s_rf, o_feats)
+                o_feats, o_rf = enc(s_imgs, s_rf)
             ent = graphs[key] = (g, s_imgs, s_rf, o_feats, o_rf)
         g, s_imgs, s_rf, o_feats, o_rf = ent
         s_imgs.copy_(imgs)

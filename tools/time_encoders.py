@@ -38,3 +38,22 @@ with torch.no_grad():
         feats_g = enc(imgs)
         out_g = vis(ray_feats, feats_g)
     print(f'encoders, hipGraph replay: {timeit(g.replay):.2f} ms (eager {timeit(lambda: vis(ray_feats, enc(imgs))):.2f} ms)')
+
+# the same layers on the HIP library (panogrf_amd/encoders_hip.py)
+from panogrf_amd.encoders_hip import HipEncoders
+with torch.no_grad():
+    he = HipEncoders(enc, vis, dev)
+    f_h, r_h = he(imgs, ray_feats)
+    f_t = enc(imgs); r_t = vis(ray_feats, f_t)
+    print('HIP vs torch: max rel err feats %.2e  ray_feats %.2e' % (float((f_h - f_t).abs().max() / f_t.abs().max()),
+                                                                  float((r_h - r_t).abs().max() / r_t.abs().max())))
+    print(f'encoders on HIP, eager launches: {timeit(lambda: he(imgs, ray_feats)):.2f} ms')
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            he(imgs, ray_feats)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        o = he(imgs, ray_feats)
+    print(f'encoders on HIP, hipGraph replay: {timeit(g2.replay):.2f} ms')
