@@ -1,0 +1,313 @@
+"""MVS stage around the spherical cost volume: the host mirror of what
+`NeuralRayGenRenderer` calls as `init_net(ref_imgs_info, src_imgs_info, is_train)`.
+
+  CostVolumeInitNet  (network/init_net.py:423-650)      depth_net + res_net + depth_conv + out_conv -> ray_feats
+  MVSDepthNet        (network/omni_mvsnet/pipeline3_model.py FullPipeline, the `net: Equi`, `cost_volume: v3_erp`,
+                      `contain_dnet` configuration that ships)  mono prior -> hypotheses -> feature net -> cost volume ->
+                      3-D regulariser -> 2-D decoders -> depth
+  Equi               (models/my_equi.py:15-141)         ERP ResNet-18 encoder + 3-level decoder -> 32 channels at 1/4
+
+Sub-module and parameter names are the reference's (`depth_net.unet.equi_encoder.layer1.0.conv1.weight`,
+`depth_net.unet3d.*`, `depth_net.decoders2.0.conv1.weight`, `res_net.*`, `depth_conv.*`, `out_conv.*`), so
+`init_net.*` entries of a reference checkpoint load unchanged.  The hypotheses, the cost volume and the 3-D
+regulariser run on the HIP library (no fallback); the 2-D networks of this stage are per-frame CNNs kept on
+PyTorch-ROCm.  NOT mirrored: the UniFuse mono-depth net and its cube-map conversion (out
+of scope): `d_net` is any module called as `d_net(erp_normalised [n,3,mh,mw], None, dnet=True)` and returning
+`{'pred_depth': [n,1,.,.], 'mono_feat': [n,32,.,.]}` (the reference's call at pipeline3_model.py:664-671), or the
+caller passes the mono outputs directly.  Pinned by tests/golden/mvs_fixtures.npz (the reference's own methods run
+with a stand-in mono net).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._lib import PgrfError
+from . import cost_volume as CV
+from .cost_reg import build_unet3d
+from .encoders import ErpPad, ResUNetLight, PreActRes, erp_conv
+
+
+# ------------------------------------------------------------------------------------------------ Equi feature net
+class ErpConv2d(nn.Conv2d):
+    """nn.Conv2d after models/convert_module.py:erp_convert: zeros above/below, circular left/right, then a valid conv."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, bias=False):
+        super().__init__(cin, cout, k, stride, 0, bias=bias)
+        self.erp_pad = pad
+
+    def forward(self, x):
+        if self.erp_pad:
+            x = F.pad(F.pad(x, (0, 0, self.erp_pad, self.erp_pad)), (self.erp_pad, self.erp_pad, 0, 0), mode='circular')
+        return F.conv2d(x, self.weight, self.bias, self.stride)
+
+
+class _BasicBlockBN(nn.Module):
+    """models/resnet.py:38-83 (BatchNorm, eval: running statistics)."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = ErpConv2d(cin, cout, 3, stride, 1)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = ErpConv2d(cout, cout, 3, 1, 1)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(ErpConv2d(cin, cout, 1, stride, 0), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class _ResNet18Erp(nn.Module):
+    """models/resnet.py:136-245 resnet18 after erp_convert (every conv and the max-pool wrap-padded); no avgpool / fc."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = ErpConv2d(3, 64, 7, 2, 3)
+        self.bn1 = nn.BatchNorm2d(64)
+        dims = [64, 64, 128, 256, 512]
+        for i in range(1, 5):
+            setattr(self, f'layer{i}', nn.Sequential(_BasicBlockBN(dims[i - 1], dims[i], 1 if i == 1 else 2),
+                                                     _BasicBlockBN(dims[i], dims[i], 1)))
+
+    @staticmethod
+    def maxpool(x):         # MaxPool2d(3, 2, 1) with the wrap padding of convert_module.py:12-27
+        return F.max_pool2d(F.pad(F.pad(x, (0, 0, 1, 1)), (1, 1, 0, 0), mode='circular'), 3, 2)
+
+
+class _Conv3x3Wrap(nn.Module):      # models/layers.py:23-44
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 3)
+        self.pad = ErpPad(1)
+
+    def forward(self, x):
+        return self.conv(self.pad(x))
+
+
+class _EquiConvBlock(nn.Module):    # models/layers.py:46-58: wrap-padded 3x3 conv + ELU
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = _Conv3x3Wrap(cin, cout)
+
+    def forward(self, x):
+        return F.elu(self.conv(x))
+
+
+class Equi(nn.Module):
+    """models/my_equi.py: [n,3,H,W] -> [n,32,H/4,W/4]."""
+
+    def __init__(self):
+        super().__init__()
+        self.equi_encoder = _ResNet18Erp()
+        enc, dec = [64, 64, 128, 256, 512], [16, 32, 64, 128, 256]
+        # upconv_5, deconv_4, upconv_4, deconv_3, upconv_3, deconv_2, upconv_2 (registration order of my_equi.py:77-84)
+        self.equi_decoder = nn.ModuleList([
+            _EquiConvBlock(enc[4], dec[4]), _EquiConvBlock(dec[4] + enc[3], dec[4]), _EquiConvBlock(dec[4], dec[3]),
+            _EquiConvBlock(dec[3] + enc[2], dec[3]), _EquiConvBlock(dec[3], dec[2]), _EquiConvBlock(dec[2] + enc[1], dec[2]),
+            _EquiConvBlock(dec[2], dec[1])])
+
+    def forward(self, x, cube=None, depth_image=None):
+        e, d = self.equi_encoder, self.equi_decoder
+        x = F.relu(e.bn1(e.conv1(x)))
+        f1 = e.layer1(e.maxpool(x))
+        f2 = e.layer2(f1)
+        f3 = e.layer3(f2)
+        f4 = e.layer4(f3)
+        up = lambda t: F.interpolate(t, scale_factor=2, mode='bilinear')
+        y = up(d[0](f4))
+        y = up(d[2](d[1](torch.cat([y, f3], 1))))
+        y = up(d[4](d[3](torch.cat([y, f2], 1))))
+        return d[6](d[5](torch.cat([y, f1], 1)))
+
+
+# ------------------------------------------------------------------------------------------------ 2-D decoders
+class _ConvBlock1x1(nn.Module):     # decoders1: ConvBlock(64, 1, kernel 1, no norm, no activation) test_models.py:148-159
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class _ConvBlock2(nn.Module):
+    """models/common_blocks.py:96-186 as decoders2 builds it: (bilinear x2) -> [wrap pad, 3x3 conv, LeakyReLU] x 2."""
+
+    def __init__(self, cin, cout, act, upscale):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3)
+        self.conv2 = nn.Conv2d(cout, cout, 3)
+        self.act, self.upscale, self.pad = act, upscale, ErpPad(1)
+
+    def forward(self, x):
+        if self.upscale:
+            x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+        a = (lambda t: F.leaky_relu(t, 0.01)) if self.act else (lambda t: t)
+        return a(self.conv2(self.pad(a(self.conv1(self.pad(x))))))
+
+
+# ------------------------------------------------------------------------------------------------ depth net
+_IMNET_MEAN = (0.485, 0.456, 0.406)
+_IMNET_STD = (0.229, 0.224, 0.225)
+
+
+class MVSDepthNet(nn.Module):
+    """FullPipeline of the shipped configuration (see module docstring).  `args`: the reference's flat cfg dict."""
+
+    def __init__(self, args, d_net=None):
+        super().__init__()
+        a = self.args = dict(args)
+        for key, want in (('net', 'Equi'), ('contain_dnet', True)):
+            if a.get(key, want) != want:
+                raise PgrfError(f"MVSDepthNet mirrors args['{key}'] = {want!r} only (got {a.get(key)!r})")
+        for key in ('mono_uncertainty', 'mono_uncert_tune', 'change_input', 'with_sin', 'wo_hdh', 'revise_range', 'group_wise',
+                    'mvs_uncertainty', 'wo_mono_feat'):
+            if a.get(key):
+                raise PgrfError(f"args['{key}'] is not implemented (no shipped configuration sets it)")
+        if not a.get('use_depth_sampling', True) or a.get('out_type', 'depth') != 'depth':
+            raise PgrfError("only use_depth_sampling=True, out_type='depth' are implemented")
+        self.unet = Equi()
+        self.unet3d = build_unet3d(a)
+        self.decoders1 = _ConvBlock1x1(64, 1)
+        self.decoders2 = nn.ModuleList([_ConvBlock2(64 + 32, 32, True, True), _ConvBlock2(32, 16, True, True),
+                                        _ConvBlock2(16, 1, False, False)])
+        if d_net is not None:
+            self.d_net = d_net
+        self.k_list = CV.depth_sampling(int(a.get('MAGNET_num_samples', 5)), a.get('MAGNET_sampling_range', 3))
+
+    # mono prior: pipeline3_model.py:630-717 (two views) / :977-1050 (multi-view)
+    def _mono(self, panos_cf, view_ids, mono, h, w):
+        """-> ref_mu [B,1,h,w], x_d3 [B,32,h,w] of the view `view_ids[0]` (the depth net runs on all listed views like the
+        reference does; only the first one is used downstream)."""
+        B = panos_cf.shape[0]
+        if mono is None:
+            if not hasattr(self, 'd_net'):
+                raise PgrfError('MVSDepthNet needs a mono-depth module (d_net=...) or mono={"pred_depth","mono_feat"}')
+            a = self.args
+            x = torch.cat([panos_cf[:, v] for v in view_ids], 0)
+            x = F.interpolate(x, (a['mono_height'], a['mono_width']), mode=a.get('interpolation_mode', 'bilinear'), align_corners=False)
+            mean = torch.tensor(_IMNET_MEAN, device=x.device).view(1, 3, 1, 1)
+            std = torch.tensor(_IMNET_STD, device=x.device).view(1, 3, 1, 1)
+            with torch.no_grad():
+                mono = self.d_net((x - mean) / std, None, dnet=True)
+        mu = F.interpolate(mono['pred_depth'], [h, w], mode='bilinear').detach()
+        x_d3 = F.interpolate(mono['mono_feat'], [h, w], mode='bilinear')
+        return mu[:B, :1], x_d3[:B]
+
+    def _tail(self, cost_volume, x_d3, ref_mu, H, W):
+        """3-D regulariser -> decoders -> depth (pipeline3_model.py:847-949)."""
+        reg = self.unet3d.forward_ndhwc(cost_volume)                      # [B,D,h,w,1]
+        cost_reg = reg[..., 0]                                            # [B,D,h,w]: depth planes as channels
+        d1 = F.interpolate(self.decoders1(cost_reg), scale_factor=4, mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
+        x = torch.cat([cost_reg, x_d3], 1)
+        for blk in self.decoders2:
+            x = blk(x)
+        if not torch.isfinite(x).all():
+            raise PgrfError('NaN in the MVS image features')              # the reference asserts (pipeline3_model.py:912)
+        depth = torch.clamp(x[:, :1], min=0).permute(0, 2, 3, 1)
+        return {'depth': depth, 'rectified_depth': depth, 'rectified_depth_d1': torch.clamp(d1, min=0),
+                'raw_image_features_d1': d1, 'cost_reg': cost_reg.permute(0, 2, 3, 1), 'mono_depth_ref': ref_mu,
+                'mid_outputs': {'cost_volume': reg.permute(0, 4, 1, 2, 3)}}
+
+    def _hypotheses(self, ref_mu, min_depth, max_depth):
+        a = self.args
+        # guided planes are clamped to args min/max depth, the uniform planes span the call's range (:732, :799)
+        if float(a['min_depth']) != float(min_depth) or float(a['max_depth']) != float(max_depth):
+            raise PgrfError('args min_depth/max_depth must equal the mvs depth range of the call (as in every shipped cfg)')
+        return CV.build_depth_volume(ref_mu, self.k_list, float(a.get('fixed_sigma', 0.5)), float(min_depth), float(max_depth), 64)
+
+    def estimate_depth_using_cost_volume(self, panos, rots, trans, min_depth=2.0, max_depth=100, mono=None):
+        """panos [B,2,H,W,3] with index 0 = source, 1 = reference (pipeline3_model.py:571-590, :602-949)."""
+        B, S, H, W, _ = panos.shape
+        if S != 2:
+            raise PgrfError('two stacked views expected; use estimate_depth_using_cost_volume_v3_erp_multiview')
+        panos_cf = panos.permute(0, 1, 4, 2, 3)
+        h, w = H // 4, W // 4
+        ref_mu, x_d3 = self._mono(panos_cf, (1, 0), mono, h, w)
+        dv = self._hypotheses(ref_mu, min_depth, max_depth)
+        f0, f1 = self.unet(panos_cf[:, 0]), self.unet(panos_cf[:, 1])
+        feats = torch.stack([f0.permute(0, 2, 3, 1), f1.permute(0, 2, 3, 1)], 1)
+        vol = CV.calculate_cost_volume_erp(self.args, feats, None, trans, rots, depth_volume=dv, cost_type='abs_diff')
+        return self._tail(vol, x_d3, ref_mu, H, W)
+
+    estimate_depth_using_cost_volume_v3_erp = estimate_depth_using_cost_volume
+
+    def estimate_depth_using_cost_volume_v3_erp_multiview(self, panos, rots, trans, curr_idx, min_depth=2.0, max_depth=100,
+                                                          mono=None):
+        """panos [B,S,H,W,3], the reference view is `curr_idx` (pipeline3_model.py:951-1300)."""
+        B, S, H, W, _ = panos.shape
+        panos_cf = panos.permute(0, 1, 4, 2, 3)
+        h, w = H // 4, W // 4
+        ref_mu, x_d3 = self._mono(panos_cf, (curr_idx,), mono, h, w)
+        dv = self._hypotheses(ref_mu, min_depth, max_depth)
+        f = self.unet(panos_cf.reshape(B * S, 3, H, W))
+        feats = f.reshape(B, S, f.shape[1], f.shape[2], f.shape[3]).permute(0, 1, 3, 4, 2)
+        vol = CV.calculate_cost_volume_erp_multiview(self.args, feats, None, trans, rots, depth_volume=dv, cost_type='abs_diff',
+                                                     curr_idx=curr_idx)
+        return self._tail(vol, x_d3, ref_mu, H, W)
+
+
+# ------------------------------------------------------------------------------------------------ init net
+def _feat_head(cin):
+    """conv3x3 + ResidualBlock(IN, wrap) + conv1x1 (network/init_net.py:541-574, network/ops.py:12-30,61-118)."""
+    return nn.Sequential(erp_conv(cin, 32, 3), PreActRes(32), nn.Conv2d(32, 32, 1, 1, bias=False))
+
+
+class CostVolumeInitNet(nn.Module):
+    """`init_net` of NeuralRayGenRenderer: forward(ref_imgs_info, src_imgs_info, is_train) -> {'ray_feats','mvs_depth'}
+    (network/init_net.py:578-650).  cfg keys: depth_height, depth_width, seq_len, mvs_min_depth, mvs_max_depth, min_depth,
+    max_depth + the MVSDepthNet args."""
+
+    def __init__(self, cfg, d_net=None):
+        super().__init__()
+        self.cfg = dict(cfg)
+        for key in ('wo_stereo', 'uncert_tune', 'use_gt_depth_ray', 'use_empty_depth_ray', 'handle_distort'):
+            if self.cfg.get(key):
+                raise PgrfError(f"cfg['{key}'] is not implemented")
+        if self.cfg.get('init_net_feature_type') == 'ERP+TP':
+            raise PgrfError('ERP+TP feature net is out of scope')
+        depth_args = dict(self.cfg, min_depth=self.cfg['mvs_min_depth'], max_depth=self.cfg['mvs_max_depth'],
+                          width=self.cfg['depth_width'], height=self.cfg['depth_height'])
+        depth_args.setdefault('mono_height', depth_args['height'])
+        depth_args.setdefault('mono_width', depth_args['width'])
+        self.depth_net = MVSDepthNet(depth_args, d_net)
+        self.res_net = ResUNetLight(self.cfg, 3, (2, 3, 6, 3), 32, inplanes=32, use_wrap_padding=True)
+        self.depth_conv = _feat_head(1)
+        self.out_conv = _feat_head(64)
+
+    def _stack(self, ref, src, key, resize):
+        c = self.cfg
+        a, b = ref[key], src[key]
+        if resize:
+            a = F.interpolate(a, (c['depth_height'], c['depth_width']), mode='bilinear')
+            b = F.interpolate(b, (c['depth_height'], c['depth_width']), mode='bilinear')
+        if int(c.get('seq_len', 3)) > 3:         # construct_input_data_mv: [ref, src[nn_ids]] (init_net.py:183-231)
+            return torch.stack([torch.cat([a[i:i + 1], b[ref['nn_ids'][i]]], 0) for i in range(a.shape[0])], 0)
+        return torch.stack([torch.stack([b[i], a[i]], 0) for i in range(a.shape[0])], 0)     # [src, ref] (init_net.py:164-182)
+
+    def forward(self, ref_imgs_info, src_imgs_info, is_train=False, mono=None):
+        c = self.cfg
+        with torch.no_grad():
+            panos = self._stack(ref_imgs_info, src_imgs_info, 'imgs', True).permute(0, 1, 3, 4, 2)
+            rots = self._stack(ref_imgs_info, src_imgs_info, 'rots', False)
+            trans = self._stack(ref_imgs_info, src_imgs_info, 'trans', False)
+            if int(c.get('seq_len', 3)) > 3:
+                ret = self.depth_net.estimate_depth_using_cost_volume_v3_erp_multiview(panos, rots, trans, 0, c['mvs_min_depth'],
+                                                                                       c['mvs_max_depth'], mono=mono)
+            else:
+                ret = self.depth_net.estimate_depth_using_cost_volume(panos, rots, trans, c['mvs_min_depth'], c['mvs_max_depth'],
+                                                                      mono=mono)
+            depth = torch.clamp_min(ret['depth'], 0.0).permute(0, 3, 1, 2)
+        ref_feats = self.res_net(F.interpolate(ref_imgs_info['imgs'], (c['depth_height'], c['depth_width']), mode='bilinear'))
+        # extract_depth_for_init_impl (init_net.py:112-124): normalised inverse depth in [0,1] of the RENDER depth range
+        near_inv, far_inv = -1.0 / c['min_depth'], -1.0 / c['max_depth']
+        d = (-1.0 / torch.clamp(depth, min=1e-5) - near_inv) / (far_inv - near_inv)
+        d = F.interpolate(torch.clamp(d, min=0, max=1.0), scale_factor=0.25, mode='bilinear', align_corners=False)
+        ray_feats = self.out_conv(torch.cat([ref_feats, self.depth_conv(d)], 1))
+        return {'mvs_depth': depth, 'ray_feats': ray_feats}
+
+
+name2init_net = {'cost_volume': CostVolumeInitNet}

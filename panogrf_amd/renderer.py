@@ -306,17 +306,23 @@ class NeuralRayBaseRenderer(nn.Module):
 
 
 class NeuralRayGenRenderer(NeuralRayBaseRenderer):
-    """Generalisable renderer (network/renderer.py:688-786).  The init net (mono-guided 360-degree MVS:
-    network/init_net.py + network/omni_mvsnet/pipeline3_model.py) is per-frame 2-D CNN work that SURVEY.md
-    section 8 f-2 ranks 'next'; pass any module with the reference's call signature
-    `init_net(ref_imgs_info, src_imgs_info, is_train) -> {'ray_feats','depth',...}` as `init_net=`.  Its
-    cost-volume and 3-D regulariser stages are available natively (panogrf_amd.cost_volume / cost_reg)."""
+    """Generalisable renderer (network/renderer.py:688-786).  With cfg['init_net_type'] == 'cost_volume' (the shipped
+    yaml) the init net is panogrf_amd.mvs.CostVolumeInitNet — the mono-guided 360-degree MVS stage of
+    network/init_net.py + network/omni_mvsnet/pipeline3_model.py with the reference's parameter names, hypotheses / cost
+    volume / 3-D regulariser on the HIP library; its mono-depth net (UniFuse, out of scope)
+    is passed as `d_net=`.  Any other module with the reference's call signature
+    `init_net(ref_imgs_info, src_imgs_info, is_train) -> {'ray_feats','mvs_depth',...}` can be given as `init_net=`."""
     default_cfg = {'init_net_type': 'depth', 'init_net_cfg': {}, 'use_depth_loss': False, 'depth_loss_coords_num': 8192}
 
-    def __init__(self, cfg, init_net=None):
+    def __init__(self, cfg, init_net=None, d_net=None):
         super().__init__({**self.default_cfg, **cfg})
         if init_net is not None:
             self.init_net = init_net
+        elif self.cfg.get('init_net_type') == 'cost_volume' and 'depth_height' in self.cfg:
+            # name2init_net[cfg['init_net_type']](cfg) of the reference (network/renderer.py:700); the mono-depth net is
+            # not mirrored: pass it as d_net= (see panogrf_amd/mvs.py)
+            from .mvs import CostVolumeInitNet
+            self.init_net = CostVolumeInitNet(self.cfg, d_net)
 
     def render_call(self, que_imgs_info, ref_imgs_info, is_train, src_imgs_info=None, is_perspec=False):
         if not hasattr(self, 'init_net'):

@@ -1,0 +1,125 @@
+"""MVS stage around the cost volume against vectors captured from the reference's own FullPipeline /
+CostVolumeInitNet methods (tests/golden/make_mvs_fixtures.py; the mono-depth net is the fixture's stand-in)."""
+import pytest
+import torch
+
+from tests import mvs_fixtures as MF
+from tests.fixtures import max_abs
+
+
+def _args(H=32, W=64):
+    return dict(MF.MVS_ARGS, height=H, width=W, mono_height=H, mono_width=W, depth_height=H, depth_width=W)
+
+
+def _depth_net(device='cpu'):
+    from panogrf_amd.mvs import MVSDepthNet
+    fx = MF.load()
+    shapes = MF.key_shapes(fx['pipe']['keys'])
+    net = MVSDepthNet(_args(), d_net=MF.StubMono()).eval()
+    return net, fx, shapes
+
+
+def test_state_dict_keys_match_reference():
+    """CPU: the `init_net.*` entries of a reference checkpoint must load with strict=True."""
+    from panogrf_amd.mvs import CostVolumeInitNet
+    net, fx, shapes = _depth_net()
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == dict(shapes)
+    net.load_state_dict(MF.seeded_state(shapes, 61), strict=True)
+    cfg = dict(_args(), use_wrap_padding=True, seq_len=3, min_depth=0.5, max_depth=15.0)
+    inet = CostVolumeInitNet(cfg, d_net=MF.StubMono())
+    ishapes = MF.key_shapes(fx['init']['keys'])
+    mine = {k: tuple(v.shape) for k, v in inet.state_dict().items() if not k.startswith('depth_net.')}
+    assert mine == dict(ishapes)
+    assert {k[len('depth_net.'):] for k in inet.state_dict() if k.startswith('depth_net.')} == set(dict(shapes))
+
+
+def test_equi_feature_net_vs_reference():
+    """CPU: ERP ResNet-18 encoder + decoder (models/my_equi.py) in torch."""
+    torch.set_num_threads(4)
+    net, fx, shapes = _depth_net()
+    net.load_state_dict(MF.seeded_state(shapes, 61))
+    with torch.no_grad():
+        out = net.unet(fx['equi']['x'])
+    assert out.shape == fx['equi']['out'].shape
+    assert max_abs(out, fx['equi']['out']) < 2e-4 * max(1.0, float(fx['equi']['out'].abs().max()))
+
+
+@pytest.mark.gpu
+def test_two_view_depth_vs_reference():
+    net, fx, shapes = _depth_net()
+    net.load_state_dict(MF.seeded_state(shapes, 61))
+    net = net.cuda()
+    t = fx['two']
+    with torch.no_grad():
+        ret = net.estimate_depth_using_cost_volume(t['panos'].cuda(), t['rots'].cuda(), t['trans'].cuda(), 0.1, 10.0)
+    assert max_abs(ret['mono_depth_ref'].cpu(), t['mono_depth_ref']) < 1e-5
+    scale = max(1.0, float(t['cost_reg'].abs().max()))
+    assert max_abs(ret['cost_reg'].cpu(), t['cost_reg']) < 2e-4 * scale
+    assert max_abs(ret['mid_outputs']['cost_volume'].cpu(), t['cost_volume']) < 2e-4 * scale
+    assert max_abs(ret['rectified_depth_d1'].cpu(), t['rectified_depth_d1']) < 2e-4 * max(1.0, float(t['rectified_depth_d1'].max()))
+    assert ret['depth'].shape == t['depth'].shape
+    assert max_abs(ret['depth'].cpu(), t['depth']) < 2e-4 * max(1.0, float(t['depth'].max()))
+
+
+@pytest.mark.gpu
+def test_multiview_depth_vs_reference():
+    net, fx, shapes = _depth_net()
+    net.load_state_dict(MF.seeded_state(shapes, 61))
+    net = net.cuda()
+    t = fx['mv']
+    with torch.no_grad():
+        ret = net.estimate_depth_using_cost_volume_v3_erp_multiview(t['panos'].cuda(), t['rots'].cuda(), t['trans'].cuda(), 0, 0.1, 10.0)
+    assert max_abs(ret['cost_reg'].cpu(), t['cost_reg']) < 2e-4 * max(1.0, float(t['cost_reg'].abs().max()))
+    assert max_abs(ret['depth'].cpu(), t['depth']) < 2e-4 * max(1.0, float(t['depth'].max()))
+
+
+@pytest.mark.gpu
+def test_init_net_vs_reference_and_through_the_renderer():
+    """CostVolumeInitNet.forward (depth -> ray_feats) vs the reference, and as `init_net` of NeuralRayGenRenderer."""
+    from panogrf_amd.mvs import CostVolumeInitNet
+    from panogrf_amd import PgrfError
+    fx = MF.load()
+    shapes, ishapes = MF.key_shapes(fx['pipe']['keys']), MF.key_shapes(fx['init']['keys'])
+    cfg = dict(_args(), use_wrap_padding=True, seq_len=3, min_depth=0.5, max_depth=15.0)
+    inet = CostVolumeInitNet(cfg, d_net=MF.StubMono()).eval()
+    inet.load_state_dict({**MF.seeded_state(ishapes, 91), **{'depth_net.' + k: v for k, v in MF.seeded_state(shapes, 61).items()}})
+    inet = inet.cuda()
+    t = fx['init']
+    ref = {'imgs': t['ref_imgs'].cuda(), 'rots': t['ref_rots'].cuda(), 'trans': t['ref_trans'].cuda()}
+    src = {'imgs': t['src_imgs'].cuda(), 'rots': t['src_rots'].cuda(), 'trans': t['src_trans'].cuda()}
+    with torch.no_grad():
+        out = inet(ref, src, False)
+    assert max_abs(out['mvs_depth'].cpu(), t['mvs_depth']) < 2e-4 * max(1.0, float(t['mvs_depth'].max()))
+    assert out['ray_feats'].shape == t['ray_feats'].shape
+    assert max_abs(out['ray_feats'].cpu(), t['ray_feats']) < 5e-4 * max(1.0, float(t['ray_feats'].abs().max()))
+    # without a mono prior the stage refuses to run instead of inventing one
+    bare = CostVolumeInitNet(cfg).cuda().eval()
+    with pytest.raises(PgrfError):
+        bare(ref, src, False)
+
+
+@pytest.mark.gpu
+def test_gen_renderer_end_to_end_with_the_mvs_stage():
+    """name2network['neuray_gen'](cfg) with init_net_type 'cost_volume': init net (MVS stage) -> 2-D encoders -> per-ray
+    renderer in one `renderer(data)` call, the reference's render.py flow (render.py:264-278)."""
+    import numpy as np
+    from panogrf_amd.renderer import name2network
+    from panogrf_amd.imgs_info import build_imgs_info, build_render_imgs_info, imgs_info_to_torch
+    H, W, dn = 64, 128, 32
+    cfg = dict(_args(32, 64), network='neuray_gen', init_net_type='cost_volume', use_wrap_padding=True, seq_len=3, height=H, width=W,
+               use_disp=True, use_hierarchical_sampling=True, render_depth=True, depth_sample_num=dn, fine_depth_sample_num=dn,
+               sample_num=dn, dist_decoder_cfg={'use_vis': False}, fine_dist_decoder_cfg={'use_vis': False})
+    cfg.update(min_depth=0.5, max_depth=15.0)                 # render range; the MVS range stays mvs_min/max_depth
+    torch.manual_seed(0)
+    net = name2network['neuray_gen'](cfg, d_net=MF.StubMono()).cuda().eval()
+    assert any(k.startswith('init_net.depth_net.unet3d') for k in net.state_dict())
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.rand(2, 3, H, W, generator=g).numpy()
+    pose = lambda tx: np.concatenate([np.eye(3), np.array([[tx], [0.0], [0.0]])], 1)
+    ref = imgs_info_to_torch(build_imgs_info(imgs, np.stack([pose(0.5), pose(-0.5)]), [[0.5, 15.0]] * 2), 'cuda')
+    src = imgs_info_to_torch(build_imgs_info(imgs[::-1].copy(), np.stack([pose(-0.5), pose(0.5)]), [[0.5, 15.0]] * 2), 'cuda')
+    que = imgs_info_to_torch(build_render_imgs_info(pose(0.0), (H, W), [0.5, 15.0]), 'cuda')
+    with torch.no_grad():
+        out = net({'que_imgs_info': que, 'ref_imgs_info': ref, 'src_imgs_info': src, 'eval': True})
+    assert out['pixel_colors_nr_fine'].shape == (1, H * W, 3) and torch.isfinite(out['pixel_colors_nr_fine']).all()
+    assert out['render_depth_fine'].shape == (1, H * W) and float(out['render_depth_fine'].min()) >= 0.0
