@@ -267,12 +267,18 @@ int pgrf_upsample3d_2(const float* in, int in_cs, int in_coff, float* out, int o
 size_t pgrf_conv2d_packed_floats(int Cout, int Cin);
 int pgrf_pack_conv2d(const float* w_host, const float* bias_host, int Cout, int Cin, int ksize, float* packed_host);
 int pgrf_conv2d(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
-                const float* packed, int has_bias, int wrap_w, int N, int H, int W, int stride, const float* residual,
-                int res_cs, int res_coff, void* stream);
-/* Stem: direct k x k convolution (k odd <= 7, stride 1|2, pad k/2, no bias) of an NCHW input with Cin <= 4 into a
- * channel-last map; w_dev [Cout,Cin,k,k] DEVICE pointer, Cout 16|32.  ResUNetLight.conv1 (network/ops.py:262-268). */
-int pgrf_conv2d_direct(const float* in_nchw, int N, int Cin, int H, int W, const float* w_dev, int Cout, int ksize, int stride,
-                       int wrap_w, float* out, int out_cs, int out_coff, void* stream);
+                const float* packed, int has_bias, int wrap_w, int N, int H, int W, int stride,
+                int act /* 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 ELU */, const float* residual, int res_cs, int res_coff,
+                int residual_first /* 1: act(conv + residual) as in a ResNet BasicBlock; 0: act(conv) + residual */,
+                void* stream);
+/* Stem: direct k x k convolution (k odd <= 7, stride 1|2, pad k/2) of an NCHW input with Cin <= 4 into a channel-last
+ * map, + optional bias [Cout] and ReLU (a BatchNorm folded into the conv); w_dev [Cout,Cin,k,k] and bias_dev are DEVICE
+ * pointers, Cout 16|32|64.  ResUNetLight.conv1 (network/ops.py:262-268), resnet18.conv1 (models/resnet.py:160-164). */
+int pgrf_conv2d_direct(const float* in_nchw, int N, int Cin, int H, int W, const float* w_dev, const float* bias_dev, int Cout,
+                       int ksize, int stride, int wrap_w, int relu, float* out, int out_cs, int out_coff, void* stream);
+/* nn.MaxPool2d(3, 2, 1) with the ERP padding of models/convert_module.py:12-27 (zeros along H, circular along W). */
+int pgrf_maxpool3s2_wrap(const float* in, int in_cs, int in_coff, int C, int N, int H, int W, float* out, int out_cs, int out_coff,
+                         void* stream);
 /* nn.InstanceNorm2d(C, affine=True, track_running_stats=False) + activation (0 none, 1 ReLU, 2 ELU), with an optional
  * residual added BEFORE the activation (BasicBlock: relu(bn2(conv2) + shortcut), network/ops.py:127-196).  gamma/beta
  * may be NULL.  `partial`: caller-owned scratch of N * pgrf_instnorm_chunks(HW) * C * 2 floats.  In place is allowed

@@ -88,9 +88,10 @@ SYMBOLS = {
     "pgrf_conv2d_packed_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "pgrf_pack_conv2d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_conv2d": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
-                              C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
-    "pgrf_conv2d_direct": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
-                                     C.c_int, C.c_int, _P]),
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "pgrf_conv2d_direct": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, _P, C.c_int, C.c_int, _P]),
+    "pgrf_maxpool3s2_wrap": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "pgrf_instnorm_chunks": (C.c_int, [C.c_int]),
     "pgrf_instnorm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P, C.c_int,
                                 C.c_int, _P, C.c_int, C.c_int, _P, _P]),

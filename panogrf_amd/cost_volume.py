@@ -24,6 +24,18 @@ def depth_sampling(n_samples=5, sampling_range=3):
     return list((k[1:] + k[:-1]) / 2)
 
 
+_UNIFORM = {}
+
+
+def _uniform_planes(lo, hi, n, device):
+    """torch.linspace(lo, hi, n) on the device, made once per (range, count, device): a host->device copy per call would
+    also forbid capturing the MVS stage into a hipGraph."""
+    key = (lo, hi, n, str(device))
+    if key not in _UNIFORM:
+        _UNIFORM[key] = torch.linspace(lo, hi, n).to(device)
+    return _UNIFORM[key]
+
+
 def build_depth_volume(ref_mu, k_list, fixed_sigma, min_depth, max_depth, n_total=64):
     """ref_mu [B,1,h,w] (CUDA) -> sorted hypothesis volume [B,n_total,h,w]
     (pipeline3_model.py:723-733,774-815 with the shipped flags)."""
@@ -35,7 +47,7 @@ def build_depth_volume(ref_mu, k_list, fixed_sigma, min_depth, max_depth, n_tota
     n_g = len(k_list)
     n_u = n_total - n_g
     offs = (C.c_float * max(n_g, 1))(*[float(k * fixed_sigma) for k in k_list])
-    uni = torch.linspace(min_depth, max_depth, n_u).to(ref_mu.device) if n_u > 0 else None
+    uni = _uniform_planes(float(min_depth), float(max_depth), n_u, ref_mu.device) if n_u > 0 else None
     out = torch.empty(B, n_total, h, w, dtype=torch.float32, device=ref_mu.device)
     lib.check(lib.pgrf_depth_hypotheses(_ptr(ref_mu), B, h * w, offs, n_g, float(min_depth), float(max_depth),
                                         _ptr(uni), n_u, _ptr(out), _stream()))

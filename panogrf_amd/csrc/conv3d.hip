@@ -44,7 +44,13 @@ struct ConvArgs {
   int tapmajor;           // pointwise projection of the Cout == 1 fast path: write out[row][voxel] (row < 27) instead of
                           // channel-last, so that the 27-tap gather that follows reads consecutive voxels of one row
   int wrap_w;             // 1: circular padding along W (ERP wrap); 0: zeros (the 2-D `upconv` blocks, network/ops.py:226-233)
+  int elu;                // 1: ELU instead of LeakyReLU(slope) (2-D encoder blocks)
+  int res_first;          // 1: the residual is added BEFORE the activation (ResNet BasicBlock), 0: after (CostRegNet skips)
 };
+
+__device__ __forceinline__ float conv_act(const ConvArgs& a, float v) {
+  return a.elu ? (v > 0.f ? v : expm1f(v)) : (v > 0.f ? v : v * a.slope);
+}
 
 // packed weight index helpers (shared with the host packer below)
 __host__ __device__ inline size_t wpk_index(int cot, int tap, int chunk, int chunks, int s, int lane, int ntaps = 27) {
@@ -409,12 +415,11 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
         const int c = (cot0 + m) * 32 + q * 8 + kk * 4;
         if (c + 4 > a.Cout) continue;
         float4 v = make_float4(acc[t][m][q * 4], acc[t][m][q * 4 + 1], acc[t][m][q * 4 + 2], acc[t][m][q * 4 + 3]);
-        v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
-        v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-        if (a.residual) {
-          const float4 rr = *reinterpret_cast<const float4*>(a.residual + ov * a.res_cs + a.res_coff + c);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
+        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.residual) rr = *reinterpret_cast<const float4*>(a.residual + ov * a.res_cs + a.res_coff + c);
+        if (a.res_first) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+        v.x = conv_act(a, v.x); v.y = conv_act(a, v.y); v.z = conv_act(a, v.z); v.w = conv_act(a, v.w);
+        if (!a.res_first) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
         *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
       }
     }
@@ -591,6 +596,7 @@ __global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, con
   for (int tap = 0; tap < 27; ++tap) {
     const int zi = z * a.stride + tap / 9 - 1, yi = y * a.stride + (tap / 3) % 3 - 1;
     int xi = x * a.stride + tap % 3 - 1;
+    if (!a.wrap_w && (xi < 0 || xi >= a.W)) continue;
     xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
     if (zi < 0 || zi >= a.D || yi < 0 || yi >= a.H) continue;
     const float* ip = a.in + ((((long long)b * a.D + zi) * a.H + yi) * a.W + xi) * a.in_cs + a.in_coff;
@@ -608,8 +614,10 @@ __global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, con
   for (int off = lpv >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
   if (ok && sub == 0) {
     if (has_bias) s += wlin[27 * a.Cin];
-    s = s > 0.f ? s : s * a.slope;
-    if (a.residual) s += a.residual[ov * a.res_cs + a.res_coff];
+    const float rr = a.residual ? a.residual[ov * a.res_cs + a.res_coff] : 0.f;
+    if (a.res_first) s += rr;
+    s = conv_act(a, s);
+    if (!a.res_first) s += rr;
     a.out[ov * a.out_cs + a.out_coff] = s;
   }
 }
@@ -757,7 +765,7 @@ int pgrf_pack_conv3d(const float* w_host, const float* bias_host, int Cout, int 
 
 static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                             const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
-                            const float* residual, int res_cs, int res_coff, int wrap_w, void* stream) {
+                            const float* residual, int res_cs, int res_coff, int wrap_w, int elu, int res_first, void* stream) {
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wrap: null pointer");
   if (stride != 1 && stride != 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wrap: stride %d", stride);
   if (B < 1 || D < 1 || H < 1 || W < 2) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wrap: bad dims");
@@ -772,7 +780,7 @@ static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, fl
   a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
   a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
   a.chunks = (Cin + 31) / 32; a.cot_total = (Cout + 31) / 32;
-  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0; a.wrap_w = wrap_w;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0; a.wrap_w = wrap_w; a.elu = elu; a.res_first = res_first;
   const size_t a_floats = (size_t)a.cot_total * 27 * a.chunks * 1024;
   a.wpk = packed;
   a.bias = has_bias ? packed + a_floats : nullptr;
@@ -823,7 +831,7 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
                      const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
                      const float* residual, int res_cs, int res_coff, void* stream) {
   return conv3d_wrap_impl(in, in_cs, in_coff, Cin, out, out_cs, out_coff, Cout, packed, has_bias, B, D, H, W, stride,
-                          lrelu_slope, residual, res_cs, res_coff, 1, stream);
+                          lrelu_slope, residual, res_cs, res_coff, 1, 0, 0, stream);
 }
 
 // ---- 2-D convolutions of the per-frame encoders: the same kernel on a depth-1 volume ------------------------------
@@ -847,11 +855,12 @@ int pgrf_pack_conv2d(const float* w_host, const float* bias_host, int Cout, int 
 }
 
 int pgrf_conv2d(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
-                const float* packed, int has_bias, int wrap_w, int N, int H, int W, int stride, const float* residual,
-                int res_cs, int res_coff, void* stream) {
-  if (Cout == 1) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv2d: Cout == 1");
-  return conv3d_wrap_impl(in, in_cs, in_coff, Cin, out, out_cs, out_coff, Cout, packed, has_bias, N, 1, H, W, stride, 1.f,
-                          residual, res_cs, res_coff, wrap_w ? 1 : 0, stream);
+                const float* packed, int has_bias, int wrap_w, int N, int H, int W, int stride, int act, const float* residual,
+                int res_cs, int res_coff, int residual_first, void* stream) {
+  if (act < 0 || act > 3) return set_error(PGRF_ERR_ARG, "pgrf_conv2d: act %d (0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 ELU)", act);
+  const float slope = act == 0 ? 1.f : (act == 1 ? 0.f : 0.01f);
+  return conv3d_wrap_impl(in, in_cs, in_coff, Cin, out, out_cs, out_coff, Cout, packed, has_bias, N, 1, H, W, stride, slope,
+                          residual, res_cs, res_coff, wrap_w ? 1 : 0, act == 3 ? 1 : 0, residual_first ? 1 : 0, stream);
 }
 
 // ---- narrow layers (conv3d_small_kernel) -------------------------------------------------------------------------
@@ -908,7 +917,7 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
   a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff;
   a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
   a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
-  a.chunks = 1; a.cot_total = 1; a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0; a.wrap_w = 1;
+  a.chunks = 1; a.cot_total = 1; a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 27; a.tapmajor = 0; a.wrap_w = 1; a.elu = 0; a.res_first = 0;
   if (nshift > 1 && (stride != 1 || a.Do % nshift))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small: nshift %d needs stride 1 and D %% nshift == 0", nshift);
   sa.ns = nshift; sa.nsteps = small_steps(Cin, nshift);
@@ -952,7 +961,7 @@ int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, 
   ConvArgs a;
   a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = y; a.out_cs = 32; a.out_coff = 0; a.Cout = 32;
   a.B = B; a.D = D; a.H = H; a.W = W; a.stride = 1; a.slope = 1.f; a.Do = D; a.Ho = H; a.Wo = W;
-  a.chunks = (Cin + 31) / 32; a.cot_total = 1; a.residual = nullptr; a.res_cs = 0; a.res_coff = 0; a.wtaps = 1; a.tapmajor = 1; a.wrap_w = 1;
+  a.chunks = (Cin + 31) / 32; a.cot_total = 1; a.residual = nullptr; a.res_cs = 0; a.res_coff = 0; a.wtaps = 1; a.tapmajor = 1; a.wrap_w = 1; a.elu = 0; a.res_first = 0;
   const size_t a_floats = (size_t)27 * a.chunks * 1024;
   a.wpk = packed + a_floats + 32 + (((size_t)27 * Cin + 1 + 3) & ~(size_t)3);
   a.bias = nullptr;

@@ -29,7 +29,8 @@ template <int COUT, int PX>
 __global__ void __launch_bounds__(256) conv2d_direct_kernel(const float* __restrict__ in, int N, int Cin, int H, int W,
                                                             const float* __restrict__ wgt /* [COUT][Cin][K][K] */, int K,
                                                             int stride, int wrap_w, float* __restrict__ out, int out_cs,
-                                                            int out_coff, int Ho, int Wo) {
+                                                            int out_coff, int Ho, int Wo, const float* __restrict__ bias,
+                                                            int relu) {
   extern __shared__ float s_w[];          // [Cin*K*K][COUT]
   const int taps = Cin * K * K;
   for (int i = threadIdx.x; i < taps * COUT; i += blockDim.x) {
@@ -87,8 +88,12 @@ __global__ void __launch_bounds__(256) conv2d_direct_kernel(const float* __restr
       if (xo0 + j >= Wo) continue;
       float* op = out + ((((size_t)n * Ho + yo) * Wo) + xo0 + j) * out_cs + out_coff;
 #pragma unroll
-      for (int q = 0; q < COUT / 4; ++q)
-        *reinterpret_cast<float4*>(op + 4 * q) = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+      for (int q = 0; q < COUT / 4; ++q) {
+        float4 v = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+        if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * q); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(op + 4 * q) = v;
+      }
     }
   }
 }
@@ -212,6 +217,35 @@ __global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __res
   }
 }
 
+// MaxPool2d(3, 2, 1) as models/convert_module.py:12-27 pads it: zeros above/below (the zeros take part in the max),
+// circular left/right; channel-last, thread per (output pixel, 4-channel group).
+__global__ void __launch_bounds__(256) maxpool3s2_wrap_kernel(const float* __restrict__ in, int in_cs, int in_coff, int C, int N, int H,
+                                                              int W, float* __restrict__ out, int out_cs, int out_coff, int Ho, int Wo) {
+  const int quads = C / 4;
+  const long long total = (long long)N * Ho * Wo * quads;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % quads);
+    long long p = i / quads;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yi = 2 * yo + ky - 1;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        int xi = 2 * xo + kx - 1;
+        xi = xi < 0 ? xi + W : (xi >= W ? xi - W : xi);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yi >= 0 && yi < H) v = *reinterpret_cast<const float4*>(in + (((size_t)n * H + yi) * W + xi) * in_cs + in_coff + q * 4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<float4*>(out + (((size_t)n * Ho + yo) * Wo + xo) * out_cs + out_coff + q * 4) = m;
+  }
+}
+
 static int grid_for(long long total, int cap = 8192) {
   long long b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -223,13 +257,13 @@ using namespace pgrf;
 
 extern "C" {
 
-int pgrf_conv2d_direct(const float* in_nchw, int N, int Cin, int H, int W, const float* w_dev, int Cout, int ksize, int stride,
-                       int wrap_w, float* out, int out_cs, int out_coff, void* stream) {
+int pgrf_conv2d_direct(const float* in_nchw, int N, int Cin, int H, int W, const float* w_dev, const float* bias_dev, int Cout,
+                       int ksize, int stride, int wrap_w, int relu, float* out, int out_cs, int out_coff, void* stream) {
   if (!in_nchw || !w_dev || !out) return set_error(PGRF_ERR_ARG, "pgrf_conv2d_direct: null pointer");
   if (Cin < 1 || Cin > 4 || (ksize & 1) == 0 || ksize < 1 || ksize > 7 || (stride != 1 && stride != 2))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv2d_direct: Cin %d (1..4), ksize %d (odd <= 7), stride %d (1|2)", Cin, ksize, stride);
-  if (!(Cout == 16 || Cout == 32) || (out_cs & 3) || (out_coff & 3))
-    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv2d_direct: Cout %d (16|32), channel stride/offset multiples of 4", Cout);
+  if (!(Cout == 16 || Cout == 32 || Cout == 64) || (out_cs & 3) || (out_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv2d_direct: Cout %d (16|32|64), channel stride/offset multiples of 4", Cout);
   if (N < 1 || H < 1 || W < 1) return set_error(PGRF_ERR_ARG, "pgrf_conv2d_direct: bad dims");
   const int pad = ksize / 2;
   const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -237,11 +271,15 @@ int pgrf_conv2d_direct(const float* in_nchw, int N, int Cin, int H, int W, const
   if (Cout == 16) {
     const long long total = (long long)N * Ho * Wo;
     hipLaunchKernelGGL((conv2d_direct_kernel<16, 1>), dim3(grid_for(total)), dim3(256), shmem, (hipStream_t)stream, in_nchw, N, Cin, H, W,
-                       w_dev, ksize, stride, wrap_w, out, out_cs, out_coff, Ho, Wo);
+                       w_dev, ksize, stride, wrap_w, out, out_cs, out_coff, Ho, Wo, bias_dev, relu);
+  } else if (Cout == 64) {
+    const long long total = (long long)N * Ho * Wo;
+    hipLaunchKernelGGL((conv2d_direct_kernel<64, 1>), dim3(grid_for(total)), dim3(256), shmem, (hipStream_t)stream, in_nchw, N, Cin, H, W,
+                       w_dev, ksize, stride, wrap_w, out, out_cs, out_coff, Ho, Wo, bias_dev, relu);
   } else {
     const long long total = (long long)N * Ho * Wo;
     hipLaunchKernelGGL((conv2d_direct_kernel<32, 1>), dim3(grid_for(total)), dim3(256), shmem, (hipStream_t)stream, in_nchw, N, Cin, H, W,
-                       w_dev, ksize, stride, wrap_w, out, out_cs, out_coff, Ho, Wo);
+                       w_dev, ksize, stride, wrap_w, out, out_cs, out_coff, Ho, Wo, bias_dev, relu);
   }
   PGRF_CHECK_LAUNCH("conv2d_direct");
   return PGRF_OK;
@@ -266,6 +304,20 @@ int pgrf_instnorm(const float* x, int cs, int coff, int C, int N, int HW, const 
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total, 1024), N), dim3(256), 0, (hipStream_t)stream, x, cs, coff, C, N, HW,
                      partial, nchunk, gamma, beta, eps, act, residual, res_cs, res_coff, out, out_cs, out_coff);
   PGRF_CHECK_LAUNCH("instnorm_apply");
+  return PGRF_OK;
+}
+
+int pgrf_maxpool3s2_wrap(const float* in, int in_cs, int in_coff, int C, int N, int H, int W, float* out, int out_cs, int out_coff,
+                         void* stream) {
+  if (!in || !out) return set_error(PGRF_ERR_ARG, "pgrf_maxpool3s2_wrap: null pointer");
+  if ((C & 3) || C < 4 || (in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_maxpool3s2_wrap: C and strides/offsets must be multiples of 4");
+  if (N < 1 || H < 1 || W < 2) return set_error(PGRF_ERR_ARG, "pgrf_maxpool3s2_wrap: bad dims");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3s2_wrap_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_cs, in_coff, C, N, H, W, out,
+                     out_cs, out_coff, Ho, Wo);
+  PGRF_CHECK_LAUNCH("maxpool3s2_wrap");
   return PGRF_OK;
 }
 

@@ -33,10 +33,25 @@ class _Map:
         return _Map(self.buf, self.coff + coff, C)
 
 
+def fold_bn(conv, bn):
+    """conv (+ bias) followed by an eval-mode BatchNorm2d -> equivalent (weight, bias) of one conv."""
+    w = conv.weight.detach().to('cpu', torch.float32)
+    scale = bn.weight.detach().cpu().float() / torch.sqrt(bn.running_var.detach().cpu().float() + bn.eps)
+    b0 = conv.bias.detach().cpu().float() if conv.bias is not None else torch.zeros(w.shape[0])
+    return (w * scale.view(-1, 1, 1, 1)).contiguous(), ((b0 - bn.running_mean.detach().cpu().float()) * scale + bn.bias.detach().cpu().float()).contiguous()
+
+
 class _Conv:
-    def __init__(self, conv, device):
-        w = conv.weight.detach().to('cpu', torch.float32).contiguous()
-        b = None if conv.bias is None else conv.bias.detach().to('cpu', torch.float32).contiguous()
+    def __init__(self, conv, device, bn=None, pad_cin=0):
+        """conv: nn.Conv2d (1x1 or 3x3); bn: an eval-mode BatchNorm2d folded into it; pad_cin: zero input channels
+        appended so that a 1-channel input can sit in a 4-channel map."""
+        if bn is not None:
+            w, b = fold_bn(conv, bn)
+        else:
+            w = conv.weight.detach().to('cpu', torch.float32).contiguous()
+            b = None if conv.bias is None else conv.bias.detach().to('cpu', torch.float32).contiguous()
+        if pad_cin > w.shape[1]:
+            w = torch.cat([w, torch.zeros(w.shape[0], pad_cin - w.shape[1], w.shape[2], w.shape[3])], 1).contiguous()
         self.cout, self.cin, k, k2 = w.shape
         if k != k2 or k not in (1, 3):
             raise PgrfError(f'conv kernel {k}x{k2}: only 1x1 and 3x3 go through pgrf_conv2d')
@@ -60,7 +75,7 @@ class HipEncoders:
 
     # ------------------------------------------------------------------ weights
     def _state_key(self):
-        return tuple((k, v._version, v.data_ptr()) for m in (self.ie, self.ve) for k, v in m.state_dict().items())
+        return tuple((k, v._version, v.data_ptr()) for m in (self.ie, self.ve) if m is not None for k, v in m.state_dict().items())
 
     def _pack(self):
         key = self._state_key()
@@ -79,24 +94,46 @@ class HipEncoders:
         for name in ('iconv3', 'iconv2'):
             P[name] = _Conv(_plain(getattr(ie, name).conv), d)
         P['out'] = _Conv(ie.out_conv, d)
-        oc = ve.out_conv
-        P['v.in'] = _Conv(_plain(oc[0]), d)
-        for r in (1, 2):
-            P[f'v.res{r}.a'] = _Conv(oc[r].conv[3], d)
-            P[f'v.res{r}.b'] = _Conv(oc[r].conv[7], d)
-        P['v.out'] = _Conv(oc[3], d)
+        if ve is not None:
+            P.update(self.pack_head('v', ve.out_conv))
         self._packed, self._key = P, key
         return P
 
+    def pack_head(self, tag, seq):
+        """conv3x3 -> n x PreActRes -> conv1x1 (DefaultVisEncoder.out_conv, the init net's depth_conv / out_conv)."""
+        d, P = self.device, {}
+        cin = _plain(seq[0]).in_channels
+        P[f'{tag}.in'] = _Conv(_plain(seq[0]), d, pad_cin=(cin + 3) // 4 * 4)
+        for r in range(1, len(seq) - 1):
+            P[f'{tag}.res{r}.a'] = _Conv(seq[r].conv[3], d)
+            P[f'{tag}.res{r}.b'] = _Conv(seq[r].conv[7], d)
+        P[f'{tag}.out'] = _Conv(seq[len(seq) - 1], d)
+        return P
+
+    def run_head(self, P, tag, seq, x):
+        """x: _Map with the head's input channels -> channel-last [N,h,w,32] tensor."""
+        d = self.device
+        v = self._conv(P[f'{tag}.in'], x, _Map.empty(x.N, x.H, x.W, P[f'{tag}.in'].cout, d))
+        for r in range(1, len(seq) - 1):
+            blk = seq[r].conv
+            t = self._norm(v, blk[0], 'relu', out=_Map.empty(x.N, x.H, x.W, v.C, d))
+            t2 = self._conv(P[f'{tag}.res{r}.a'], t, _Map.empty(x.N, x.H, x.W, v.C, d))
+            self._norm(t2, blk[4], 'relu')
+            v = self._conv(P[f'{tag}.res{r}.b'], t2, t, residual=v)           # conv + x (PreAct residual block)
+        return self._conv(P[f'{tag}.out'], v, _Map.empty(x.N, x.H, x.W, P[f'{tag}.out'].cout, d)).buf
+
     # ------------------------------------------------------------------ primitives
-    def _conv(self, pc, x, out, wrap=True, residual=None):
+    _ACT = {'none': 0, 'relu': 1, 'lrelu': 2, 'elu': 3}
+
+    def _conv(self, pc, x, out, wrap=True, residual=None, act='none', residual_first=False):
+        """3x3 / 1x1 conv (+ bias) -> activation; residual added after the activation, or before it (residual_first)."""
         if x.C != pc.cin or out.C != pc.cout:
             raise PgrfError(f'conv2d: map has {x.C}->{out.C} channels, weights {pc.cin}->{pc.cout}')
         lib.check(lib.pgrf_conv2d(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout, _ptr(pc.dev),
-                                  int(pc.has_bias), int(wrap), x.N, x.H, x.W, pc.stride,
+                                  int(pc.has_bias), int(wrap), x.N, x.H, x.W, pc.stride, self._ACT[act],
                                   _ptr(residual.buf) if residual is not None else None,
                                   residual.cs if residual is not None else 0, residual.coff if residual is not None else 0,
-                                  _stream()))
+                                  int(residual_first), _stream()))
         return out
 
     def _norm(self, x, norm, act, out=None, residual=None):
@@ -139,8 +176,10 @@ class HipEncoders:
         N, Cin, H, W = imgs.shape
         if H % 16 or W % 16:
             raise PgrfError(f'HIP encoders need H, W multiples of 16 (got {H}x{W}); use cfg["hip_encoders"]=False')
-        x0 = _Map.empty(N, H // 2, W // 2, 16, d)
-        lib.check(lib.pgrf_conv2d_direct(_ptr(imgs), N, Cin, H, W, _ptr(P['stem']), 16, 7, 2, 1, _ptr(x0.buf), x0.cs, 0, _stream()))
+        c0 = P['stem'].shape[0]                                # stem width: 16 (image_encoder) or 32 (init net's res_net)
+        x0 = _Map.empty(N, H // 2, W // 2, c0, d)
+        lib.check(lib.pgrf_conv2d_direct(_ptr(imgs), N, Cin, H, W, _ptr(P['stem']), None, c0, 7, 2, 1, 0, _ptr(x0.buf), x0.cs, 0,
+                                         _stream()))
         self._norm(x0, ie.bn1, 'relu')
         cat2 = _Map.empty(N, H // 4, W // 4, 64, d)            # [upconv2 out (32) | x1 (32)]: input of iconv2
         cat3 = _Map.empty(N, H // 8, W // 8, 128, d)           # [upconv3 out (64) | x2 (64)]: input of iconv3
@@ -179,15 +218,7 @@ class HipEncoders:
         else:
             cat.buf[..., :32] = img_feats_nhwc
         cat.buf[..., 32:] = pack_map(ray_feats)
-        oc = ve.out_conv
-        v = self._conv(P['v.in'], cat, _Map.empty(N, hr, wr, 32, d))
-        for r in (1, 2):
-            seq = oc[r].conv
-            t = self._norm(v, seq[0], 'relu', out=_Map.empty(N, hr, wr, 32, d))
-            t2 = self._conv(P[f'v.res{r}.a'], t, _Map.empty(N, hr, wr, 32, d))
-            self._norm(t2, seq[4], 'relu')
-            v = self._conv(P[f'v.res{r}.b'], t2, t, residual=v)           # conv + x (PreAct residual block)
-        return self._conv(P['v.out'], v, _Map.empty(N, hr, wr, 32, d)).buf
+        return self.run_head(P, 'v', ve.out_conv, cat)
 
     def __call__(self, imgs, ray_feats):
         """-> (img_feats, ray_feats) as NCHW-shaped VIEWS of channel-last memory (what the reference interface expects

@@ -176,6 +176,8 @@ class MVSDepthNet(nn.Module):
                                         _ConvBlock2(16, 1, False, False)])
         if d_net is not None:
             self.d_net = d_net
+        self.register_buffer('_im_mean', torch.tensor(_IMNET_MEAN).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer('_im_std', torch.tensor(_IMNET_STD).view(1, 3, 1, 1), persistent=False)
         self.k_list = CV.depth_sampling(int(a.get('MAGNET_num_samples', 5)), a.get('MAGNET_sampling_range', 3))
 
     # mono prior: pipeline3_model.py:630-717 (two views) / :977-1050 (multi-view)
@@ -189,10 +191,8 @@ class MVSDepthNet(nn.Module):
             a = self.args
             x = torch.cat([panos_cf[:, v] for v in view_ids], 0)
             x = F.interpolate(x, (a['mono_height'], a['mono_width']), mode=a.get('interpolation_mode', 'bilinear'), align_corners=False)
-            mean = torch.tensor(_IMNET_MEAN, device=x.device).view(1, 3, 1, 1)
-            std = torch.tensor(_IMNET_STD, device=x.device).view(1, 3, 1, 1)
             with torch.no_grad():
-                mono = self.d_net((x - mean) / std, None, dnet=True)
+                mono = self.d_net((x - self._im_mean) / self._im_std, None, dnet=True)
         mu = F.interpolate(mono['pred_depth'], [h, w], mode='bilinear').detach()
         x_d3 = F.interpolate(mono['mono_feat'], [h, w], mode='bilinear')
         return mu[:B, :1], x_d3[:B]
@@ -205,8 +205,9 @@ class MVSDepthNet(nn.Module):
         x = torch.cat([cost_reg, x_d3], 1)
         for blk in self.decoders2:
             x = blk(x)
-        if not torch.isfinite(x).all():
-            raise PgrfError('NaN in the MVS image features')              # the reference asserts (pipeline3_model.py:912)
+        # the reference asserts finiteness here (pipeline3_model.py:912): a device->host sync per frame, so opt-in
+        if self.args.get('hip_check_nan') and not torch.isfinite(x).all():
+            raise PgrfError('NaN in the MVS image features')
         depth = torch.clamp(x[:, :1], min=0).permute(0, 2, 3, 1)
         return {'depth': depth, 'rectified_depth': depth, 'rectified_depth_d1': torch.clamp(d1, min=0),
                 'raw_image_features_d1': d1, 'cost_reg': cost_reg.permute(0, 2, 3, 1), 'mono_depth_ref': ref_mu,

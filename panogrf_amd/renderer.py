@@ -233,6 +233,32 @@ class NeuralRayBaseRenderer(nn.Module):
             he = self.__dict__['_hip_enc'] = HipEncoders(self.image_encoder, self.vis_encoder, imgs.device)
         return he
 
+    def _graphed(self, tag, fn, inputs):
+        """Run fn(*inputs) (CUDA tensors in, tuple of CUDA tensors out, static shapes, no host sync inside) as a replayed
+        hipGraph: captured once per (tag, input shapes), replayed on copies of the inputs; outputs are cloned because the
+        next replay overwrites the graph's buffers."""
+        key = (tag,) + tuple((tuple(t.shape), t.dtype, str(t.device)) for t in inputs)
+        graphs = self.__dict__.setdefault('_graphs', {})
+        ent = graphs.get(key)
+        if ent is None:
+            dev = inputs[0].device
+            statics = [t.clone() for t in inputs]
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):                      # warm-up outside capture (weight packing, MIOpen find, allocations)
+                    fn(*statics)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                outs = fn(*statics)
+            ent = graphs[key] = (g, statics, tuple(outs))
+        g, statics, outs = ent
+        for s_, t in zip(statics, inputs):
+            s_.copy_(t)
+        g.replay()
+        return tuple(o.clone() for o in outs)
+
     def _encode(self, imgs, ray_feats):
         """The two per-frame 2-D encoders (network/renderer.py:639-642).  On a GPU their ~70 small kernels are
         launch-bound (3.4 ms eager for 2x512x1024), so the launch sequence is captured once per input shape into a
@@ -240,26 +266,7 @@ class NeuralRayBaseRenderer(nn.Module):
         enc = self._encoder_fn(imgs)
         if not (imgs.is_cuda and self.cfg.get('hip_graph_encoders', True)) or torch.is_grad_enabled():
             return enc(imgs, ray_feats)
-        key = (tuple(imgs.shape), tuple(ray_feats.shape), imgs.device, imgs.dtype, ray_feats.dtype, enc is self._torch_encoders)
-        graphs = self.__dict__.setdefault('_enc_graphs', {})
-        ent = graphs.get(key)
-        if ent is None:
-            s_imgs, s_rf = imgs.clone(), ray_feats.clone()
-            side = torch.cuda.Stream(device=imgs.device)
-            side.wait_stream(torch.cuda.current_stream(imgs.device))
-            with torch.cuda.stream(side):
-                for _ in range(2):                      # warm-up outside capture (weight packing, MIOpen find, allocations)
-                    enc(s_imgs, s_rf)
-            torch.cuda.current_stream(imgs.device).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                o_feats, o_rf = enc(s_imgs, s_rf)
-            ent = graphs[key] = (g, s_imgs, s_rf, o_feats, o_rf)
-        g, s_imgs, s_rf, o_feats, o_rf = ent
-        s_imgs.copy_(imgs)
-        s_rf.copy_(ray_feats)
-        g.replay()
-        return o_feats.clone(), o_rf.clone()            # the graph's output buffers are overwritten by the next frame
+        return self._graphed('enc_torch' if enc == self._torch_encoders else 'enc_hip', enc, (imgs.contiguous(), ray_feats.contiguous()))
 
     def _make_frame(self, que, ref, is_perspec):
         """ERP query: que['c2w'] (render_ops.py:76-106).  Pinhole query (is_perspec, render_cubes.py): que['poses'] and
@@ -328,11 +335,39 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         if not hasattr(self, 'init_net'):
             raise PgrfError('NeuralRayGenRenderer needs an init_net module (see class docstring); '
                             'or put ray_feats into ref_imgs_info and call render()')
-        ret = self.init_net(ref_imgs_info, src_imgs_info, is_train)
+        ret = self._run_init_net(ref_imgs_info, src_imgs_info, is_train)
         ref_imgs_info['ray_feats'] = ret['ray_feats']
         if 'mvs_depth' in ret:
             ref_imgs_info['mvs_depth'] = ret['mvs_depth']
         return self.render(que_imgs_info, ref_imgs_info, is_train, is_perspec)
+
+    def _run_init_net(self, ref, src, is_train):
+        """The MVS stage is ~150 small launches (2-D CNNs on MIOpen + the HIP cost-volume / regulariser kernels) with static
+        shapes: like the encoders it is captured into a hipGraph once per input shape and replayed
+        (cfg['hip_graph_init_net']=False keeps eager launches; the two-view panogrf_amd.mvs.CostVolumeInitNet only: a
+        user-supplied init net, or a mono net that syncs with the host, cannot be captured)."""
+        from .mvs import CostVolumeInitNet
+        net = self.init_net
+        ok = (isinstance(net, CostVolumeInitNet) and int(net.cfg.get('seq_len', 3)) <= 3 and src is not None and
+              ref['imgs'].is_cuda and not torch.is_grad_enabled() and self.cfg.get('hip_graph_init_net', True) and
+              not net.cfg.get('hip_check_nan'))
+        if not ok:
+            return net(ref, src, is_train)
+        run = net
+        if self.cfg.get('hip_init_net', True) and net.cfg['depth_height'] % 32 == 0 and net.cfg['depth_width'] % 32 == 0:
+            # the stage's 2-D networks on the HIP library as well (panogrf_amd/mvs_hip.py)
+            run = self.__dict__.get('_hip_init')
+            if run is None or run.device != ref['imgs'].device or run.net is not net:
+                from .mvs_hip import HipInitNet
+                run = self.__dict__['_hip_init'] = HipInitNet(net, ref['imgs'].device)
+
+        def fn(ri, rr, rt, si, sr, st):
+            o = run({'imgs': ri, 'rots': rr, 'trans': rt}, {'imgs': si, 'rots': sr, 'trans': st}, False)
+            return o['ray_feats'], o['mvs_depth']
+        f = lambda t: t.detach().float().contiguous()
+        ray_feats, depth = self._graphed('init_net_hip' if run is not net else 'init_net', fn, (f(ref['imgs']), f(ref['rots']), f(ref['trans']), f(src['imgs']),
+                                                          f(src['rots']), f(src['trans'])))
+        return {'ray_feats': ray_feats, 'mvs_depth': depth}
 
     def forward(self, data, is_perspec=False):          # renderer(data, is_perspec=True): render_cubes.py:274
         ref = dict(data['ref_imgs_info'])

@@ -54,8 +54,8 @@ def test_stem_conv_vs_torch():
     with torch.no_grad():
         ref = stem(x)
     out = torch.empty(2, 16, 32, 16, device='cuda')
-    lib.check(lib.pgrf_conv2d_direct(_ptr(x), 2, 3, 32, 64, _ptr(stem[1].weight.detach().contiguous()), 16, 7, 2, 1, _ptr(out), 16, 0,
-                                     _stream()))
+    lib.check(lib.pgrf_conv2d_direct(_ptr(x), 2, 3, 32, 64, _ptr(stem[1].weight.detach().contiguous()), None, 16, 7, 2, 1, 0, _ptr(out), 16,
+                                     0, _stream()))
     assert _relerr(out, _nhwc(ref)) < 1e-5
 
 

@@ -123,3 +123,31 @@ def test_gen_renderer_end_to_end_with_the_mvs_stage():
         out = net({'que_imgs_info': que, 'ref_imgs_info': ref, 'src_imgs_info': src, 'eval': True})
     assert out['pixel_colors_nr_fine'].shape == (1, H * W, 3) and torch.isfinite(out['pixel_colors_nr_fine']).all()
     assert out['render_depth_fine'].shape == (1, H * W) and float(out['render_depth_fine'].min()) >= 0.0
+
+
+@pytest.mark.gpu
+def test_hip_init_net_vs_reference():
+    """The same stage with its 2-D networks on the HIP library (panogrf_amd/mvs_hip.py: BatchNorm-folded ERP ResNet-18,
+    decoders, ResUNetLight, heads) against the reference's outputs and against the torch mirror."""
+    from panogrf_amd.mvs import CostVolumeInitNet
+    from panogrf_amd.mvs_hip import HipInitNet
+    fx = MF.load()
+    shapes, ishapes = MF.key_shapes(fx['pipe']['keys']), MF.key_shapes(fx['init']['keys'])
+    cfg = dict(_args(), use_wrap_padding=True, seq_len=3, min_depth=0.5, max_depth=15.0)
+    inet = CostVolumeInitNet(cfg, d_net=MF.StubMono()).eval()
+    inet.load_state_dict({**MF.seeded_state(ishapes, 91), **{'depth_net.' + k: v for k, v in MF.seeded_state(shapes, 61).items()}})
+    inet = inet.cuda()
+    hip = HipInitNet(inet, 'cuda:0')
+    with torch.no_grad():
+        f = hip.equi(fx['equi']['x'].cuda()).permute(0, 3, 1, 2)
+    assert max_abs(f.cpu(), fx['equi']['out']) < 2e-4 * max(1.0, float(fx['equi']['out'].abs().max()))
+    t = fx['init']
+    ref = {'imgs': t['ref_imgs'].cuda(), 'rots': t['ref_rots'].cuda(), 'trans': t['ref_trans'].cuda()}
+    src = {'imgs': t['src_imgs'].cuda(), 'rots': t['src_rots'].cuda(), 'trans': t['src_trans'].cuda()}
+    with torch.no_grad():
+        out = hip(ref, src, False)
+        tor = inet(ref, src, False)
+    assert max_abs(out['mvs_depth'].cpu(), t['mvs_depth']) < 2e-4 * max(1.0, float(t['mvs_depth'].max()))
+    assert out['ray_feats'].shape == t['ray_feats'].shape
+    assert max_abs(out['ray_feats'].cpu(), t['ray_feats']) < 5e-4 * max(1.0, float(t['ray_feats'].abs().max()))
+    assert max_abs(out['ray_feats'], tor['ray_feats']) < 5e-4 * max(1.0, float(t['ray_feats'].abs().max()))

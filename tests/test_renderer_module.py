@@ -144,7 +144,7 @@ def test_encoder_graph_replay_equals_eager():
                 noise = max(float((e_f - e_f2).abs().max()), 1e-6)        # eager vs eager
                 assert float((a_f - e_f).abs().max()) <= 4 * noise + 1e-5 * float(e_f.abs().max())
                 assert float((a_r - e_r).abs().max()) <= 1e-4 * max(1.0, float(e_r.abs().max()))
-    assert len(net._enc_graphs) == 2
+    assert len(net._graphs) == 2
 
 
 def test_pixel_colors_gt_is_bilinear_with_zero_padding():
