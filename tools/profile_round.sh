@@ -38,5 +38,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cv_trace -- python3
 grep -E "hypotheses|cost volume|CostRegNet|UNet2" $OUT/cv_128x256.log
 cp $(find $OUT/cv_trace -name "*kernel_stats.csv" | head -1) $OUT/cv_kernel_stats_128x256.csv
 python3 $R/tools/time_cost_volume.py 64 128 2>&1 | grep -E "hypotheses|cost volume|CostRegNet|UNet2" | tee $OUT/cv_64x128.log
+# 5. the other bench configurations (one JSON line each)
+python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --fine > $OUT/bench_config4_fine.json 2>/dev/null
+python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --views 3 > $OUT/bench_views3.json 2>/dev/null
+python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --views 4 > $OUT/bench_views4.json 2>/dev/null
+python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --precision f16x3 > $OUT/bench_f16x3.json 2>/dev/null
+python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --with-cost-volume > $OUT/bench_config3.json 2>/dev/null
+python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --with-cost-volume --reg costregnet > $OUT/bench_config3_costregnet.json 2>/dev/null
+python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --views 4 --height 1024 --width 2048 > $OUT/bench_config5_1gpu.json 2>/dev/null
+# 6. per-frame 2-D encoders and the MVS stage (init net)
+python3 $R/tools/time_encoders.py 2>&1 | grep -E "ms|err" > $OUT/encoders_timing.txt
+python3 $R/tools/time_mvs.py 256 512 2>&1 | grep -E "ms|err" > $OUT/mvs_stage_timing_256x512.txt
+python3 $R/tools/time_mvs.py 512 1024 2>&1 | grep -E "ms|err" > $OUT/mvs_stage_timing_512x1024.txt
 rm -rf $OUT/pmc[0-9] $OUT/bench_trace $OUT/cv_trace
 ls $OUT
