@@ -87,6 +87,11 @@ def test_render_script_runs(tmp_path):
                         '--num-poses', '2', '--out', str(tmp_path)], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-1500:]
     assert os.path.exists(tmp_path / '1-nr_fine.ppm') and os.path.exists(tmp_path / '1-depth.npy')
+    # the whole flow incl. the MVS stage (init net) in front of the renderer
+    r = subprocess.run([sys.executable, os.path.join(root, 'render.py'), '--height', '128', '--width', '256', '--samples', '32',
+                        '--num-poses', '1', '--mvs', '--out', str(tmp_path / 'mvs')], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert os.path.exists(tmp_path / 'mvs' / '0-nr_fine.ppm')
 
 
 @pytest.mark.gpu
