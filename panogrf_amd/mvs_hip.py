@@ -112,20 +112,33 @@ class HipInitNet:
     def __call__(self, ref, src, is_train=False, mono=None):
         net, dn, c, d, T = self.net, self.dn, self.net.cfg, self.device, self.T
         P = self._pack()
-        if int(c.get('seq_len', 3)) > 3:
-            raise PgrfError('HipInitNet covers the two-view stage (seq_len <= 3)')
         dh, dw = c['depth_height'], c['depth_width']
         h, w = dh // 4, dw // 4
         ref_s = F.interpolate(ref['imgs'].float(), (dh, dw), mode='bilinear')
         src_s = F.interpolate(src['imgs'].float(), (dh, dw), mode='bilinear')
         B = ref_s.shape[0]
-        pair = torch.stack([src_s, ref_s], 1)                                    # [B,2,3,dh,dw]: 0 = source, 1 = reference
-        rots = torch.stack([src['rots'], ref['rots']], 1).float()
-        trans = torch.stack([src['trans'], ref['trans']], 1).float()
-        ref_mu, x_d3 = dn._mono(pair, (1, 0), mono, h, w)
-        dv = dn._hypotheses(ref_mu.contiguous(), c['mvs_min_depth'], c['mvs_max_depth'])
-        feats = self.equi(pair.reshape(B * 2, 3, dh, dw)).view(B, 2, h, w, 32)
-        vol = CV.calculate_cost_volume_erp(dn.args, feats, None, trans, rots, depth_volume=dv, cost_type='abs_diff')
+        if int(c.get('seq_len', 3)) > 3:
+            # construct_input_data_mv (init_net.py:183-231): per reference view [ref, src[nn_ids]]; the reference is view 0.
+            # nn_ids as a device tensor keeps the gather free of host copies (hipGraph capture)
+            nn_ids = torch.as_tensor(ref['nn_ids']).to(d).long().view(B, -1)
+            gather = lambda a, b: torch.cat([a.unsqueeze(1), b[nn_ids]], 1)
+            views = gather(ref_s, src_s)                                          # [B,S,3,dh,dw]
+            rots = gather(ref['rots'].float(), src['rots'].float())
+            trans = gather(ref['trans'].float(), src['trans'].float())
+            S = views.shape[1]
+            ref_mu, x_d3 = dn._mono(views, (0,), mono, h, w)
+            dv = dn._hypotheses(ref_mu.contiguous(), c['mvs_min_depth'], c['mvs_max_depth'])
+            feats = self.equi(views.reshape(B * S, 3, dh, dw)).view(B, S, h, w, 32)
+            vol = CV.calculate_cost_volume_erp_multiview(dn.args, feats, None, trans, rots, depth_volume=dv, cost_type='abs_diff',
+                                                         curr_idx=0)
+        else:
+            pair = torch.stack([src_s, ref_s], 1)                                # [B,2,3,dh,dw]: 0 = source, 1 = reference
+            rots = torch.stack([src['rots'], ref['rots']], 1).float()
+            trans = torch.stack([src['trans'], ref['trans']], 1).float()
+            ref_mu, x_d3 = dn._mono(pair, (1, 0), mono, h, w)
+            dv = dn._hypotheses(ref_mu.contiguous(), c['mvs_min_depth'], c['mvs_max_depth'])
+            feats = self.equi(pair.reshape(B * 2, 3, dh, dw)).view(B, 2, h, w, 32)
+            vol = CV.calculate_cost_volume_erp(dn.args, feats, None, trans, rots, depth_volume=dv, cost_type='abs_diff')
         reg = dn.unet3d.forward_ndhwc(vol)                                       # [B,D,h,w,1]
         cat96 = _Map.empty(B, h, w, 96, d)
         cat96.buf[..., :64] = reg[..., 0].permute(0, 2, 3, 1)                    # depth planes become channels

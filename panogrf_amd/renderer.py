@@ -9,6 +9,7 @@ PyTorch-ROCm; everything per ray goes to the HIP library.  The Linear layers bel
 their forward is never called.  Inference; training mode (`'eval' not in data`) is forward-only: the reference's
 random sampling and extra outputs, no backward pass.
 """
+import itertools
 import math
 
 import torch
@@ -233,13 +234,19 @@ class NeuralRayBaseRenderer(nn.Module):
             he = self.__dict__['_hip_enc'] = HipEncoders(self.image_encoder, self.vis_encoder, imgs.device)
         return he
 
-    def _graphed(self, tag, fn, inputs):
+    def _graphed(self, tag, fn, inputs, modules=()):
         """Run fn(*inputs) (CUDA tensors in, tuple of CUDA tensors out, static shapes, no host sync inside) as a replayed
         hipGraph: captured once per (tag, input shapes), replayed on copies of the inputs; outputs are cloned because the
-        next replay overwrites the graph's buffers."""
+        next replay overwrites the graph's buffers.  `modules`: the nn.Modules fn reads weights from -- the HIP paths
+        keep packed copies of them, which a replay would not refresh, so any in-place update or re-assignment of a
+        parameter / buffer (load_state_dict, an optimiser step) drops the capture and takes a new one."""
         key = (tag,) + tuple((tuple(t.shape), t.dtype, str(t.device)) for t in inputs)
+        version = hash(tuple((v._version, v.data_ptr()) for m in modules for v in itertools.chain(m.parameters(), m.buffers())))
         graphs = self.__dict__.setdefault('_graphs', {})
         ent = graphs.get(key)
+        if ent is not None and ent[3] != version:
+            ent = None
+            del graphs[key]
         if ent is None:
             dev = inputs[0].device
             statics = [t.clone() for t in inputs]
@@ -252,8 +259,8 @@ class NeuralRayBaseRenderer(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 outs = fn(*statics)
-            ent = graphs[key] = (g, statics, tuple(outs))
-        g, statics, outs = ent
+            ent = graphs[key] = (g, statics, tuple(outs), version)
+        g, statics, outs, _ = ent
         for s_, t in zip(statics, inputs):
             s_.copy_(t)
         g.replay()
@@ -266,7 +273,8 @@ class NeuralRayBaseRenderer(nn.Module):
         enc = self._encoder_fn(imgs)
         if not (imgs.is_cuda and self.cfg.get('hip_graph_encoders', True)) or torch.is_grad_enabled():
             return enc(imgs, ray_feats)
-        return self._graphed('enc_torch' if enc == self._torch_encoders else 'enc_hip', enc, (imgs.contiguous(), ray_feats.contiguous()))
+        return self._graphed('enc_torch' if enc == self._torch_encoders else 'enc_hip', enc, (imgs.contiguous(), ray_feats.contiguous()),
+                             modules=(self.image_encoder, self.vis_encoder))
 
     def _make_frame(self, que, ref, is_perspec):
         """ERP query: que['c2w'] (render_ops.py:76-106).  Pinhole query (is_perspec, render_cubes.py): que['poses'] and
@@ -344,11 +352,12 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
     def _run_init_net(self, ref, src, is_train):
         """The MVS stage is ~150 small launches (2-D CNNs on MIOpen + the HIP cost-volume / regulariser kernels) with static
         shapes: like the encoders it is captured into a hipGraph once per input shape and replayed
-        (cfg['hip_graph_init_net']=False keeps eager launches; the two-view panogrf_amd.mvs.CostVolumeInitNet only: a
+        (cfg['hip_graph_init_net']=False keeps eager launches; panogrf_amd.mvs.CostVolumeInitNet only, two-view or multi-view: a
         user-supplied init net, or a mono net that syncs with the host, cannot be captured)."""
         from .mvs import CostVolumeInitNet
         net = self.init_net
-        ok = (isinstance(net, CostVolumeInitNet) and int(net.cfg.get('seq_len', 3)) <= 3 and src is not None and
+        mv = int(net.cfg.get('seq_len', 3)) > 3 if isinstance(net, CostVolumeInitNet) else False
+        ok = (isinstance(net, CostVolumeInitNet) and src is not None and (not mv or 'nn_ids' in ref) and
               ref['imgs'].is_cuda and not torch.is_grad_enabled() and self.cfg.get('hip_graph_init_net', True) and
               not net.cfg.get('hip_check_nan'))
         if not ok:
@@ -361,12 +370,17 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
                 from .mvs_hip import HipInitNet
                 run = self.__dict__['_hip_init'] = HipInitNet(net, ref['imgs'].device)
 
-        def fn(ri, rr, rt, si, sr, st):
-            o = run({'imgs': ri, 'rots': rr, 'trans': rt}, {'imgs': si, 'rots': sr, 'trans': st}, False)
+        def fn(ri, rr, rt, si, sr, st, nn_ids=None):
+            r = {'imgs': ri, 'rots': rr, 'trans': rt}
+            if nn_ids is not None:
+                r['nn_ids'] = nn_ids
+            o = run(r, {'imgs': si, 'rots': sr, 'trans': st}, False)
             return o['ray_feats'], o['mvs_depth']
         f = lambda t: t.detach().float().contiguous()
-        ray_feats, depth = self._graphed('init_net_hip' if run is not net else 'init_net', fn, (f(ref['imgs']), f(ref['rots']), f(ref['trans']), f(src['imgs']),
-                                                          f(src['rots']), f(src['trans'])))
+        inputs = (f(ref['imgs']), f(ref['rots']), f(ref['trans']), f(src['imgs']), f(src['rots']), f(src['trans']))
+        if mv:      # neighbour ids as a device tensor: the [ref, src[nn_ids]] gather then has no host copy inside the capture
+            inputs += (torch.as_tensor(ref['nn_ids']).long().to(ref['imgs'].device).view(ref['imgs'].shape[0], -1),)
+        ray_feats, depth = self._graphed('init_net_hip' if run is not net else 'init_net', fn, inputs, modules=(net,))
         return {'ray_feats': ray_feats, 'mvs_depth': depth}
 
     def forward(self, data, is_perspec=False):          # renderer(data, is_perspec=True): render_cubes.py:274

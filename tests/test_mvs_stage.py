@@ -151,3 +151,38 @@ def test_hip_init_net_vs_reference():
     assert out['ray_feats'].shape == t['ray_feats'].shape
     assert max_abs(out['ray_feats'].cpu(), t['ray_feats']) < 5e-4 * max(1.0, float(t['ray_feats'].abs().max()))
     assert max_abs(out['ray_feats'], tor['ray_feats']) < 5e-4 * max(1.0, float(t['ray_feats'].abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_init_net_multiview_vs_reference():
+    """seq_len > 3 (the 4-view config): per reference view [ref, src[nn_ids]] through the HIP Equi net and the multi-view
+    cost volume; depth against the reference's multiview run, ray features against the torch mirror, and the same through
+    the renderer's hipGraph capture (neighbour ids travel as a device tensor)."""
+    from panogrf_amd.mvs import CostVolumeInitNet
+    from panogrf_amd.mvs_hip import HipInitNet
+    from panogrf_amd.renderer import name2network
+    fx = MF.load()
+    shapes, ishapes = MF.key_shapes(fx['pipe']['keys']), MF.key_shapes(fx['init']['keys'])
+    cfg = dict(_args(), use_wrap_padding=True, seq_len=5, min_depth=0.5, max_depth=15.0)
+    inet = CostVolumeInitNet(cfg, d_net=MF.StubMono()).eval()
+    inet.load_state_dict({**MF.seeded_state(ishapes, 91), **{'depth_net.' + k: v for k, v in MF.seeded_state(shapes, 61).items()}})
+    inet = inet.cuda()
+    t = fx['mv']
+    panos = t['panos'].permute(0, 1, 4, 2, 3).contiguous()            # [1,4,3,H,W], view 0 = reference
+    ref = {'imgs': panos[:, 0].cuda(), 'rots': t['rots'][:, 0].cuda(), 'trans': t['trans'][:, 0].cuda(), 'nn_ids': [[0, 1, 2]]}
+    src = {'imgs': panos[0, 1:].cuda(), 'rots': t['rots'][0, 1:].cuda(), 'trans': t['trans'][0, 1:].cuda()}
+    hip = HipInitNet(inet, 'cuda:0')
+    with torch.no_grad():
+        out = hip(ref, src, False)
+        tor = inet(ref, src, False)
+    want = t['depth'].permute(0, 3, 1, 2)
+    assert max_abs(out['mvs_depth'].cpu(), want) < 2e-4 * max(1.0, float(want.max()))
+    assert max_abs(out['ray_feats'], tor['ray_feats']) < 5e-4 * max(1.0, float(tor['ray_feats'].abs().max()))
+    rcfg = dict(cfg, network='neuray_gen', init_net_type='cost_volume', height=32, width=64)
+    net = name2network['neuray_gen'](rcfg, init_net=inet).cuda().eval()
+    with torch.no_grad():
+        for _ in range(2):
+            got = net._run_init_net(ref, src, False)
+    assert any(k[0] == 'init_net_hip' for k in net._graphs)
+    assert max_abs(got['ray_feats'], out['ray_feats']) < 1e-5 * max(1.0, float(tor['ray_feats'].abs().max()))
+    assert max_abs(got['mvs_depth'], out['mvs_depth']) < 1e-5 * max(1.0, float(want.max()))

@@ -150,6 +150,19 @@ def test_encoder_graph_replay_equals_eager():
                 assert float((a_f - e_f).abs().max()) <= 4 * noise + 1e-5 * float(e_f.abs().max())
                 assert float((a_r - e_r).abs().max()) <= 1e-4 * max(1.0, float(e_r.abs().max()))
     assert len(net._graphs) == 2
+    # a weight update after the capture (load_state_dict / optimiser step) must reach the replayed path: the HIP encoders
+    # hold packed copies, so the capture is retaken
+    with torch.no_grad():
+        before, _ = net._encode(imgs, rf)
+        for p in net.image_encoder.parameters():
+            p.mul_(1.25)
+        a_f, a_r = net._encode(imgs, rf)
+        e_f = net.image_encoder(imgs)
+        e_r = net.vis_encoder(rf, e_f)
+    assert float((before - e_f).abs().max()) > 1e-3 * float(e_f.abs().max())
+    assert float((a_f - e_f).abs().max()) <= 1e-4 * float(e_f.abs().max())
+    assert float((a_r - e_r).abs().max()) <= 1e-4 * max(1.0, float(e_r.abs().max()))
+    assert len(net._graphs) == 2
 
 
 def test_pixel_colors_gt_is_bilinear_with_zero_padding():
