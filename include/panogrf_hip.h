@@ -291,6 +291,20 @@ int pgrf_instnorm(const float* x, int cs, int coff, int C, int N, int HW, const 
  * align_corners=True; network/vis_encoder.py:27-29 resize to the ray-feature resolution with align_corners=False). */
 int pgrf_resize_bilinear(const float* in, int in_cs, int in_coff, int C, int N, int H, int W, float* out, int out_cs, int out_coff,
                          int Ho, int Wo, int align_corners, void* stream);
+/* ERP -> cube map [face_w x 6*face_w], faces F R B L U D side by side: replaces `Equirec2Cube.run`
+ * (UniFuse-Unidirectional-Fusion/UniFuse/datasets/util.py:72-111), which the reference calls per view and frame on the
+ * CPU through scipy.ndimage.map_coordinates (FullPipeline.e2c_process, network/omni_mvsnet/pipeline3_model.py:266-282).
+ * erp / out: any strided [N,H,W,C] / [N,face_w,6*face_w,C] views (strides in floats: NCHW and channel-last both work).
+ * coor_y / coor_x: the converter's coordinate tables [face_w*6*face_w] (util.py:60-70, built once on the host).
+ * order 1 = linear (images), 0 = nearest (depth).  The image is sampled as scipy does: padded below with its last and
+ * first rows rolled by W/2, legacy 'wrap' (period len-1), double arithmetic in scipy's tap order -> the same floats.
+ * pix_scale (NULL or [face_w*6*face_w]): multiplied in afterwards (the cos map that turns ray distance into z-depth,
+ * util.py:22-24,105).  mean / stdv (both NULL or device [C]): (v - mean[c]) / stdv[c] afterwards (normalize_input,
+ * pipeline3_model.py:226-244). */
+int pgrf_equirec_to_cube(const float* erp, int N, int H, int W, int C, long long in_sn, long long in_sh, long long in_sw, long long in_sc,
+                         const float* coor_y, const float* coor_x, int face_w, int order, const float* pix_scale, const float* mean,
+                         const float* stdv, float* out, long long out_sn, long long out_sh, long long out_sw, long long out_sc,
+                         void* stream);
 
 #ifdef __cplusplus
 }

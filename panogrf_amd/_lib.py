@@ -97,6 +97,9 @@ SYMBOLS = {
                                 C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "pgrf_resize_bilinear": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, _P]),
+    "pgrf_equirec_to_cube": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong,
+                                       _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_longlong, C.c_longlong, C.c_longlong,
+                                       C.c_longlong, _P]),
     "pgrf_render_rays_train": (C.c_int, [C.POINTER(PgrfFrame), _P, _P, C.POINTER(PgrfRenderCfg), _P, C.c_int, _P, _P,
                                          C.POINTER(PgrfPassOut), C.POINTER(PgrfPassOut), _P, _P, _P, C.c_size_t, _P]),
 }

@@ -246,6 +246,67 @@ __global__ void __launch_bounds__(256) maxpool3s2_wrap_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------ ERP -> cube map
+// Equirec2Cube.run (UniFuse/datasets/util.py:72-111) = scipy.ndimage.map_coordinates(order, mode='wrap') at a fixed
+// coordinate table, on the image padded BELOW with its last and first rows rolled by W/2.  The padding is virtual here
+// (rows H and H+1 index rows H-1 and 0 at column x - W/2); the legacy 'wrap' has period len-1; arithmetic in double, in
+// scipy's tap order and without contraction, so the result is the same float.
+__device__ __forceinline__ double legacy_wrap(double c, int len) {
+  const double sz = (double)(len - 1);
+  if (c < 0.0) c = c + sz * trunc(-c / sz) + sz;
+  else if (c > sz) c = c - sz * trunc(c / sz);
+  return c;
+}
+
+__global__ void __launch_bounds__(256) equirec_to_cube_kernel(const float* __restrict__ erp, int N, int H, int W, int C, long long in_sn,
+                                                              long long in_sh, long long in_sw, long long in_sc,
+                                                              const float* __restrict__ coor_y, const float* __restrict__ coor_x,
+                                                              int face_w, int order, const float* __restrict__ pix_scale,
+                                                              const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                              float* __restrict__ out, long long out_sn, long long out_sh,
+                                                              long long out_sw, long long out_sc) {
+  const int Wo = 6 * face_w;
+  const long long total = (long long)N * face_w * Wo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % ((long long)face_w * Wo));
+    const int n = (int)(i / ((long long)face_w * Wo));
+    const double y = legacy_wrap((double)coor_y[p], H + 2), x = legacy_wrap((double)coor_x[p], W);
+    // padded-row index -> (source row, column shift)
+    auto src = [&](int r, int c) -> long long {
+      if (r >= H) { c -= W / 2; if (c < 0) c += W; r = (r == H) ? H - 1 : 0; }
+      return (long long)r * in_sh + (long long)c * in_sw;
+    };
+    const float* ip = erp + n * in_sn;
+    float* op = out + n * out_sn + (long long)(p / Wo) * out_sh + (long long)(p % Wo) * out_sw;
+    const float ps = pix_scale ? pix_scale[p] : 1.f;
+    if (order == 0) {
+      const int r = min(max((int)floor(y + 0.5), 0), H + 1), c = min(max((int)floor(x + 0.5), 0), W - 1);
+      const long long o = src(r, c);
+      for (int ch = 0; ch < C; ++ch) {
+        float v = ip[o + ch * in_sc];
+        if (pix_scale) v = __fmul_rn(v, ps);
+        if (mean) v = __fdiv_rn(__fsub_rn(v, mean[ch]), stdv[ch]);
+        op[ch * out_sc] = v;
+      }
+    } else {
+      const double y0 = floor(y), x0 = floor(x), fy = y - y0, fx = x - x0, gy = 1.0 - fy, gx = 1.0 - fx;
+      const int r0 = (int)y0, c0 = (int)x0, r1 = min(r0 + 1, H + 1), c1 = min(c0 + 1, W - 1);
+      const long long o00 = src(r0, c0), o01 = src(r0, c1), o10 = src(r1, c0), o11 = src(r1, c1);
+      for (int ch = 0; ch < C; ++ch) {
+        const float* q = ip + ch * in_sc;
+        double t = __dmul_rn(__dmul_rn((double)q[o00], gy), gx);
+        t = __dadd_rn(t, __dmul_rn(__dmul_rn((double)q[o01], gy), fx));
+        t = __dadd_rn(t, __dmul_rn(__dmul_rn((double)q[o10], fy), gx));
+        t = __dadd_rn(t, __dmul_rn(__dmul_rn((double)q[o11], fy), fx));
+        float v = (float)t;
+        if (pix_scale) v = __fmul_rn(v, ps);
+        if (mean) v = __fdiv_rn(__fsub_rn(v, mean[ch]), stdv[ch]);
+        op[ch * out_sc] = v;
+      }
+    }
+  }
+}
+
 static int grid_for(long long total, int cap = 8192) {
   long long b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -331,6 +392,21 @@ int pgrf_resize_bilinear(const float* in, int in_cs, int in_coff, int C, int N, 
   hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_cs, in_coff, C, N, H, W,
                      out, out_cs, out_coff, Ho, Wo, align_corners ? 1 : 0);
   PGRF_CHECK_LAUNCH("resize_bilinear");
+  return PGRF_OK;
+}
+
+int pgrf_equirec_to_cube(const float* erp, int N, int H, int W, int C, long long in_sn, long long in_sh, long long in_sw, long long in_sc,
+                         const float* coor_y, const float* coor_x, int face_w, int order, const float* pix_scale, const float* mean,
+                         const float* stdv, float* out, long long out_sn, long long out_sh, long long out_sw, long long out_sc,
+                         void* stream) {
+  if (!erp || !out || !coor_y || !coor_x) return set_error(PGRF_ERR_ARG, "pgrf_equirec_to_cube: null pointer");
+  if (N < 1 || H < 2 || W < 2 || C < 1 || face_w < 1) return set_error(PGRF_ERR_ARG, "pgrf_equirec_to_cube: bad dims");
+  if (order != 0 && order != 1) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_equirec_to_cube: order must be 0 (nearest) or 1 (linear)");
+  if ((mean == nullptr) != (stdv == nullptr)) return set_error(PGRF_ERR_ARG, "pgrf_equirec_to_cube: mean and std go together");
+  const long long total = (long long)N * face_w * 6 * face_w;
+  hipLaunchKernelGGL(equirec_to_cube_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, erp, N, H, W, C, in_sn, in_sh,
+                     in_sw, in_sc, coor_y, coor_x, face_w, order, pix_scale, mean, stdv, out, out_sn, out_sh, out_sw, out_sc);
+  PGRF_CHECK_LAUNCH("equirec_to_cube");
   return PGRF_OK;
 }
 

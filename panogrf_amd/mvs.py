@@ -180,6 +180,19 @@ class MVSDepthNet(nn.Module):
         self.register_buffer('_im_std', torch.tensor(_IMNET_STD).view(1, 3, 1, 1), persistent=False)
         self.k_list = CV.depth_sampling(int(a.get('MAGNET_num_samples', 5)), a.get('MAGNET_sampling_range', 3))
 
+    def _cube_input(self, x):
+        """Normalised cube maps [n,3,fw,6fw] of the mono net's ERP input x [n,3,mh,mw] (e2c_process + normalize_input,
+        pipeline3_model.py:149, :644-654): one launch on the device (panogrf_amd/cubemap.py) where the reference goes
+        through the host and scipy per view.  args['hip_cube_input']=False passes None (a mono net that ignores it)."""
+        if not (x.is_cuda and self.args.get('hip_cube_input', True)):
+            return None
+        from .cubemap import Equirec2Cube
+        mh, mw = x.shape[-2:]
+        e2c = self.__dict__.get('_e2c_mono')
+        if e2c is None or (e2c.equ_h, e2c.equ_w, e2c.device) != (mh, mw, x.device):
+            e2c = self.__dict__['_e2c_mono'] = Equirec2Cube(mh, mw, mh // 2, x.device)
+        return e2c.to_cube(x, channels_first=True, mean=self._im_mean.reshape(-1), std=self._im_std.reshape(-1))
+
     # mono prior: pipeline3_model.py:630-717 (two views) / :977-1050 (multi-view)
     def _mono(self, panos_cf, view_ids, mono, h, w):
         """-> ref_mu [B,1,h,w], x_d3 [B,32,h,w] of the view `view_ids[0]` (the depth net runs on all listed views like the
@@ -192,7 +205,7 @@ class MVSDepthNet(nn.Module):
             x = torch.cat([panos_cf[:, v] for v in view_ids], 0)
             x = F.interpolate(x, (a['mono_height'], a['mono_width']), mode=a.get('interpolation_mode', 'bilinear'), align_corners=False)
             with torch.no_grad():
-                mono = self.d_net((x - self._im_mean) / self._im_std, None, dnet=True)
+                mono = self.d_net((x - self._im_mean) / self._im_std, self._cube_input(x), dnet=True)
         mu = F.interpolate(mono['pred_depth'], [h, w], mode='bilinear').detach()
         x_d3 = F.interpolate(mono['mono_feat'], [h, w], mode='bilinear')
         return mu[:B, :1], x_d3[:B]
