@@ -63,8 +63,11 @@ __host__ __device__ inline size_t wpk_index(int cot, int tap, int chunk, int chu
 #ifndef PGRF_CONV_WAVES
 #define PGRF_CONV_WAVES 1        // minimum waves per SIMD the register allocation must allow (tuning knob)
 #endif
-template <int MT, int NT, bool SPLIT>
-__global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const ConvArgs a) {
+// LEAN: two waves per SIMD (<= 256 registers): ONE operand buffer of half a step (16 of the chunk's 32 channels),
+// refilled in place behind the MFMAs that read it, for interior AND boundary waves (the latter with masked operands).
+// Needs Cin % 32 == 0 and the 27-tap mode; everything else takes the LEAN = false instantiations.
+template <int MT, int NT, bool SPLIT, bool LEAN = false>
+__global__ void __launch_bounds__(256, LEAN ? 2 : PGRF_CONV_WAVES) conv3d_wrap_kernel(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float red[SPLIT ? 3 * MT * NT * 16 * 64 : 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -280,14 +283,36 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         mfma_group(st, m, s4);
+#ifndef PGRF_CONV_ABL_NOREFILL_A      // timing experiments: no weight / no activation refills (stale operands)
         st.av[m][s4] = ap[m][s4 * 64];
+#endif
+#ifndef PGRF_CONV_ABL_NOREFILL_B
         if (m == MT - 1) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) st.bv[t][s4] = *reinterpret_cast<const float4*>(sb + voff[t][dxi] + s4 * 16);
         }
+#endif
+#ifndef PGRF_CONV_SPREAD_REFILL   // default: refills in one batch behind the group (spreading them measured 0.8 % slower)
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                       // the group's MFMAs ...
+#if !defined(PGRF_CONV_ABL_NOREFILL_A) && !defined(PGRF_CONV_ABL_NOREFILL_B)
         if (m == MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1 + NT, 0);      // ... then the refills
         else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#endif
+#else
+        if (m == MT - 1) {
+          // experiment: tile t's B quad is last read by MFMA 3*NT + t of the group; its refill right behind that MFMA
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT + 1, 0);
+#pragma unroll
+          for (int t = 0; t < NT - 1; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#endif
       }
   };
   auto mfma_all = [&](const Step& st) {
@@ -319,19 +344,139 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
   // generic loop with masked loads.
   // (every tap row that is needed at all is in range for every lane: also the depth-1 volumes of the 2-D encoders, whose
   // dz = +-1 rows are skipped as a whole)
+  if constexpr (LEAN) {
+    struct Half {
+      float4 bv[NT][2];
+      float4 av[MT][2];
+    };
+    Half P;
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+    // masked path: per-tile range bits (bit d: depth offset d-1 in range, bit 3+d: height offset d-1 in range; all zero for
+    // the voxels of a ragged last tile) and the validity of what P currently holds (bit t: tile t)
+    unsigned tb[NT], pm = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      tb[t] = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (vok[t] && (unsigned)(zin[t] + d - 1) < (unsigned)a.D) tb[t] |= 1u << d;
+        if (vok[t] && (unsigned)(yin[t] + d - 1) < (unsigned)a.H) tb[t] |= 8u << d;
+      }
+    }
+    constexpr unsigned kAllTiles = (1u << NT) - 1u;
+    auto group = [&](int m, int s) {                      // 4 k-steps x NT voxel tiles of one A float4
+      const float av[4] = {P.av[m][s].x, P.av[m][s].y, P.av[m][s].z, P.av[m][s].w};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 bq = P.bv[t][s];
+          const float bs = (jj == 0) ? bq.x : (jj == 1) ? bq.y : (jj == 2) ? bq.z : bq.w;
+          acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], bs, acc[t][m], 0, 0, 0);
+        }
+    };
+    // One half step: (mask and) multiply what P holds while P is refilled in place with the operands of
+    // (row, ch, dx, h): A quad (m, s) right behind its MFMA group, the B quads s behind the last cout tile's group.
+    // COMPUTE = false is the prologue (loads only).
+    auto half_step = [&](int row, int ch, auto dx_tag, auto h_tag, auto masked_tag, auto compute_tag) {
+      constexpr int dxi = decltype(dx_tag)::value, h = decltype(h_tag)::value;
+      constexpr bool MASKED = decltype(masked_tag)::value, COMPUTE = decltype(compute_tag)::value;
+      const int dzi = row / 3, dyi = row % 3, tap = row * 3 + dxi;
+      const long long rowoff = (long long)((dzi - 1) * a.H + (dyi - 1)) * a.W * a.in_cs * 4;
+      const char* cb = reinterpret_cast<const char*>(a.in) + ch * 128 + h * 32;       // wave-uniform
+      const char* sb = cb + rowoff;
+      unsigned off[NT], npm = 0;
+      if constexpr (MASKED) {
+        if (COMPUTE && !__all(pm == kAllTiles)) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const bool ok = (pm >> t) & 1u;
+              P.bv[t][q].x = ok ? P.bv[t][q].x : 0.f; P.bv[t][q].y = ok ? P.bv[t][q].y : 0.f;
+              P.bv[t][q].z = ok ? P.bv[t][q].z : 0.f; P.bv[t][q].w = ok ? P.bv[t][q].w : 0.f;
+            }
+        }
+        // always-valid addresses: the tap's voxel, or the centre voxel where the tap is padding
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bool ok = ((tb[t] >> dzi) & (tb[t] >> (3 + dyi)) & 1u) && !((xbad[t] >> dxi) & 1u);
+          off[t] = ok ? voff[t][dxi] + (unsigned)rowoff : voff[t][1];
+          npm |= (ok ? 1u : 0u) << t;
+        }
+      }
+      const float4* ap[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        ap[m] = reinterpret_cast<const float4*>(a.wpk + wpk_index(cot0 + m, tap, ch, a.chunks, 0, 0, 27)) + lane + h * 128;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if constexpr (COMPUTE) group(m, q);
+#ifdef PGRF_CONV_ABL_NOREFILL_A
+          if (!COMPUTE)
+#endif
+          P.av[m][q] = ap[m][q * 64];
+#ifdef PGRF_CONV_ABL_NOREFILL_B
+          if (!COMPUTE)
+#endif
+          if (m == MT - 1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              if constexpr (MASKED) P.bv[t][q] = *reinterpret_cast<const float4*>(cb + off[t] + q * 16);
+              else P.bv[t][q] = *reinterpret_cast<const float4*>(sb + voff[t][dxi] + q * 16);
+            }
+          }
+#if !defined(PGRF_CONV_ABL_NOREFILL_A) && !defined(PGRF_CONV_ABL_NOREFILL_B)
+          if constexpr (COMPUTE) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                       // the group's MFMAs ...
+            if (m == MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1 + NT, 0);      // ... then the refills
+            else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+#endif
+        }
+      if constexpr (MASKED) pm = npm;
+    };
+    auto run = [&](auto masked_tag) {
+      typedef std::true_type Y;
+      half_step(row, ch, DX0(), H0(), masked_tag, std::false_type());
+      bool more;
+      do {
+        half_step(row, ch, DX0(), H1(), masked_tag, Y());
+        half_step(row, ch, DX1(), H0(), masked_tag, Y());
+        half_step(row, ch, DX1(), H1(), masked_tag, Y());
+        half_step(row, ch, DX2(), H0(), masked_tag, Y());
+        half_step(row, ch, DX2(), H1(), masked_tag, Y());
+        const int prow = row, pch = ch;
+        advance();
+        more = row >= 0;
+        half_step(more ? row : prow, more ? ch : pch, DX0(), H0(), masked_tag, Y());     // (last: a reload nobody reads)
+      } while (more);
+    };
+    const bool interior = a.wrap_w && zam == zm_ && yam == ym_;
+    if (row >= 0) {
+      if (interior) run(std::false_type());
+      else run(std::true_type());
+    }
+  } else {
   const bool interior = kFuse && full_chunks && a.wrap_w && zam == zm_ && yam == ym_ && a.wtaps == 27 && tapmask != 0u;
   if (interior && row >= 0) {              // (row < 0: a split-K wave that got no macro step)
     Step P;
     P.need_mask = false;
     issue(P, row, ch, DX0());                  // fast path of issue(): plain loads
-    while (true) {
+    // bottom-tested loop of whole macro steps (a mid-loop exit made the compiler rotate the loop and copy half of the
+    // accumulator AGPRs twice per iteration); the last iteration's third step reloads its own row instead of a next one
+    bool more;
+    do {
       step_fast(P, row, ch, DX1());
       step_fast(P, row, ch, DX2());
+      const int prow = row, pch = ch;
       advance();
-      if (row < 0) break;
-      step_fast(P, row, ch, DX0());
-    }
-    mfma_all(P);
+      more = row >= 0;
+      step_fast(P, more ? row : prow, more ? ch : pch, DX0());
+    } while (more);
   } else if (row >= 0 && a.wtaps == 1) {          // pointwise product: the centre tap of every chunk
     Step P, Q;
     issue(P, row, ch, DX1()); advance();
@@ -364,6 +509,7 @@ __global__ void __launch_bounds__(256, PGRF_CONV_WAVES) conv3d_wrap_kernel(const
       compute(Q);
       if (!more2) break;
     }
+  }
   }
   if (SPLIT) {
     if (wave > 0) {
@@ -815,7 +961,13 @@ static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, fl
     return PGRF_OK;
   }
   dim3 grid((unsigned)((tiles + 4 * nt - 1) / (4 * nt)), (unsigned)(a.cot_total / mt));
-#define PGRF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv3d_wrap_kernel<MT_, NT_, false>), grid, dim3(256), 0, (hipStream_t)stream, a)
+  bool lean = (Cin & 31) == 0 && a.wtaps == 27;
+  if (const char* e = getenv("PGRF_CONV_LEAN")) lean = lean && atoi(e) != 0;                               // tuning knob
+#define PGRF_LAUNCH(MT_, NT_)                                                                                               \
+  do {                                                                                                                      \
+    if (lean) hipLaunchKernelGGL((conv3d_wrap_kernel<MT_, NT_, false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
+    else hipLaunchKernelGGL((conv3d_wrap_kernel<MT_, NT_, false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);      \
+  } while (0)
   if (mt == 2 && nt == 4) PGRF_LAUNCH(2, 4);
   else if (mt == 2 && nt == 2) PGRF_LAUNCH(2, 2);
   else if (mt == 2) PGRF_LAUNCH(2, 1);
