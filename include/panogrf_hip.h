@@ -231,6 +231,17 @@ int pgrf_pack_conv3d(const float* w_host, const float* bias_host, int Cout, int 
 int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                      const float* packed, int has_bias, int B, int D, int H, int W, int stride, float lrelu_slope,
                      const float* residual, int res_cs, int res_coff, void* stream);
+/* The same convolution (stride 1) by Winograd F(2x2x2, 3x3x3): 8 multiply-adds per output and channel pair instead of
+ * 27, fp32 throughout (csrc/conv3d_wino.hip).  For the wide UNet2 layers (models/common_blocks.py:366-455 via
+ * models/test_models.py:102-146): needs Cin, Cout multiples of 32, even D and H, W a multiple of 64
+ * (pgrf_conv3d_wino_supported).  `packed` from pgrf_pack_conv3d_wino (filters transformed on the host in double).
+ * Results equal pgrf_conv3d_wrap to ~1e-6 relative (transform round-off). */
+size_t pgrf_conv3d_wino_packed_floats(int Cout, int Cin);
+int pgrf_pack_conv3d_wino(const float* w_host, const float* bias_host, int Cout, int Cin, float* packed_host);
+int pgrf_conv3d_wino_supported(int Cin, int Cout, int D, int H, int W);
+int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                     const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                     int res_cs, int res_coff, void* stream);
 /* Narrow layers of CostRegNet (models/cost_reg.py:99-175: 8/16/32-channel convs): the same wrap-padded 3x3x3 conv,
  * but the reduction is cut into 32-deep steps over (tap, channel) (two or four taps per step when Cin is 16 or 8) and
  * `nshift` consecutive output depths share one 32-row tile (nshift * Cout <= 32; nshift > 1 needs stride 1 and

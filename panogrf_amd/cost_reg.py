@@ -29,7 +29,16 @@ class _PackedConv:
         lib.check(lib.pgrf_pack_conv3d(_ptr(w), _ptr(b), cout, cin, _ptr(host)))
         self.dev = host.to(device)
         self.cout, self.cin, self.has_bias = cout, cin, b is not None
-        self._w, self._b, self._device, self._small = w, b, device, {}
+        self._w, self._b, self._device, self._small, self._wino = w, b, device, {}, None
+
+    def wino(self):
+        """Packed block of the Winograd kernel (pgrf_conv3d_wino): filters transformed on the host, built on first use."""
+        if self._wino is None:
+            n = lib.pgrf_conv3d_wino_packed_floats(self.cout, self.cin)
+            host = torch.empty(n, dtype=torch.float32)
+            lib.check(lib.pgrf_pack_conv3d_wino(_ptr(self._w), _ptr(self._b), self.cout, self.cin, _ptr(host)))
+            self._wino = host.to(self._device)
+        return self._wino
 
     def small(self, nshift):
         """Packed block of the narrow-layer kernel (pgrf_conv3d_small), built on first use per depth-shift count."""
@@ -88,6 +97,15 @@ def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
                                         _ptr(residual.buf) if residual is not None else None,
                                         residual.cs if residual is not None else 0,
                                         residual.coff if residual is not None else 0, _stream()))
+        return out
+    if (stride == 1 and os.environ.get('PANOGRF_CONV_WINOGRAD', '1') != '0' and
+            lib.pgrf_conv3d_wino_supported(pc.cin, pc.cout, x.D, x.H, x.W)):
+        # wide stride-1 layers: Winograd F(2x2x2, 3x3x3), 3.4x fewer MFMAs (csrc/conv3d_wino.hip)
+        lib.check(lib.pgrf_conv3d_wino(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                       _ptr(pc.wino()), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope),
+                                       _ptr(residual.buf) if residual is not None else None,
+                                       residual.cs if residual is not None else 0,
+                                       residual.coff if residual is not None else 0, _stream()))
         return out
     lib.check(lib.pgrf_conv3d_wrap(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
                                    _ptr(pc.dev), int(pc.has_bias), x.B, x.D, x.H, x.W, stride, float(slope),

@@ -1,0 +1,429 @@
+// 3x3x3 wrap-padded convolution (stride 1) by the Winograd minimal-filtering algorithm F(2x2x2, 3x3x3) on
+// v_mfma_f32_32x32x2_f32 (the UNet2 regulariser is 1.75 TFLOP per 128x256x64
+// volume and the largest FLOP item of a frame).  Per 2x2x2 output tile the 27-tap correlation becomes 64 independent
+// element-wise products in the transformed domain, i.e. 64 GEMMs [Cout x Cin] x [Cin x tiles]: 8 MACs per output and
+// channel pair instead of 27 (3.375x fewer MFMAs).  Transform matrices (Lavin & Gray, "Fast Algorithms for
+// Convolutional Neural Networks", 2016), applied along z, y and x:
+//     Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   (input patch 4 -> 4)
+//     G  = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]        (filter 3 -> 4; on the host in double, pgrf_pack_conv3d_wino)
+//     At = [1 1 1 0; 0 1 -1 -1]                       (products 4 -> outputs 2)
+// Only 0 and +-1 on the device side: the input and output transforms are additions.
+//
+// Workgroup = 4 waves = 32 consecutive tiles along x (64 output voxels) of one (b, z pair, y pair) x MT*32 output
+// channels.  Per 32-channel block of Cin:
+//   phase A  all threads: load the 4 x 4 x 66 x 32 input patch (zeros outside D/H, circular along W; prefetched into
+//            registers during phase B of the previous block), transform it along z and y in registers and write
+//            T[fz][fy][c][x] to LDS (135 KB, x split into even / odd columns so that the reads below are conflict free);
+//   phase B  wave w owns the 16 frequencies with fz = w: for each (fy, fx) the B operand of k-step (c pair) is formed
+//            on the fly as the x transform of two LDS values (one VALU op), 16 k-steps x MT MFMAs accumulate
+//            M = U_f . V_f over the block's channels, and M is added with signs into the wave's FOUR partially
+//            transformed accumulators R[oy][ox] (the y and x output transforms; 2.25 adds per MFMA row block instead of
+//            3.4 for the full 3-D transform, and 128 accumulator registers instead of 256).
+// After the last block the z output transform (out[oz=0] = R0 + R1 + R2, out[oz=1] = R1 - R2 - R3 over the waves'
+// fz) runs through LDS; bias + LeakyReLU in the epilogue, stores as in conv3d.hip.
+// Accuracy: fp32 throughout; the transforms add ~1e-6 relative round-off (tests compare with the direct kernel and with
+// the oracle at the regulariser tolerances).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "conv3d_common.h"
+
+namespace pgrf {
+
+constexpr int kTW = 33;                               // entries per parity array (patch columns p = 0..65)
+constexpr int kTFloats = 16 * 32 * 2 * kTW;           // T block: [fz*4+fy][c][parity][kTW]
+constexpr int kStageFloats = 16 * 16 * 4;             // halo staging: 16 items x 16 (dz,dy) float4
+constexpr int kWinoLdsBytes = (kTFloats + kStageFloats) * 4;
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) (the 64-group loop below is too large
+// for `#pragma unroll` and must not become a run-time loop: its indices select registers)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// Bt applied to (d0, d1, d2, d3) in place
+__device__ __forceinline__ void bt4(float4& d0, float4& d1, float4& d2, float4& d3) {
+  const float4 t0 = f4sub(d0, d2), t1 = f4add(d1, d2), t2 = f4sub(d2, d1), t3 = f4sub(d1, d3);
+  d0 = t0; d1 = t1; d2 = t2; d3 = t3;
+}
+
+__global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int nrows) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* T = lds;
+  float* stage = lds + kTFloats;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  const int fzw = wave & 3, mw = wave >> 2;              // phase B: this wave's fz and its cout tile within the group of 2
+  const int Wg = a.W >> 6, Ht = a.H >> 1, Dt = a.D >> 1, cgroups = a.cot_total >> 1;
+  const long long rowstride = (long long)a.W * a.in_cs;              // floats between consecutive y
+  const long long planestride = rowstride * a.H;
+  const int hitem = (tid >> 4) & 15, hzy = tid & 15;
+  const bool hthread = tid < 256;
+
+  // A "row" = 32 consecutive 2x2x2 tiles along x (64 output voxels) of one (b, z pair, y pair) x one group of 64 output
+  // channels.  The kernel is persistent: one workgroup per CU (the LDS block allows no more) loops over rows, so that a
+  // row's start-up (dispatch, first loads) hides under the previous row's MFMAs.
+  struct Row {               // wave-uniform
+    unsigned zyok;           // bit dz*4+dy: that patch row is inside the volume
+    int b, z0, y0, x0, cot0;
+  };
+  auto setup = [&](int rowi) {
+    Row r;
+    int g = rowi;
+    r.cot0 = (g % cgroups) * 2; g /= cgroups;
+    const int txg = g % Wg; g /= Wg;
+    const int ty = g % Ht; g /= Ht;
+    const int tz = g % Dt;
+    r.b = g / Dt;
+    r.x0 = txg * 64; r.y0 = ty * 2; r.z0 = tz * 2;
+    r.zyok = 0;
+#pragma unroll
+    for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy)
+        if ((unsigned)(r.z0 - 1 + dz) < (unsigned)a.D && (unsigned)(r.y0 - 1 + dy) < (unsigned)a.H) r.zyok |= 1u << (dz * 4 + dy);
+    return r;
+  };
+
+  // Phase A loads: address = batch element base + byte offset of the patch row (dz, dy) [scalar] + a per-lane 32-bit byte
+  // offset (the launcher checks that one batch element is < 4 GiB).  Main item: patch column p = lane, channel quad
+  // cq = wave.  Halo items (p = 64, 65), threads 0..255: item = tid >> 4 (hp = item >> 3, cq = item & 7), (dz, dy) = tid & 15.
+  // The per-lane offset is made opaque per call: otherwise the compiler hoists the 17 64-bit per-lane addresses out of
+  // the row/block loops, keeps them live across phase B and spills them.
+  const unsigned ps4 = (unsigned)planestride * 4u, rs4 = (unsigned)rowstride * 4u;         // bytes
+  float4 raw[16];
+  float4 hraw;
+  auto prefetch = [&](const Row& r, int blk) {
+    const char* eb = reinterpret_cast<const char*>(a.in + (long long)r.b * a.D * planestride + a.in_coff);
+    int xm = r.x0 - 1 + lane;
+    xm = xm < 0 ? xm + a.W : (xm >= a.W ? xm - a.W : xm);
+    unsigned moff = ((unsigned)xm * (unsigned)a.in_cs + wave * 4 + blk * 32) * 4u;
+    asm volatile("" : "+v"(moff));
+    // loads are unconditional (rows outside the volume read the nearest row inside and are zeroed in transform_store):
+    // no control flow between the requests; interior rows (all but the volume faces) need no clamping at all
+    if (r.zyok == 0xffffu) {
+      const unsigned row0 = (unsigned)(r.z0 - 1) * ps4 + (unsigned)(r.y0 - 1) * rs4;
+#pragma unroll
+      for (int zy = 0; zy < 16; ++zy) raw[zy] = *reinterpret_cast<const float4*>(eb + (row0 + (zy >> 2) * ps4 + (zy & 3) * rs4) + moff);
+    } else {
+#pragma unroll
+      for (int zy = 0; zy < 16; ++zy) {
+        const int zc = min(max(r.z0 - 1 + (zy >> 2), 0), a.D - 1), yc = min(max(r.y0 - 1 + (zy & 3), 0), a.H - 1);
+        raw[zy] = *reinterpret_cast<const float4*>(eb + ((unsigned)zc * ps4 + (unsigned)yc * rs4) + moff);
+      }
+    }
+    int xh = r.x0 + 63 + (hitem >> 3);
+    xh = xh >= a.W ? xh - a.W : xh;
+    const int hz = min(max(r.z0 - 1 + (hzy >> 2), 0), a.D - 1), hy = min(max(r.y0 - 1 + (hzy & 3), 0), a.H - 1);
+    unsigned hoff = (unsigned)hz * ps4 + (unsigned)hy * rs4 + ((unsigned)xh * (unsigned)a.in_cs + (hitem & 7) * 4 + blk * 32) * 4u;
+    asm volatile("" : "+v"(hoff));
+    if (hthread) hraw = *reinterpret_cast<const float4*>(eb + hoff);
+  };
+  // T index of (fzfy, channel c, patch column p)
+  auto tidx = [](int fzfy, int c, int p) { return ((fzfy * 32 + c) * 2 + (p & 1)) * kTW + (p >> 1); };
+  auto transform_store = [&](unsigned zyok) {
+    if (zyok != 0xffffu) {                               // volume faces only
+#pragma unroll
+      for (int zy = 0; zy < 16; ++zy)
+        if (!((zyok >> zy) & 1u)) raw[zy] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) bt4(raw[0 * 4 + dy], raw[1 * 4 + dy], raw[2 * 4 + dy], raw[3 * 4 + dy]);   // along z
+#pragma unroll
+    for (int fz = 0; fz < 4; ++fz) bt4(raw[fz * 4 + 0], raw[fz * 4 + 1], raw[fz * 4 + 2], raw[fz * 4 + 3]);   // along y
+    const int c0 = wave * 4;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      T[tidx(f, c0 + 0, lane)] = raw[f].x; T[tidx(f, c0 + 1, lane)] = raw[f].y;
+      T[tidx(f, c0 + 2, lane)] = raw[f].z; T[tidx(f, c0 + 3, lane)] = raw[f].w;
+    }
+  };
+  // halo columns: thread (item, fz, fy) combines the 2 x 2 raw values its transformed entry is made of
+  auto halo_store = [&]() {
+    if (!hthread) return;
+    const int fz = hzy >> 2, fy = hzy & 3;
+    // Bt row f = +d[ia] + sb * d[ib]:   0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3
+    const int za = (fz == 0) ? 0 : (fz == 2 ? 2 : 1), zb = (fz == 2) ? 1 : (fz == 3 ? 3 : 2);
+    const int ya = (fy == 0) ? 0 : (fy == 2 ? 2 : 1), yb = (fy == 2) ? 1 : (fy == 3 ? 3 : 2);
+    const float szb = (fz == 1) ? 1.f : -1.f, syb = (fy == 1) ? 1.f : -1.f;
+    const float* sp = stage + hitem * 64;
+    const float4 daa = *reinterpret_cast<const float4*>(sp + (za * 4 + ya) * 4), dab = *reinterpret_cast<const float4*>(sp + (za * 4 + yb) * 4);
+    const float4 dba = *reinterpret_cast<const float4*>(sp + (zb * 4 + ya) * 4), dbb = *reinterpret_cast<const float4*>(sp + (zb * 4 + yb) * 4);
+    const int c0 = (hitem & 7) * 4, p = 64 + (hitem >> 3);
+    T[tidx(hzy, c0 + 0, p)] = (daa.x + syb * dab.x) + szb * (dba.x + syb * dbb.x);
+    T[tidx(hzy, c0 + 1, p)] = (daa.y + syb * dab.y) + szb * (dba.y + syb * dbb.y);
+    T[tidx(hzy, c0 + 2, p)] = (daa.z + syb * dab.z) + szb * (dba.z + syb * dbb.z);
+    T[tidx(hzy, c0 + 3, p)] = (daa.w + syb * dab.w) + szb * (dba.w + syb * dbb.w);
+  };
+
+  const float* tb = T + ((fzw * 4) * 32 + half * 16) * 2 * kTW + j;        // this lane's T base: fz = fzw, c = half*16 (+ks)
+  const unsigned lane16 = lane * 16;                     // per-lane byte offset into a packed A block; the block offset is scalar
+  const char* wb = reinterpret_cast<const char*>(a.wpk);
+  auto a_off = [&](int cot0, int blk, int fyfx) {         // byte offset of the packed block (cout tile, frequency, channel block)
+    return (((unsigned)(cot0 + mw) * 64u + fzw * 16 + fyfx) * (unsigned)a.chunks + blk) * 4096u;
+  };
+  auto a_load = [&](unsigned off) { return *reinterpret_cast<const float4*>(wb + off + lane16); };
+  float4 A[4];                                           // A operands of the current frequency, refilled in place (the SIMD's
+                                                         // other wave covers the refill latency)
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+  int rowi = blockIdx.x;
+  if (rowi >= nrows) return;
+  Row cur = setup(rowi);
+  prefetch(cur, 0);
+  {
+    const unsigned ap0 = a_off(cur.cot0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) A[s4] = a_load(ap0 + s4 * 1024);
+  }
+  bool first = true;
+  while (true) {
+    const int nrow = rowi + gridDim.x;
+    const bool has_next = nrow < nrows;
+    int ncot0 = cur.cot0;                               // cout group of the next row (for the A operands after this row's last frequency)
+    f32x16 R[2][2];                                      // [oy][ox]: this wave's fz and cout tile
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+      for (int ox = 0; ox < 2; ++ox) R[oy][ox] = zero16;
+    for (int blk = 0; blk < a.chunks; ++blk) {
+      const bool lastblk = blk + 1 == a.chunks;
+#ifndef PGRF_WINO_ABL_NOA          // timing experiments: no phase A / no phase B
+      // the halo columns' raw values go to the staging area BEFORE the barrier (nobody reads it until after the barrier;
+      // its previous readers finished before the previous block's second barrier)
+      if (hthread) *reinterpret_cast<float4*>(stage + (hitem * 16 + hzy) * 4) = ((cur.zyok >> hzy) & 1u) ? hraw : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+      if (!first) __syncthreads();                       // every wave is done reading T (or the reduction buffer)
+      first = false;
+#ifndef PGRF_WINO_ABL_NOA
+      transform_store(cur.zyok);
+      halo_store();
+      if (!lastblk) prefetch(cur, blk + 1);
+      else if (has_next) { const Row nx = setup(nrow); ncot0 = nx.cot0; prefetch(nx, 0); }
+#else
+      if (lastblk && has_next) ncot0 = setup(nrow).cot0;
+#endif
+      __syncthreads();
+#ifndef PGRF_WINO_ABL_NOB
+      // 64 groups of 4 k-steps (frequency-major).  The two T values every k-step needs are read one group ahead
+      // (tv ping-pong), so the LDS latency of group n+1 hides under the MFMAs of group n; sched_barriers keep that order.
+      float tv[2][8];
+      auto tload = [&](auto buf_tag, auto n_tag) __attribute__((always_inline)) {
+        constexpr int buf = decltype(buf_tag)::value, n = decltype(n_tag)::value;
+        constexpr int fyfx = n >> 2, g = n & 3, fy = fyfx >> 2, fx = fyfx & 3;
+        const float* tr = tb + fy * (32 * 2 * kTW) + g * 4 * 2 * kTW;
+#pragma unroll
+        for (int kl = 0; kl < 4; ++kl) {
+          const float* e = tr + kl * 2 * kTW;             // even columns; odd columns at + kTW
+          // Bt along x on patch columns (2j, 2j+1, 2j+2, 2j+3) = (E[j], O[j], E[j+1], O[j+1])
+#ifdef PGRF_WINO_ABL_NOLDS
+          if (n == 0) { tv[buf][2 * kl] = e[0]; tv[buf][2 * kl + 1] = e[1]; }
+          else { tv[buf][2 * kl] = tv[buf ^ 1][2 * kl] + 1.f; tv[buf][2 * kl + 1] = tv[buf ^ 1][2 * kl + 1]; }
+#else
+          tv[buf][2 * kl] = (fx == 0) ? e[0] : (fx == 2) ? e[1] : e[kTW];
+          tv[buf][2 * kl + 1] = (fx == 0 || fx == 1) ? e[1] : (fx == 2) ? e[kTW] : e[kTW + 1];
+#endif
+        }
+      };
+      tload(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      f32x16 M;
+      // A operands: frequency stride within the block, and where the operands after this block's last frequency are
+      // (next block / next row's first block; the very last: this block again)
+      const unsigned abase = a_off(cur.cot0, blk, 0);
+      const unsigned astride = (unsigned)a.chunks * 4096u;
+      const unsigned anext = lastblk ? a_off(ncot0, 0, 0) : abase + 4096u;
+      static_for<64>([&](auto n_tag) __attribute__((always_inline)) {
+        constexpr int n = decltype(n_tag)::value;
+        constexpr int fyfx = n >> 2, g = n & 3, fy = fyfx >> 2, fx = fyfx & 3, buf = n & 1;
+        if constexpr (n + 1 < 64) tload(std::integral_constant<int, (buf ^ 1)>{}, std::integral_constant<int, n + 1>{});
+        const unsigned nap = fyfx < 15 ? abase + (fyfx + 1) * astride : anext;
+        const float4 aq = A[g];
+#pragma unroll
+        for (int kl = 0; kl < 4; ++kl) {
+          const float bv = (fx == 1) ? tv[buf][2 * kl] + tv[buf][2 * kl + 1] : tv[buf][2 * kl] - tv[buf][2 * kl + 1];
+          const float av = kl == 0 ? aq.x : kl == 1 ? aq.y : kl == 2 ? aq.z : aq.w;
+          M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (g == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
+        }
+#ifndef PGRF_WINO_ABL_NOALOAD
+        A[g] = a_load(nap + g * 1024);
+#endif
+#ifndef PGRF_WINO_ABL_NOADD
+        if constexpr (g == 3) {
+          // y and x output transforms: At column f contributes to output 0 with + (f = 0, 1, 2) and to output 1 with
+          // + (f = 1) or - (f = 2, 3)
+#pragma unroll
+          for (int oy = 0; oy < 2; ++oy) {
+            if ((oy == 0 && fy == 3) || (oy == 1 && fy == 0)) continue;
+            const bool ny = (oy == 1 && fy >= 2);
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) {
+              if ((ox == 0 && fx == 3) || (ox == 1 && fx == 0)) continue;
+              const bool nx = (ox == 1 && fx >= 2);
+              if (ny != nx) R[oy][ox] -= M;
+              else R[oy][ox] += M;
+            }
+          }
+        }
+#else
+        if constexpr (n == 63) R[0][0] += M;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#endif
+    }
+
+    // ---- z output transform across the waves (fz) through LDS, then the epilogue.  red[wave][oy*2+ox][r][lane]
+    __syncthreads();
+    float* red = lds;
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+      for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((wave * 4 + oy * 2 + ox) * 16 + r) << 6) + lane] = R[oy][ox][r];
+    __syncthreads();
+    {
+      const int oz = fzw >> 1, oy = fzw & 1;               // this wave finishes outputs (oz, oy, ox = 0..1) of its cout tile
+      const long long ovrow = (((long long)cur.b * a.D + cur.z0 + oz) * a.H + cur.y0 + oy) * a.W + cur.x0 + 2 * j;
+      const int cot = cur.cot0 + mw;
+#pragma unroll
+      for (int ox = 0; ox < 2; ++ox) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          auto rd = [&](int fz) { return red[((((mw * 4 + fz) * 4 + oy * 2 + ox) * 16 + r) << 6) + lane]; };
+          float v = oz == 0 ? (rd(0) + rd(1)) + rd(2) : (rd(1) - rd(2)) - rd(3);
+          if (a.bias) v += a.bias[cot * 32 + half * 16 + r];
+          acc[r] = v;
+        }
+        const long long ov = ovrow + ox;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = cot * 32 + q * 8 + half * 4;
+          float4 v = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+          float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.residual) rr = *reinterpret_cast<const float4*>(a.residual + ov * a.res_cs + a.res_coff + c);
+          if (a.res_first) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+          v.x = conv_act(a, v.x); v.y = conv_act(a, v.y); v.z = conv_act(a, v.z); v.w = conv_act(a, v.w);
+          if (!a.res_first) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+          *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
+        }
+      }
+    }
+    if (!has_next) break;
+    rowi = nrow;
+    cur = setup(rowi);                                   // (recomputed rather than carried: fewer live scalars)
+  }
+}
+
+}  // namespace pgrf
+
+using namespace pgrf;
+
+extern "C" {
+
+size_t pgrf_conv3d_wino_packed_floats(int Cout, int Cin) {
+  const size_t cot = (Cout + 31) / 32, chunks = (Cin + 31) / 32;
+  return cot * 64 * chunks * 1024 + cot * 32;
+}
+
+int pgrf_pack_conv3d_wino(const float* w_host, const float* bias_host, int Cout, int Cin, float* packed_host) {
+  if (!w_host || !packed_host) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d_wino: null pointer");
+  if (Cout < 1 || Cin < 1) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d_wino: bad channels");
+  const int cot = (Cout + 31) / 32, chunks = (Cin + 31) / 32;
+  std::memset(packed_host, 0, sizeof(float) * pgrf_conv3d_wino_packed_floats(Cout, Cin));
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  std::vector<float> U((size_t)Cout * Cin * 64);
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* w = w_host + ((size_t)co * Cin + ci) * 27;           // [dz][dy][dx]
+      for (int fz = 0; fz < 4; ++fz)
+        for (int fy = 0; fy < 4; ++fy)
+          for (int fx = 0; fx < 4; ++fx) {
+            double s = 0.0;
+            for (int dz = 0; dz < 3; ++dz)
+              for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) s += G[fz][dz] * G[fy][dy] * G[fx][dx] * (double)w[(dz * 3 + dy) * 3 + dx];
+            U[((size_t)co * Cin + ci) * 64 + (fz * 4 + fy) * 4 + fx] = (float)s;
+          }
+    }
+  for (int ct = 0; ct < cot; ++ct)
+    for (int f = 0; f < 64; ++f)
+      for (int ch = 0; ch < chunks; ++ch)
+        for (int s = 0; s < 16; ++s)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = 32 * ct + (lane & 31), ci = 32 * ch + 16 * (lane >> 5) + s;
+            if (co < Cout && ci < Cin) packed_host[wpk_index(ct, f, ch, chunks, s, lane, 64)] = U[((size_t)co * Cin + ci) * 64 + f];
+          }
+  float* B = packed_host + (size_t)cot * 64 * chunks * 1024;
+  for (int ct = 0; ct < cot; ++ct)
+    for (int h = 0; h < 2; ++h)
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * ct + rho_(r, h);
+        B[ct * 32 + h * 16 + r] = (bias_host && co < Cout) ? bias_host[co] : 0.f;
+      }
+  return PGRF_OK;
+}
+
+int pgrf_conv3d_wino_supported(int Cin, int Cout, int D, int H, int W) {
+  return (Cin % 32 == 0) && (Cout % 64 == 0) && (D % 2 == 0) && (H % 2 == 0) && (W % 64 == 0) && D >= 2 && H >= 2;
+}
+
+int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                     const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                     int res_cs, int res_coff, void* stream) {
+  if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino: null pointer");
+  if (!pgrf_conv3d_wino_supported(Cin, Cout, D, H, W))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: needs Cin a multiple of 32, Cout a multiple of 64, even D and H, W a multiple of 64 "
+                     "(got Cin %d Cout %d D %d H %d W %d); use pgrf_conv3d_wrap", Cin, Cout, D, H, W);
+  if (B < 1) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino: bad dims");
+  if ((double)(Cout / 32) * 64.0 * (Cin / 32) * 4096.0 >= 4294967296.0)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: packed weights of >= 4 GiB");
+  if ((double)D * H * W * in_cs * 4.0 >= 4294967296.0)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: one batch element of the input is >= 4 GiB (32-bit byte offsets)");
+  if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: channel strides/offsets must be multiples of 4");
+  ConvArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff;
+  a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W; a.stride = 1; a.slope = lrelu_slope;
+  a.chunks = Cin / 32; a.cot_total = Cout / 32;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 64; a.wrap_w = 1;
+  a.wpk = packed;
+  a.bias = has_bias ? packed + (size_t)a.cot_total * 64 * a.chunks * 1024 : nullptr;
+  const long long nrows_ll = (long long)B * (D / 2) * (H / 2) * (W / 64) * (a.cot_total / 2);
+  if (nrows_ll >= (1ll << 31)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: too many tile rows");
+  const int nrows = (int)nrows_ll;
+  static int ncu = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLdsBytes) != hipSuccess)
+      return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot reserve %d bytes of LDS", kWinoLdsBytes);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot query the device");
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    attr_done = true;
+  }
+  // persistent: one workgroup (8 waves) per CU (the 139 KB LDS block allows no more), each loops over rows
+  int wgs = ncu;
+  if (const char* e = getenv("PGRF_WINO_WGS")) { const int v = atoi(e); if (v > 0) wgs = v; }          // tuning knob
+  dim3 grid((unsigned)(nrows < wgs ? nrows : wgs));
+  hipLaunchKernelGGL(conv3d_wino_kernel, grid, dim3(512), kWinoLdsBytes, (hipStream_t)stream, a, nrows);
+  PGRF_CHECK_LAUNCH("conv3d_wino");
+  return PGRF_OK;
+}
+
+}  // extern "C"

@@ -1,9 +1,10 @@
 #!/bin/bash
-# build a variant of the library with extra -D flags for ONE source file (cost_volume | conv3d | aux_kernels | capi):
+# build a variant of the library with extra -D flags for ONE source file (cost_volume | conv3d | conv3d_wino | aux_kernels | capi):
 #   tools/build_variant_src.sh NAME SRC "-DX=1 ..."   -> panogrf_amd/libpanogrf_hip_NAME.so  (select with PANOGRF_HIP_LIB)
 set -e
 cd "$(dirname "$0")/../panogrf_amd/csrc"
 NAME=$1; SRC=$2; FLAGS=$3
+[ "$SRC" = conv3d_wino ] && FLAGS="$FLAGS -mllvm -amdgpu-mfma-vgpr-form=1"
 mkdir -p build/var_$NAME
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -I../../include $FLAGS -c $SRC.hip -o build/var_$NAME/$SRC.o
 OBJS=$(ls build/*.o | grep -v "build/$SRC.o")
