@@ -50,6 +50,32 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// 16-byte global load as  scalar base (SGPR pair) + ONE per-lane 32-bit byte offset  (global_load_dwordx4 v, voff, s[..]).
+// The base is made opaque, otherwise the compiler reassociates base + scalar + lane offset into a 64-bit per-lane pointer per
+// load, hoists them out of the loops and spills them.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const char __attribute__((address_space(1)))* gptr_t;
+__device__ __forceinline__ float4 sload16(const char* sbase, unsigned voff) {
+  // (64-bit address arithmetic may have gone through the vector ALU: bring the wave-uniform value into SGPRs explicitly)
+  const unsigned long long u = (unsigned long long)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  gptr_t sp = (gptr_t)(((unsigned long long)hi << 32) | lo);
+  asm volatile("" : "+s"(sp), "+v"(voff));               // (voff too: its zero-extension must stay next to the load)
+  const f32x4_t v = *(const f32x4_t __attribute__((address_space(1)))*)(sp + voff);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+// r -= m on a 16-register accumulator as 8 packed adds with negated source (plain `-=` compiles to 16 v_sub_f32)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sub16(f32x16& r, const f32x16& m) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x2_t a = {r[2 * i], r[2 * i + 1]};
+    const f32x2_t b = {m[2 * i], m[2 * i + 1]};
+    asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(a) : "v"(b));
+    r[2 * i] = a.x; r[2 * i + 1] = a.y;
+  }
+}
+
 // Bt applied to (d0, d1, d2, d3) in place
 __device__ __forceinline__ void bt4(float4& d0, float4& d1, float4& d2, float4& d3) {
   const float4 t0 = f4sub(d0, d2), t1 = f4add(d1, d2), t2 = f4sub(d2, d1), t3 = f4sub(d1, d3);
@@ -107,26 +133,24 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
     int xm = r.x0 - 1 + lane;
     xm = xm < 0 ? xm + a.W : (xm >= a.W ? xm - a.W : xm);
     unsigned moff = ((unsigned)xm * (unsigned)a.in_cs + wave * 4 + blk * 32) * 4u;
-    asm volatile("" : "+v"(moff));
     // loads are unconditional (rows outside the volume read the nearest row inside and are zeroed in transform_store):
     // no control flow between the requests; interior rows (all but the volume faces) need no clamping at all
     if (r.zyok == 0xffffu) {
       const unsigned row0 = (unsigned)(r.z0 - 1) * ps4 + (unsigned)(r.y0 - 1) * rs4;
 #pragma unroll
-      for (int zy = 0; zy < 16; ++zy) raw[zy] = *reinterpret_cast<const float4*>(eb + (row0 + (zy >> 2) * ps4 + (zy & 3) * rs4) + moff);
+      for (int zy = 0; zy < 16; ++zy) raw[zy] = sload16(eb + (row0 + (zy >> 2) * ps4 + (zy & 3) * rs4), moff);
     } else {
 #pragma unroll
       for (int zy = 0; zy < 16; ++zy) {
         const int zc = min(max(r.z0 - 1 + (zy >> 2), 0), a.D - 1), yc = min(max(r.y0 - 1 + (zy & 3), 0), a.H - 1);
-        raw[zy] = *reinterpret_cast<const float4*>(eb + ((unsigned)zc * ps4 + (unsigned)yc * rs4) + moff);
+        raw[zy] = sload16(eb + ((unsigned)zc * ps4 + (unsigned)yc * rs4), moff);
       }
     }
     int xh = r.x0 + 63 + (hitem >> 3);
     xh = xh >= a.W ? xh - a.W : xh;
     const int hz = min(max(r.z0 - 1 + (hzy >> 2), 0), a.D - 1), hy = min(max(r.y0 - 1 + (hzy & 3), 0), a.H - 1);
     unsigned hoff = (unsigned)hz * ps4 + (unsigned)hy * rs4 + ((unsigned)xh * (unsigned)a.in_cs + (hitem & 7) * 4 + blk * 32) * 4u;
-    asm volatile("" : "+v"(hoff));
-    if (hthread) hraw = *reinterpret_cast<const float4*>(eb + hoff);
+    if (hthread) hraw = sload16(eb, hoff);
   };
   // T index of (fzfy, channel c, patch column p)
   auto tidx = [](int fzfy, int c, int p) { return ((fzfy * 32 + c) * 2 + (p & 1)) * kTW + (p >> 1); };
@@ -171,7 +195,7 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
   auto a_off = [&](int cot0, int blk, int fyfx) {         // byte offset of the packed block (cout tile, frequency, channel block)
     return (((unsigned)(cot0 + mw) * 64u + fzw * 16 + fyfx) * (unsigned)a.chunks + blk) * 4096u;
   };
-  auto a_load = [&](unsigned off) { return *reinterpret_cast<const float4*>(wb + off + lane16); };
+  auto a_load = [&](unsigned off) { return sload16(wb + off, lane16); };
   float4 A[4];                                           // A operands of the current frequency, refilled in place (the SIMD's
                                                          // other wave covers the refill latency)
   f32x16 zero16;
@@ -192,11 +216,21 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
     const int nrow = rowi + gridDim.x;
     const bool has_next = nrow < nrows;
     int ncot0 = cur.cot0;                               // cout group of the next row (for the A operands after this row's last frequency)
+    // The bias enters through the accumulators of the fz = 1 waves: R1 appears with + in both z outputs
+    // (out[oz=0] = R0 + R1 + R2, out[oz=1] = R1 - R2 - R3), so the epilogue has no dependent bias loads.
     f32x16 R[2][2];                                      // [oy][ox]: this wave's fz and cout tile
+    {
+      f32x16 binit = zero16;
+      if (a.bias && fzw == 1) {
+        const float4* bp = reinterpret_cast<const float4*>(a.bias + (cur.cot0 + mw) * 32 + half * 16);
+        const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        binit = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+      }
 #pragma unroll
-    for (int oy = 0; oy < 2; ++oy)
+      for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
-      for (int ox = 0; ox < 2; ++ox) R[oy][ox] = zero16;
+        for (int ox = 0; ox < 2; ++ox) R[oy][ox] = binit;
+    }
     for (int blk = 0; blk < a.chunks; ++blk) {
       const bool lastblk = blk + 1 == a.chunks;
 #ifndef PGRF_WINO_ABL_NOA          // timing experiments: no phase A / no phase B
@@ -253,7 +287,11 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
         for (int kl = 0; kl < 4; ++kl) {
           const float bv = (fx == 1) ? tv[buf][2 * kl] + tv[buf][2 * kl + 1] : tv[buf][2 * kl] - tv[buf][2 * kl + 1];
           const float av = kl == 0 ? aq.x : kl == 1 ? aq.y : kl == 2 ? aq.z : aq.w;
+#ifdef PGRF_WINO_ABL_NOADD            // timing experiment: one accumulation chain over the whole block, one add at its end
+          M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (n == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
+#else
           M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (g == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
+#endif
         }
 #ifndef PGRF_WINO_ABL_NOALOAD
         A[g] = a_load(nap + g * 1024);
@@ -270,7 +308,7 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
             for (int ox = 0; ox < 2; ++ox) {
               if ((ox == 0 && fx == 3) || (ox == 1 && fx == 0)) continue;
               const bool nx = (ox == 1 && fx >= 2);
-              if (ny != nx) R[oy][ox] -= M;
+              if (ny != nx) sub16(R[oy][ox], M);
               else R[oy][ox] += M;
             }
           }
@@ -303,20 +341,17 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           auto rd = [&](int fz) { return red[((((mw * 4 + fz) * 4 + oy * 2 + ox) * 16 + r) << 6) + lane]; };
-          float v = oz == 0 ? (rd(0) + rd(1)) + rd(2) : (rd(1) - rd(2)) - rd(3);
-          if (a.bias) v += a.bias[cot * 32 + half * 16 + r];
-          acc[r] = v;
+          acc[r] = oz == 0 ? (rd(0) + rd(1)) + rd(2) : (rd(1) - rd(2)) - rd(3);
         }
         const long long ov = ovrow + ox;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int c = cot * 32 + q * 8 + half * 4;
           float4 v = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
-          float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (a.residual) rr = *reinterpret_cast<const float4*>(a.residual + ov * a.res_cs + a.res_coff + c);
-          if (a.res_first) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-          v.x = conv_act(a, v.x); v.y = conv_act(a, v.y); v.z = conv_act(a, v.z); v.w = conv_act(a, v.w);
-          if (!a.res_first) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+          // LeakyReLU only (slope 1 = none): the ELU / residual epilogues of conv3d.hip are not needed by the layers
+          // this kernel serves, and their code (expm1f per value) would run on the f32 MFMA's own pipe
+          v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+          v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
           *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
         }
       }
@@ -388,6 +423,7 @@ int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* ou
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: needs Cin a multiple of 32, Cout a multiple of 64, even D and H, W a multiple of 64 "
                      "(got Cin %d Cout %d D %d H %d W %d); use pgrf_conv3d_wrap", Cin, Cout, D, H, W);
   if (B < 1) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino: bad dims");
+  if (residual) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: no residual epilogue (use pgrf_conv3d_wrap)");
   if ((double)(Cout / 32) * 64.0 * (Cin / 32) * 4096.0 >= 4294967296.0)
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: packed weights of >= 4 GiB");
   if ((double)D * H * W * in_cs * 4.0 >= 4294967296.0)

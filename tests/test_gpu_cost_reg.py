@@ -118,3 +118,76 @@ def test_interior_wave_pipeline_vs_oracle(cin, cout, nt, split, monkeypatch):
     assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
     # the interior planes/rows (fused pipeline) separately from the faces
     assert max_abs(got[:, :, 1:-1, 1:-1], ref[:, :, 1:-1, 1:-1]) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('cin,cout,B,D,H,W,bias,slope', [(32, 64, 1, 4, 4, 64, True, 0.01), (64, 64, 2, 4, 6, 128, True, 0.01),
+                                                         (128, 64, 1, 2, 4, 64, False, 1.0), (64, 128, 1, 6, 2, 64, True, 0.2),
+                                                         (32, 64, 1, 8, 8, 128, True, 0.01), (96, 192, 1, 2, 2, 64, True, 0.01)])
+def test_winograd_conv_vs_oracle(cin, cout, B, D, H, W, bias, slope, monkeypatch):
+    """pgrf_conv3d_wino (Winograd F(2x2x2, 3x3x3), csrc/conv3d_wino.hip) against F.conv3d of the oracle: volume faces
+    (zero padding along D and H), the circular W seam, interior rows (D = H = 8), several channel blocks and cout groups,
+    more rows than one workgroup pass, a channel-sliced input and output.  The same tolerance as the direct kernel: the
+    transforms only add ~1e-6 relative round-off."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    from panogrf_amd._lib import lib
+    monkeypatch.setenv('PANOGRF_CONV_WINOGRAD', '1')
+    monkeypatch.setenv('PGRF_WINO_WGS', '3')                     # few workgroups: every one loops over several rows
+    assert lib.pgrf_conv3d_wino_supported(cin, cout, D, H, W) == 1
+    g = torch.Generator().manual_seed(cin * 31 + cout * 7 + D + H + W)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5}
+    if bias:
+        w['c.bias'] = torch.randn(cout, generator=g) * 0.1
+    ref = torch.nn.functional.leaky_relu(O._conv3(w, 'c', x, 1), slope)
+    pc = R._PackedConv(w['c.weight'], w.get('c.bias'), 'cuda')
+    wide_in = torch.full((B, D, H, W, cin + 8), 3.0, device='cuda')
+    wide_in[..., 4:4 + cin] = R._to_ndhwc(x.cuda())
+    wide_out = R._Vol.empty(B, D, H, W, cout + 8, 'cuda')
+    wide_out.buf.fill_(7.0)
+    out = R._conv(pc, R._Vol(wide_in, 4, cin), wide_out.slice(4, cout), stride=1, slope=slope)
+    got = out.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
+    assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert bool((out.buf[..., :4] == 7.0).all()) and bool((out.buf[..., 4 + cout:] == 7.0).all())
+    # and it really was the Winograd kernel: the direct one gives (slightly) different round-off
+    monkeypatch.setenv('PANOGRF_CONV_WINOGRAD', '0')
+    direct = R._conv(pc, R._Vol(wide_in, 4, cin), R._Vol.empty(B, D, H, W, cout, 'cuda'), stride=1, slope=slope)
+    d = max_abs(direct.buf.permute(0, 4, 1, 2, 3).cpu(), got)
+    assert 0.0 < d < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_winograd_conv_rejects_what_it_cannot_do():
+    import ctypes
+    from panogrf_amd._lib import lib
+    sup = lib.pgrf_conv3d_wino_supported
+    assert sup(64, 64, 4, 4, 64) == 1
+    assert sup(48, 64, 4, 4, 64) == 0 and sup(64, 32, 4, 4, 64) == 0          # Cin % 32, Cout % 64
+    assert sup(64, 64, 5, 4, 64) == 0 and sup(64, 64, 4, 3, 64) == 0 and sup(64, 64, 4, 4, 96) == 0    # odd D / H, W % 64
+    x = torch.zeros(1, 5, 4, 64, 64, device='cuda')
+    p = ctypes.c_void_p(x.data_ptr())
+    assert lib.pgrf_conv3d_wino(p, 64, 0, 64, p, 64, 0, 64, p, 0, 1, 5, 4, 64, 0.01, None, 0, 0, None) != 0
+    assert b'pgrf_conv3d_wino' in lib.pgrf_last_error()
+    x = torch.zeros(1, 4, 4, 64, 64, device='cuda')
+    p = ctypes.c_void_p(x.data_ptr())
+    assert lib.pgrf_conv3d_wino(p, 64, 0, 64, p, 64, 0, 64, p, 0, 1, 4, 4, 64, 0.01, p, 64, 0, None) != 0     # residual
+    assert b'residual' in lib.pgrf_last_error()
+    assert lib.pgrf_conv3d_wino_packed_floats(64, 32) == 2 * 64 * 1 * 1024 + 64
+
+
+def test_unet2_winograd_equals_direct(monkeypatch):
+    """The whole UNet2 regulariser with its wide layers on the Winograd kernel vs all layers on the direct kernel (a volume
+    wide enough that the first two resolution levels qualify)."""
+    from panogrf_amd.cost_reg import UNet2Reg
+    torch.manual_seed(3)
+    net = UNet2Reg().eval().cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+    x = torch.randn(1, 32, 16, 16, 128, generator=torch.Generator().manual_seed(4)).cuda()
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PANOGRF_CONV_WINOGRAD', flag)
+        with torch.no_grad():
+            outs.append(net(x).clone())
+    d = max_abs(outs[0], outs[1])
+    assert 0.0 < d < 1e-4 * max(1.0, float(outs[1].abs().max()))
