@@ -92,6 +92,9 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
   const int Wg = a.W >> 6, Ht = a.H >> 1, Dt = a.D >> 1, cgroups = a.cot_total >> 1;
   const long long rowstride = (long long)a.W * a.in_cs;              // floats between consecutive y
   const long long planestride = rowstride * a.H;
+  // phase A main item of this thread: patch column ip, channel quad icq.  Eight consecutive lanes read the eight quads
+  // (one 128-byte line) of one voxel, so a wave's load touches 8 lines (one lane per voxel touched 64)
+  const int ip = tid >> 3, icq = tid & 7;
   const int hitem = (tid >> 4) & 15, hzy = tid & 15;
   const bool hthread = tid < 256;
 
@@ -130,9 +133,9 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
   float4 hraw;
   auto prefetch = [&](const Row& r, int blk) {
     const char* eb = reinterpret_cast<const char*>(a.in + (long long)r.b * a.D * planestride + a.in_coff);
-    int xm = r.x0 - 1 + lane;
+    int xm = r.x0 - 1 + ip;
     xm = xm < 0 ? xm + a.W : (xm >= a.W ? xm - a.W : xm);
-    unsigned moff = ((unsigned)xm * (unsigned)a.in_cs + wave * 4 + blk * 32) * 4u;
+    unsigned moff = ((unsigned)xm * (unsigned)a.in_cs + icq * 4 + blk * 32) * 4u;
     // loads are unconditional (rows outside the volume read the nearest row inside and are zeroed in transform_store):
     // no control flow between the requests; interior rows (all but the volume faces) need no clamping at all
     if (r.zyok == 0xffffu) {
@@ -164,11 +167,11 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
     for (int dy = 0; dy < 4; ++dy) bt4(raw[0 * 4 + dy], raw[1 * 4 + dy], raw[2 * 4 + dy], raw[3 * 4 + dy]);   // along z
 #pragma unroll
     for (int fz = 0; fz < 4; ++fz) bt4(raw[fz * 4 + 0], raw[fz * 4 + 1], raw[fz * 4 + 2], raw[fz * 4 + 3]);   // along y
-    const int c0 = wave * 4;
+    const int c0 = icq * 4;
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
-      T[tidx(f, c0 + 0, lane)] = raw[f].x; T[tidx(f, c0 + 1, lane)] = raw[f].y;
-      T[tidx(f, c0 + 2, lane)] = raw[f].z; T[tidx(f, c0 + 3, lane)] = raw[f].w;
+      T[tidx(f, c0 + 0, ip)] = raw[f].x; T[tidx(f, c0 + 1, ip)] = raw[f].y;
+      T[tidx(f, c0 + 2, ip)] = raw[f].z; T[tidx(f, c0 + 3, ip)] = raw[f].w;
     }
   };
   // halo columns: thread (item, fz, fy) combines the 2 x 2 raw values its transformed entry is made of
