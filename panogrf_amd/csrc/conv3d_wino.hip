@@ -76,6 +76,9 @@ __device__ __forceinline__ void sub16(f32x16& r, const f32x16& m) {
   }
 }
 
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding global load).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Bt applied to (d0, d1, d2, d3) in place
 __device__ __forceinline__ void bt4(float4& d0, float4& d1, float4& d2, float4& d3) {
   const float4 t0 = f4sub(d0, d2), t1 = f4add(d1, d2), t2 = f4sub(d2, d1), t3 = f4sub(d1, d3);
@@ -241,7 +244,7 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
       // its previous readers finished before the previous block's second barrier)
       if (hthread) *reinterpret_cast<float4*>(stage + (hitem * 16 + hzy) * 4) = ((cur.zyok >> hzy) & 1u) ? hraw : make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
-      if (!first) __syncthreads();                       // every wave is done reading T (or the reduction buffer)
+      if (!first) lds_barrier();                       // every wave is done reading T (or the reduction buffer)
       first = false;
 #ifndef PGRF_WINO_ABL_NOA
       transform_store(cur.zyok);
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
 #else
       if (lastblk && has_next) ncot0 = setup(nrow).cot0;
 #endif
-      __syncthreads();
+      lds_barrier();
 #ifndef PGRF_WINO_ABL_NOB
       // 64 groups of 4 k-steps (frequency-major).  The two T values every k-step needs are read one group ahead
       // (tv ping-pong), so the LDS latency of group n+1 hides under the MFMAs of group n; sched_barriers keep that order.
@@ -325,7 +328,7 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
     }
 
     // ---- z output transform across the waves (fz) through LDS, then the epilogue.  red[wave][oy*2+ox][r][lane]
-    __syncthreads();
+    lds_barrier();
     float* red = lds;
 #pragma unroll
     for (int oy = 0; oy < 2; ++oy)
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
       for (int ox = 0; ox < 2; ++ox)
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[(((wave * 4 + oy * 2 + ox) * 16 + r) << 6) + lane] = R[oy][ox][r];
-    __syncthreads();
+    lds_barrier();
     {
       const int oz = fzw >> 1, oy = fzw & 1;               // this wave finishes outputs (oz, oy, ox = 0..1) of its cout tile
       const long long ovrow = (((long long)cur.b * a.D + cur.z0 + oz) * a.H + cur.y0 + oy) * a.W + cur.x0 + 2 * j;

@@ -50,5 +50,8 @@ python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --views 4 --height 10
 python3 $R/tools/time_encoders.py 2>&1 | grep -E "ms|err" > $OUT/encoders_timing.txt
 python3 $R/tools/time_mvs.py 256 512 2>&1 | grep -E "ms|err" > $OUT/mvs_stage_timing_256x512.txt
 python3 $R/tools/time_mvs.py 512 1024 2>&1 | grep -E "ms|err" > $OUT/mvs_stage_timing_512x1024.txt
+# 7. Winograd vs direct 3-D convolution per UNet2 layer shape, and the per-dispatch durations of one UNet2 forward
+python3 $R/tools/check_wino.py time 2>&1 | grep "winograd" > $OUT/winograd_vs_direct_layers.txt
+bash $R/tools/layer_trace.sh unet2 128 256 2>&1 | grep -E "dur_us|sum_us" > $OUT/unet2_layer_trace_128x256.txt
 rm -rf $OUT/pmc[0-9] $OUT/bench_trace $OUT/cv_trace
 ls $OUT
