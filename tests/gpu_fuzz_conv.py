@@ -31,3 +31,18 @@ for it in range(n):
     worst = max(worst, e)
     print(f'{it:3d} cin={cin:3d} cout={cout:3d} s={stride} B={B} D={D} H={H} W={W:2d} res={int(use_res)} ns={ns}  err {e:.2e}' + ('' if e < 2e-5 else '  <-- CHECK'))
 print('worst', worst)
+# shapes the Winograd kernel takes (Cin % 32 = 0, Cout % 64 = 0, even D and H, W % 64 = 0, stride 1, no residual)
+worst_w = 0.0
+for it in range(max(4, n // 3)):
+    cin = [32, 64, 96, 128][ri(0, 4)]
+    cout = [64, 128][ri(0, 2)]
+    B, D, H, W = ri(1, 3), 2 * ri(1, 5), 2 * ri(1, 5), 64 * ri(1, 3)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5, 'c.bias': torch.randn(cout, generator=g) * 0.1}
+    ref = torch.nn.functional.leaky_relu(O._conv3(w, 'c', x, 1), 0.01)
+    pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
+    out = R._conv(pc, R._Vol(R._to_ndhwc(x.cuda()), 0, cin), R._Vol.empty(B, D, H, W, cout, 'cuda'), stride=1)
+    e = float((out.buf.permute(0, 4, 1, 2, 3).cpu() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    worst_w = max(worst_w, e)
+    print(f'wino {it:3d} cin={cin:3d} cout={cout:3d} B={B} D={D} H={H} W={W:3d}  err {e:.2e}' + ('' if e < 2e-5 else '  <-- CHECK'))
+print('worst winograd', worst_w)
