@@ -118,6 +118,46 @@ def test_conv3d_packing_on_host():
         assert A[ct, tap, ch, s // 4, lane, s % 4] == np.float32(exp)
 
 
+def test_winograd_filter_transform_on_host():
+    """pgrf_pack_conv3d_wino (host side of csrc/conv3d_wino.hip): unpack U[co][ci][f] from the packed A operands and run
+    the whole F(2x2x2, 3x3x3) algorithm in numpy on a random 4x4x4 patch: out = At (U .* (Bt d)) must equal the
+    27-tap correlation.  Pins the transform matrices and the (frequency, channel block, lane) layout without a GPU."""
+    import numpy as np
+    from panogrf_amd._lib import lib
+    g = torch.Generator().manual_seed(2)
+    cout, cin = 64, 32
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g)
+    b = torch.randn(cout, generator=g)
+    n = lib.pgrf_conv3d_wino_packed_floats(cout, cin)
+    assert n == 2 * 64 * 1 * 1024 + 64
+    host = torch.empty(n)
+    assert lib.pgrf_pack_conv3d_wino(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), cout, cin, C.c_void_p(host.data_ptr())) == 0
+    A = host[:2 * 64 * 1024].reshape(2, 64, 1, 4, 64, 4).numpy()             # [cout tile][f][chunk][s/4][lane][s%4]
+    U = np.zeros((cout, cin, 64), np.float64)
+    for ct in range(2):
+        for lane in range(64):
+            for s in range(16):
+                U[32 * ct + (lane & 31), 16 * (lane >> 5) + s] = A[ct, :, 0, s // 4, lane, s % 4]
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    d = torch.randn(cin, 4, 4, 4, generator=g).double().numpy()
+    V = np.einsum('ai,bj,ck,nijk->nabc', Bt, Bt, Bt, d).reshape(cin, 64)
+    M = np.einsum('onf,nf->of', U, V).reshape(cout, 4, 4, 4)
+    out = np.einsum('ai,bj,ck,oijk->oabc', At, At, At, M)                    # [cout, 2, 2, 2]
+    ref = np.zeros((cout, 2, 2, 2))
+    wn = w.double().numpy()
+    for oz in range(2):
+        for oy in range(2):
+            for ox in range(2):
+                ref[:, oz, oy, ox] = np.einsum('onijk,nijk->o', wn, d[:, oz:oz + 3, oy:oy + 3, ox:ox + 3])
+    assert np.abs(out - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+    # bias block in accumulator order (register r of lane half h = output row (r&3) + 8*(r>>2) + 4*h)
+    B = host[2 * 64 * 1024:].numpy()
+    for (ct, h, r) in [(0, 0, 0), (1, 1, 5), (0, 1, 15)]:
+        assert B[ct * 32 + h * 16 + r] == b[32 * ct + (r & 3) + 8 * (r >> 2) + 4 * h]
+    assert lib.pgrf_conv3d_wino_supported(64, 64, 4, 4, 64) == 1 and lib.pgrf_conv3d_wino_supported(64, 64, 4, 4, 32) == 0
+
+
 def test_tile_sharding_math():
     from panogrf_amd import dist as D
     for H in [512, 13, 7]:
