@@ -35,6 +35,16 @@
 
 namespace pgrf {
 
+#ifndef PGRF_WINO_TV_PINGPONG
+#define PGRF_WINO_TV_PINGPONG 0    // 1: the LDS values of group n+1 are read during group n (8 more registers; the budget is 128)
+#endif
+#ifdef PGRF_WINO_TIMING   // debug build: per-phase cycle totals of wave 0 (s_memtime), written to the buffer passed as `residual`
+#define WT_DECL unsigned long long wt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_t = __builtin_readcyclecounter();
+#define WT_TICK(k) { const unsigned long long wt_n = __builtin_readcyclecounter(); wt_acc[k] += wt_n - wt_t; wt_t = wt_n; }
+#else
+#define WT_DECL
+#define WT_TICK(k)
+#endif
 constexpr int kTW = 33;                               // entries per parity array (patch columns p = 0..65)
 constexpr int kTFloats = 16 * 32 * 2 * kTW;           // T block: [fz*4+fy][c][parity][kTW]
 constexpr int kStageFloats = 16 * 16 * 4;             // halo staging: 16 items x 16 (dz,dy) float4
@@ -76,7 +86,9 @@ __device__ __forceinline__ void sub16(f32x16& r, const f32x16& m) {
   }
 }
 
-// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding global load).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL load
+// (s_waitcnt vmcnt(0) in front of s_barrier), i.e. for the input patch that was requested a moment earlier precisely so
+// that its latency hides under the MFMA phase: measured 25 % of the kernel.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Bt applied to (d0, d1, d2, d3) in place
@@ -85,25 +97,19 @@ __device__ __forceinline__ void bt4(float4& d0, float4& d1, float4& d2, float4& 
   d0 = t0; d1 = t1; d2 = t2; d3 = t3;
 }
 
-__global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int nrows) {
+__global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int nrows) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* T = lds;
   float* stage = lds + kTFloats;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, half = lane >> 5;
-  const int fzw = wave & 3, mw = wave >> 2;              // phase B: this wave's fz and its cout tile within the group of 2
+  const bool loader = wave >= 8;                         // waves 8..15 feed LDS, waves 0..7 run the MFMAs (two + two per SIMD)
   const int Wg = a.W >> 6, Ht = a.H >> 1, Dt = a.D >> 1, cgroups = a.cot_total >> 1;
   const long long rowstride = (long long)a.W * a.in_cs;              // floats between consecutive y
   const long long planestride = rowstride * a.H;
-  // phase A main item of this thread: patch column ip, channel quad icq.  Eight consecutive lanes read the eight quads
-  // (one 128-byte line) of one voxel, so a wave's load touches 8 lines (one lane per voxel touched 64)
-  const int ip = tid >> 3, icq = tid & 7;
-  const int hitem = (tid >> 4) & 15, hzy = tid & 15;
-  const bool hthread = tid < 256;
 
   // A "row" = 32 consecutive 2x2x2 tiles along x (64 output voxels) of one (b, z pair, y pair) x one group of 64 output
-  // channels.  The kernel is persistent: one workgroup per CU (the LDS block allows no more) loops over rows, so that a
-  // row's start-up (dispatch, first loads) hides under the previous row's MFMAs.
+  // channels.  The kernel is persistent: one workgroup per CU (the LDS block allows no more) loops over rows.
   struct Row {               // wave-uniform
     unsigned zyok;           // bit dz*4+dy: that patch row is inside the volume
     int b, z0, y0, x0, cot0;
@@ -125,76 +131,151 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
         if ((unsigned)(r.z0 - 1 + dz) < (unsigned)a.D && (unsigned)(r.y0 - 1 + dy) < (unsigned)a.H) r.zyok |= 1u << (dz * 4 + dy);
     return r;
   };
-
-  // Phase A loads: address = batch element base + byte offset of the patch row (dz, dy) [scalar] + a per-lane 32-bit byte
-  // offset (the launcher checks that one batch element is < 4 GiB).  Main item: patch column p = lane, channel quad
-  // cq = wave.  Halo items (p = 64, 65), threads 0..255: item = tid >> 4 (hp = item >> 3, cq = item & 7), (dz, dy) = tid & 15.
-  // The per-lane offset is made opaque per call: otherwise the compiler hoists the 17 64-bit per-lane addresses out of
-  // the row/block loops, keeps them live across phase B and spills them.
-  const unsigned ps4 = (unsigned)planestride * 4u, rs4 = (unsigned)rowstride * 4u;         // bytes
-  float4 raw[16];
-  float4 hraw;
-  auto prefetch = [&](const Row& r, int blk) {
-    const char* eb = reinterpret_cast<const char*>(a.in + (long long)r.b * a.D * planestride + a.in_coff);
-    int xm = r.x0 - 1 + ip;
-    xm = xm < 0 ? xm + a.W : (xm >= a.W ? xm - a.W : xm);
-    unsigned moff = ((unsigned)xm * (unsigned)a.in_cs + icq * 4 + blk * 32) * 4u;
-    // loads are unconditional (rows outside the volume read the nearest row inside and are zeroed in transform_store):
-    // no control flow between the requests; interior rows (all but the volume faces) need no clamping at all
-    if (r.zyok == 0xffffu) {
-      const unsigned row0 = (unsigned)(r.z0 - 1) * ps4 + (unsigned)(r.y0 - 1) * rs4;
+  // T index of (fzfy, channel c, patch column p)
+  auto tidx = [](int fzfy, int c, int p) { return ((fzfy * 32 + c) * 2 + (p & 1)) * kTW + (p >> 1); };
+  float* red = lds;                                      // z-reduction buffer (reuses T): [m][fz][oy*2+ox][r][lane]
+  auto ridx = [&](int fz, int oyox, int m, int r) { return ((((m * 4 + fz) * 4 + oyox) * 16 + r) << 6) + lane; };
+  // Epilogue of one row, the 8 MFMA waves: wave w finishes cout tile w >> 2, outputs (oz, oy) = ((w >> 1) & 1, w & 1), both ox:
+  // the z output transform over the four fz partials, LeakyReLU, stores.
+  auto epilogue = [&](const Row& cur) {
+    const int m = wave >> 2, oz = (wave >> 1) & 1, oy = wave & 1;
+    const long long ovrow = (((long long)cur.b * a.D + cur.z0 + oz) * a.H + cur.y0 + oy) * a.W + cur.x0 + 2 * j;
+    const int cot = cur.cot0 + m;
 #pragma unroll
-      for (int zy = 0; zy < 16; ++zy) raw[zy] = sload16(eb + (row0 + (zy >> 2) * ps4 + (zy & 3) * rs4), moff);
-    } else {
+    for (int ox = 0; ox < 2; ++ox) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        auto rd = [&](int fz) { return red[ridx(fz, oy * 2 + ox, m, r)]; };
+        acc[r] = oz == 0 ? (rd(0) + rd(1)) + rd(2) : (rd(1) - rd(2)) - rd(3);
+      }
+      const long long ov = ovrow + ox;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = cot * 32 + q * 8 + half * 4;
+        float4 v = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+        // LeakyReLU only (slope 1 = none): the ELU / residual epilogues of conv3d.hip are not needed by the layers
+        // this kernel serves
+        v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+        v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+        *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
+      }
+    }
+  };
+
+  int rowi = blockIdx.x;
+  if (rowi >= nrows) return;
+  // Barrier protocol per 32-channel block (all 8 waves):  B1 = "T may be overwritten" (the MFMA waves are done with the
+  // previous block / everybody is done with the reduction buffer), B2 = "T is complete".  Per row two more around the
+  // z reduction: E1 = "T is dead", E2 = "partials are in LDS".
+  if (loader) {
+    // ------------------------------------------------------------------------------------------------ loader waves
+    // They own the global loads of the input patch, so that the in-order vmcnt counter of the MFMA waves only ever
+    // sees their short weight refills (one wave doing both had to wait for the whole patch before its first MFMA of
+    // every block: 25 % of the kernel).  Thread lt handles the main items (patch column p, channel quad cq) =
+    // (lt >> 3, lt & 7) and (32 + (lt >> 3), lt & 7) -- eight consecutive lanes read one 128-byte line -- and one
+    // (dz, dy) entry of one halo item (columns 64, 65): item = lt >> 4 (hp = item >> 3, cq = item & 7), (dz, dy) = lt & 15.
+    const int lt = tid - 512;                              // 0..511
+    const int ip = lt >> 3, icq = lt & 7;                  // main item: patch column 0..63, channel quad
+    const bool hthread = lt < 256;
+    const int hitem = (lt >> 4) & 15, hzy = lt & 15;
+    const unsigned ps4 = (unsigned)planestride * 4u, rs4 = (unsigned)rowstride * 4u;       // bytes; one batch element < 4 GiB
+    float4 raw[16];
+    float4 hraw = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto prefetch = [&](const Row& r, int blk) {
+      const char* eb = reinterpret_cast<const char*>(a.in + (long long)r.b * a.D * planestride + a.in_coff);
+      int xm = r.x0 - 1 + ip;
+      xm = xm < 0 ? xm + a.W : (xm >= a.W ? xm - a.W : xm);
+      const unsigned moff = ((unsigned)xm * (unsigned)a.in_cs + icq * 4 + blk * 32) * 4u;
+      // rows outside the volume read the nearest row inside (and are zeroed before the transform): unconditional loads
 #pragma unroll
       for (int zy = 0; zy < 16; ++zy) {
         const int zc = min(max(r.z0 - 1 + (zy >> 2), 0), a.D - 1), yc = min(max(r.y0 - 1 + (zy & 3), 0), a.H - 1);
         raw[zy] = sload16(eb + ((unsigned)zc * ps4 + (unsigned)yc * rs4), moff);
       }
+      if (hthread) {
+        int xh = r.x0 + 63 + (hitem >> 3);
+        xh = xh >= a.W ? xh - a.W : xh;
+        const int hz = min(max(r.z0 - 1 + (hzy >> 2), 0), a.D - 1), hy = min(max(r.y0 - 1 + (hzy & 3), 0), a.H - 1);
+        const unsigned hoff = (unsigned)hz * ps4 + (unsigned)hy * rs4 + ((unsigned)xh * (unsigned)a.in_cs + (hitem & 7) * 4 + blk * 32) * 4u;
+        hraw = sload16(eb, hoff);
+      }
+    };
+    // z and y transforms in registers (while the MFMA waves are still busy with the previous block) ...
+    auto transform = [&](unsigned zyok) {
+      if (zyok != 0xffffu) {                               // volume faces only
+#pragma unroll
+        for (int zy = 0; zy < 16; ++zy)
+          if (!((zyok >> zy) & 1u)) raw[zy] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy) bt4(raw[0 * 4 + dy], raw[1 * 4 + dy], raw[2 * 4 + dy], raw[3 * 4 + dy]);   // along z
+#pragma unroll
+      for (int fz = 0; fz < 4; ++fz) bt4(raw[fz * 4 + 0], raw[fz * 4 + 1], raw[fz * 4 + 2], raw[fz * 4 + 3]);   // along y
+    };
+    // ... and only the LDS stores between the two barriers
+    auto store = [&]() {
+      const int c0 = icq * 4;
+#pragma unroll
+      for (int f = 0; f < 16; ++f) {
+        T[tidx(f, c0 + 0, ip)] = raw[f].x; T[tidx(f, c0 + 1, ip)] = raw[f].y;
+        T[tidx(f, c0 + 2, ip)] = raw[f].z; T[tidx(f, c0 + 3, ip)] = raw[f].w;
+      }
+    };
+    // halo columns: thread (item, fz, fy) combines the 2 x 2 raw values its transformed entry is made of
+    auto halo_store = [&]() {
+      if (!hthread) return;
+      const int fz = hzy >> 2, fy = hzy & 3;
+      // Bt row f = +d[ia] + sb * d[ib]:   0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3
+      const int za = (fz == 0) ? 0 : (fz == 2 ? 2 : 1), zb = (fz == 2) ? 1 : (fz == 3 ? 3 : 2);
+      const int ya = (fy == 0) ? 0 : (fy == 2 ? 2 : 1), yb = (fy == 2) ? 1 : (fy == 3 ? 3 : 2);
+      const float szb = (fz == 1) ? 1.f : -1.f, syb = (fy == 1) ? 1.f : -1.f;
+      const float* sp = stage + hitem * 64;
+      const float4 daa = *reinterpret_cast<const float4*>(sp + (za * 4 + ya) * 4), dab = *reinterpret_cast<const float4*>(sp + (za * 4 + yb) * 4);
+      const float4 dba = *reinterpret_cast<const float4*>(sp + (zb * 4 + ya) * 4), dbb = *reinterpret_cast<const float4*>(sp + (zb * 4 + yb) * 4);
+      const int c0 = (hitem & 7) * 4, p = 64 + (hitem >> 3);
+      T[tidx(hzy, c0 + 0, p)] = (daa.x + syb * dab.x) + szb * (dba.x + syb * dbb.x);
+      T[tidx(hzy, c0 + 1, p)] = (daa.y + syb * dab.y) + szb * (dba.y + syb * dbb.y);
+      T[tidx(hzy, c0 + 2, p)] = (daa.z + syb * dab.z) + szb * (dba.z + syb * dbb.z);
+      T[tidx(hzy, c0 + 3, p)] = (daa.w + syb * dab.w) + szb * (dba.w + syb * dbb.w);
+    };
+    Row cur = setup(rowi);
+#ifndef PGRF_WINO_ABL_NOA
+    prefetch(cur, 0);
+#endif
+    while (true) {
+      const int nrow = rowi + gridDim.x;
+      const bool has_next = nrow < nrows;
+      for (int blk = 0; blk < a.chunks; ++blk) {
+        // the halo columns' raw values go to the staging area before B1 (only this wave reads them, after B1)
+#ifndef PGRF_WINO_ABL_NOA
+        if (hthread) *reinterpret_cast<float4*>(stage + (hitem * 16 + hzy) * 4) = ((cur.zyok >> hzy) & 1u) ? hraw : make_float4(0.f, 0.f, 0.f, 0.f);
+        transform(cur.zyok);
+#endif
+        lds_barrier();                                     // B1
+#ifndef PGRF_WINO_ABL_NOA
+        store();
+        halo_store();
+#endif
+        lds_barrier();                                     // B2
+#ifndef PGRF_WINO_ABL_NOA
+        if (blk + 1 < a.chunks) prefetch(cur, blk + 1);
+        else if (has_next) prefetch(setup(nrow), 0);
+#endif
+      }
+      lds_barrier();                                       // E1
+      lds_barrier();                                       // E2
+      if (!has_next) break;
+      rowi = nrow;
+      cur = setup(rowi);
     }
-    int xh = r.x0 + 63 + (hitem >> 3);
-    xh = xh >= a.W ? xh - a.W : xh;
-    const int hz = min(max(r.z0 - 1 + (hzy >> 2), 0), a.D - 1), hy = min(max(r.y0 - 1 + (hzy & 3), 0), a.H - 1);
-    unsigned hoff = (unsigned)hz * ps4 + (unsigned)hy * rs4 + ((unsigned)xh * (unsigned)a.in_cs + (hitem & 7) * 4 + blk * 32) * 4u;
-    if (hthread) hraw = sload16(eb, hoff);
-  };
-  // T index of (fzfy, channel c, patch column p)
-  auto tidx = [](int fzfy, int c, int p) { return ((fzfy * 32 + c) * 2 + (p & 1)) * kTW + (p >> 1); };
-  auto transform_store = [&](unsigned zyok) {
-    if (zyok != 0xffffu) {                               // volume faces only
-#pragma unroll
-      for (int zy = 0; zy < 16; ++zy)
-        if (!((zyok >> zy) & 1u)) raw[zy] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int dy = 0; dy < 4; ++dy) bt4(raw[0 * 4 + dy], raw[1 * 4 + dy], raw[2 * 4 + dy], raw[3 * 4 + dy]);   // along z
-#pragma unroll
-    for (int fz = 0; fz < 4; ++fz) bt4(raw[fz * 4 + 0], raw[fz * 4 + 1], raw[fz * 4 + 2], raw[fz * 4 + 3]);   // along y
-    const int c0 = icq * 4;
-#pragma unroll
-    for (int f = 0; f < 16; ++f) {
-      T[tidx(f, c0 + 0, ip)] = raw[f].x; T[tidx(f, c0 + 1, ip)] = raw[f].y;
-      T[tidx(f, c0 + 2, ip)] = raw[f].z; T[tidx(f, c0 + 3, ip)] = raw[f].w;
-    }
-  };
-  // halo columns: thread (item, fz, fy) combines the 2 x 2 raw values its transformed entry is made of
-  auto halo_store = [&]() {
-    if (!hthread) return;
-    const int fz = hzy >> 2, fy = hzy & 3;
-    // Bt row f = +d[ia] + sb * d[ib]:   0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3
-    const int za = (fz == 0) ? 0 : (fz == 2 ? 2 : 1), zb = (fz == 2) ? 1 : (fz == 3 ? 3 : 2);
-    const int ya = (fy == 0) ? 0 : (fy == 2 ? 2 : 1), yb = (fy == 2) ? 1 : (fy == 3 ? 3 : 2);
-    const float szb = (fz == 1) ? 1.f : -1.f, syb = (fy == 1) ? 1.f : -1.f;
-    const float* sp = stage + hitem * 64;
-    const float4 daa = *reinterpret_cast<const float4*>(sp + (za * 4 + ya) * 4), dab = *reinterpret_cast<const float4*>(sp + (za * 4 + yb) * 4);
-    const float4 dba = *reinterpret_cast<const float4*>(sp + (zb * 4 + ya) * 4), dbb = *reinterpret_cast<const float4*>(sp + (zb * 4 + yb) * 4);
-    const int c0 = (hitem & 7) * 4, p = 64 + (hitem >> 3);
-    T[tidx(hzy, c0 + 0, p)] = (daa.x + syb * dab.x) + szb * (dba.x + syb * dbb.x);
-    T[tidx(hzy, c0 + 1, p)] = (daa.y + syb * dab.y) + szb * (dba.y + syb * dbb.y);
-    T[tidx(hzy, c0 + 2, p)] = (daa.z + syb * dab.z) + szb * (dba.z + syb * dbb.z);
-    T[tidx(hzy, c0 + 3, p)] = (daa.w + syb * dab.w) + szb * (dba.w + syb * dbb.w);
-  };
+    return;
+  }
 
+  // -------------------------------------------------------------------------------------------------- MFMA waves
+  // Wave w owns the 16 frequencies (fz = w & 3, fy, fx) of cout tile w >> 2 of the row's group; two waves per SIMD.
+  const int fzw = wave & 3, mw = wave >> 2;
+  WT_DECL
   const float* tb = T + ((fzw * 4) * 32 + half * 16) * 2 * kTW + j;        // this lane's T base: fz = fzw, c = half*16 (+ks)
   const unsigned lane16 = lane * 16;                     // per-lane byte offset into a packed A block; the block offset is scalar
   const char* wb = reinterpret_cast<const char*>(a.wpk);
@@ -202,29 +283,20 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
     return (((unsigned)(cot0 + mw) * 64u + fzw * 16 + fyfx) * (unsigned)a.chunks + blk) * 4096u;
   };
   auto a_load = [&](unsigned off) { return sload16(wb + off, lane16); };
-  float4 A[4];                                           // A operands of the current frequency, refilled in place (the SIMD's
-                                                         // other wave covers the refill latency)
+  float4 A[4];                                           // A operands of the current frequency, refilled in place
   f32x16 zero16;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-
-  int rowi = blockIdx.x;
-  if (rowi >= nrows) return;
   Row cur = setup(rowi);
-  prefetch(cur, 0);
-  {
-    const unsigned ap0 = a_off(cur.cot0, 0, 0);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) A[s4] = a_load(ap0 + s4 * 1024);
-  }
-  bool first = true;
+  for (int s4 = 0; s4 < 4; ++s4) A[s4] = a_load(a_off(cur.cot0, 0, 0) + s4 * 1024);
   while (true) {
     const int nrow = rowi + gridDim.x;
     const bool has_next = nrow < nrows;
-    int ncot0 = cur.cot0;                               // cout group of the next row (for the A operands after this row's last frequency)
+    const int ncot0 = has_next ? setup(nrow).cot0 : cur.cot0;     // (for the A operands after this row's last frequency)
     // The bias enters through the accumulators of the fz = 1 waves: R1 appears with + in both z outputs
     // (out[oz=0] = R0 + R1 + R2, out[oz=1] = R1 - R2 - R3), so the epilogue has no dependent bias loads.
-    f32x16 R[2][2];                                      // [oy][ox]: this wave's fz and cout tile
+    f32x16 R[2][2];                                      // [oy][ox]
     {
       f32x16 binit = zero16;
       if (a.bias && fzw == 1) {
@@ -239,26 +311,15 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
     }
     for (int blk = 0; blk < a.chunks; ++blk) {
       const bool lastblk = blk + 1 == a.chunks;
-#ifndef PGRF_WINO_ABL_NOA          // timing experiments: no phase A / no phase B
-      // the halo columns' raw values go to the staging area BEFORE the barrier (nobody reads it until after the barrier;
-      // its previous readers finished before the previous block's second barrier)
-      if (hthread) *reinterpret_cast<float4*>(stage + (hitem * 16 + hzy) * 4) = ((cur.zyok >> hzy) & 1u) ? hraw : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-      if (!first) lds_barrier();                       // every wave is done reading T (or the reduction buffer)
-      first = false;
-#ifndef PGRF_WINO_ABL_NOA
-      transform_store(cur.zyok);
-      halo_store();
-      if (!lastblk) prefetch(cur, blk + 1);
-      else if (has_next) { const Row nx = setup(nrow); ncot0 = nx.cot0; prefetch(nx, 0); }
-#else
-      if (lastblk && has_next) ncot0 = setup(nrow).cot0;
-#endif
-      lds_barrier();
+      WT_TICK(0)                                           // row setup / R init / previous epilogue
+      lds_barrier();                                       // B1
+      WT_TICK(1)
+      lds_barrier();                                       // B2
+      WT_TICK(2)
 #ifndef PGRF_WINO_ABL_NOB
       // 64 groups of 4 k-steps (frequency-major).  The two T values every k-step needs are read one group ahead
       // (tv ping-pong), so the LDS latency of group n+1 hides under the MFMAs of group n; sched_barriers keep that order.
-      float tv[2][8];
+      float tv[PGRF_WINO_TV_PINGPONG ? 2 : 1][8];
       auto tload = [&](auto buf_tag, auto n_tag) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_tag)::value, n = decltype(n_tag)::value;
         constexpr int fyfx = n >> 2, g = n & 3, fy = fyfx >> 2, fx = fyfx & 3;
@@ -267,13 +328,8 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
         for (int kl = 0; kl < 4; ++kl) {
           const float* e = tr + kl * 2 * kTW;             // even columns; odd columns at + kTW
           // Bt along x on patch columns (2j, 2j+1, 2j+2, 2j+3) = (E[j], O[j], E[j+1], O[j+1])
-#ifdef PGRF_WINO_ABL_NOLDS
-          if (n == 0) { tv[buf][2 * kl] = e[0]; tv[buf][2 * kl + 1] = e[1]; }
-          else { tv[buf][2 * kl] = tv[buf ^ 1][2 * kl] + 1.f; tv[buf][2 * kl + 1] = tv[buf ^ 1][2 * kl + 1]; }
-#else
           tv[buf][2 * kl] = (fx == 0) ? e[0] : (fx == 2) ? e[1] : e[kTW];
           tv[buf][2 * kl + 1] = (fx == 0 || fx == 1) ? e[1] : (fx == 2) ? e[kTW] : e[kTW + 1];
-#endif
         }
       };
       tload(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -285,24 +341,21 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
       const unsigned anext = lastblk ? a_off(ncot0, 0, 0) : abase + 4096u;
       static_for<64>([&](auto n_tag) __attribute__((always_inline)) {
         constexpr int n = decltype(n_tag)::value;
+#if PGRF_WINO_TV_PINGPONG
         constexpr int fyfx = n >> 2, g = n & 3, fy = fyfx >> 2, fx = fyfx & 3, buf = n & 1;
         if constexpr (n + 1 < 64) tload(std::integral_constant<int, (buf ^ 1)>{}, std::integral_constant<int, n + 1>{});
-        const unsigned nap = fyfx < 15 ? abase + (fyfx + 1) * astride : anext;
+#else
+        constexpr int fyfx = n >> 2, g = n & 3, fy = fyfx >> 2, fx = fyfx & 3, buf = 0;
+        if constexpr (n > 0) tload(std::integral_constant<int, 0>{}, n_tag);
+#endif
         const float4 aq = A[g];
 #pragma unroll
         for (int kl = 0; kl < 4; ++kl) {
           const float bv = (fx == 1) ? tv[buf][2 * kl] + tv[buf][2 * kl + 1] : tv[buf][2 * kl] - tv[buf][2 * kl + 1];
           const float av = kl == 0 ? aq.x : kl == 1 ? aq.y : kl == 2 ? aq.z : aq.w;
-#ifdef PGRF_WINO_ABL_NOADD            // timing experiment: one accumulation chain over the whole block, one add at its end
-          M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (n == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
-#else
           M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (g == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
-#endif
         }
-#ifndef PGRF_WINO_ABL_NOALOAD
-        A[g] = a_load(nap + g * 1024);
-#endif
-#ifndef PGRF_WINO_ABL_NOADD
+        A[g] = a_load((fyfx < 15 ? abase + (fyfx + 1) * astride : anext) + g * 1024);
         if constexpr (g == 3) {
           // y and x output transforms: At column f contributes to output 0 with + (f = 0, 1, 2) and to output 1 with
           // + (f = 1) or - (f = 2, 3)
@@ -319,53 +372,35 @@ __global__ void __launch_bounds__(512) conv3d_wino_kernel(const ConvArgs a, int 
             }
           }
         }
-#else
-        if constexpr (n == 63) R[0][0] += M;
-#endif
         __builtin_amdgcn_sched_barrier(0);
       });
 #endif
+      WT_TICK(3)                                           // MFMA phase
     }
-
-    // ---- z output transform across the waves (fz) through LDS, then the epilogue.  red[wave][oy*2+ox][r][lane]
-    lds_barrier();
-    float* red = lds;
+    lds_barrier();                                         // E1: T is dead
+    WT_TICK(4)
 #pragma unroll
     for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
       for (int ox = 0; ox < 2; ++ox)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(((wave * 4 + oy * 2 + ox) * 16 + r) << 6) + lane] = R[oy][ox][r];
-    lds_barrier();
-    {
-      const int oz = fzw >> 1, oy = fzw & 1;               // this wave finishes outputs (oz, oy, ox = 0..1) of its cout tile
-      const long long ovrow = (((long long)cur.b * a.D + cur.z0 + oz) * a.H + cur.y0 + oy) * a.W + cur.x0 + 2 * j;
-      const int cot = cur.cot0 + mw;
-#pragma unroll
-      for (int ox = 0; ox < 2; ++ox) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          auto rd = [&](int fz) { return red[((((mw * 4 + fz) * 4 + oy * 2 + ox) * 16 + r) << 6) + lane]; };
-          acc[r] = oz == 0 ? (rd(0) + rd(1)) + rd(2) : (rd(1) - rd(2)) - rd(3);
-        }
-        const long long ov = ovrow + ox;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = cot * 32 + q * 8 + half * 4;
-          float4 v = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
-          // LeakyReLU only (slope 1 = none): the ELU / residual epilogues of conv3d.hip are not needed by the layers
-          // this kernel serves, and their code (expm1f per value) would run on the f32 MFMA's own pipe
-          v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
-          v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-          *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
-        }
-      }
-    }
+        for (int r = 0; r < 16; ++r) red[ridx(fzw, oy * 2 + ox, mw, r)] = R[oy][ox][r];
+    WT_TICK(5)                                             // partials to LDS
+    lds_barrier();                                         // E2: partials are in LDS
+    WT_TICK(6)
+    epilogue(cur);
+    WT_TICK(7)
     if (!has_next) break;
     rowi = nrow;
-    cur = setup(rowi);                                   // (recomputed rather than carried: fewer live scalars)
+    cur = setup(rowi);
   }
+#ifdef PGRF_WINO_TIMING
+  if (tid == 0 && a.residual) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.residual));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&dbg[k], wt_acc[k]);
+  }
+#endif
 }
 
 }  // namespace pgrf
@@ -429,7 +464,9 @@ int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* ou
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: needs Cin a multiple of 32, Cout a multiple of 64, even D and H, W a multiple of 64 "
                      "(got Cin %d Cout %d D %d H %d W %d); use pgrf_conv3d_wrap", Cin, Cout, D, H, W);
   if (B < 1) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino: bad dims");
+#ifndef PGRF_WINO_TIMING
   if (residual) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: no residual epilogue (use pgrf_conv3d_wrap)");
+#endif
   if ((double)(Cout / 32) * 64.0 * (Cin / 32) * 4096.0 >= 4294967296.0)
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: packed weights of >= 4 GiB");
   if ((double)D * H * W * in_cs * 4.0 >= 4294967296.0)
@@ -459,11 +496,11 @@ int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* ou
     ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     attr_done = true;
   }
-  // persistent: one workgroup (8 waves) per CU (the 139 KB LDS block allows no more), each loops over rows
+  // persistent: one workgroup (8 MFMA waves + 8 loader waves) per CU (the 139 KB LDS block allows no more), each loops over rows
   int wgs = ncu;
   if (const char* e = getenv("PGRF_WINO_WGS")) { const int v = atoi(e); if (v > 0) wgs = v; }          // tuning knob
   dim3 grid((unsigned)(nrows < wgs ? nrows : wgs));
-  hipLaunchKernelGGL(conv3d_wino_kernel, grid, dim3(512), kWinoLdsBytes, (hipStream_t)stream, a, nrows);
+  hipLaunchKernelGGL(conv3d_wino_kernel, grid, dim3(1024), kWinoLdsBytes, (hipStream_t)stream, a, nrows);
   PGRF_CHECK_LAUNCH("conv3d_wino");
   return PGRF_OK;
 }
