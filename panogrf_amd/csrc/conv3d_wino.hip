@@ -132,7 +132,10 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
     return r;
   };
   // T index of (fzfy, channel c, patch column p)
-  auto tidx = [](int fzfy, int c, int p) { return ((fzfy * 32 + c) * 2 + (p & 1)) * kTW + (p >> 1); };
+  // T index (in floats) of the 4 channels of quad q at (fzfy, patch column p): [fzfy][quad 8][parity][kTW][4 channels].
+  // Channel quads are innermost so that a loader writes its float4 with ONE ds_write_b128 and an MFMA wave reads the
+  // four k-steps of a group (lane half h, group g -> quad 4h + g) with ONE ds_read_b128 per patch column.
+  auto tq = [](int fzfy, int q, int p) { return (((fzfy * 8 + q) * 2 + (p & 1)) * kTW + (p >> 1)) * 4; };
   float* red = lds;                                      // z-reduction buffer (reuses T): [m][fz][oy*2+ox][r][lane]
   auto ridx = [&](int fz, int oyox, int m, int r) { return ((((m * 4 + fz) * 4 + oyox) * 16 + r) << 6) + lane; };
   // Epilogue of one row, the 8 MFMA waves: wave w finishes cout tile w >> 2, outputs (oz, oy) = ((w >> 1) & 1, w & 1), both ox:
@@ -215,11 +218,9 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
     };
     // ... and only the LDS stores between the two barriers
     auto store = [&]() {
-      const int c0 = icq * 4;
 #pragma unroll
       for (int f = 0; f < 16; ++f) {
-        T[tidx(f, c0 + 0, ip)] = raw[f].x; T[tidx(f, c0 + 1, ip)] = raw[f].y;
-        T[tidx(f, c0 + 2, ip)] = raw[f].z; T[tidx(f, c0 + 3, ip)] = raw[f].w;
+        *reinterpret_cast<float4*>(T + tq(f, icq, ip)) = raw[f];
       }
     };
     // halo columns: thread (item, fz, fy) combines the 2 x 2 raw values its transformed entry is made of
@@ -233,11 +234,10 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
       const float* sp = stage + hitem * 64;
       const float4 daa = *reinterpret_cast<const float4*>(sp + (za * 4 + ya) * 4), dab = *reinterpret_cast<const float4*>(sp + (za * 4 + yb) * 4);
       const float4 dba = *reinterpret_cast<const float4*>(sp + (zb * 4 + ya) * 4), dbb = *reinterpret_cast<const float4*>(sp + (zb * 4 + yb) * 4);
-      const int c0 = (hitem & 7) * 4, p = 64 + (hitem >> 3);
-      T[tidx(hzy, c0 + 0, p)] = (daa.x + syb * dab.x) + szb * (dba.x + syb * dbb.x);
-      T[tidx(hzy, c0 + 1, p)] = (daa.y + syb * dab.y) + szb * (dba.y + syb * dbb.y);
-      T[tidx(hzy, c0 + 2, p)] = (daa.z + syb * dab.z) + szb * (dba.z + syb * dbb.z);
-      T[tidx(hzy, c0 + 3, p)] = (daa.w + syb * dab.w) + szb * (dba.w + syb * dbb.w);
+      const int p = 64 + (hitem >> 3);
+      *reinterpret_cast<float4*>(T + tq(hzy, hitem & 7, p)) =
+          make_float4((daa.x + syb * dab.x) + szb * (dba.x + syb * dbb.x), (daa.y + syb * dab.y) + szb * (dba.y + syb * dbb.y),
+                      (daa.z + syb * dab.z) + szb * (dba.z + syb * dbb.z), (daa.w + syb * dab.w) + szb * (dba.w + syb * dbb.w));
     };
     Row cur = setup(rowi);
 #ifndef PGRF_WINO_ABL_NOA
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
   // Wave w owns the 16 frequencies (fz = w & 3, fy, fx) of cout tile w >> 2 of the row's group; two waves per SIMD.
   const int fzw = wave & 3, mw = wave >> 2;
   WT_DECL
-  const float* tb = T + ((fzw * 4) * 32 + half * 16) * 2 * kTW + j;        // this lane's T base: fz = fzw, c = half*16 (+ks)
+  const float* tb = T + (((fzw * 4) * 8 + half * 4) * 2 * kTW + j) * 4;    // this lane's T base: fz = fzw, quad = 4*half (+g), column j
   const unsigned lane16 = lane * 16;                     // per-lane byte offset into a packed A block; the block offset is scalar
   const char* wb = reinterpret_cast<const char*>(a.wpk);
   auto a_off = [&](int cot0, int blk, int fyfx) {         // byte offset of the packed block (cout tile, frequency, channel block)
@@ -319,18 +319,17 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
 #ifndef PGRF_WINO_ABL_NOB
       // 64 groups of 4 k-steps (frequency-major).  The two T values every k-step needs are read one group ahead
       // (tv ping-pong), so the LDS latency of group n+1 hides under the MFMAs of group n; sched_barriers keep that order.
-      float tv[PGRF_WINO_TV_PINGPONG ? 2 : 1][8];
+      float4 tv[PGRF_WINO_TV_PINGPONG ? 2 : 1][2];
       auto tload = [&](auto buf_tag, auto n_tag) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_tag)::value, n = decltype(n_tag)::value;
         constexpr int fyfx = n >> 2, g = n & 3, fy = fyfx >> 2, fx = fyfx & 3;
-        const float* tr = tb + fy * (32 * 2 * kTW) + g * 4 * 2 * kTW;
-#pragma unroll
-        for (int kl = 0; kl < 4; ++kl) {
-          const float* e = tr + kl * 2 * kTW;             // even columns; odd columns at + kTW
-          // Bt along x on patch columns (2j, 2j+1, 2j+2, 2j+3) = (E[j], O[j], E[j+1], O[j+1])
-          tv[buf][2 * kl] = (fx == 0) ? e[0] : (fx == 2) ? e[1] : e[kTW];
-          tv[buf][2 * kl + 1] = (fx == 0 || fx == 1) ? e[1] : (fx == 2) ? e[kTW] : e[kTW + 1];
-        }
+        const float* tr = tb + (fy * 8 + g) * (2 * kTW * 4);       // even columns of (fy, quad 4*half + g); odd columns at + kTW*4
+        // Bt along x on patch columns (2j, 2j+1, 2j+2, 2j+3) = (E[j], O[j], E[j+1], O[j+1]); the two operands of the group's
+        // difference / sum, four k-steps (channels) each
+        constexpr int o0 = (fx == 0) ? 0 : (fx == 2) ? 4 : kTW * 4;
+        constexpr int o1 = (fx == 0 || fx == 1) ? 4 : (fx == 2) ? kTW * 4 : kTW * 4 + 4;
+        tv[buf][0] = *reinterpret_cast<const float4*>(tr + o0);
+        tv[buf][1] = *reinterpret_cast<const float4*>(tr + o1);
       };
       tload(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       f32x16 M;
@@ -346,16 +345,31 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
         if constexpr (n + 1 < 64) tload(std::integral_constant<int, (buf ^ 1)>{}, std::integral_constant<int, n + 1>{});
 #else
         constexpr int fyfx = n >> 2, g = n & 3, fy = fyfx >> 2, fx = fyfx & 3, buf = 0;
+#ifdef PGRF_WINO_ABL_NOLDS
+        if constexpr (n > 0) { tv[0][0].x += 1.f; tv[0][1].y += 1.f; }
+#else
         if constexpr (n > 0) tload(std::integral_constant<int, 0>{}, n_tag);
+#endif
 #endif
         const float4 aq = A[g];
 #pragma unroll
         for (int kl = 0; kl < 4; ++kl) {
-          const float bv = (fx == 1) ? tv[buf][2 * kl] + tv[buf][2 * kl + 1] : tv[buf][2 * kl] - tv[buf][2 * kl + 1];
+          const float t0 = kl == 0 ? tv[buf][0].x : kl == 1 ? tv[buf][0].y : kl == 2 ? tv[buf][0].z : tv[buf][0].w;
+          const float t1 = kl == 0 ? tv[buf][1].x : kl == 1 ? tv[buf][1].y : kl == 2 ? tv[buf][1].z : tv[buf][1].w;
+          const float bv = (fx == 1) ? t0 + t1 : t0 - t1;
           const float av = kl == 0 ? aq.x : kl == 1 ? aq.y : kl == 2 ? aq.z : aq.w;
+#ifdef PGRF_WINO_ABL_NOADD
+          M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (n == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
+#else
           M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (g == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
+#endif
         }
+#ifndef PGRF_WINO_ABL_NOALOAD      // timing experiments: stale weights / stale LDS values / one accumulation chain
         A[g] = a_load((fyfx < 15 ? abase + (fyfx + 1) * astride : anext) + g * 1024);
+#endif
+#ifdef PGRF_WINO_ABL_NOADD
+        if constexpr (n == 63) R[0][0] += M;
+#else
         if constexpr (g == 3) {
           // y and x output transforms: At column f contributes to output 0 with + (f = 0, 1, 2) and to output 1 with
           // + (f = 1) or - (f = 2, 3)
@@ -372,6 +386,7 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
             }
           }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
 #endif
