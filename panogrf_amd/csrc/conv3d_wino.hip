@@ -215,12 +215,21 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
       for (int dy = 0; dy < 4; ++dy) bt4(raw[0 * 4 + dy], raw[1 * 4 + dy], raw[2 * 4 + dy], raw[3 * 4 + dy]);   // along z
 #pragma unroll
       for (int fz = 0; fz < 4; ++fz) bt4(raw[fz * 4 + 0], raw[fz * 4 + 1], raw[fz * 4 + 2], raw[fz * 4 + 3]);   // along y
+      // pin the results here: the scheduler otherwise sinks the whole transform behind the barrier that follows, into
+      // the window in which the MFMA waves wait for T
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(raw[q].x), "+v"(raw[q].y), "+v"(raw[q].z), "+v"(raw[q].w));
     };
     // ... and only the LDS stores between the two barriers
     auto store = [&]() {
+      // two base addresses + compile-time offsets (a ds_write offset field is 16 bits; with one base the compiler
+      // precomputed 16 addresses, spilled half of them and reloaded each from scratch in front of its store)
+      float* b0 = T + tq(0, icq, ip);
+      float* b1 = T + tq(8, icq, ip);
 #pragma unroll
-      for (int f = 0; f < 16; ++f) {
-        *reinterpret_cast<float4*>(T + tq(f, icq, ip)) = raw[f];
+      for (int f = 0; f < 8; ++f) {
+        *reinterpret_cast<float4*>(b0 + f * (8 * 2 * kTW * 4)) = raw[f];
+        *reinterpret_cast<float4*>(b1 + f * (8 * 2 * kTW * 4)) = raw[8 + f];
       }
     };
     // halo columns: thread (item, fz, fy) combines the 2 x 2 raw values its transformed entry is made of
@@ -351,17 +360,24 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
         if constexpr (n > 0) tload(std::integral_constant<int, 0>{}, n_tag);
 #endif
 #endif
+        // The four corner frequencies (fy, fx in {0, 3}) contribute to exactly ONE output (oy, ox) = (fy == 3, fx == 3),
+        // with sign (-1)^(fy == 3) (-1)^(fx == 3): their MFMAs accumulate straight into that R, no products to add.
+        constexpr bool kCorner = (fy == 0 || fy == 3) && (fx == 0 || fx == 3);
+        constexpr int kCy = fy == 3 ? 1 : 0, kCx = fx == 3 ? 1 : 0;
+        constexpr bool kCornerNeg = (fy == 3) != (fx == 3);
         const float4 aq = A[g];
 #pragma unroll
         for (int kl = 0; kl < 4; ++kl) {
           const float t0 = kl == 0 ? tv[buf][0].x : kl == 1 ? tv[buf][0].y : kl == 2 ? tv[buf][0].z : tv[buf][0].w;
           const float t1 = kl == 0 ? tv[buf][1].x : kl == 1 ? tv[buf][1].y : kl == 2 ? tv[buf][1].z : tv[buf][1].w;
-          const float bv = (fx == 1) ? t0 + t1 : t0 - t1;
+          // (corner frequencies: the sign of their single output-transform term is folded into the operand)
+          const float bv = (fx == 1) ? t0 + t1 : (kCorner && kCornerNeg) ? t1 - t0 : t0 - t1;
           const float av = kl == 0 ? aq.x : kl == 1 ? aq.y : kl == 2 ? aq.z : aq.w;
 #ifdef PGRF_WINO_ABL_NOADD
           M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (n == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
 #else
-          M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (g == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
+          if constexpr (kCorner) R[kCy][kCx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, R[kCy][kCx], 0, 0, 0);
+          else M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (g == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
 #endif
         }
 #ifndef PGRF_WINO_ABL_NOALOAD      // timing experiments: stale weights / stale LDS values / one accumulation chain
@@ -370,7 +386,7 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
 #ifdef PGRF_WINO_ABL_NOADD
         if constexpr (n == 63) R[0][0] += M;
 #else
-        if constexpr (g == 3) {
+        if constexpr (g == 3 && !kCorner) {
           // y and x output transforms: At column f contributes to output 0 with + (f = 0, 1, 2) and to output 1 with
           // + (f = 1) or - (f = 2, 3)
 #pragma unroll
