@@ -233,12 +233,15 @@ int pgrf_conv3d_wrap(const float* in, int in_cs, int in_coff, int Cin, float* ou
                      const float* residual, int res_cs, int res_coff, void* stream);
 /* The same convolution (stride 1) by Winograd F(2x2x2, 3x3x3): 8 multiply-adds per output and channel pair instead of
  * 27, fp32 throughout (csrc/conv3d_wino.hip).  For the wide UNet2 layers (models/common_blocks.py:366-455 via
- * models/test_models.py:102-146): needs Cin, Cout multiples of 32, even D and H, W a multiple of 64
+ * models/test_models.py:102-146): needs Cin a multiple of 32, Cout a multiple of 64, even D, and W % 64 == 0 with even H or
+ * W % 32 == 0 with H % 4 == 0
  * (pgrf_conv3d_wino_supported).  `packed` from pgrf_pack_conv3d_wino (filters transformed on the host in double).
  * Results equal pgrf_conv3d_wrap to ~1e-6 relative (transform round-off). */
 size_t pgrf_conv3d_wino_packed_floats(int Cout, int Cin);
 int pgrf_pack_conv3d_wino(const float* w_host, const float* bias_host, int Cout, int Cin, float* packed_host);
 int pgrf_conv3d_wino_supported(int Cin, int Cout, int D, int H, int W);
+/* 1 when supported AND the layer has enough tile rows to fill the chip (otherwise pgrf_conv3d_wrap is faster) */
+int pgrf_conv3d_wino_preferred(int Cin, int Cout, int B, int D, int H, int W);
 int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                      const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
                      int res_cs, int res_coff, void* stream);

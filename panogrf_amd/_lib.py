@@ -76,6 +76,7 @@ SYMBOLS = {
     "pgrf_conv3d_wino_packed_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "pgrf_pack_conv3d_wino": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_wino_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pgrf_conv3d_wino_preferred": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pgrf_conv3d_wino": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_small_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -99,7 +99,8 @@ def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
                                         residual.coff if residual is not None else 0, _stream()))
         return out
     if (stride == 1 and residual is None and os.environ.get('PANOGRF_CONV_WINOGRAD', '1') != '0' and
-            lib.pgrf_conv3d_wino_supported(pc.cin, pc.cout, x.D, x.H, x.W)):
+            (lib.pgrf_conv3d_wino_preferred(pc.cin, pc.cout, x.B, x.D, x.H, x.W) or
+             (os.environ.get('PANOGRF_CONV_WINOGRAD') == 'force' and lib.pgrf_conv3d_wino_supported(pc.cin, pc.cout, x.D, x.H, x.W)))):
         # wide stride-1 layers: Winograd F(2x2x2, 3x3x3), 3.4x fewer MFMAs (csrc/conv3d_wino.hip)
         lib.check(lib.pgrf_conv3d_wino(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
                                        _ptr(pc.wino()), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope), None, 0, 0, _stream()))

@@ -45,10 +45,17 @@ namespace pgrf {
 #define WT_DECL
 #define WT_TICK(k)
 #endif
-constexpr int kTW = 33;                               // entries per parity array (patch columns p = 0..65)
-constexpr int kTFloats = 16 * 32 * 2 * kTW;           // T block: [fz*4+fy][c][parity][kTW]
-constexpr int kStageFloats = 16 * 16 * 4;             // halo staging: 16 items x 16 (dz,dy) float4
-constexpr int kWinoLdsBytes = (kTFloats + kStageFloats) * 4;
+// Tile grid of a row: TX x TY = 32 tiles (= the 32 columns of the MFMA tile).  TWO = false: 32 x 1 (64 output voxels along
+// x; needs W % 64 == 0); TWO = true: 16 x 2 (32 voxels along x, two y tile rows; W % 32 == 0 and H % 4 == 0 -- the
+// half-width levels of a volume).
+template <bool TWO> struct WinoGeom {
+  static constexpr int TX = TWO ? 16 : 32, TY = TWO ? 2 : 1;
+  static constexpr int XW = TX + 1;                    // entries per x-parity array (patch columns p = 0 .. 2 TX + 1)
+  static constexpr int kFStride = TY * 8 * 2 * XW * 4; // floats per (fz, fy) slab of T: [tyy][quad 8][parity][XW][4 channels]
+  static constexpr int kTFloats = 16 * kFStride;
+  static constexpr int kStageFloats = 16 * TY * 16 * 4;   // halo staging: 16 TY items x 16 (dz,dy) float4
+  static constexpr int kLdsBytes = (kTFloats + kStageFloats) * 4;
+};
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -97,21 +104,24 @@ __device__ __forceinline__ void bt4(float4& d0, float4& d1, float4& d2, float4& 
   d0 = t0; d1 = t1; d2 = t2; d3 = t3;
 }
 
+template <bool TWO>
 __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int nrows) {
+  typedef WinoGeom<TWO> G;
+  constexpr int TX = G::TX, TY = G::TY, XW = G::XW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* T = lds;
-  float* stage = lds + kTFloats;
+  float* stage = lds + G::kTFloats;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, half = lane >> 5;
   const bool loader = wave >= 8;                         // waves 8..15 feed LDS, waves 0..7 run the MFMAs (two + two per SIMD)
-  const int Wg = a.W >> 6, Ht = a.H >> 1, Dt = a.D >> 1, cgroups = a.cot_total >> 1;
+  const int Wg = a.W / (2 * TX), Ht = a.H / (2 * TY), Dt = a.D >> 1, cgroups = a.cot_total >> 1;
   const long long rowstride = (long long)a.W * a.in_cs;              // floats between consecutive y
   const long long planestride = rowstride * a.H;
 
   // A "row" = 32 consecutive 2x2x2 tiles along x (64 output voxels) of one (b, z pair, y pair) x one group of 64 output
   // channels.  The kernel is persistent: one workgroup per CU (the LDS block allows no more) loops over rows.
   struct Row {               // wave-uniform
-    unsigned zyok;           // bit dz*4+dy: that patch row is inside the volume
+    unsigned zyok[TY];       // per y tile row: bit dz*4+dy: that patch row is inside the volume
     int b, z0, y0, x0, cot0;
   };
   auto setup = [&](int rowi) {
@@ -122,27 +132,31 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
     const int ty = g % Ht; g /= Ht;
     const int tz = g % Dt;
     r.b = g / Dt;
-    r.x0 = txg * 64; r.y0 = ty * 2; r.z0 = tz * 2;
-    r.zyok = 0;
+    r.x0 = txg * 2 * TX; r.y0 = ty * 2 * TY; r.z0 = tz * 2;
 #pragma unroll
-    for (int dz = 0; dz < 4; ++dz)
+    for (int t = 0; t < TY; ++t) {
+      r.zyok[t] = 0;
 #pragma unroll
-      for (int dy = 0; dy < 4; ++dy)
-        if ((unsigned)(r.z0 - 1 + dz) < (unsigned)a.D && (unsigned)(r.y0 - 1 + dy) < (unsigned)a.H) r.zyok |= 1u << (dz * 4 + dy);
+      for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+          if ((unsigned)(r.z0 - 1 + dz) < (unsigned)a.D && (unsigned)(r.y0 + 2 * t - 1 + dy) < (unsigned)a.H) r.zyok[t] |= 1u << (dz * 4 + dy);
+    }
     return r;
   };
   // T index of (fzfy, channel c, patch column p)
-  // T index (in floats) of the 4 channels of quad q at (fzfy, patch column p): [fzfy][quad 8][parity][kTW][4 channels].
+  // T index (in floats) of the 4 channels of quad q at (fzfy, y tile row, patch column p): [fzfy][tyy][quad 8][parity][XW][4].
   // Channel quads are innermost so that a loader writes its float4 with ONE ds_write_b128 and an MFMA wave reads the
   // four k-steps of a group (lane half h, group g -> quad 4h + g) with ONE ds_read_b128 per patch column.
-  auto tq = [](int fzfy, int q, int p) { return (((fzfy * 8 + q) * 2 + (p & 1)) * kTW + (p >> 1)) * 4; };
+  auto tq = [](int fzfy, int tyy, int q, int p) { return ((((fzfy * TY + tyy) * 8 + q) * 2 + (p & 1)) * XW + (p >> 1)) * 4; };
   float* red = lds;                                      // z-reduction buffer (reuses T): [m][fz][oy*2+ox][r][lane]
   auto ridx = [&](int fz, int oyox, int m, int r) { return ((((m * 4 + fz) * 4 + oyox) * 16 + r) << 6) + lane; };
   // Epilogue of one row, the 8 MFMA waves: wave w finishes cout tile w >> 2, outputs (oz, oy) = ((w >> 1) & 1, w & 1), both ox:
   // the z output transform over the four fz partials, LeakyReLU, stores.
   auto epilogue = [&](const Row& cur) {
     const int m = wave >> 2, oz = (wave >> 1) & 1, oy = wave & 1;
-    const long long ovrow = (((long long)cur.b * a.D + cur.z0 + oz) * a.H + cur.y0 + oy) * a.W + cur.x0 + 2 * j;
+    const int tyy = TWO ? (j >> 4) : 0, tx = TWO ? (j & 15) : j;            // this lane's tile within the row
+    const long long ovrow = (((long long)cur.b * a.D + cur.z0 + oz) * a.H + cur.y0 + 2 * tyy + oy) * a.W + cur.x0 + 2 * tx;
     const int cot = cur.cot0 + m;
 #pragma unroll
     for (int ox = 0; ox < 2; ++ox) {
@@ -179,9 +193,10 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
     // (lt >> 3, lt & 7) and (32 + (lt >> 3), lt & 7) -- eight consecutive lanes read one 128-byte line -- and one
     // (dz, dy) entry of one halo item (columns 64, 65): item = lt >> 4 (hp = item >> 3, cq = item & 7), (dz, dy) = lt & 15.
     const int lt = tid - 512;                              // 0..511
-    const int ip = lt >> 3, icq = lt & 7;                  // main item: patch column 0..63, channel quad
-    const bool hthread = lt < 256;
-    const int hitem = (lt >> 4) & 15, hzy = lt & 15;
+    const int ityy = TWO ? (lt >> 8) : 0, ip = TWO ? ((lt >> 3) & 31) : (lt >> 3), icq = lt & 7;   // main item: y tile row, patch column 0 .. 2 TX - 1, channel quad
+    const bool hthread = lt < 256 * TY;
+    const int hitem = lt >> 4, hzy = lt & 15;              // halo item (16 TY of them): y tile row (TWO), column 2 TX + hp, quad
+    const int htyy = TWO ? (hitem >> 4) : 0, hp = (hitem >> 3) & 1, hcq = hitem & 7;
     const unsigned ps4 = (unsigned)planestride * 4u, rs4 = (unsigned)rowstride * 4u;       // bytes; one batch element < 4 GiB
     float4 raw[16];
     float4 hraw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -193,14 +208,14 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
       // rows outside the volume read the nearest row inside (and are zeroed before the transform): unconditional loads
 #pragma unroll
       for (int zy = 0; zy < 16; ++zy) {
-        const int zc = min(max(r.z0 - 1 + (zy >> 2), 0), a.D - 1), yc = min(max(r.y0 - 1 + (zy & 3), 0), a.H - 1);
+        const int zc = min(max(r.z0 - 1 + (zy >> 2), 0), a.D - 1), yc = min(max(r.y0 + 2 * ityy - 1 + (zy & 3), 0), a.H - 1);
         raw[zy] = sload16(eb + ((unsigned)zc * ps4 + (unsigned)yc * rs4), moff);
       }
       if (hthread) {
-        int xh = r.x0 + 63 + (hitem >> 3);
+        int xh = r.x0 + 2 * TX - 1 + hp;
         xh = xh >= a.W ? xh - a.W : xh;
-        const int hz = min(max(r.z0 - 1 + (hzy >> 2), 0), a.D - 1), hy = min(max(r.y0 - 1 + (hzy & 3), 0), a.H - 1);
-        const unsigned hoff = (unsigned)hz * ps4 + (unsigned)hy * rs4 + ((unsigned)xh * (unsigned)a.in_cs + (hitem & 7) * 4 + blk * 32) * 4u;
+        const int hz = min(max(r.z0 - 1 + (hzy >> 2), 0), a.D - 1), hy = min(max(r.y0 + 2 * htyy - 1 + (hzy & 3), 0), a.H - 1);
+        const unsigned hoff = (unsigned)hz * ps4 + (unsigned)hy * rs4 + ((unsigned)xh * (unsigned)a.in_cs + hcq * 4 + blk * 32) * 4u;
         hraw = sload16(eb, hoff);
       }
     };
@@ -224,12 +239,12 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
     auto store = [&]() {
       // two base addresses + compile-time offsets (a ds_write offset field is 16 bits; with one base the compiler
       // precomputed 16 addresses, spilled half of them and reloaded each from scratch in front of its store)
-      float* b0 = T + tq(0, icq, ip);
-      float* b1 = T + tq(8, icq, ip);
+      float* b0 = T + tq(0, ityy, icq, ip);
+      float* b1 = T + tq(8, ityy, icq, ip);
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        *reinterpret_cast<float4*>(b0 + f * (8 * 2 * kTW * 4)) = raw[f];
-        *reinterpret_cast<float4*>(b1 + f * (8 * 2 * kTW * 4)) = raw[8 + f];
+        *reinterpret_cast<float4*>(b0 + f * G::kFStride) = raw[f];
+        *reinterpret_cast<float4*>(b1 + f * G::kFStride) = raw[8 + f];
       }
     };
     // halo columns: thread (item, fz, fy) combines the 2 x 2 raw values its transformed entry is made of
@@ -243,8 +258,7 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
       const float* sp = stage + hitem * 64;
       const float4 daa = *reinterpret_cast<const float4*>(sp + (za * 4 + ya) * 4), dab = *reinterpret_cast<const float4*>(sp + (za * 4 + yb) * 4);
       const float4 dba = *reinterpret_cast<const float4*>(sp + (zb * 4 + ya) * 4), dbb = *reinterpret_cast<const float4*>(sp + (zb * 4 + yb) * 4);
-      const int p = 64 + (hitem >> 3);
-      *reinterpret_cast<float4*>(T + tq(hzy, hitem & 7, p)) =
+      *reinterpret_cast<float4*>(T + tq(hzy, htyy, hcq, 2 * TX + hp)) =
           make_float4((daa.x + syb * dab.x) + szb * (dba.x + syb * dbb.x), (daa.y + syb * dab.y) + szb * (dba.y + syb * dbb.y),
                       (daa.z + syb * dab.z) + szb * (dba.z + syb * dbb.z), (daa.w + syb * dab.w) + szb * (dba.w + syb * dbb.w));
     };
@@ -258,8 +272,8 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
       for (int blk = 0; blk < a.chunks; ++blk) {
         // the halo columns' raw values go to the staging area before B1 (only this wave reads them, after B1)
 #ifndef PGRF_WINO_ABL_NOA
-        if (hthread) *reinterpret_cast<float4*>(stage + (hitem * 16 + hzy) * 4) = ((cur.zyok >> hzy) & 1u) ? hraw : make_float4(0.f, 0.f, 0.f, 0.f);
-        transform(cur.zyok);
+        if (hthread) *reinterpret_cast<float4*>(stage + (hitem * 16 + hzy) * 4) = ((cur.zyok[htyy] >> hzy) & 1u) ? hraw : make_float4(0.f, 0.f, 0.f, 0.f);
+        transform(cur.zyok[ityy]);
 #endif
         lds_barrier();                                     // B1
 #ifndef PGRF_WINO_ABL_NOA
@@ -285,7 +299,8 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
   // Wave w owns the 16 frequencies (fz = w & 3, fy, fx) of cout tile w >> 2 of the row's group; two waves per SIMD.
   const int fzw = wave & 3, mw = wave >> 2;
   WT_DECL
-  const float* tb = T + (((fzw * 4) * 8 + half * 4) * 2 * kTW + j) * 4;    // this lane's T base: fz = fzw, quad = 4*half (+g), column j
+  const int tyy = TWO ? (j >> 4) : 0, tx = TWO ? (j & 15) : j;               // this lane's tile (MFMA column j) within the row
+  const float* tb = T + tq(fzw * 4, tyy, half * 4, 2 * tx);                  // its T base: fz = fzw, fy = 0, quad = 4*half (+g), even column of tile tx
   const unsigned lane16 = lane * 16;                     // per-lane byte offset into a packed A block; the block offset is scalar
   const char* wb = reinterpret_cast<const char*>(a.wpk);
   auto a_off = [&](int cot0, int blk, int fyfx) {         // byte offset of the packed block (cout tile, frequency, channel block)
@@ -332,11 +347,11 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
       auto tload = [&](auto buf_tag, auto n_tag) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_tag)::value, n = decltype(n_tag)::value;
         constexpr int fyfx = n >> 2, g = n & 3, fy = fyfx >> 2, fx = fyfx & 3;
-        const float* tr = tb + (fy * 8 + g) * (2 * kTW * 4);       // even columns of (fy, quad 4*half + g); odd columns at + kTW*4
+        const float* tr = tb + fy * G::kFStride + g * (2 * XW * 4);  // even columns of (fy, quad 4*half + g); odd columns at + XW*4
         // Bt along x on patch columns (2j, 2j+1, 2j+2, 2j+3) = (E[j], O[j], E[j+1], O[j+1]); the two operands of the group's
         // difference / sum, four k-steps (channels) each
-        constexpr int o0 = (fx == 0) ? 0 : (fx == 2) ? 4 : kTW * 4;
-        constexpr int o1 = (fx == 0 || fx == 1) ? 4 : (fx == 2) ? kTW * 4 : kTW * 4 + 4;
+        constexpr int o0 = (fx == 0) ? 0 : (fx == 2) ? 4 : XW * 4;
+        constexpr int o1 = (fx == 0 || fx == 1) ? 4 : (fx == 2) ? XW * 4 : XW * 4 + 4;
         tv[buf][0] = *reinterpret_cast<const float4*>(tr + o0);
         tv[buf][1] = *reinterpret_cast<const float4*>(tr + o1);
       };
@@ -484,7 +499,18 @@ int pgrf_pack_conv3d_wino(const float* w_host, const float* bias_host, int Cout,
 }
 
 int pgrf_conv3d_wino_supported(int Cin, int Cout, int D, int H, int W) {
-  return (Cin % 32 == 0) && (Cout % 64 == 0) && (D % 2 == 0) && (H % 2 == 0) && (W % 64 == 0) && D >= 2 && H >= 2;
+  // rows of 32 x 1 tiles (W % 64 == 0), else of 16 x 2 tiles (W % 32 == 0 and H % 4 == 0)
+  const bool geom = (W % 64 == 0 && H % 2 == 0) || (W % 32 == 0 && H % 4 == 0);
+  return (Cin % 32 == 0) && (Cout % 64 == 0) && (D % 2 == 0) && geom && D >= 2 && H >= 2 && W >= 32;
+}
+
+int pgrf_conv3d_wino_preferred(int Cin, int Cout, int B, int D, int H, int W) {
+  if (!pgrf_conv3d_wino_supported(Cin, Cout, D, H, W)) return 0;
+  // the kernel is persistent with one workgroup per CU and a row is its unit of work: below ~100 rows most of the chip
+  // idles and the split-K direct kernel wins (measured: 512 -> 128 at 16x16x32, 64 rows: 335 vs 277 us)
+  const bool two = (W % 64) != 0;
+  const long long rows = (long long)B * (D / 2) * (H / (two ? 4 : 2)) * (W / (two ? 32 : 64)) * (Cout / 64);
+  return rows >= 96 ? 1 : 0;
 }
 
 int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
@@ -492,7 +518,7 @@ int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* ou
                      int res_cs, int res_coff, void* stream) {
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino: null pointer");
   if (!pgrf_conv3d_wino_supported(Cin, Cout, D, H, W))
-    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: needs Cin a multiple of 32, Cout a multiple of 64, even D and H, W a multiple of 64 "
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: needs Cin a multiple of 32, Cout a multiple of 64, even D, and W % 64 == 0 with even H or W % 32 == 0 with H % 4 == 0 "
                      "(got Cin %d Cout %d D %d H %d W %d); use pgrf_conv3d_wrap", Cin, Cout, D, H, W);
   if (B < 1) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino: bad dims");
 #ifndef PGRF_WINO_TIMING
@@ -512,14 +538,17 @@ int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* ou
   a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 64; a.wrap_w = 1;
   a.wpk = packed;
   a.bias = has_bias ? packed + (size_t)a.cot_total * 64 * a.chunks * 1024 : nullptr;
-  const long long nrows_ll = (long long)B * (D / 2) * (H / 2) * (W / 64) * (a.cot_total / 2);
+  const bool two = (W % 64) != 0;                        // 16 x 2 tile rows for the half-width levels
+  const int tx = two ? 16 : 32, ty = two ? 2 : 1;
+  const long long nrows_ll = (long long)B * (D / 2) * (H / (2 * ty)) * (W / (2 * tx)) * (a.cot_total / 2);
   if (nrows_ll >= (1ll << 31)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: too many tile rows");
   const int nrows = (int)nrows_ll;
   static int ncu = 0;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLdsBytes) != hipSuccess)
-      return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot reserve %d bytes of LDS", kWinoLdsBytes);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeom<false>::kLdsBytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeom<true>::kLdsBytes) != hipSuccess)
+      return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot reserve %d bytes of LDS", WinoGeom<true>::kLdsBytes);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
@@ -527,11 +556,12 @@ int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* ou
     ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     attr_done = true;
   }
-  // persistent: one workgroup (8 MFMA waves + 8 loader waves) per CU (the 139 KB LDS block allows no more), each loops over rows
+  // persistent: one workgroup (8 MFMA waves + 8 loader waves) per CU (the ~140 KB LDS block allows no more), each loops over rows
   int wgs = ncu;
   if (const char* e = getenv("PGRF_WINO_WGS")) { const int v = atoi(e); if (v > 0) wgs = v; }          // tuning knob
   dim3 grid((unsigned)(nrows < wgs ? nrows : wgs));
-  hipLaunchKernelGGL(conv3d_wino_kernel, grid, dim3(1024), kWinoLdsBytes, (hipStream_t)stream, a, nrows);
+  if (two) hipLaunchKernelGGL(conv3d_wino_kernel<true>, grid, dim3(1024), WinoGeom<true>::kLdsBytes, (hipStream_t)stream, a, nrows);
+  else hipLaunchKernelGGL(conv3d_wino_kernel<false>, grid, dim3(1024), WinoGeom<false>::kLdsBytes, (hipStream_t)stream, a, nrows);
   PGRF_CHECK_LAUNCH("conv3d_wino");
   return PGRF_OK;
 }

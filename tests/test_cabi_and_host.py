@@ -155,7 +155,7 @@ def test_winograd_filter_transform_on_host():
     B = host[2 * 64 * 1024:].numpy()
     for (ct, h, r) in [(0, 0, 0), (1, 1, 5), (0, 1, 15)]:
         assert B[ct * 32 + h * 16 + r] == b[32 * ct + (r & 3) + 8 * (r >> 2) + 4 * h]
-    assert lib.pgrf_conv3d_wino_supported(64, 64, 4, 4, 64) == 1 and lib.pgrf_conv3d_wino_supported(64, 64, 4, 4, 32) == 0
+    assert lib.pgrf_conv3d_wino_supported(64, 64, 4, 4, 64) == 1 and lib.pgrf_conv3d_wino_supported(64, 64, 4, 4, 16) == 0
 
 
 def test_tile_sharding_math():

@@ -122,7 +122,9 @@ def test_interior_wave_pipeline_vs_oracle(cin, cout, nt, split, monkeypatch):
 
 @pytest.mark.parametrize('cin,cout,B,D,H,W,bias,slope', [(32, 64, 1, 4, 4, 64, True, 0.01), (64, 64, 2, 4, 6, 128, True, 0.01),
                                                          (128, 64, 1, 2, 4, 64, False, 1.0), (64, 128, 1, 6, 2, 64, True, 0.2),
-                                                         (32, 64, 1, 8, 8, 128, True, 0.01), (96, 192, 1, 2, 2, 64, True, 0.01)])
+                                                         (32, 64, 1, 8, 8, 128, True, 0.01), (96, 192, 1, 2, 2, 64, True, 0.01),
+                                                         (32, 64, 1, 4, 4, 32, True, 0.01), (64, 128, 2, 6, 8, 96, True, 0.01),
+                                                         (128, 64, 1, 2, 12, 32, False, 0.2)])
 def test_winograd_conv_vs_oracle(cin, cout, B, D, H, W, bias, slope, monkeypatch):
     """pgrf_conv3d_wino (Winograd F(2x2x2, 3x3x3), csrc/conv3d_wino.hip) against F.conv3d of the oracle: volume faces
     (zero padding along D and H), the circular W seam, interior rows (D = H = 8), several channel blocks and cout groups,
@@ -131,7 +133,7 @@ def test_winograd_conv_vs_oracle(cin, cout, B, D, H, W, bias, slope, monkeypatch
     from oracle import cost_volume_oracle as O
     from panogrf_amd import cost_reg as R
     from panogrf_amd._lib import lib
-    monkeypatch.setenv('PANOGRF_CONV_WINOGRAD', '1')
+    monkeypatch.setenv('PANOGRF_CONV_WINOGRAD', 'force')         # also for layers with too few rows to be preferred
     monkeypatch.setenv('PGRF_WINO_WGS', '3')                     # few workgroups: every one loops over several rows
     assert lib.pgrf_conv3d_wino_supported(cin, cout, D, H, W) == 1
     g = torch.Generator().manual_seed(cin * 31 + cout * 7 + D + H + W)
@@ -162,7 +164,8 @@ def test_winograd_conv_rejects_what_it_cannot_do():
     sup = lib.pgrf_conv3d_wino_supported
     assert sup(64, 64, 4, 4, 64) == 1
     assert sup(48, 64, 4, 4, 64) == 0 and sup(64, 32, 4, 4, 64) == 0          # Cin % 32, Cout % 64
-    assert sup(64, 64, 5, 4, 64) == 0 and sup(64, 64, 4, 3, 64) == 0 and sup(64, 64, 4, 4, 96) == 0    # odd D / H, W % 64
+    assert sup(64, 64, 5, 4, 64) == 0 and sup(64, 64, 4, 3, 64) == 0 and sup(64, 64, 4, 4, 48) == 0    # odd D / H, W % 32
+    assert sup(64, 64, 4, 4, 96) == 1 and sup(64, 64, 4, 6, 96) == 0 and sup(64, 64, 4, 6, 128) == 1   # 16 x 2 tile rows need H % 4 == 0
     x = torch.zeros(1, 5, 4, 64, 64, device='cuda')
     p = ctypes.c_void_p(x.data_ptr())
     assert lib.pgrf_conv3d_wino(p, 64, 0, 64, p, 64, 0, 64, p, 0, 1, 5, 4, 64, 0.01, None, 0, 0, None) != 0
@@ -172,6 +175,8 @@ def test_winograd_conv_rejects_what_it_cannot_do():
     assert lib.pgrf_conv3d_wino(p, 64, 0, 64, p, 64, 0, 64, p, 0, 1, 4, 4, 64, 0.01, p, 64, 0, None) != 0     # residual
     assert b'residual' in lib.pgrf_last_error()
     assert lib.pgrf_conv3d_wino_packed_floats(64, 32) == 2 * 64 * 1 * 1024 + 64
+    pref = lib.pgrf_conv3d_wino_preferred
+    assert pref(64, 64, 1, 64, 128, 256) == 1 and pref(512, 128, 1, 16, 16, 32) == 0 and pref(48, 64, 1, 64, 128, 256) == 0
 
 
 def test_unet2_winograd_equals_direct(monkeypatch):
