@@ -78,3 +78,34 @@ def allgather_views(local, n_views, group=None):
         for i, v in enumerate(view_shard(g, world, n_views)):
             out[v] = full[g, i]
     return torch.stack(out, 0)
+
+
+# ---- generic ray sharding for the renderer module (any coords list, not only whole row tiles)
+
+def ray_shard(rank, world, n):
+    """Contiguous chunk [r0, r1) of n rays for `rank`; the first n % world ranks get one ray more."""
+    return tile_rows(rank, world, n)
+
+
+def allgather_rays(local, n, dim=1, group=None):
+    """local [..., n_rank, ...] (this rank's chunk of ray_shard along `dim`) -> [..., n, ...] on every rank, in ray order.
+    Chunks differ by at most one ray: every rank contributes ceil(n / world) padded slots to ONE all-gather."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    if dist.get_backend(group) == 'gloo' and local.is_cuda:      # test-only: ranks sharing one GPU
+        return allgather_rays(local.cpu(), n, dim, group).to(local.device)
+    was_bool = local.dtype == torch.bool
+    x = local.to(torch.uint8) if was_bool else local
+    x = x.movedim(dim, 0).contiguous()
+    slots = -(-n // world)
+    pad = torch.zeros((slots,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[:x.shape[0]] = x
+    full = torch.empty((world * slots,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(full, pad, group=group)
+    parts = []
+    for g in range(world):
+        r0, r1 = ray_shard(g, world, n)
+        parts.append(full[g * slots:g * slots + (r1 - r0)])
+    out = torch.cat(parts, 0).movedim(0, dim)
+    return out.to(torch.bool) if was_bool else out

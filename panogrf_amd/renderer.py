@@ -300,6 +300,16 @@ class NeuralRayBaseRenderer(nn.Module):
         ref = dict(ref_imgs_info)
         ref['_pgrf_frame'] = self._make_frame(que_imgs_info, ref, is_perspec)
         coords = que_imgs_info['coords']
+        # Multi-GPU (new, the reference is single-GPU): under an initialised process group every rank renders a
+        # contiguous chunk of the rays (whole row tiles for a full panorama) and ONE all-gather per output reassembles them.
+        # cfg['hip_shard_rays']=False keeps every rank on all rays; cfg['hip_gather']='all' also gathers the per-sample
+        # tensors (colors_nr, density_nr, hit_prob_nr: hundreds of MB per frame), the default 'image' returns per-ray keys only.
+        shard = self._ray_shard_world()
+        n_all = coords.shape[1]
+        if shard is not None:
+            from . import dist as D
+            r0, r1 = D.ray_shard(shard[0], shard[1], n_all)
+            coords = coords[:, r0:r1]
         rb = self.cfg['ray_batch_num']
         # rays are independent: the reference's batch loop (renderer.py:656-683) only bounds memory, so by default
         # batches are merged up to `hip_ray_batch_num` rays per launch (results are batching-invariant)
@@ -312,7 +322,20 @@ class NeuralRayBaseRenderer(nn.Module):
                 if k.startswith('hit_prob') and not is_train:        # kept in training mode only (renderer.py:675)
                     continue
                 parts.setdefault(k, []).append(v)
-        return {k: torch.cat(v, 1) if len(v) > 1 else v[0] for k, v in parts.items()}
+        out = {k: torch.cat(v, 1) if len(v) > 1 else v[0] for k, v in parts.items()}
+        if shard is not None:
+            per_ray = ('pixel_colors', 'render_depth', 'ray_mask')
+            keep = out if self.cfg.get('hip_gather', 'image') == 'all' else {k: v for k, v in out.items() if k.startswith(per_ray)}
+            out = {k: D.allgather_rays(v, n_all, 1) for k, v in keep.items()}
+        return out
+
+    def _ray_shard_world(self):
+        """(rank, world) when rays are to be sharded over the default process group, else None."""
+        import torch.distributed as tdist
+        if not (self.cfg.get('hip_shard_rays', True) and tdist.is_available() and tdist.is_initialized()):
+            return None
+        world = tdist.get_world_size()
+        return (tdist.get_rank(), world) if world > 1 else None
 
     def forward(self, data, is_perspec=False):
         ref = dict(data['ref_imgs_info'])
@@ -343,11 +366,43 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         if not hasattr(self, 'init_net'):
             raise PgrfError('NeuralRayGenRenderer needs an init_net module (see class docstring); '
                             'or put ray_feats into ref_imgs_info and call render()')
-        ret = self._run_init_net(ref_imgs_info, src_imgs_info, is_train)
+        ret = self._run_init_net_sharded(ref_imgs_info, src_imgs_info, is_train)
         ref_imgs_info['ray_feats'] = ret['ray_feats']
         if 'mvs_depth' in ret:
             ref_imgs_info['mvs_depth'] = ret['mvs_depth']
         return self.render(que_imgs_info, ref_imgs_info, is_train, is_perspec)
+
+    def _run_init_net_sharded(self, ref, src, is_train):
+        """Multi-GPU: the MVS stage builds one cost volume per reference view, independent of each other (init_net.py:164-171),
+        so under a process group the views are dealt round-robin to the ranks (panogrf_amd.dist.view_shard) and the
+        per-view results all-gathered (ray_feats + mvs_depth: < 1 MB per view).  cfg['hip_shard_views']=False disables."""
+        from .mvs import CostVolumeInitNet
+        from . import dist as D
+        import torch.distributed as tdist
+        net = self.init_net
+        B = ref['imgs'].shape[0]
+        if not (self.cfg.get('hip_shard_views', True) and tdist.is_available() and tdist.is_initialized() and
+                tdist.get_world_size() > 1 and B > 1 and isinstance(net, CostVolumeInitNet) and src is not None and not is_train):
+            return self._run_init_net(ref, src, is_train)
+        rank, world = tdist.get_rank(), tdist.get_world_size()
+        mine = D.view_shard(rank, world, B)
+        dev = ref['imgs'].device
+        dh, dw = net.cfg['depth_height'], net.cfg['depth_width']
+        if mine:
+            idx = torch.as_tensor(mine, device=dev)
+            ref_l = {k: ref[k][idx] for k in ('imgs', 'rots', 'trans')}
+            if int(net.cfg.get('seq_len', 3)) > 3:          # multi-view: [ref_i, src[nn_ids_i]] needs all source views
+                nn = torch.as_tensor(ref['nn_ids']).long().view(B, -1)
+                ref_l['nn_ids'] = nn[torch.as_tensor(mine)]
+                src_l = src
+            else:                                            # two-view: source i pairs with reference i
+                src_l = {k: src[k][idx] for k in ('imgs', 'rots', 'trans')}
+            out = self._run_init_net(ref_l, src_l, is_train)
+            rf, dp = out['ray_feats'].float().contiguous(), out['mvs_depth'].float().contiguous()
+        else:
+            rf = torch.zeros(0, 32, dh // 4, dw // 4, device=dev)
+            dp = torch.zeros(0, 1, dh, dw, device=dev)
+        return {'ray_feats': D.allgather_views(rf, B), 'mvs_depth': D.allgather_views(dp, B)}
 
     def _run_init_net(self, ref, src, is_train):
         """The MVS stage is ~150 small launches (2-D CNNs on MIOpen + the HIP cost-volume / regulariser kernels) with static

@@ -85,3 +85,33 @@ def test_allgather_views_world2_even():
 def test_allgather_views_world2_ragged_and_idle_rank():
     _run_views(2, 3)
     _run_views(2, 1)
+
+
+def _ray_worker(rank, world, port, n, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from panogrf_amd import dist as D
+    r0, r1 = D.ray_shard(rank, world, n)
+    idx = torch.arange(r0, r1, dtype=torch.float32)
+    colours = torch.stack([idx, idx * 2, idx + 0.5], -1).unsqueeze(0)        # [1, n_rank, 3] like 'pixel_colors_nr'
+    mask = (torch.arange(r0, r1) % 3 == 0).unsqueeze(0)                      # [1, n_rank] bool like 'ray_mask'
+    full_c, full_m = D.allgather_rays(colours, n, 1), D.allgather_rays(mask, n, 1)
+    all_idx = torch.arange(n, dtype=torch.float32)
+    ok = (torch.equal(full_c, torch.stack([all_idx, all_idx * 2, all_idx + 0.5], -1).unsqueeze(0)) and full_m.dtype == torch.bool and
+          torch.equal(full_m, (torch.arange(n) % 3 == 0).unsqueeze(0)))
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_rays_world2_ragged_and_bool():
+    """The renderer module's sharding (renderer.render under a process group): contiguous ray chunks that differ by one ray,
+    reassembled in ray order, bool masks included."""
+    for n in (10, 11):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_ray_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
+        assert all(ret[r] for r in range(2)), dict(ret)
+    from panogrf_amd import dist as D
+    assert [D.ray_shard(g, 3, 10) for g in range(3)] == [(0, 4), (4, 7), (7, 10)]
