@@ -9,18 +9,21 @@
 //     At = [1 1 1 0; 0 1 -1 -1]                       (products 4 -> outputs 2)
 // Only 0 and +-1 on the device side: the input and output transforms are additions.
 //
-// Workgroup = 4 waves = 32 consecutive tiles along x (64 output voxels) of one (b, z pair, y pair) x MT*32 output
-// channels.  Per 32-channel block of Cin:
-//   phase A  all threads: load the 4 x 4 x 66 x 32 input patch (zeros outside D/H, circular along W; prefetched into
-//            registers during phase B of the previous block), transform it along z and y in registers and write
-//            T[fz][fy][c][x] to LDS (135 KB, x split into even / odd columns so that the reads below are conflict free);
-//   phase B  wave w owns the 16 frequencies with fz = w: for each (fy, fx) the B operand of k-step (c pair) is formed
-//            on the fly as the x transform of two LDS values (one VALU op), 16 k-steps x MT MFMAs accumulate
-//            M = U_f . V_f over the block's channels, and M is added with signs into the wave's FOUR partially
-//            transformed accumulators R[oy][ox] (the y and x output transforms; 2.25 adds per MFMA row block instead of
-//            3.4 for the full 3-D transform, and 128 accumulator registers instead of 256).
-// After the last block the z output transform (out[oz=0] = R0 + R1 + R2, out[oz=1] = R1 - R2 - R3 over the waves'
-// fz) runs through LDS; bias + LeakyReLU in the epilogue, stores as in conv3d.hip.
+// Workgroup (persistent, one per CU) = 8 MFMA waves + 8 loader waves; a "row" = 32 output tiles (32 x 1 along x, or
+// 16 x 2 for the half-width levels) of one (b, z pair) x 64 output channels.  Per 32-channel block of Cin:
+//   loader waves  request the 4 x 4 x (2 TX + 2) x 32 input patch of every y tile row (rows outside D/H read the nearest
+//            row and are zeroed, circular along W), transform it along z and y in registers while the MFMA waves are still
+//            busy with the previous block, and between two barriers store T[fz][fy][tyy][channel quad][x parity][x][4] to
+//            LDS (~140 KB; one ds_write_b128 per entry);
+//   MFMA wave (fz, cout tile)  for each of its 16 frequencies (fy, fx): the B operand of a k-step is the x transform of two
+//            LDS values (one ds_read_b128 per patch column and group of four k-steps, one VALU op per k-step), 16 k-steps
+//            accumulate M = U_f . V_f over the block's channels, and M is added with signs into the wave's FOUR partially
+//            transformed accumulators R[oy][ox] (the y and x output transforms: 2.25 adds per frequency instead of 3.4 for
+//            the full 3-D transform, 64 accumulator registers instead of 128; corner frequencies go straight into R).
+// After the last block the z output transform (out[oz=0] = R0 + R1 + R2, out[oz=1] = R1 - R2 - R3 over the four fz
+// waves of a cout tile; the bias is the initial value of R1) runs through LDS; LeakyReLU and the stores in the epilogue.
+// The patch loads live in loader waves because a wave's vmcnt counter is in order: in the MFMA waves every weight refill
+// issued behind them would wait for them.
 // Accuracy: fp32 throughout; the transforms add ~1e-6 relative round-off (tests compare with the direct kernel and with
 // the oracle at the regulariser tolerances).
 #include <hip/hip_runtime.h>
