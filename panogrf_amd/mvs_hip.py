@@ -116,6 +116,17 @@ class HipInitNet:
         h, w = dh // 4, dw // 4
         ref_s = F.interpolate(ref['imgs'].float(), (dh, dw), mode='bilinear')
         src_s = F.interpolate(src['imgs'].float(), (dh, dw), mode='bilinear')
+        # res_net (the init net's ResUNetLight on the reference images) depends on nothing else in the stage and, like the
+        # feature net, is a chain of ~30 small launches that cannot fill the chip: it runs on a side stream next to the
+        # feature net / cost volume and is joined in front of out_conv (both streams end up in the same hipGraph capture).
+        main = torch.cuda.current_stream(d)
+        side = self.__dict__.get('_side')
+        if side is None:
+            side = self.__dict__['_side'] = torch.cuda.Stream(device=d)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            res_feats = T.image_encoder(ref_s)
+            ref_s.record_stream(side)
         B = ref_s.shape[0]
         if int(c.get('seq_len', 3)) > 3:
             # construct_input_data_mv (init_net.py:183-231): per reference view [ref, src[nn_ids]]; the reference is view 0.
@@ -147,7 +158,8 @@ class HipInitNet:
         mvs_depth = depth.view(B, 1, dh, dw)                                      # one channel: NHWC == NCHW
         # ray features: res_net(resized reference image) ++ depth_conv(normalised inverse depth at 1/4) -> out_conv
         cat64 = _Map.empty(B, h, w, 64, d)
-        cat64.buf[..., :32] = T.image_encoder(ref_s)
+        main.wait_stream(side)
+        cat64.buf[..., :32] = res_feats
         near_inv, far_inv = -1.0 / c['min_depth'], -1.0 / c['max_depth']
         dd = (-1.0 / torch.clamp(mvs_depth, min=1e-5) - near_inv) / (far_inv - near_inv)
         dd = F.interpolate(torch.clamp(dd, min=0, max=1.0), scale_factor=0.25, mode='bilinear', align_corners=False)

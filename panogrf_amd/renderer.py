@@ -273,8 +273,38 @@ class NeuralRayBaseRenderer(nn.Module):
         enc = self._encoder_fn(imgs)
         if not (imgs.is_cuda and self.cfg.get('hip_graph_encoders', True)) or torch.is_grad_enabled():
             return enc(imgs, ray_feats)
+        early = self.__dict__.pop('_early_feats', None)
+        if early is not None and early[0] is imgs:
+            # the image encoder was started on a side stream in front of the MVS stage (_encode_images_early): join it and
+            # run the visibility encoder alone
+            feats, side = early[1], early[2]
+            main = torch.cuda.current_stream(imgs.device)
+            main.wait_stream(side)
+            feats.record_stream(main)
+            hip = enc != self._torch_encoders
+            vis = (lambda rf, f: (enc.vis_encoder(rf, f.permute(0, 2, 3, 1)).permute(0, 3, 1, 2),)) if hip else \
+                  (lambda rf, f: (self.vis_encoder(rf, f),))
+            return feats, self._graphed('enc_vis_hip' if hip else 'enc_vis_torch', vis, (ray_feats.contiguous(), feats), modules=(self.vis_encoder,))[0]
         return self._graphed('enc_torch' if enc == self._torch_encoders else 'enc_hip', enc, (imgs.contiguous(), ray_feats.contiguous()),
                              modules=(self.image_encoder, self.vis_encoder))
+
+    def _encode_images_early(self, imgs):
+        """The image encoder depends on the source images only, the MVS stage in front of render() on nothing the encoder
+        produces, and both are chains of small launches: start the encoder's hipGraph on a side stream so that it runs next
+        to the MVS stage; _encode() joins it.  (GPU, no autograd, graphs enabled; otherwise a no-op.)"""
+        if not (imgs.is_cuda and self.cfg.get('hip_graph_encoders', True) and self.cfg.get('hip_overlap_encoders', True)) or torch.is_grad_enabled():
+            return
+        enc = self._encoder_fn(imgs)
+        hip = enc != self._torch_encoders
+        dev = imgs.device
+        side = self.__dict__.get('_enc_stream')
+        if side is None or side.device != dev:
+            side = self.__dict__['_enc_stream'] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        img_fn = (lambda x: (enc.image_encoder(x).permute(0, 3, 1, 2),)) if hip else (lambda x: (self.image_encoder(x),))
+        with torch.cuda.stream(side):
+            feats = self._graphed('enc_img_hip' if hip else 'enc_img_torch', img_fn, (imgs.contiguous(),), modules=(self.image_encoder,))[0]
+        self.__dict__['_early_feats'] = (imgs, feats, side)
 
     def _make_frame(self, que, ref, is_perspec):
         """ERP query: que['c2w'] (render_ops.py:76-106).  Pinhole query (is_perspec, render_cubes.py): que['poses'] and
@@ -366,6 +396,7 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         if not hasattr(self, 'init_net'):
             raise PgrfError('NeuralRayGenRenderer needs an init_net module (see class docstring); '
                             'or put ray_feats into ref_imgs_info and call render()')
+        self._encode_images_early(ref_imgs_info['imgs'])
         ret = self._run_init_net_sharded(ref_imgs_info, src_imgs_info, is_train)
         ref_imgs_info['ray_feats'] = ret['ray_feats']
         if 'mvs_depth' in ret:

@@ -120,9 +120,18 @@ def test_gen_renderer_end_to_end_with_the_mvs_stage():
     src = imgs_info_to_torch(build_imgs_info(imgs[::-1].copy(), np.stack([pose(-0.5), pose(0.5)]), [[0.5, 15.0]] * 2), 'cuda')
     que = imgs_info_to_torch(build_render_imgs_info(pose(0.0), (H, W), [0.5, 15.0]), 'cuda')
     with torch.no_grad():
-        out = net({'que_imgs_info': que, 'ref_imgs_info': ref, 'src_imgs_info': src, 'eval': True})
+        out = net({'que_imgs_info': dict(que), 'ref_imgs_info': dict(ref), 'src_imgs_info': dict(src), 'eval': True})
     assert out['pixel_colors_nr_fine'].shape == (1, H * W, 3) and torch.isfinite(out['pixel_colors_nr_fine']).all()
     assert out['render_depth_fine'].shape == (1, H * W) and float(out['render_depth_fine'].min()) >= 0.0
+    # the image encoder runs on a side stream next to the MVS stage (cfg['hip_overlap_encoders']): same launches on the same
+    # inputs, so the frame is bit-identical with the overlap off, and a second frame replays the captured graphs
+    assert '_early_feats' not in net.__dict__
+    with torch.no_grad():
+        again = net({'que_imgs_info': dict(que), 'ref_imgs_info': dict(ref), 'src_imgs_info': dict(src), 'eval': True})
+        net.cfg['hip_overlap_encoders'] = False
+        serial = net({'que_imgs_info': dict(que), 'ref_imgs_info': dict(ref), 'src_imgs_info': dict(src), 'eval': True})
+    for k in ('pixel_colors_nr_fine', 'render_depth_fine', 'pixel_colors_nr'):
+        assert torch.equal(out[k], again[k]) and torch.equal(out[k], serial[k]), k
 
 
 @pytest.mark.gpu
