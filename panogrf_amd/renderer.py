@@ -12,6 +12,8 @@ random sampling and extra outputs, no backward pass.
 import itertools
 import math
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 
@@ -115,6 +117,32 @@ class _SphHolder(nn.Module):
         super().__init__()
         regs = [0.0] + [0.001] * 3 + [0.005] * 5 + [0.05] * 7
         self.register_buffer('regs', torch.tensor(regs, dtype=torch.float32))
+
+
+def _snapshot(named):
+    """[(name, value)] -> the same with each tensor's version counter: what `_unchanged` compares the next frame's inputs to.
+    Holds the tensors themselves (no copies): an in-place write bumps the counter and invalidates the snapshot."""
+    return [(k, v, v._version if torch.is_tensor(v) else None) for k, v in named]
+
+
+def _unchanged(snap, named):
+    """True when every input equals the snapshot's: the same tensor object at the same version counter (no device work), or
+    a tensor of equal contents (one device compare and a host sync per tensor that is a new object)."""
+    named = list(named)
+    if snap is None or len(snap) != len(named):
+        return False
+    for (k0, v0, ver0), (k, v) in zip(snap, named):
+        if k0 != k or torch.is_tensor(v0) != torch.is_tensor(v):
+            return False
+        if not torch.is_tensor(v):
+            if v0 is not v and not np.array_equal(np.asarray(v0), np.asarray(v)):
+                return False
+            continue
+        if v0._version != ver0:
+            return False
+        if v is not v0 and (v.shape != v0.shape or v.dtype != v0.dtype or v.device != v0.device or not torch.equal(v, v0)):
+            return False
+    return True
 
 
 class NeuralRayBaseRenderer(nn.Module):
@@ -288,6 +316,31 @@ class NeuralRayBaseRenderer(nn.Module):
         return self._graphed('enc_torch' if enc == self._torch_encoders else 'enc_hip', enc, (imgs.contiguous(), ray_feats.contiguous()),
                              modules=(self.image_encoder, self.vis_encoder))
 
+    @staticmethod
+    def _weights_version(modules):
+        return hash(tuple((v._version, v.data_ptr()) for m in modules for v in itertools.chain(m.parameters(), m.buffers())))
+
+    def _reuse_enabled(self, imgs, is_train):
+        """Source-map reuse (new; the reference recomputes per frame): a trajectory renders many query poses against the
+        SAME source views (render.py:248-278 rebuilds identical ref/src infos for every frame), and everything in front of
+        the per-ray kernel -- MVS stage, 2-D encoders: 8.5 of 84 ms at the shipped configuration -- depends on the source
+        views and the weights only.  With cfg['hip_reuse_source_maps'] (default on; eval, GPU, no autograd) those results
+        are kept and returned again while the inputs are unchanged (`_unchanged`) and the weights' version counters are."""
+        return bool(self.cfg.get('hip_reuse_source_maps', True)) and imgs.is_cuda and not is_train and not torch.is_grad_enabled()
+
+    def _encode_reusing(self, imgs, ray_feats, is_train):
+        if not self._reuse_enabled(imgs, is_train):
+            return self._encode(imgs, ray_feats)
+        named = [('imgs', imgs), ('ray_feats', ray_feats)]
+        wver = self._weights_version((self.image_encoder, self.vis_encoder))
+        c = self.__dict__.get('_enc_cache')
+        if (c is not None and c['wver'] == wver and all(o._version == ver for o, ver in c['outs']) and _unchanged(c['snap'], named)):
+            self.__dict__.pop('_early_feats', None)
+            return c['outs'][0][0], c['outs'][1][0]
+        outs = self._encode(imgs, ray_feats)
+        self.__dict__['_enc_cache'] = dict(snap=_snapshot(named), wver=wver, outs=[(o, o._version) for o in outs])
+        return outs
+
     def _encode_images_early(self, imgs):
         """The image encoder depends on the source images only, the MVS stage in front of render() on nothing the encoder
         produces, and both are chains of small launches: start the encoder's hipGraph on a side stream so that it runs next
@@ -324,7 +377,7 @@ class NeuralRayBaseRenderer(nn.Module):
         """Whole query view (network/renderer.py:635-686).  Mutates ref_imgs_info['img_feats'/'ray_feats'] and
         que_imgs_info['coords'] like the reference does."""
         self._check_train(is_train)
-        ref_img_feats, ray_feats = self._encode(ref_imgs_info['imgs'], ref_imgs_info['ray_feats'])
+        ref_img_feats, ray_feats = self._encode_reusing(ref_imgs_info['imgs'], ref_imgs_info['ray_feats'], is_train)
         ref_imgs_info['img_feats'] = ref_img_feats
         ref_imgs_info['ray_feats'] = ray_feats
         ref = dict(ref_imgs_info)
@@ -396,12 +449,31 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         if not hasattr(self, 'init_net'):
             raise PgrfError('NeuralRayGenRenderer needs an init_net module (see class docstring); '
                             'or put ray_feats into ref_imgs_info and call render()')
-        self._encode_images_early(ref_imgs_info['imgs'])
-        ret = self._run_init_net_sharded(ref_imgs_info, src_imgs_info, is_train)
+        ret = self._init_net_reusing(ref_imgs_info, src_imgs_info, is_train)
         ref_imgs_info['ray_feats'] = ret['ray_feats']
         if 'mvs_depth' in ret:
             ref_imgs_info['mvs_depth'] = ret['mvs_depth']
         return self.render(que_imgs_info, ref_imgs_info, is_train, is_perspec)
+
+    def _init_net_reusing(self, ref, src, is_train):
+        """MVS stage, or its kept result when the source views and the weights are those of the previous frame (see
+        `_reuse_enabled`).  Entries this module writes itself (ray_feats, img_feats, mvs_depth) are not part of the key."""
+        reuse = self._reuse_enabled(ref['imgs'], is_train)
+        if reuse:
+            mine = ('ray_feats', 'img_feats', 'mvs_depth')
+            named = [('ref.' + k, ref[k]) for k in sorted(ref) if k not in mine and not k.startswith('_pgrf')]
+            named += [('src.' + k, src[k]) for k in sorted(src or {})]
+            wver = self._weights_version((self.init_net,)) if isinstance(self.init_net, nn.Module) else None
+            c = self.__dict__.get('_init_cache')
+            if (c is not None and wver is not None and c['wver'] == wver and all(o._version == ver for o, ver in c['outs']) and
+                    _unchanged(c['snap'], named)):
+                return dict(c['ret'])
+        self._encode_images_early(ref['imgs'])
+        ret = self._run_init_net_sharded(ref, src, is_train)
+        if reuse and wver is not None:
+            self.__dict__['_init_cache'] = dict(snap=_snapshot(named), wver=wver, ret=dict(ret),
+                                                outs=[(o, o._version) for o in ret.values() if torch.is_tensor(o)])
+        return ret
 
     def _run_init_net_sharded(self, ref, src, is_train):
         """Multi-GPU: the MVS stage builds one cost volume per reference view, independent of each other (init_net.py:164-171),

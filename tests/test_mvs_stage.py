@@ -135,6 +135,73 @@ def test_gen_renderer_end_to_end_with_the_mvs_stage():
 
 
 @pytest.mark.gpu
+def test_source_maps_are_reused_only_while_inputs_and_weights_are_unchanged():
+    """cfg['hip_reuse_source_maps']: a trajectory against fixed source views runs the MVS stage and the encoders once.  Same
+    frames as without the reuse; any change of a source pixel / pose (new tensor or in-place write) or of a weight recomputes."""
+    import numpy as np
+    from panogrf_amd.renderer import name2network
+    from panogrf_amd.imgs_info import build_imgs_info, build_render_imgs_info, imgs_info_to_torch
+    H, W, dn = 64, 128, 32
+    cfg = dict(_args(32, 64), network='neuray_gen', init_net_type='cost_volume', use_wrap_padding=True, seq_len=3, height=H, width=W,
+               use_disp=True, use_hierarchical_sampling=True, render_depth=True, depth_sample_num=dn, fine_depth_sample_num=dn,
+               sample_num=dn, dist_decoder_cfg={'use_vis': False}, fine_dist_decoder_cfg={'use_vis': False})
+    cfg.update(min_depth=0.5, max_depth=15.0)
+    torch.manual_seed(0)
+    net = name2network['neuray_gen'](cfg, d_net=MF.StubMono()).cuda().eval()
+    calls = []
+    inner = net._run_init_net_sharded
+    net.__dict__['_run_init_net_sharded'] = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.rand(2, 3, H, W, generator=g).numpy()
+    pose = lambda tx: np.concatenate([np.eye(3), np.array([[tx], [0.0], [0.0]])], 1)
+    mk = lambda im: (imgs_info_to_torch(build_imgs_info(im, np.stack([pose(0.5), pose(-0.5)]), [[0.5, 15.0]] * 2), 'cuda'),
+                     imgs_info_to_torch(build_imgs_info(im[::-1].copy(), np.stack([pose(-0.5), pose(0.5)]), [[0.5, 15.0]] * 2), 'cuda'))
+    ref, src = mk(imgs)
+    que = [imgs_info_to_torch(build_render_imgs_info(pose(t), (H, W), [0.5, 15.0]), 'cuda') for t in (0.0, 0.2)]
+    frame = lambda q, r, s: net({'que_imgs_info': dict(q), 'ref_imgs_info': dict(r), 'src_imgs_info': dict(s), 'eval': True})
+    key = 'pixel_colors_nr_fine'
+    with torch.no_grad():
+        a0 = frame(que[0], ref, src)
+        a1 = frame(que[1], ref, src)                  # same tensor objects: no compare, no MVS stage
+        assert len(calls) == 1
+        ref2, src2 = mk(imgs)                         # new tensors, equal contents (what render.py's loop builds per frame)
+        a1b = frame(que[1], ref2, src2)
+        assert len(calls) == 1 and torch.equal(a1[key], a1b[key])
+        net.cfg['hip_reuse_source_maps'] = False
+        b0, b1 = frame(que[0], ref, src), frame(que[1], ref, src)
+        assert len(calls) == 3
+        for k in (key, 'render_depth_fine', 'pixel_colors_nr'):
+            assert torch.equal(a0[k], b0[k]) and torch.equal(a1[k], b1[k]), k
+        assert not torch.equal(a0[key], a1[key])
+        net.cfg['hip_reuse_source_maps'] = True
+        frame(que[0], ref, src)
+        n = len(calls)
+        ref['imgs'][0, :, 10:20, 30:50] = 0.25        # in-place write: version counter
+        c0 = frame(que[0], ref, src)
+        assert len(calls) == n + 1 and not torch.equal(c0[key], a0[key])
+        imgs3 = imgs.copy()
+        imgs3[0, :, 10:20, 30:50] = 0.25
+        ref3, src3 = mk(imgs3)
+        src3['imgs'] = src['imgs']                    # sources as in the previous frame, reference = the edited pixels
+        c0b = frame(que[0], ref3, src3)               # equal contents again
+        assert len(calls) == n + 1 and torch.equal(c0[key], c0b[key])
+        src3['trans'] = src3['trans'] * 1.5           # a pose change
+        frame(que[0], ref3, src3)
+        assert len(calls) == n + 2
+        frame(que[0], ref3, src3)
+        assert len(calls) == n + 2
+        for p in net.init_net.parameters():           # weight update
+            p.mul_(1.0)
+            break
+        frame(que[0], ref3, src3)
+        assert len(calls) == n + 3
+        d0 = frame(que[1], ref3, src3)
+        next(net.image_encoder.parameters()).mul_(1.5)          # encoder weights: MVS result stays, encoders rerun
+        d1 = frame(que[1], ref3, src3)
+        assert len(calls) == n + 3 and not torch.equal(d0[key], d1[key])
+
+
+@pytest.mark.gpu
 def test_hip_init_net_vs_reference():
     """The same stage with its 2-D networks on the HIP library (panogrf_amd/mvs_hip.py: BatchNorm-folded ERP ResNet-18,
     decoders, ResUNetLight, heads) against the reference's outputs and against the torch mirror."""

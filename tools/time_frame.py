@@ -1,6 +1,6 @@
 """Whole `renderer(data)` frame at the shipped configuration (512x1024 query and sources, 2 views, 64 + 64 samples, MVS
 stage at depth 256x512, a constant mono-depth prior standing in for UniFuse): ms per frame with and without the
-encoder / MVS-stage overlap.  python tools/time_frame.py [H W]"""
+encoder / MVS-stage overlap and the source-map reuse.  python tools/time_frame.py [H W]"""
 import os
 import sys
 import time
@@ -30,8 +30,10 @@ def frame():
 
 
 outs = {}
-for overlap in (True, False, True):
+MODES = ((True, True),) if os.environ.get('PGRF_FRAME_MODES') == 'reuse' else ((True, False), (False, False), (True, False), (True, True))
+for overlap, reuse in MODES:
     net.cfg['hip_overlap_encoders'] = overlap
+    net.cfg['hip_reuse_source_maps'] = reuse
     for _ in range(3):
         out = frame()
     torch.cuda.synchronize()
@@ -41,7 +43,9 @@ for overlap in (True, False, True):
         out = frame()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
-    outs[overlap] = out['pixel_colors_nr_fine'].clone()
-    print(f'renderer(data) {H}x{W}, 64+64 samples, MVS stage {H//2}x{W//2}, encoder overlap {overlap}: {ms:.2f} ms per frame '
+    outs[(overlap, reuse)] = out['pixel_colors_nr_fine'].clone()
+    print(f'renderer(data) {H}x{W}, 64+64 samples, MVS stage {H//2}x{W//2}, encoder overlap {overlap}, source-map reuse {reuse}: {ms:.2f} ms per frame '
           f'({H*W/ms/1e3:.2f} M rays/s end to end)')
-print('max |overlap - no overlap| =', float((outs[True] - outs[False]).abs().max()))
+if len(MODES) > 1:
+    print('max |overlap - no overlap| =', float((outs[(True, False)] - outs[(False, False)]).abs().max()),
+          ' max |reuse - no reuse| =', float((outs[(True, True)] - outs[(True, False)]).abs().max()))
