@@ -1,5 +1,7 @@
 // Small HBM-bound kernels around the fused render pass: map re-layout, depth samplers, c2f merge.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 
 #include "pgrf_internal.h"
 #include "ray_dir.h"
@@ -134,6 +136,22 @@ __device__ __forceinline__ bool sorts_before(float o, int k, float v, int j) {
   return o < v || (o == v && k < j);
 }
 
+// Arithmetic shared by the two sampler kernels below (one expression each, so that both compile to the same operations).
+__device__ __forceinline__ float fd_norm_depth(float z, float n_, float f_, int use_disp) {
+  return use_disp ? (-1.f / z - n_) / (f_ - n_) : z;
+}
+__device__ __forceinline__ float fd_sample(float u, float c0, float c1, float b0, float b1, float n_, float f_, int use_disp) {
+  float denom = c1 - c0;
+  if (denom < 1e-5f) denom = 1.f;
+  const float t = (u - c0) / denom;
+  float fd = b0 + t * (b1 - b0);
+  if (use_disp) {
+    fd = fd * (f_ - n_) + n_;
+    fd = -1.f / fd;
+  }
+  return fd;
+}
+
 __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict__ depth, const float* __restrict__ hit,
                                                          float qnear, float qfar, int use_disp, int use_all, int rn,
                                                          int dn, int fdn, const float* __restrict__ urand,
@@ -151,7 +169,7 @@ __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict
   float part = 0.f;
   for (int i = lane; i < dn; i += 64) {
     const float z = depth[(size_t)rayc * dn + i];
-    const float d = use_disp ? (-1.f / z - n_) / (f_ - n_) : z;
+    const float d = fd_norm_depth(z, n_, f_, use_disp);
     const float hp = hit[(size_t)rayc * dn + i] + 1e-5f;
     s_d[wv][i] = d;
     s_pdf[wv][i] = hp;
@@ -185,15 +203,7 @@ __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict
     const int below = max(inds - 1, 0), above = min(inds, dn);
     const float c0 = s_cdf[wv][below], c1 = s_cdf[wv][above];
     const float b0 = s_ctr[wv][below], b1 = s_ctr[wv][above];
-    float denom = c1 - c0;
-    if (denom < 1e-5f) denom = 1.f;
-    const float t = (u - c0) / denom;
-    float fd = b0 + t * (b1 - b0);
-    if (use_disp) {
-      fd = fd * (f_ - n_) + n_;
-      fd = -1.f / fd;
-    }
-    s_val[wv][base + j] = fd;
+    s_val[wv][base + j] = fd_sample(u, c0, c1, b0, b1, n_, f_, use_disp);
   }
   __syncthreads();
   // stable rank sort of the (nearly sorted) values
@@ -209,8 +219,135 @@ __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict
   }
 }
 
+// The same sampler with ONE LANE PER RAY (dn == fdn in {32, 64}: the shipped 64 + 64 and 32 + 32 configurations).  In the
+// wave-per-ray kernel above every ray pays three O(dn) loops of LDS round trips in all 64 lanes (872 us for a 512x1024 frame,
+// 1 % of a coarse + fine frame; its bytes would take 50 us at the HBM rate).  Here a wave takes 64 rays: the two input tiles
+// (64 rays x DN floats, contiguous in memory) are loaded coalesced and transposed through LDS (row stride 2*DN+1: a whole-wave
+// access of one column is conflict-free), each lane then runs the reference's serial algorithm on its own row -- the
+// normalising sum as the wave kernel's butterfly tree, the cdf left to right, searchsorted(right=True) as a branch-free upper
+// bound (the cdf is a running sum of positives, hence monotone: same count as the comparison loop), four searches in flight
+// -- sorts its row by insertion (the values arrive almost sorted; NaNs last, every slot written) and the tile is written
+// back coalesced.  Bit-identical to the wave kernel (tests/test_gpu_render.py).
+template <int DN>
+__global__ void __launch_bounds__(64) fine_depth_lane_kernel(const float* __restrict__ depth, const float* __restrict__ hit,
+                                                             float qnear, float qfar, int use_disp, int use_all, int rn,
+                                                             const float* __restrict__ urand, float* __restrict__ out) {
+  constexpr int ROW = 2 * DN + 1;     // [0,DN): normalised depth d, later the coarse z (use_all);  [DN,2DN): hit -> cdf[1..DN] -> fine z
+  __shared__ float s[64 * ROW];
+  const int lane = threadIdx.x;
+  const size_t ray0 = (size_t)blockIdx.x * 64;
+  const float n_ = -1.f / qnear, f_ = -1.f / qfar;
+  constexpr int LPR = DN / 4;         // lanes per ray row in a tile load (float4 each)
+  auto load_tile = [&](const float* __restrict__ src, int col0) {
+#pragma unroll
+    for (int it = 0; it < DN / 4; ++it) {
+      const int e = it * 64 + lane, r = e / LPR, i = (e % LPR) * 4;
+      const size_t gr = min(ray0 + (size_t)r, (size_t)rn - 1);
+      const float4 v = *reinterpret_cast<const float4*>(src + gr * DN + i);
+      float* q = s + r * ROW + col0 + i;
+      q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    }
+  };
+  load_tile(depth, 0);
+  load_tile(hit, DN);
+  __syncthreads();
+  float* row = s + lane * ROW;
+  float t[DN];
+#pragma unroll
+  for (int i = 0; i < DN; ++i) {
+    row[i] = fd_norm_depth(row[i], n_, f_, use_disp);
+    t[i] = row[DN + i] + 1e-5f;
+  }
+  {   // the wave kernel's sum: lanes >= DN contribute 0 (x + 0 = x), then xor-butterfly = pairs (i, i + half)
+    float u[DN];
+#pragma unroll
+    for (int i = 0; i < DN; ++i) u[i] = t[i];
+#pragma unroll
+    for (int half = DN / 2; half >= 1; half >>= 1)
+#pragma unroll
+      for (int i = 0; i < half; ++i) u[i] = u[i] + u[i + half];
+    const float total = u[0];
+    float c = 0.f;
+#pragma unroll
+    for (int k = 0; k < DN; ++k) {
+      c += t[k] / total;
+      row[DN + k] = c;                // cdf[k + 1]; cdf[0] = 0 is implicit
+    }
+  }
+  const float interval = (float)(1.0 / (double)DN);
+  const float half_iv = (float)(0.5 * (1.0 / (double)DN));
+  const size_t ray = min(ray0 + (size_t)lane, (size_t)rn - 1);
+  const float* cdf = row + DN;        // cdf[k] for k >= 1 at cdf[k - 1]
+  auto ctr = [&](int k) { return k == 0 ? row[0] : (k == DN ? row[DN - 1] : (row[k] + row[k - 1]) / 2.f); };
+#pragma unroll
+  for (int j0 = 0; j0 < DN; j0 += 4) {
+    float u[4];
+    int cnt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u[q] = urand ? urand[ray * DN + j0 + q] : half_iv + (float)(j0 + q) * interval;
+      cnt[q] = 0;
+    }
+#pragma unroll
+    for (int step = DN / 2; step >= 1; step >>= 1)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cnt[q] += (cdf[cnt[q] + step - 1] <= u[q]) ? step : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cnt[q] += (cdf[cnt[q]] <= u[q]) ? 1 : 0;           // number of cdf[1..DN] <= u; with cdf[0] = 0 <= u: inds = cnt + 1
+      const int below = cnt[q], above = min(cnt[q] + 1, DN);
+      const float c0 = below == 0 ? 0.f : cdf[below - 1], c1 = cdf[above - 1];
+      t[j0 + q] = fd_sample(u[q], c0, c1, ctr(below), ctr(above), n_, f_, use_disp);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DN; ++j) row[DN + j] = t[j];
+  if (use_all) {
+    __syncthreads();
+    load_tile(depth, 0);
+    __syncthreads();
+  }
+  const int base = use_all ? 0 : DN, total = use_all ? 2 * DN : DN;
+  float* a = row + base;
+  for (int j = 1; j < total; ++j) {
+    const float v = a[j];
+    int i = j - 1;
+    float o = a[i];
+    // o sorts after v: o > v, or o is NaN and v is not
+    while (!(o <= v) && v == v) {
+      a[i + 1] = o;
+      if (--i < 0) break;
+      o = a[i];
+    }
+    a[i + 1] = v;
+  }
+  __syncthreads();
+  const int lpr = total / 4;
+  for (int it = 0; it < total / 4; ++it) {
+    const int e = it * 64 + lane, r = e / lpr, i = (e % lpr) * 4;
+    if (ray0 + r < (size_t)rn) {
+      const float* q = s + r * ROW + base + i;
+      *reinterpret_cast<float4*>(out + (ray0 + r) * total + i) = make_float4(q[0], q[1], q[2], q[3]);
+    }
+  }
+}
+
 int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
                       int dn, int fdn, const float* urand, float* out, void* stream) {
+  const char* knob = getenv("PGRF_FINE_DEPTH");          // "wave": the wave-per-ray kernel for every shape (A/B, tests)
+  const bool wave_only = knob && !strcmp(knob, "wave");
+  const bool aligned = (((uintptr_t)depth | (uintptr_t)hit | (uintptr_t)out) & 15) == 0;
+  if (!wave_only && dn == fdn && (dn == 32 || dn == 64) && aligned && rn > 0) {
+    const int blocks = (rn + 63) / 64;
+    if (dn == 64)
+      hipLaunchKernelGGL(fine_depth_lane_kernel<64>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, depth, hit, qnear, qfar,
+                         use_disp, use_all, rn, urand, out);
+    else
+      hipLaunchKernelGGL(fine_depth_lane_kernel<32>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, depth, hit, qnear, qfar,
+                         use_disp, use_all, rn, urand, out);
+    PGRF_CHECK_LAUNCH("fine_depth_lane");
+    return PGRF_OK;
+  }
   const int blocks = (rn + 3) / 4;
   hipLaunchKernelGGL(fine_depth_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, hit, qnear, qfar, use_disp,
                      use_all, rn, dn, fdn, urand, out);

@@ -62,25 +62,10 @@ __device__ __forceinline__ float xmax(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 // ELU(x) = median(x, exp(x)-1, 0): x > 0 -> exp(x)-1 >= x > 0; x < 0 -> x <= exp(x)-1 < 0.  One v_med3 instead of cmp+cndmask.
-#ifndef PGRF_ELU_MODE
-#define PGRF_ELU_MODE 0
-#endif
-#if PGRF_ELU_MODE == 0
+// (Tried: min(exp(x),1) - 1 via the v_exp's clamp modifier, then a two-operand v_max with x.  As fmaxf it costs a second,
+// canonicalising v_max on the raw accumulator (IEEE mode) and is 0.8 % slower; as an inline-asm v_max it measured +0.3 % but
+// gave wrong, run-to-run varying results -- hazard tracking does not see through the asm.)
 __device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
-#else
-// min(exp(x), 1) - 1 is exp(x)-1 for x < 0 and exactly 0 otherwise, so ELU(x) = max(x, that): the clamp is the v_exp's
-// output modifier and the two-operand max issues at the full VALU rate, where the three-operand v_med3 does not.
-__device__ __forceinline__ float elu1(float x) {
-  float t, r;
-  asm("v_exp_f32_e64 %0, %1 clamp" : "=v"(t) : "v"(x * 1.4426950408889634f));
-#if PGRF_ELU_MODE == 1
-  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t - 1.f));
-#else
-  r = fmaxf(x, t - 1.f);
-#endif
-  return r;
-}
-#endif
 __device__ __forceinline__ float sigmoid1(float x) { return rcp1(1.f + __expf(-x)); }
 // nn.Softplus (beta 1, threshold 20) as max(x,0) + log(1 + exp(-|x|)) on v_exp/v_log: absolute error ~1e-7, the size of one
 // fp32 rounding of the result's integer part; libm's log1pf is a ~140-instruction double-float routine (measured: the

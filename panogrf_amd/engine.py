@@ -32,6 +32,16 @@ def _f32c(t, device=None):
     return t.to(torch.float32).contiguous()
 
 
+def host_floats(t, n):
+    """First n values of a small tensor as Python floats for a by-value kernel argument.  A tensor that
+    panogrf_amd.imgs_info.imgs_info_to_torch moved to the GPU carries its host values (`_pgrf_host`), so no device->host copy
+    and no host sync happens; any other GPU tensor is read back."""
+    mirror = getattr(t, '_pgrf_host', None)
+    if mirror is not None and mirror[1] == t._version and mirror[0].numel() >= n:
+        return [float(x) for x in mirror[0][:n]]
+    return [float(x) for x in _f32c(t, 'cpu').reshape(-1)[:n]]
+
+
 def raw_names():
     return [lib.pgrf_raw_name(i).decode() for i in range(lib.pgrf_raw_count())]
 
@@ -97,11 +107,11 @@ class Frame:
         self.perspective = que_K is not None
         self.que_kinv = [0.0] * 9
         if self.perspective:
-            pose = _f32c(que_pose, 'cpu').reshape(3, 4)
+            pose = torch.tensor(host_floats(que_pose, 12)).reshape(3, 4)
             rot = pose[:, :3].t().contiguous()
             trans = -rot @ pose[:, 3:]
             que_c2w = torch.cat([rot, trans], 1)
-            self.que_kinv = [float(x) for x in torch.inverse(_f32c(que_K, 'cpu').reshape(3, 3)).reshape(-1)]
+            self.que_kinv = [float(x) for x in torch.inverse(torch.tensor(host_floats(que_K, 9)).reshape(3, 3)).reshape(-1)]
         dev = torch.device(device)
         if img_feats.shape[1] != FEAT_CH or ray_feats.shape[1] != FEAT_CH or imgs.shape[1] != 3:
             raise PgrfError(f"expected imgs [rfn,3,H,W], img_feats/ray_feats [rfn,{FEAT_CH},h,w]")
@@ -111,8 +121,8 @@ class Frame:
         self.ray_feats = _channel_last(ray_feats, dev)
         self.w2c = _f32c(w2c, dev).reshape(self.rfn, 12)
         self.ref_dr = _f32c(ref_depth_range, dev).reshape(self.rfn, 2)
-        self.que_c2w = [float(x) for x in _f32c(que_c2w, 'cpu').reshape(-1)[:12]]
-        self.que_dr = [float(x) for x in _f32c(que_depth_range, 'cpu').reshape(-1)[:2]]
+        self.que_c2w = host_floats(que_c2w, 12)
+        self.que_dr = host_floats(que_depth_range, 2)
         self.device = dev
 
     def c_struct(self):

@@ -367,11 +367,11 @@ class NeuralRayBaseRenderer(nn.Module):
             if que['poses'].shape[0] != 1:
                 raise PgrfError('one query view per call (qn = 1)')
             return E.Frame(ref['imgs'], ref['img_feats'], ref['ray_feats'], ref['w2c'], ref['depth_range'], None,
-                           que['depth_range'][0], que_pose=que['poses'][0], que_K=que['Ks'][0], **kw)
+                           que['depth_range'], que_pose=que['poses'], que_K=que['Ks'], **kw)
         if que['c2w'].shape[0] != 1:
             raise PgrfError('que_imgs_info c2w.shape[0]=1')
-        return E.Frame(ref['imgs'], ref['img_feats'], ref['ray_feats'], ref['w2c'], ref['depth_range'], que['c2w'][0],
-                       que['depth_range'][0], **kw)
+        return E.Frame(ref['imgs'], ref['img_feats'], ref['ray_feats'], ref['w2c'], ref['depth_range'], que['c2w'],
+                       que['depth_range'], **kw)       # whole [1,...] tensors: the first view's values lead (host_floats)
 
     def render(self, que_imgs_info, ref_imgs_info, is_train, is_perspec=False):
         """Whole query view (network/renderer.py:635-686).  Mutates ref_imgs_info['img_feats'/'ray_feats'] and

@@ -478,6 +478,30 @@ def test_sampler_writes_every_slot_with_nan_inputs():
                 assert bool((fin[1:] >= fin[:-1]).all()) and torch.isnan(fd[3, fin.numel():]).all()
 
 
+def test_lane_per_ray_sampler_equals_wave_per_ray_sampler(monkeypatch):
+    """dn == fdn in {32, 64} runs the importance sampler with one lane per ray (aux_kernels.hip: fine_depth_lane_kernel); the
+    wave-per-ray kernel, pinned to the reference fixtures above, stays for every other shape.  Same bits from both: eval and
+    training draws, appended coarse samples, ragged last tile, peaked and flat pdfs."""
+    E = _engine()
+    g = torch.Generator().manual_seed(5)
+    for dn in (32, 64):
+        for rn in (1, 63, 64, 65, 1000):
+            depth = E.sample_coarse_depth(0.5, 15.0, rn, dn)
+            hit = torch.rand(rn, dn, generator=g) ** 4
+            hit[: rn // 3] = 0.0                                   # empty rays: uniform pdf of 1e-5 per bin
+            hit[rn // 3: rn // 2, dn // 2] = 1.0                   # one dominant bin
+            hit = hit.cuda()
+            u = torch.rand(rn, dn, generator=g)
+            for use_all in (False, True):
+                for draws in (None, u):
+                    monkeypatch.setenv('PGRF_FINE_DEPTH', 'wave')
+                    want = E.sample_fine_depth(depth, hit, (0.5, 15.0), dn, use_all=use_all, u=draws)
+                    monkeypatch.delenv('PGRF_FINE_DEPTH')
+                    got = E.sample_fine_depth(depth, hit, (0.5, 15.0), dn, use_all=use_all, u=draws)
+                    assert got.shape == want.shape == (rn, dn * (2 if use_all else 1))
+                    assert torch.equal(got, want), (dn, rn, use_all, draws is not None)
+
+
 def test_training_mode_forward_vs_reference():
     """is_train=True through the C ABI (pgrf_render_rays_train): coarse depths stay deterministic, the importance
     sampler takes torch.rand draws from the CPU generator like the reference (render_ops.py:449) — seeded like the
