@@ -41,6 +41,9 @@
 #define PGRF_PREC_NS p16
 #endif
 
+#ifndef PGRF_PV_PACKED
+#define PGRF_PV_PACKED 1
+#endif
 namespace pgrf {
 namespace PGRF_PREC_NS {
 
@@ -283,24 +286,20 @@ __device__ __forceinline__ void mfma_small(const float* __restrict__ S, const fl
       for (int i = 0; i < 4; ++i) out[t][4 * g + i] = xsum(acc[t][g][i]);
 }
 
-// VALU head: out = sum_r w[half][r] * x[r], summed over both lane halves (bias added by caller).
-template <int R>
-__device__ __forceinline__ float head_dot(const float* __restrict__ w, int half, const f32x16& x) {
-  const float* wp = w + half * R;
-  float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < R; ++r) s = fmaf(wp[r], x[r], s);
-  return xsum(s);
-}
-
 // partial dot over this lane half's R features (no cross-half sum)
 template <int R>
 __device__ __forceinline__ float head_partial(const float* __restrict__ w, int half, const f32x16& x) {
   const float* wp = w + half * R;
+  // (even / odd features on the halves of one v_pk_fma_f32 chain: measured 0.5 % slower)
   float s = 0.f;
 #pragma unroll
   for (int r = 0; r < R; ++r) s = fmaf(wp[r], x[r], s);
   return s;
+}
+// VALU head: out = sum_r w[half][r] * x[r], summed over both lane halves (bias added by caller).
+template <int R>
+__device__ __forceinline__ float head_dot(const float* __restrict__ w, int half, const f32x16& x) {
+  return xsum(head_partial<R>(w, half, x));
 }
 // s0, s1 = per-half partial sums of view 0 / view 1 -> the full sum of view `half` (one swap + one add for both views)
 __device__ __forceinline__ float pair_mine(float s0, float s1) {
@@ -1211,6 +1210,25 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
       mx = xmax(mx);
       float l = 0.f, o0, o1, o2, o3;
 #ifndef PGRF_PV_MFMA
+#if PGRF_PV_PACKED
+      {
+        // the four value dimensions of a head as two v_pk_fma_f32 (5.1 cycles per pair against 2 x 4.4 for v_fmac: tools/ubench/valu_rates)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
+#pragma unroll
+        for (int k2 = 0; k2 < KT; ++k2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
+            const float4 vv = *reinterpret_cast<const float4*>(&lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4]);
+            l += pe;
+            const f32x2 pp = {pe, pe};
+            o01 = __builtin_elementwise_fma(pp, (f32x2){vv.x, vv.y}, o01);
+            o23 = __builtin_elementwise_fma(pp, (f32x2){vv.z, vv.w}, o23);
+          }
+        o0 = o01[0]; o1 = o01[1]; o2 = o23[0]; o3 = o23[1];
+      }
+#else
       o0 = o1 = o2 = o3 = 0.f;
 #pragma unroll
       for (int k2 = 0; k2 < KT; ++k2)
@@ -1221,6 +1239,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
           l += pe;
           o0 = fmaf(pe, vv.x, o0); o1 = fmaf(pe, vv.y, o1); o2 = fmaf(pe, vv.z, o2); o3 = fmaf(pe, vv.w, o3);
         }
+#endif
 #else
       // experiment (measured slower: 38.2 -> 39.0 ms): softmax-weighted values on v_mfma_f32_4x4x1_16b_f32: block = 4
       // consecutive lanes = 4 queries with the SAME key (k2, r, half); B = the lane's own weight for that key, A = value
