@@ -352,8 +352,25 @@ def main():
         # PSNR of the HIP image against the oracle on the sampled rays
         idx = (ccoords[:, 1].long() * W + ccoords[:, 0].long()).to(dev)
         key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'
-        mse = float(((img[idx].cpu().double() - cout[key].double()) ** 2).mean())
+        mine, want = img[idx].cpu(), cout[key]
+        mse = float(((mine.double() - want.double()) ** 2).mean())
         res['psnr_vs_oracle_db'] = 10 * math.log10(1.0 / max(mse, 1e-20))
+        # the reference's own metrics on the same rays (network/metrics.py): uint8 PSNR after
+        # color_map_backward, WS-PSNR with the rays' row weights, and |PSNR(HIP, GT) - PSNR(oracle, GT)| against a fixed
+        # target image (source view 0 at the query pixels: the synthetic views share no scene, any fixed image does)
+        from panogrf_amd import metrics as MT
+        rows = ccoords[:, 1].long()
+        gt = case['frame']['imgs'][0].permute(1, 2, 0).reshape(-1, 3)[idx.cpu()]
+        u8 = lambda t: MT.color_map_backward(t.numpy())
+        same8 = bool((u8(mine) == u8(want)).all())
+        res['psnr'] = {
+            'float_vs_oracle_db': res['psnr_vs_oracle_db'],
+            'uint8_vs_oracle_db': None if same8 else float(MT.compute_psnr(u8(want), u8(mine))),
+            'uint8_images_identical': same8,
+            'ws_vs_oracle_db': MT.WSPSNR.ws_psnr_rays(mine, want, rows, H),
+            'hip_vs_gt_db': MT.psnr_float(mine, gt), 'oracle_vs_gt_db': MT.psnr_float(want, gt),
+            'abs_delta_vs_gt_db': abs(MT.psnr_float(mine, gt) - MT.psnr_float(want, gt)),
+            'rays': int(idx.numel())}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
