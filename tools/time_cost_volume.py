@@ -10,12 +10,12 @@ from panogrf_amd import cost_reg as R
 
 h, w = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 128)
 only = sys.argv[3] if len(sys.argv) > 3 else None     # 'costregnet' | 'unet2': time just that regulariser
-B, D, C = 1, 64, 32
+B, D, C = int(os.environ.get('PGRF_TCV_B', '1')), 64, 32      # PGRF_TCV_B=2: the two reference views of the MVS stage in one batch
 g = torch.Generator().manual_seed(0)
 feats = torch.randn(B, 2, h, w, C, generator=g).cuda()
 ref_mu = (1 + 7 * torch.rand(B, 1, h, w, generator=g)).cuda()
 eye = torch.eye(3).view(1, 1, 3, 3).repeat(B, 2, 1, 1).cuda()
-trans = torch.tensor([[[0.5, 0, 0], [-0.5, 0, 0]]]).cuda()
+trans = torch.tensor([[[0.5, 0, 0], [-0.5, 0, 0]]]).repeat(B, 1, 1).cuda()
 args = dict(dataset_name='m3d', contain_dnet=True)
 k = CV.depth_sampling(5, 3)
 
