@@ -125,13 +125,7 @@ template <int V> constexpr bool kRecomputeNf = false;
 #else
 template <int V> constexpr bool kRecomputeNf = kTwoWave<V> && V > 3;
 #endif
-// Waves per workgroup.  8 (experiment, -DPGRF_WG8_MAX_V=2): ONE workgroup per CU instead of two, so the two waves of every SIMD
-// share one LDS image, which then has room for the whole A block of every layer but the five largest (image mode 2).
-#ifndef PGRF_WG8_MAX_V
-#define PGRF_WG8_MAX_V 0
-#endif
-template <int V> constexpr int kWaves = (kPrec == 0 && kTwoWave<V> && V <= PGRF_WG8_MAX_V) ? 8 : 4;
-template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : ((kTwoWave<V> && kWaves<V> == 4) ? 0 : 2);
+template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (kTwoWave<V> ? 0 : 2);
 // no image in the split-f16 mode (see above).  (Tried for > 2 views at two waves: image dropped in favour of parking the
 // first view group's prob_embed features through stage B — the register allocator answered with MORE spills, 170 -> 289.)
 #ifdef PGRF_NO_LDS_IMG
@@ -961,19 +955,18 @@ constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast flo
 // compiled in cost 1.2 % through 5 more spilled registers); GEN = true: run-time switch over PgrfFrame.dataset /
 // .perspective.
 template <int KT, int V, bool DBG, bool GEN>
-__global__ void __launch_bounds__(64 * kWaves<V>, ((kTwoWave<V> && kWaves<V> == 4) ? 2 : 1)) render_pass_kernel(const PassArgs p) {
+__global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel(const PassArgs p) {
   constexpr int DN = 32 * KT;
-  constexpr int NW = kWaves<V>;
-  constexpr int RPW = NW / KT;         // rays per workgroup
-  __shared__ __attribute__((aligned(16))) float lds_v[NW * 32 * kVStride];
-  __shared__ float lds_k[NW * 32 * kKStride];
-  __shared__ float lds_alpha[NW];    // per-wave transmittance totals
-  __shared__ float lds_red[NW][4];
+  constexpr int RPW = 4 / KT;          // rays per workgroup
+  __shared__ __attribute__((aligned(16))) float lds_v[128 * kVStride];
+  __shared__ float lds_k[128 * kKStride];
+  __shared__ float lds_alpha[4];     // per-wave transmittance totals
+  __shared__ float lds_red[4][4];
   __shared__ __attribute__((aligned(16))) float lds_img[kHasImg<V> ? img_floats(kImgMode<V>) : 4];
   const float* LI = lds_img;
   if constexpr (kHasImg<V>) {   // every workgroup copies the image once; the barrier sits after ray generation
     const float4* src = reinterpret_cast<const float4*>(p.blob + img_blob_off(kImgMode<V>));
-    for (int i = threadIdx.x; i < img_floats(kImgMode<V>) / 4; i += 64 * NW) reinterpret_cast<float4*>(lds_img)[i] = src[i];
+    for (int i = threadIdx.x; i < img_floats(kImgMode<V>) / 4; i += 256) reinterpret_cast<float4*>(lds_img)[i] = src[i];
   }
   // debug builds: the 12 dump pointers live in LDS, not in SGPRs (24 live SGPRs made the compiler spill scalars)
   __shared__ float* lds_dbg[DBG ? 12 : 1];
@@ -983,6 +976,7 @@ __global__ void __launch_bounds__(64 * kWaves<V>, ((kTwoWave<V> && kWaves<V> == 
     __syncthreads();
   }
 
+  const int lane = threadIdx.x & 63;
 #ifdef PGRF_ONE_WG_PER_CU   // experiment: 84 KB of LDS ballast -> one workgroup (one wave per SIMD) per CU
   __shared__ float lds_ballast[21000];
   if (p.rn < 0) lds_ballast[threadIdx.x * 80] = 1.f;
@@ -990,32 +984,18 @@ __global__ void __launch_bounds__(64 * kWaves<V>, ((kTwoWave<V> && kWaves<V> == 
 #ifdef PGRF_STAGE_TIMING
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
+  const int wave = threadIdx.x >> 6;
+  const int half = lane >> 5;
+  const int pl = lane & 31;
+  const int ray_local = wave / KT;
+  const int kt = wave % KT;
   // XCD-aware block -> ray mapping: consecutive workgroups are dispatched round-robin over the 8 XCDs, so give
   // every XCD one CONTIGUOUS span of rays (a band of image rows): its private L2 then holds one band of the
   // source maps instead of all of them.  Bijective for any grid size; speed only, never correctness.
-  // 8-wave workgroups are persistent (one per CU, the 80 KB image is copied once): virtual block vb = blockIdx.x, + gridDim.x, ...
-#ifdef PGRF_PERSIST
-  constexpr bool kPersist = true;
-#else
-  constexpr bool kPersist = (NW == 8);
-#endif
-  const int nb_virtual = kPersist ? (p.rn + RPW - 1) / RPW : (int)gridDim.x;
-  for (int vb = blockIdx.x; vb < nb_virtual; vb += gridDim.x) {
-  int tid = threadIdx.x;
-  // persistent loop: the thread id is opaque per iteration, so that nothing derived from it (operand offsets, tap setups) is
-  // hoisted out of the loop and kept in registers across it (290 spilled registers otherwise)
-  if constexpr (kPersist) asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
-  const int half = lane >> 5;
-  const int pl = lane & 31;
-  const int wave = kPersist ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);       // wave-uniform (the opaque tid hides it)
-  const int ray_local = wave / KT;
-  const int kt = wave % KT;
-  int wg = vb;
+  int wg = blockIdx.x;
 #ifndef PGRF_NO_XCD_REMAP
   {
-    // (a persistent grid is a multiple of 8 workgroups or a single round, so vb & 7 stays the XCD of this workgroup)
-    const int nb = nb_virtual, q = nb >> 3, r = nb & 7, xcd = wg & 7, idx = wg >> 3;
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
 #endif
@@ -1083,14 +1063,14 @@ __global__ void __launch_bounds__(64 * kWaves<V>, ((kTwoWave<V> && kWaves<V> == 
 #else
   constexpr bool kPark = kTwoWave<V>;
 #endif
-  __shared__ float lds_park[kPark ? V * 7 : 1][64 * NW];
+  __shared__ float lds_park[kPark ? V * 7 : 1][256];
   if constexpr (kPark) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) lds_park[v * 7 + c][tid] = vs[v].dd[c];
+      for (int c = 0; c < 4; ++c) lds_park[v * 7 + c][threadIdx.x] = vs[v].dd[c];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) lds_park[v * 7 + 4 + c][tid] = vs[v].rgb[c];
+      for (int c = 0; c < 3; ++c) lds_park[v * 7 + 4 + c][threadIdx.x] = vs[v].rgb[c];
     }
   }
 
@@ -1336,9 +1316,9 @@ __global__ void __launch_bounds__(64 * kWaves<V>, ((kTwoWave<V> && kWaves<V> == 
 #pragma unroll
       for (int v = 0; v < V; ++v) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) vs[v].dd[c] = *(volatile float*)&lds_park[v * 7 + c][tid];
+        for (int c = 0; c < 4; ++c) vs[v].dd[c] = *(volatile float*)&lds_park[v * 7 + c][threadIdx.x];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vs[v].rgb[c] = *(volatile float*)&lds_park[v * 7 + 4 + c][tid];
+        for (int c = 0; c < 3; ++c) vs[v].rgb[c] = *(volatile float*)&lds_park[v * 7 + 4 + c][threadIdx.x];
       }
     }
     stage_rgb<V, 0, kNT0<V>>(p, LI, vs, lane, logit);
@@ -1409,24 +1389,16 @@ __global__ void __launch_bounds__(64 * kWaves<V>, ((kTwoWave<V> && kWaves<V> == 
     else if (p.out_depth) p.out_depth[ray] = s;
   }
   PGRF_TICK(9);   // composite
-  if constexpr (kPersist) PGRF_SYNC();      // the next tile overwrites lds_red / lds_alpha / K / V
-  else break;
-  }
 }
 
 template <int KT, int V, bool DBG>
 int launch_instance(const PassArgs& a, void* stream) {
-  constexpr int RPW = kWaves<V> / KT;
-  constexpr int TPB = 64 * kWaves<V>;
-  int blocks = (a.rn + RPW - 1) / RPW;
-  if (kWaves<V> == 8 && blocks > 256) blocks = 256;      // persistent: one workgroup per CU
-#ifdef PGRF_PERSIST
-  if (kWaves<V> == 4 && blocks > PGRF_PERSIST) blocks = PGRF_PERSIST;
-#endif
+  constexpr int RPW = 4 / KT;
+  const int blocks = (a.rn + RPW - 1) / RPW;
   // debug instances exist in the general form only (they serve every convention at test sizes)
   const bool general = DBG || a.dataset != PGRF_DATASET_M3D || a.perspective;
-  if (general) hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG, true>), dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG, DBG>), dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, a);
+  if (general) hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG, DBG>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(PGRF_ERR_LAUNCH, "render_pass launch failed: %s", hipGetErrorString(e));
   return PGRF_OK;
