@@ -115,6 +115,45 @@ def flop_per_ray(rfn, dn, passes):
 
 
 # ------------------------------------------------------------------------------------------------
+def end_to_end_frames(H, W, V, dn, fine, dev, frames=5):
+    """SURVEY.md 8d asks for the rate 'with / without per-frame encoders and cost volume': the drop-in module's whole
+    `renderer(data)` call (MVS stage at depth H/2 x W/2 as shipped -> 2-D encoders -> render passes; random-init networks, a
+    constant mono-depth prior standing in for UniFuse) timed next to the headline.  Reported beside `value`, never as it."""
+    import numpy as np
+    from render import DEFAULT_CFG, MVS_CFG, ConstantMono
+    from panogrf_amd.imgs_info import build_imgs_info, build_render_imgs_info, imgs_info_to_torch
+    from panogrf_amd.renderer import name2network
+    cfg = dict(DEFAULT_CFG, height=H, width=W, depth_sample_num=dn, fine_depth_sample_num=dn, sample_num=dn,
+               use_hierarchical_sampling=bool(fine))
+    cfg.update(MVS_CFG, depth_height=H // 2, depth_width=W // 2)
+    torch.manual_seed(0)
+    net = name2network['neuray_gen'](cfg, d_net=ConstantMono(3.0)).to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.rand(V, 3, H, W, generator=g).numpy()
+    pose = lambda tx: np.concatenate([np.eye(3), np.array([[tx], [0.0], [0.0]])], 1)
+    w2c = np.stack([pose(0.5 - v / max(V - 1, 1)) for v in range(V)])
+    rng = [[0.5, 15.0]] * V
+    ref = imgs_info_to_torch(build_imgs_info(imgs, w2c, rng), dev)
+    src = imgs_info_to_torch(build_imgs_info(imgs[::-1].copy(), w2c[::-1].copy(), rng), dev)
+    que = imgs_info_to_torch(build_render_imgs_info(pose(0.0), (H, W), [0.5, 15.0]), dev)
+
+    def run(reuse):
+        net.cfg['hip_reuse_source_maps'] = reuse
+        with torch.no_grad():
+            for i in range(2 + frames):
+                if i == 2:
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                net({'que_imgs_info': dict(que), 'ref_imgs_info': dict(ref), 'src_imgs_info': dict(src), 'eval': True})
+            torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / frames * 1e3
+    every, kept = run(False), run(True)
+    return {'what': f'renderer(data) of the drop-in module: MVS stage (depth {H // 2}x{W // 2}, UNet2) + 2-D encoders + '
+                    f'{"coarse and fine passes" if fine else "one pass"}; constant mono prior',
+            'ms_per_frame_everything_per_frame': every, 'rays_per_s_everything_per_frame': H * W / every * 1e3,
+            'ms_per_frame_source_maps_reused': kept, 'rays_per_s_source_maps_reused': H * W / kept * 1e3}
+
+
 def cpu_baseline(case, budget_s=15.0):
     """The CPU oracle (a port of the reference algorithm) timed on a bounded sample of the workload."""
     from oracle import render_oracle as O
@@ -186,6 +225,7 @@ def main():
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f32',
                     help="f32 = exact fp32 MFMA (default); f16x3 = opt-in split-f16 MFMA (3 per product, fp32 accumulate)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-end-to-end', action='store_true', help='skip the whole-module frame timing reported beside the headline (--no-cpu-baseline skips it too)')
     ap.add_argument('--eager-baseline', action='store_true', help='also time the eager PyTorch-ROCm port on this GPU')
     args = ap.parse_args()
 
@@ -346,6 +386,8 @@ def main():
         eg['value_ray_batch_4096'] = eg4['value']
         eg['speedup_hip_over_eager'] = rays_per_s / max(eg['value'], eg4['value'])
         res['torch_eager_gpu_baseline'] = eg
+    if rank == 0 and world == 1 and not (args.no_end_to_end or args.no_cpu_baseline) and V == 2 and args.precision == 'f32' and H % 64 == 0 and W % 64 == 0:
+        res['end_to_end'] = end_to_end_frames(H, W, V, dn, args.fine, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ccoords, cout = cpu_baseline(case)
         res['cpu_baseline'] = base
