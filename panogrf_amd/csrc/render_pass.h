@@ -999,7 +999,14 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
 #endif
-  const int ray_raw = wg * RPW + ray_local;
+  int ray_raw = wg * RPW + ray_local;
+  if (p.order_w) {          // tiled visiting order (render_pass_args.h); wave-uniform integer arithmetic
+    const int per_tile = p.order_tw * p.order_th, tiles_x = p.order_w / p.order_tw;
+    const int t = ray_raw / per_tile, in = ray_raw - t * per_tile;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int iy = in / p.order_tw, ix = in - iy * p.order_tw;
+    ray_raw = (ty * p.order_th + iy) * p.order_w + tx * p.order_tw + ix;
+  }
   const bool ray_ok = ray_raw < p.rn;
   const int ray = ray_ok ? ray_raw : p.rn - 1;
   const int si = kt * 32 + pl;                       // sample index on the ray

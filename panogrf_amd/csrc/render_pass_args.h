@@ -23,6 +23,9 @@ struct PassArgs {
   const float* depth;       // [rn,dn]
   const float* raytab;      // [rn,4] world-space ray directions (ray_dir.h) or null = compute per sample
   int rn;
+  // processing order: 0 = ray i is processed i-th; else ray ids are visited in tw x th pixel tiles of a row-major grid of width
+  // order_w (a bijection on [0, rn): results cannot depend on it, only the gathers' cache locality does)
+  int order_w, order_tw, order_th;
   // network
   const float* blob;
   int use_vis;

@@ -177,6 +177,29 @@ def test_full_size_properties_and_oracle_strip():
     assert FX.psnr(px[strip], ref['pixel_colors_nr']) > 90.0
 
 
+def test_ray_visiting_order_does_not_change_results(monkeypatch):
+    """Whole row tiles of a panorama are visited in 2-D pixel tiles when the source maps are large (capi.hip, PGRF_RAY_TILE):
+    a bijection on the ray ids, so every output is bit-identical with the tiling forced on, off, or ragged (not applicable)."""
+    E = _engine()
+    from bench import synthetic_case
+    H, W = 64, 128
+    case = synthetic_case(H, W, 2, 32, seed=4, fine=True)
+    fr = _frame(E, case['frame'])
+    rr = E.RayRenderer(case['cfg'], case['weights'])
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    outs = {}
+    for tile in ('0', '16 16', '32 8', '128 64'):
+        monkeypatch.setenv('PGRF_RAY_TILE', tile)
+        outs[tile] = rr.render_rays(fr, coords)
+        part = rr.render_rays(fr, coords[: 16 * W + 5])          # ragged: not whole tile rows -> plain order
+        for k in ('pixel_colors_nr_fine', 'render_depth_fine', 'density_nr'):
+            assert torch.equal(part[k], outs[tile][k][: 16 * W + 5]), (tile, k)
+    for tile, o in outs.items():
+        for k, v in outs['0'].items():
+            assert torch.equal(v, o[k]), (tile, k)
+
+
 @pytest.mark.parametrize('rn', [1, 3, 130])
 def test_ragged_ray_counts_vs_oracle(rn):
     """Ray counts that do not fill a workgroup (4 rays at dn=32, 2 at dn=64) and odd sizes."""
