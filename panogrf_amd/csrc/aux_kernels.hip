@@ -375,12 +375,33 @@ __global__ void __launch_bounds__(256) merge_c2f_kernel(const float* __restrict_
   for (int i = lane; i < total; i += 64)
     s_z[wv][i] = (i < dnc) ? zc[(size_t)rayc * dnc + i] : zf[(size_t)rayc * dnf + (i - dnc)];
   __syncthreads();
+  // Both lists normally arrive sorted (the coarse sampler's and the importance sampler's outputs): the stable rank of an
+  // element is then its own index plus a binary search in the OTHER list (coarse before fine on ties, NaNs last: the same
+  // total order as sorts_before).  Anything else -- a NaN inside the coarse depths, a caller's unsorted list -- takes the
+  // all-pairs rank sort, which writes every slot exactly once for any input.  (All-pairs for every ray: 2.5 ms per frame.)
+  auto lt = [](float o, float v) { return (o < v) || (v != v && o == o); };      // o strictly before v, index ties aside
+  bool mine_sorted = true;
+  for (int j = lane; j + 1 < total; j += 64)
+    if (j + 1 != dnc && lt(s_z[wv][j + 1], s_z[wv][j])) mine_sorted = false;
+  const bool presorted = __all(mine_sorted);
   for (int j = lane; j < total; j += 64) {
     const float v = s_z[wv][j];
     int rank = 0;
-    for (int k = 0; k < total; ++k) {
-      const float w = s_z[wv][k];
-      rank += sorts_before(w, k, v, j) ? 1 : 0;
+    if (presorted) {
+      const bool coarse = j < dnc;
+      const float* other = &s_z[wv][coarse ? dnc : 0];
+      int lo = 0, hi = coarse ? dnf : dnc;
+      while (lo < hi) {          // coarse: number of fine values strictly before v; fine: number of coarse values not after v
+        const int mid = (lo + hi) >> 1;
+        const float o = other[mid];
+        if (coarse ? lt(o, v) : !lt(v, o)) lo = mid + 1; else hi = mid;
+      }
+      rank = (coarse ? j : j - dnc) + lo;
+    } else {
+      for (int k = 0; k < total; ++k) {
+        const float w = s_z[wv][k];
+        rank += sorts_before(w, k, v, j) ? 1 : 0;
+      }
     }
     const float den = (j < dnc) ? denc[(size_t)rayc * dnc + j] : denf[(size_t)rayc * dnf + (j - dnc)];
     const float* cp = (j < dnc) ? colc + ((size_t)rayc * dnc + j) * 3 : colf + ((size_t)rayc * dnf + (j - dnc)) * 3;
@@ -391,9 +412,24 @@ __global__ void __launch_bounds__(256) merge_c2f_kernel(const float* __restrict_
   }
   __syncthreads();
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = lane; i < total; i += 64) {
-    float T = 1.f;
-    for (int j = 0; j < i; ++j) T *= (1.f - s_a[wv][j] + 1e-10f);
+  // transmittance T_i = prod_{j<i} (1 - alpha_j + 1e-10): an inclusive product scan over the lanes per block of 64 sorted
+  // samples, times the product of the earlier blocks (the serial loop over LDS it replaces was most of this kernel: a frame's
+  // merge took 2.5 ms)
+  float carry = 1.f;
+  for (int i = lane; i < total + lane; i += 64) {       // every lane runs every block: the shuffles need the whole wave
+    const bool in = i < total;
+    const float f = in ? (1.f - s_a[wv][i] + 1e-10f) : 1.f;
+    float incl = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl *= up;
+    }
+    float T = __shfl_up(incl, 1, 64);
+    if (lane == 0) T = 1.f;
+    T *= carry;
+    carry *= __shfl(incl, 63, 64);
+    if (!in) continue;
     const float hitp = s_a[wv][i] * T;
     const size_t pt = (size_t)ray * total + i;
     if (ok) {

@@ -525,6 +525,57 @@ def test_lane_per_ray_sampler_equals_wave_per_ray_sampler(monkeypatch):
                     assert torch.equal(got, want), (dn, rn, use_all, draws is not None)
 
 
+def test_c2f_merge_presorted_ties_unsorted_and_nan():
+    """pgrf_merge_c2f (renderer.py:484-518): sorted inputs take the binary-search ranks, anything else the all-pairs rank sort;
+    both are the STABLE sort of concat(coarse, fine) (coarse first on ties, NaNs last) followed by one composite."""
+    import ctypes as C
+    from panogrf_amd._lib import lib, PgrfPassOut
+    from oracle import render_oracle as O
+    g = torch.Generator().manual_seed(11)
+    rn, dnc, dnf = 37, 64, 64
+    zc = torch.sort(0.5 + 14.5 * torch.rand(rn, dnc, generator=g), -1)[0]
+    zf = torch.sort(0.5 + 14.5 * torch.rand(rn, dnf, generator=g), -1)[0]
+    zf[:, ::5] = zc[:, ::5]                                    # exact ties across the two lists ...
+    zf = torch.sort(zf, -1)[0]
+    zc[3, 10:14] = zc[3, 10]                                   # ... and inside one
+    colc, colf = torch.rand(rn, dnc, 3, generator=g), torch.rand(rn, dnf, 3, generator=g)
+    denc, denf = 2 * torch.rand(rn, dnc, generator=g) - 0.3, 2 * torch.rand(rn, dnf, generator=g) - 0.3
+
+    def run(zc, zf):
+        dev = [t.cuda().contiguous() for t in (zc, colc, denc, zf, colf, denf)]
+        total = dnc + dnf
+        out = dict(pixel=torch.empty(rn, 3), depth=torch.empty(rn), hit=torch.empty(rn, total), col=torch.empty(rn, total, 3),
+                   den=torch.empty(rn, total))
+        out = {k: v.cuda() for k, v in out.items()}
+        po = PgrfPassOut(out['pixel'].data_ptr(), out['depth'].data_ptr(), out['hit'].data_ptr(), out['col'].data_ptr(),
+                         out['den'].data_ptr(), None)
+        lib.check(lib.pgrf_merge_c2f(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dnc, dev[3].data_ptr(),
+                                     dev[4].data_ptr(), dev[5].data_ptr(), dnf, rn, C.byref(po),
+                                     torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return {k: v.cpu() for k, v in out.items()}
+
+    def want(zc, zf):
+        z = torch.cat([zc, zf], -1)
+        zs, idx = z.sort(dim=-1, stable=True)
+        col = torch.gather(torch.cat([colc, colf], -2), -2, idx.unsqueeze(-1).expand(-1, -1, 3))
+        den = torch.gather(torch.cat([denc, denf], -1), -1, idx)
+        hit, pixel, depth = O.composite(den, col, zs)
+        return dict(pixel=pixel, depth=depth, hit=hit, col=col, den=den)
+
+    for label, a, b in (('presorted', zc, zf), ('unsorted coarse', zc.flip(-1).contiguous(), zf)):
+        got, ref = run(a, b), want(a, b)
+        assert torch.equal(got['col'], ref['col']) and torch.equal(got['den'], ref['den']), label
+        assert FX.max_abs(got['hit'], ref['hit']) < 2e-6 and FX.max_abs(got['pixel'], ref['pixel']) < 5e-6, label
+        assert FX.max_abs(got['depth'], ref['depth']) < 5e-5, label
+    zn = zc.clone()
+    zn[5, 20] = float('nan')                                   # a NaN inside the coarse list: all-pairs path, NaN sorts last
+    got, ref = run(zn, zf), want(zn, zf)
+    ok = [r for r in range(rn) if r != 5]
+    assert torch.equal(got['col'][ok], ref['col'][ok]) and torch.equal(got['den'], ref['den'])
+    assert torch.equal(got['col'][5], ref['col'][5])           # same permutation as torch's stable sort, NaN last
+
+
 def test_training_mode_forward_vs_reference():
     """is_train=True through the C ABI (pgrf_render_rays_train): coarse depths stay deterministic, the importance
     sampler takes torch.rand draws from the CPU generator like the reference (render_ops.py:449) — seeded like the
