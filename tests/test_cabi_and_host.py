@@ -169,3 +169,28 @@ def test_tile_sharding_math():
             assert max(sizes) - min(sizes) <= 1
     c = D.tile_coords(1, 2, 4, 3)
     assert c.shape == (6, 2) and c[0].tolist() == [0.0, 2.0] and c[-1].tolist() == [2.0, 3.0]
+
+
+def test_host_mirror_of_small_pose_tensors():
+    """imgs_info_to_torch keeps the host values of poses / ranges next to their device copies, and engine.host_floats uses
+    them only while the device tensor's version counter stands (CPU: the 'device' is torch's meta device, which cannot be
+    read back -- a fallback to the device->host copy shows up as an error)."""
+    import numpy as np
+    from panogrf_amd.imgs_info import imgs_info_to_torch, build_render_imgs_info
+    from panogrf_amd import engine as E
+    pose = np.concatenate([np.eye(3), np.array([[0.25], [-0.5], [2.0]])], 1)
+    info = build_render_imgs_info(pose, (8, 16), [0.5, 15.0])
+    cpu = imgs_info_to_torch(info, 'cpu')
+    assert not hasattr(cpu['c2w'], '_pgrf_host')                       # nothing moved, nothing mirrored
+    want = [float(x) for x in cpu['c2w'].float().reshape(-1)[:12]]
+    assert E.host_floats(cpu['c2w'], 12) == want
+    dev = imgs_info_to_torch(info, 'meta')
+    assert hasattr(dev['c2w'], '_pgrf_host') and hasattr(dev['depth_range'], '_pgrf_host')
+    assert not hasattr(dev['coords'], '_pgrf_host')                    # large tensors carry no mirror
+    assert E.host_floats(dev['c2w'], 12) == want
+    assert E.host_floats(dev['depth_range'], 2) == [0.5, 15.0]
+    shallow = dict(dev)                                                # renderer.forward copies the dicts, not the tensors
+    assert E.host_floats(shallow['c2w'], 12) == want
+    dev['c2w'].mul_(2.0)                                               # in-place write: the mirror is stale -> read back
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        E.host_floats(dev['c2w'], 12)
