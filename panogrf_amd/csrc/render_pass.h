@@ -68,7 +68,15 @@ __device__ __forceinline__ float xmax(float v) {
 // (Tried: min(exp(x),1) - 1 via the v_exp's clamp modifier, then a two-operand v_max with x.  As fmaxf it costs a second,
 // canonicalising v_max on the raw accumulator (IEEE mode) and is 0.8 % slower; as an inline-asm v_max it measured +0.3 % but
 // gave wrong, run-to-run varying results -- hazard tracking does not see through the asm.)
+#if defined(PGRF_ABL_ELU) && PGRF_ABL_ELU == 1      // ablations (timing only, wrong numbers): 1 = identity, 2 = no multiply, 3 = ReLU
+__device__ __forceinline__ float elu1(float x) { return x; }
+#elif defined(PGRF_ABL_ELU) && PGRF_ABL_ELU == 2
+__device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __builtin_amdgcn_exp2f(x) - 1.f, 0.f); }
+#elif defined(PGRF_ABL_ELU) && PGRF_ABL_ELU == 3
+__device__ __forceinline__ float elu1(float x) { return fmaxf(x, 0.f); }
+#else
 __device__ __forceinline__ float elu1(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
+#endif
 __device__ __forceinline__ float sigmoid1(float x) { return rcp1(1.f + __expf(-x)); }
 // nn.Softplus (beta 1, threshold 20) as max(x,0) + log(1 + exp(-|x|)) on v_exp/v_log: absolute error ~1e-7, the size of one
 // fp32 rounding of the result's integer part; libm's log1pf is a ~140-instruction double-float routine (measured: the
