@@ -297,7 +297,7 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
         std::memcpy(dst, blob + layer_h_off(id), sizeof(float) * 512);     // (m=0, g=0): [piece][lane][8 halves]
       else if (mode == 2 && img_full(id))
         std::memcpy(dst, blob + layer_a_off(id), sizeof(float) * a_size(kKS[id], kMT[id]));
-      else
+      else if (img_a_floats(id, mode) > 0)
         std::memcpy(dst, blob + layer_a_off(id) + (size_t)img_chunk(id) * 256, sizeof(float) * 256);
       if (img_has_bias(id))
         std::memcpy(dst + img_a_floats(id, mode), blob + layer_b_off(id), sizeof(float) * b_size(kMT[id]));

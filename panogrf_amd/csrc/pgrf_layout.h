@@ -147,12 +147,16 @@ constexpr int kSplitEnd = layer_h_off(L_COUNT);
 constexpr int kHeadFloats = OFF_POS - OFF_DDH_W;
 constexpr int img_chunk(int id) { return id == L_DD1 ? -1 : (id == L_PE1 ? 4 : 0); }
 constexpr bool img_has_bias(int id) { return kHasBias[id] && id != L_PE1 && id != L_DD1; }
+// image mode 3 = f32, heads and biases only (+ prob_embed.0's chunk): every workgroup copies its image once per 128 samples,
+// and for the 64-sample kernels with 2 and 3 views the 20 KB of first chunks cost more at workgroup start than they save
+// per layer (measured, per instance: render_pass.h kImgMode).
 // image modes: 0 = f32, first chunk per layer; 1 = split-f16, first k-group per layer; 2 = f32, the WHOLE A block of
 // every layer except the three largest (base_fc.0 shared/per-view, geometry_fc.0) — used by the kernels for more than
 // two views, which run one workgroup per CU (so have the LDS) and one wave per SIMD (so cannot hide an L2 round trip).
-constexpr int kImgModes = 3;
+constexpr int kImgModes = 4;
 constexpr bool img_full(int id) { return id != L_BG && id != L_BV && id != L_G1 && id != L_PE1 && id != L_DD1; }
 constexpr int img_a_floats(int id, int mode) {
+  if (mode == 3 && id != L_PE1) return 0;
   return mode == 1 ? 512 : ((mode == 2 && img_full(id)) ? a_size(kKS[id], kMT[id]) : 256);
 }
 constexpr int img_layer_size(int id, int mode) {
@@ -170,7 +174,7 @@ constexpr int img_blob_off(int mode) {
   return off;
 }
 constexpr int kBlobFloats = img_blob_off(kImgModes);
-static_assert(kHeadFloats % 4 == 0 && img_floats(0) % 4 == 0 && img_floats(1) % 4 == 0 && img_floats(2) % 4 == 0 && kSplitEnd % 4 == 0,
+static_assert(kHeadFloats % 4 == 0 && img_floats(0) % 4 == 0 && img_floats(1) % 4 == 0 && img_floats(2) % 4 == 0 && img_floats(3) % 4 == 0 && kSplitEnd % 4 == 0,
               "LDS image is copied as float4");
 
 // attention feature permutation: accumulator row rho (< 16) of the q / k / v projections holds

@@ -133,7 +133,15 @@ template <int V> constexpr bool kRecomputeNf = false;
 #else
 template <int V> constexpr bool kRecomputeNf = kTwoWave<V> && V > 3;
 #endif
-template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (kTwoWave<V> ? 0 : 2);
+// Two-wave f32 kernels: first-chunk image (mode 0) or the slim one (mode 3), per instance as measured (A/B of whole-library
+// builds, same box): 2 views x 64 samples 37.45 -> 37.18 ms and 3 views x 64 samples 54.3 -> 53.5 ms with the slim image;
+// 4 views 78.3 -> 78.6 and 2 views x 32 samples 19.07 -> 19.33 ms, so those keep the first chunks.  (No image at all:
+// 37.18 / 62.7 / 82.9 / 19.2 ms -- the register allocator again.)
+#ifndef PGRF_KT
+#define PGRF_KT 2
+#endif
+template <int V> constexpr bool kSlimImg = (PGRF_KT == 2) && (V == 2 || V == 3);
+template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (kTwoWave<V> ? (kSlimImg<V> ? 3 : 0) : 2);
 // no image in the split-f16 mode (see above).  (Tried for > 2 views at two waves: image dropped in favour of parking the
 // first view group's prob_embed features through stage B — the register allocator answered with MORE spills, 170 -> 289.)
 #ifdef PGRF_NO_LDS_IMG
@@ -233,7 +241,7 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
       const float4 a = reinterpret_cast<const float4*>(A)[lane + ((m * KS4 + s4) & 1) * 64];
 #else
       const float4 a = (Limg && limg_full)          ? reinterpret_cast<const float4*>(Limg)[(m * KS4 + s4) * 64 + lane]
-                       : (Limg && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
+                       : (Limg && limg_a > 0 && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
                                                      : reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
 #endif
       const float av[4] = {a.x, a.y, a.z, a.w};
