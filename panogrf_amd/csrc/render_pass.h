@@ -1010,7 +1010,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
   // source maps instead of all of them.  Bijective for any grid size; speed only, never correctness.
   int wg = blockIdx.x;
 #ifndef PGRF_NO_XCD_REMAP
-  {
+  if (!p.order_w) {     // with the tiled visiting order (large source maps) the plain round-robin measured better: 334.3 -> 330.0 ms
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
