@@ -331,6 +331,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     rays_per_s = H * W * args.steps / dt
+    gather_diff = None
+    if world > 1 and rank == 0:
+        # outside the timed region: the reassembled image against this rank rendering a sample of ALL pixels by itself
+        # (rays are independent and every kernel is deterministic, so the all-gathered frame must match bit for bit)
+        gsel = torch.randperm(H * W, generator=torch.Generator().manual_seed(11))[:1024].to(dev)
+        allc = torch.stack([(gsel % W).float(), (gsel // W).float()], -1)
+        fr_chk = E.Frame(fr_in['imgs'], fr_in['img_feats'], fr_in['ray_feats'], fr_in['w2c'], fr_in['ref_depth_range'],
+                         case['frame']['que_c2w'], case['frame']['que_depth_range'], device=dev)
+        chk = rr.render_rays(fr_chk, allc)['pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr']
+        gather_diff = float((chk - img[gsel]).abs().max())
 
     # dominant kernel = render_pass_kernel; events bracket render_rays on the launch stream
     # (coarse depth fill + render pass [+ sampler + fine pass]); its share is > 99.9 % render pass.
@@ -363,7 +373,8 @@ def main():
         'config': {'workload': f'{H}x{W} ERP query, {V} source views, {dn} samples/ray'
                                + (' coarse + ' + str(dn) + ' fine' if args.fine else ', single pass')
                                + ' (BASELINE configs[1])' * (not args.fine and (H, W, V, dn) == (512, 1024, 2, 64)),
-                   'rays_per_step': H * W, 'ray_tiles': world, 'parallelism': f'ray-tile x{world} + all-gather'},
+                   'rays_per_step': H * W, 'ray_tiles': world, 'parallelism': f'ray-tile x{world} + all-gather',
+                   'row_block': D.row_block(world, H), 'gathered_image_max_abs_diff_vs_unsharded': gather_diff},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
                      'frac': achieved / peak_tf, 'traffic': traffic,
                      'kernel': 'render_pass_kernel', 'kernel_ms': k_ms / launches,

@@ -49,6 +49,11 @@ def test_allgather_ragged_tiles_world2():
     _run(2, 7, 5)
 
 
+def test_allgather_interleaved_row_blocks_world4():
+    """From 4 ranks on the rows are dealt in blocks of 8 (panogrf_amd.dist.row_block); the gathered image is in row order."""
+    _run(4, 64, 5)
+
+
 def _view_worker(rank, world, port, n_views, ret):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
