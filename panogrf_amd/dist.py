@@ -1,7 +1,7 @@
 """Ray-tile sharding of one panorama across the GPUs of a node.
 
 Every ray is independent given the per-frame source maps, so rank g renders its share of the rows (a contiguous
-tile [g*H/G, (g+1)*H/G); from 4 ranks on, interleaved blocks of 8 rows: row_block) with NO data-path collective; one all-gather (RCCL over xGMI when the
+tile [g*H/G, (g+1)*H/G); from 4 ranks on, interleaved blocks of 16 rows: row_block) with NO data-path collective; one all-gather (RCCL over xGMI when the
 backend is "nccl") reassembles the final image.  The reference has no multi-GPU inference at all
 (train/trainer.py:232-234): this is new, not a translation.
 """
@@ -16,15 +16,15 @@ def tile_rows(rank, world, H):
     return r0, r0 + base + (1 if rank < rem else 0)
 
 
-ROW_BLOCK = 8
+ROW_BLOCK = 16
 
 
 def row_block(world, H):
-    """Rows per interleaved block, or 0 = contiguous tiles.  The polar rows of a panorama cost ~2.5 % more than the equatorial
-    ones (measured per 64-row tile of a 512x1024 frame: 4.62 ... 4.86 ms, tools/time_tiles.py), and a step takes as long as its
-    slowest rank: from 4 ranks on, the rows are dealt in blocks of 8 (rank g gets blocks g, g + world, ...), which evens the
-    shares out (max 4.73 ms) while a block is still thick enough for the gathers' locality.  The all-gather stays one
-    collective; the blocks are put back in row order by one reshape of the gathered tensor."""
+    """Rows per interleaved block, or 0 = contiguous tiles.  The polar rows of a panorama cost 1.5-2 % more than the equatorial
+    ones (64-row tiles of a 512x1024 frame: 4.65 ... 4.76 ms each, tools/time_tiles.py) and a step takes as long as its
+    slowest rank: from 4 ranks on, the rows are dealt in blocks of 16 (rank g gets blocks g, g + world, ...), which evens
+    the shares out (4.70 ... 4.72 ms) while a block is still as high as the render pass's ray tiles.  The all-gather stays
+    one collective; the blocks are put back in row order by one reshape of the gathered tensor."""
     return ROW_BLOCK if world >= 4 and H % (ROW_BLOCK * world) == 0 else 0
 
 

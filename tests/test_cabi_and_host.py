@@ -169,16 +169,16 @@ def test_tile_sharding_math():
             assert max(sizes) - min(sizes) <= 1
     c = D.tile_coords(1, 2, 4, 3)
     assert c.shape == (6, 2) and c[0].tolist() == [0.0, 2.0] and c[-1].tolist() == [2.0, 3.0]
-    # from 4 ranks on the rows are dealt in blocks of 8; what an all-gather would concatenate goes back into row order
-    for H, W, world in [(512, 16, 8), (64, 4, 4), (96, 4, 4), (64, 4, 8), (40, 4, 4)]:
+    # from 4 ranks on the rows are dealt in blocks of 16; what an all-gather would concatenate goes back into row order
+    for H, W, world in [(512, 16, 8), (128, 4, 4), (96, 4, 4), (64, 4, 8), (40, 4, 4), (256, 4, 8)]:
         blk = D.row_block(world, H)
-        assert blk == (8 if H % (8 * world) == 0 else 0)
+        assert blk == (16 if H % (16 * world) == 0 else 0)
         rows = [D.tile_row_indices(r, world, H) for r in range(world)]
         assert sorted(torch.cat(rows).tolist()) == list(range(H))
         if blk:
-            assert rows[1][:8].tolist() == list(range(8, 16))
-            if H >= 16 * world:
-                assert int(rows[1][8]) == 8 * world + 8
+            assert rows[1][:blk].tolist() == list(range(blk, 2 * blk))
+            if H >= 2 * blk * world:
+                assert int(rows[1][blk]) == blk * world + blk
             img = torch.arange(H * W * 3, dtype=torch.float32).view(H * W, 3)
             shards = []
             for r in range(world):

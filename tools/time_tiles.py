@@ -33,10 +33,15 @@ def ms(coords, n=5):
 ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
 full = torch.stack([xs, ys], -1).to(dev)
 print(f'whole frame: {ms(full.reshape(-1, 2)):.2f} ms -> ideal per rank at {world} ranks {ms(full.reshape(-1, 2)) / world:.2f} ms')
-tiles = [ms(D.tile_coords(g, world, H, W, device=dev)) for g in range(world)]
+contig = lambda g: full[slice(*D.tile_rows(g, world, H))].reshape(-1, 2).contiguous()
+ms(contig(0))                                   # clocks / caches warm before the first measured share
+tiles = [ms(contig(g)) for g in range(world)]
 print('contiguous row tiles :', ' '.join(f'{t:.2f}' for t in tiles), f' max {max(tiles):.2f} ms')
+print(f'  (tile 0 measured again, last: {ms(contig(0)):.2f} ms; tile {world - 1}: {ms(contig(world - 1)):.2f} ms)')
 inter = [ms(full[g::world].reshape(-1, 2).contiguous()) for g in range(world)]
 print('interleaved rows     :', ' '.join(f'{t:.2f}' for t in inter), f' max {max(inter):.2f} ms')
-blk = 8
-inter8 = [ms(full.reshape(H // blk, blk, W, 2)[g::world].reshape(-1, 2).contiguous()) for g in range(world)]
-print(f'interleaved {blk}-row blocks:', ' '.join(f'{t:.2f}' for t in inter8), f' max {max(inter8):.2f} ms')
+for blk in (8, 16, 32):
+    if H % (blk * world):
+        continue
+    inter8 = [ms(full.reshape(H // blk, blk, W, 2)[g::world].reshape(-1, 2).contiguous()) for g in range(world)]
+    print(f'interleaved {blk}-row blocks:', ' '.join(f'{t:.2f}' for t in inter8), f' max {max(inter8):.2f} ms')
