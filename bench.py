@@ -374,7 +374,7 @@ def main():
                                + (' coarse + ' + str(dn) + ' fine' if args.fine else ', single pass')
                                + ' (BASELINE configs[1])' * (not args.fine and (H, W, V, dn) == (512, 1024, 2, 64)),
                    'rays_per_step': H * W, 'ray_tiles': world, 'parallelism': f'ray-tile x{world} + all-gather',
-                   'row_block': D.row_block(world, H), 'gathered_image_max_abs_diff_vs_unsharded': gather_diff},
+                   'gathered_image_max_abs_diff_vs_unsharded': gather_diff},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
                      'frac': achieved / peak_tf, 'traffic': traffic,
                      'kernel': 'render_pass_kernel', 'kernel_ms': k_ms / launches,

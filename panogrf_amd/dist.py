@@ -1,7 +1,7 @@
 """Ray-tile sharding of one panorama across the GPUs of a node.
 
-Every ray is independent given the per-frame source maps, so rank g renders its share of the rows (a contiguous
-tile [g*H/G, (g+1)*H/G); from 4 ranks on, interleaved blocks of 16 rows: row_block) with NO data-path collective; one all-gather (RCCL over xGMI when the
+Every ray is independent given the per-frame source maps, so rank g renders the contiguous row
+tile [g*H/G, (g+1)*H/G) with NO data-path collective; one all-gather (RCCL over xGMI when the
 backend is "nccl") reassembles the final image.  The reference has no multi-GPU inference at all
 (train/trainer.py:232-234): this is new, not a translation.
 """
@@ -16,42 +16,12 @@ def tile_rows(rank, world, H):
     return r0, r0 + base + (1 if rank < rem else 0)
 
 
-ROW_BLOCK = 16
-
-
-def row_block(world, H):
-    """Rows per interleaved block, or 0 = contiguous tiles.  The polar rows of a panorama cost 1.5-2 % more than the equatorial
-    ones (64-row tiles of a 512x1024 frame: 4.65 ... 4.76 ms each, tools/time_tiles.py) and a step takes as long as its
-    slowest rank: from 4 ranks on, the rows are dealt in blocks of 16 (rank g gets blocks g, g + world, ...), which evens
-    the shares out (4.70 ... 4.72 ms) while a block is still as high as the render pass's ray tiles.  The all-gather stays
-    one collective; the blocks are put back in row order by one reshape of the gathered tensor."""
-    return ROW_BLOCK if world >= 4 and H % (ROW_BLOCK * world) == 0 else 0
-
-
-def tile_row_indices(rank, world, H, device='cpu'):
-    """Image rows of rank `rank`, ascending."""
-    blk = row_block(world, H)
-    if not blk:
-        r0, r1 = tile_rows(rank, world, H)
-        return torch.arange(r0, r1, device=device)
-    base = torch.arange(rank * blk, H, blk * world, device=device)
-    return (base[:, None] + torch.arange(blk, device=device)[None, :]).reshape(-1)
-
-
 def tile_coords(rank, world, H, W, device='cpu'):
-    """(x,y) pixel coords [rows*W,2] of this rank's rows, row-major like utils/imgs_info.py:158-181."""
-    rows = tile_row_indices(rank, world, H, device).to(torch.float32)
-    ys, xs = torch.meshgrid(rows, torch.arange(W, dtype=torch.float32, device=device), indexing='ij')
+    """(x,y) pixel coords [rows*W,2] of this rank's tile, row-major like utils/imgs_info.py:158-181."""
+    r0, r1 = tile_rows(rank, world, H)
+    ys, xs = torch.meshgrid(torch.arange(r0, r1, dtype=torch.float32, device=device),
+                            torch.arange(W, dtype=torch.float32, device=device), indexing='ij')
     return torch.stack([xs, ys], -1).reshape(-1, 2)
-
-
-def rows_in_order(gathered, world, H, W):
-    """[world * rows_g * W, C] as the all-gather leaves it (rank-major) -> image row order."""
-    blk = row_block(world, H)
-    if not blk:
-        return gathered
-    C = gathered.shape[1]
-    return gathered.view(world, H // (blk * world), blk * W, C).permute(1, 0, 2, 3).reshape(H * W, C)
 
 
 def allgather_rows(shard, H, W, group=None):
@@ -67,7 +37,7 @@ def allgather_rows(shard, H, W, group=None):
     if H % world == 0:
         full = torch.empty(H * W, C, dtype=shard.dtype, device=shard.device)
         dist.all_gather_into_tensor(full, shard.contiguous(), group=group)
-        return rows_in_order(full, world, H, W)
+        return full
     rows_max = -(-H // world)
     pad = torch.zeros(rows_max * W, C, dtype=shard.dtype, device=shard.device)
     pad[:shard.shape[0]] = shard

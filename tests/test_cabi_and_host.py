@@ -169,24 +169,6 @@ def test_tile_sharding_math():
             assert max(sizes) - min(sizes) <= 1
     c = D.tile_coords(1, 2, 4, 3)
     assert c.shape == (6, 2) and c[0].tolist() == [0.0, 2.0] and c[-1].tolist() == [2.0, 3.0]
-    # from 4 ranks on the rows are dealt in blocks of 16; what an all-gather would concatenate goes back into row order
-    for H, W, world in [(512, 16, 8), (128, 4, 4), (96, 4, 4), (64, 4, 8), (40, 4, 4), (256, 4, 8)]:
-        blk = D.row_block(world, H)
-        assert blk == (16 if H % (16 * world) == 0 else 0)
-        rows = [D.tile_row_indices(r, world, H) for r in range(world)]
-        assert sorted(torch.cat(rows).tolist()) == list(range(H))
-        if blk:
-            assert rows[1][:blk].tolist() == list(range(blk, 2 * blk))
-            if H >= 2 * blk * world:
-                assert int(rows[1][blk]) == blk * world + blk
-            img = torch.arange(H * W * 3, dtype=torch.float32).view(H * W, 3)
-            shards = []
-            for r in range(world):
-                c = D.tile_coords(r, world, H, W).long()
-                shards.append(img[c[:, 1] * W + c[:, 0]])
-            assert torch.equal(D.rows_in_order(torch.cat(shards), world, H, W), img)
-        else:
-            assert all(rows[r].tolist() == list(range(*D.tile_rows(r, world, H))) for r in range(world))
 
 
 def test_host_mirror_of_small_pose_tensors():

@@ -49,9 +49,8 @@ def test_allgather_ragged_tiles_world2():
     _run(2, 7, 5)
 
 
-def test_allgather_interleaved_row_blocks_world4():
-    """From 4 ranks on the rows are dealt in blocks of 16 (panogrf_amd.dist.row_block); the gathered image is in row order."""
-    _run(4, 128, 5)
+def test_allgather_equal_tiles_world4():
+    _run(4, 16, 5)
 
 
 def _view_worker(rank, world, port, n_views, ret):

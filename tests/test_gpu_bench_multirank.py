@@ -22,21 +22,20 @@ def test_bench_two_ranks_one_gpu():
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['config']['ray_tiles'] == 2 and d['scaling'] == 'strong'
     assert d['roofline']['rays_per_launch'] == 64 * 128 // 2
-    assert d['value'] > 0 and d['config']['row_block'] == 0
+    assert d['value'] > 0
     assert d['config']['gathered_image_max_abs_diff_vs_unsharded'] == 0.0
 
 
-def test_bench_four_ranks_interleaved_row_blocks():
-    """From 4 ranks on the rows are dealt in blocks of 16 (dist.row_block); bench.py itself checks the reassembled frame
-    against unsharded rendering of a pixel sample."""
+def test_bench_four_ranks_gathered_frame_is_the_unsharded_frame():
+    """4 ranks, coarse + fine: bench.py itself checks the reassembled frame against unsharded rendering of a pixel sample."""
     env = dict(os.environ, PGRF_BENCH_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
            '--master-port', '29523', os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '1',
-           '--height', '128', '--width', '128', '--samples', '32', '--fine']
+           '--height', '64', '--width', '128', '--samples', '32', '--fine']
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    assert d['n_gpus'] == 4 and d['config']['row_block'] == 16
+    assert d['n_gpus'] == 4 and d['config']['ray_tiles'] == 4
     assert d['config']['gathered_image_max_abs_diff_vs_unsharded'] == 0.0
 
 
