@@ -228,12 +228,17 @@ __global__ void __launch_bounds__(256) fine_depth_kernel(const float* __restrict
 // bound (the cdf is a running sum of positives, hence monotone: same count as the comparison loop), four searches in flight
 // -- sorts its row by insertion (the values arrive almost sorted; NaNs last, every slot written) and the tile is written
 // back coalesced.  Bit-identical to the wave kernel (tests/test_gpu_render.py).
-template <int DN>
+// SHARED: every ray has the SAME coarse depths (the eval-mode coarse pass of pgrf_render_rays: no jitter), and they are not
+// appended to the output -- the normalised-depth half of the tile then is one 256-byte row per wave instead of 16 KB, and
+// a wave's LDS block shrinks from 33 to 17 KB (9 instead of 4 waves per CU).
+template <int DN, bool SHARED>
 __global__ void __launch_bounds__(64) fine_depth_lane_kernel(const float* __restrict__ depth, const float* __restrict__ hit,
                                                              float qnear, float qfar, int use_disp, int use_all, int rn,
                                                              const float* __restrict__ urand, float* __restrict__ out) {
-  constexpr int ROW = 2 * DN + 1;     // [0,DN): normalised depth d, later the coarse z (use_all);  [DN,2DN): hit -> cdf[1..DN] -> fine z
+  constexpr int ROW = (SHARED ? DN : 2 * DN) + 1;   // [0,DN): normalised depth d, later the coarse z (use_all) -- absent when SHARED;
+  constexpr int HP0 = SHARED ? 0 : DN;              // [HP0,HP0+DN): hit -> cdf[1..DN] -> fine z
   __shared__ float s[64 * ROW];
+  __shared__ float sd[SHARED ? DN : 1];
   const int lane = threadIdx.x;
   const size_t ray0 = (size_t)blockIdx.x * 64;
   const float n_ = -1.f / qnear, f_ = -1.f / qfar;
@@ -248,15 +253,19 @@ __global__ void __launch_bounds__(64) fine_depth_lane_kernel(const float* __rest
       q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
     }
   };
-  load_tile(depth, 0);
-  load_tile(hit, DN);
+  if constexpr (SHARED) {
+    if (lane < DN) sd[lane] = fd_norm_depth(depth[lane], n_, f_, use_disp);
+  } else {
+    load_tile(depth, 0);
+  }
+  load_tile(hit, HP0);
   __syncthreads();
   float* row = s + lane * ROW;
   float t[DN];
 #pragma unroll
   for (int i = 0; i < DN; ++i) {
-    row[i] = fd_norm_depth(row[i], n_, f_, use_disp);
-    t[i] = row[DN + i] + 1e-5f;
+    if constexpr (!SHARED) row[i] = fd_norm_depth(row[i], n_, f_, use_disp);
+    t[i] = row[HP0 + i] + 1e-5f;
   }
   {   // the wave kernel's sum: lanes >= DN contribute 0 (x + 0 = x), then xor-butterfly = pairs (i, i + half)
     float u[DN];
@@ -271,14 +280,15 @@ __global__ void __launch_bounds__(64) fine_depth_lane_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < DN; ++k) {
       c += t[k] / total;
-      row[DN + k] = c;                // cdf[k + 1]; cdf[0] = 0 is implicit
+      row[HP0 + k] = c;               // cdf[k + 1]; cdf[0] = 0 is implicit
     }
   }
   const float interval = (float)(1.0 / (double)DN);
   const float half_iv = (float)(0.5 * (1.0 / (double)DN));
   const size_t ray = min(ray0 + (size_t)lane, (size_t)rn - 1);
-  const float* cdf = row + DN;        // cdf[k] for k >= 1 at cdf[k - 1]
-  auto ctr = [&](int k) { return k == 0 ? row[0] : (k == DN ? row[DN - 1] : (row[k] + row[k - 1]) / 2.f); };
+  const float* cdf = row + HP0;       // cdf[k] for k >= 1 at cdf[k - 1]
+  const float* dd = SHARED ? sd : row;
+  auto ctr = [&](int k) { return k == 0 ? dd[0] : (k == DN ? dd[DN - 1] : (dd[k] + dd[k - 1]) / 2.f); };
 #pragma unroll
   for (int j0 = 0; j0 < DN; j0 += 4) {
     float u[4];
@@ -301,13 +311,15 @@ __global__ void __launch_bounds__(64) fine_depth_lane_kernel(const float* __rest
     }
   }
 #pragma unroll
-  for (int j = 0; j < DN; ++j) row[DN + j] = t[j];
-  if (use_all) {
-    __syncthreads();
-    load_tile(depth, 0);
-    __syncthreads();
+  for (int j = 0; j < DN; ++j) row[HP0 + j] = t[j];
+  if constexpr (!SHARED) {
+    if (use_all) {
+      __syncthreads();
+      load_tile(depth, 0);
+      __syncthreads();
+    }
   }
-  const int base = use_all ? 0 : DN, total = use_all ? 2 * DN : DN;
+  const int base = (use_all && !SHARED) ? 0 : HP0, total = (use_all && !SHARED) ? 2 * DN : DN;
   float* a = row + base;
   for (int j = 1; j < total; ++j) {
     const float v = a[j];
@@ -333,18 +345,18 @@ __global__ void __launch_bounds__(64) fine_depth_lane_kernel(const float* __rest
 }
 
 int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
-                      int dn, int fdn, const float* urand, float* out, void* stream) {
+                      int dn, int fdn, const float* urand, float* out, void* stream, int rows_equal) {
   const char* knob = getenv("PGRF_FINE_DEPTH");          // "wave": the wave-per-ray kernel for every shape (A/B, tests)
   const bool wave_only = knob && !strcmp(knob, "wave");
   const bool aligned = (((uintptr_t)depth | (uintptr_t)hit | (uintptr_t)out) & 15) == 0;
   if (!wave_only && dn == fdn && (dn == 32 || dn == 64) && aligned && rn > 0) {
     const int blocks = (rn + 63) / 64;
-    if (dn == 64)
-      hipLaunchKernelGGL(fine_depth_lane_kernel<64>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, depth, hit, qnear, qfar,
-                         use_disp, use_all, rn, urand, out);
-    else
-      hipLaunchKernelGGL(fine_depth_lane_kernel<32>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, depth, hit, qnear, qfar,
-                         use_disp, use_all, rn, urand, out);
+    const bool shared = rows_equal && !use_all && !(knob && !strcmp(knob, "noshare"));
+#define PGRF_FD(DN_, SH_) hipLaunchKernelGGL((fine_depth_lane_kernel<DN_, SH_>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, \
+                                             depth, hit, qnear, qfar, use_disp, use_all, rn, urand, out)
+    if (dn == 64) { if (shared) PGRF_FD(64, true); else PGRF_FD(64, false); }
+    else { if (shared) PGRF_FD(32, true); else PGRF_FD(32, false); }
+#undef PGRF_FD
     PGRF_CHECK_LAUNCH("fine_depth_lane");
     return PGRF_OK;
   }

@@ -26,7 +26,7 @@ int launch_project_ray_feats(const float* rf, const float* blob, int npix, int u
 int launch_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream);
 int launch_coarse_depth(float near, float far, int use_disp, int rn, int dn, const float* jitter, float* depth, void* stream);
 int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
-                      int dn, int fdn, const float* urand, float* out, void* stream);
+                      int dn, int fdn, const float* urand, float* out, void* stream, int rows_equal);
 int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
                      const float* denf, int dnf, int rn, const PgrfPassOut& o, void* stream);
 
@@ -171,14 +171,19 @@ int pgrf_sample_coarse_depth(float min_depth, float max_depth, int use_disp, int
   return pgrf_sample_coarse_depth_train(min_depth, max_depth, use_disp, rn, dn, nullptr, depth, stream);
 }
 
-int pgrf_sample_fine_depth_train(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
-                                 int use_all, int rn, int dn, int fdn, const float* u, float* out, void* stream) {
+static int sample_fine_checked(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
+                               int use_all, int rn, int dn, int fdn, const float* u, float* out, void* stream, int rows_equal) {
   if (!depth || !hit_prob || !out) return set_error(PGRF_ERR_ARG, "pgrf_sample_fine_depth: null pointer");
   if (dn < 2 || dn > PGRF_MAX_DN || fdn < 1 || fdn > PGRF_MAX_DN)
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_sample_fine_depth: dn=%d fdn=%d outside [2,%d]/[1,%d]", dn, fdn, PGRF_MAX_DN, PGRF_MAX_DN);
   if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_sample_fine_depth: rn < 0");
   if (rn == 0) return PGRF_OK;
-  return launch_fine_depth(depth, hit_prob, que_near, que_far, use_disp, use_all, rn, dn, fdn, u, out, stream);
+  return launch_fine_depth(depth, hit_prob, que_near, que_far, use_disp, use_all, rn, dn, fdn, u, out, stream, rows_equal);
+}
+
+int pgrf_sample_fine_depth_train(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
+                                 int use_all, int rn, int dn, int fdn, const float* u, float* out, void* stream) {
+  return sample_fine_checked(depth, hit_prob, que_near, que_far, use_disp, use_all, rn, dn, fdn, u, out, stream, 0);
 }
 
 int pgrf_sample_fine_depth(const float* depth, const float* hit_prob, float que_near, float que_far, int use_disp,
@@ -275,8 +280,9 @@ int pgrf_render_rays_train(const PgrfFrame* frame, const float* blob_coarse, con
   rc = do_render_pass(frame, blob_coarse, (cfg->use_vis_coarse ? PGRF_PASS_USE_VIS : 0) | pf, coords, depth_c, rn, cfg->dn, &oc, nullptr, prj_ws, prj_bytes, stream, raytab);
   if (rc || !cfg->hierarchical) return rc;
   float* fd = fine_depth_out ? fine_depth_out : depth_f;
-  rc = pgrf_sample_fine_depth_train(depth_c, oc.hit_prob, frame->que_depth_range[0], frame->que_depth_range[1], cfg->use_disp,
-                                    cfg->fine_use_all, rn, cfg->dn, cfg->fdn, fine_u, fd, stream);
+  // the coarse depths generated here without jitter are the same row for every ray, which the lane-per-ray sampler exploits
+  rc = sample_fine_checked(depth_c, oc.hit_prob, frame->que_depth_range[0], frame->que_depth_range[1], cfg->use_disp,
+                           cfg->fine_use_all, rn, cfg->dn, cfg->fdn, fine_u, fd, stream, coarse_jitter ? 0 : 1);
   if (rc) return rc;
   if (!cfg->c2f_all) return do_render_pass(frame, blob_fine, (cfg->use_vis_fine ? PGRF_PASS_USE_VIS : 0) | pf, coords, fd, rn, fdn_eff, &of, nullptr, prj_ws, prj_bytes, stream, raytab);
   // fine pass into scratch, then one composite over the union (renderer.py:484-518)
