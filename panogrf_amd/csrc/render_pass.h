@@ -416,9 +416,10 @@ __device__ unsigned long long g_stage_cycles[32];
 #else
 // stage boundaries are scheduling fences: measured 47.5 -> 46.3 ms/frame (fewer live ranges crossing stages)
 // Per view count: with 3 views the fences cost more than they save (53.6 -> 52.7 ms without them, although 26 instead of 6
-// registers spill); 2 views: +-0.2 %, 4 views: 77.9 -> 79.0 ms without.  (V is in scope wherever a stage ends.)
+// registers spill), with 2 views x 32 samples as well (19.09 -> 18.91 ms); 2 views x 64: +-0.2 %, 4 views: 77.9 -> 79.0 ms
+// without.  (V is in scope wherever a stage ends.)
 #ifndef PGRF_FENCE_MASK
-#define PGRF_FENCE_MASK (V == 3 ? 0u : 0xffffffffu)      // bit i = stage boundary i is a fence (tuning knob)
+#define PGRF_FENCE_MASK ((V == 3 || (PGRF_KT == 1 && V == 2)) ? 0u : 0xffffffffu)      // bit i = stage boundary i is a fence (tuning knob)
 #endif
 #define PGRF_TICK(i) do { if (((PGRF_FENCE_MASK) >> (i)) & 1u) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
