@@ -1013,7 +1013,11 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
   // source maps instead of all of them.  Bijective for any grid size; speed only, never correctness.
   int wg = blockIdx.x;
 #ifndef PGRF_NO_XCD_REMAP
-  if (!p.order_w) {     // with the tiled visiting order (large source maps) the plain round-robin measured better: 334.3 -> 330.0 ms
+  // Per view count, as measured at the end of round 2 (it was +0.9 % for every instance when introduced): with 3 and 4 views the
+  // bands help (53.2 -> 52.8 ms, 79.0 -> 78.3 ms); with 1 and 2 views the plain round-robin is faster (2 views x 64 samples
+  // 37.32 -> 37.16 ms, x 32 samples 18.97 -> 18.85 ms, split-f16 23.41 -> 22.86 ms), as it is under the tiled visiting
+  // order of large source maps (334.3 -> 330.0 ms).
+  if (V >= 3 && !p.order_w) {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
