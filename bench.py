@@ -208,6 +208,59 @@ def eager_gpu_baseline(case, dev, ray_batch_num=2048, frames=1):
                 kind='port of the reference eager path on torch-ROCm, same GPU', ms_per_frame=dt / frames * 1e3), out
 
 
+def eager_strip_baseline(case, dev, rows=64, budget_s=20.0):
+    """Bounded, DEFAULT leg of the same denominator (the '>= 10x the reference single-GPU PyTorch rays/s' of the north star):
+    the eager port timed on a fixed strip of `rows` query rows around the equator of the same frame, through the
+    reference's ray_batch_num loop (network/renderer.py:656-683) at 2048 (its default) and 4096 (render.py) rays per
+    batch.  Per-batch cost does not depend on which rays a batch holds, so the strip rate is the frame rate."""
+    from oracle import render_oracle as O
+    fr = {k: v.to(dev) for k, v in case['frame'].items()}
+    w = {k: v.to(dev) for k, v in case['weights'].items()}
+    H, W = fr['imgs'].shape[-2:]
+    rows = min(rows, H)
+    r0 = (H - rows) // 2
+    ys, xs = torch.meshgrid(torch.arange(r0, r0 + rows, dtype=torch.float32, device=dev),
+                            torch.arange(W, dtype=torch.float32, device=dev), indexing='ij')
+    coords = torch.stack([xs, ys], -1).reshape(-1, 2)
+    res = {'unit': 'rays/s', 'kind': 'port, strip-extrapolated',
+           'sample': f'{rows} rows x {W} px around the equator of the same frame ({coords.shape[0]} rays), eager torch-ROCm port of '
+                     f'the reference path on this GPU, ray_batch_num 2048 and 4096'}
+    t_start = time.perf_counter()
+    outs = None
+    with torch.no_grad():
+        O.render_rays(w, fr, coords[:2048], case['cfg'])            # warm-up (allocator, kernel selection)
+        torch.cuda.synchronize()
+        for rb in (2048, 4096):
+            n_done, parts = 0, []
+            t0 = time.perf_counter()
+            for s_ in range(0, coords.shape[0], rb):
+                parts.append(O.render_rays(w, fr, coords[s_:s_ + rb], case['cfg']))
+                n_done += min(rb, coords.shape[0] - s_)
+                if time.perf_counter() - t_start > budget_s:         # hard bound on slow hosts
+                    break
+            torch.cuda.synchronize()
+            res[f'value_ray_batch_{rb}'] = n_done / (time.perf_counter() - t0)
+            if rb == 2048:
+                outs = (coords[:n_done], parts)
+    res['value'] = max(res['value_ray_batch_2048'], res['value_ray_batch_4096'])
+    return res, outs
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as a CHILD torchrun (this process has not
+    touched the GPU yet and never execs), relay their output and rank 0's JSON line, exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -226,16 +279,20 @@ def main():
                     help="f32 = exact fp32 MFMA (default); f16x3 = opt-in split-f16 MFMA (3 per product, fp32 accumulate)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the whole-module frame timing reported beside the headline (--no-cpu-baseline skips it too)')
-    ap.add_argument('--eager-baseline', action='store_true', help='also time the eager PyTorch-ROCm port on this GPU')
+    ap.add_argument('--eager-baseline', action='store_true', help='also time the eager PyTorch-ROCm port on this GPU over the WHOLE frame (minutes); a bounded strip is timed by default')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise the process group and run every collective even with ONE rank (exercises the RCCL branch on a 1-GPU box)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU
+        # (torch.cuda.is_available() not called yet), and the ranks are fresh child processes, not an exec of this one.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        # never re-exec from here (a process that touched the GPU must not exec): tell the caller how to launch
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 as  python -m torch.distributed.run '
-                         f'--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the HIP renderer has no CPU fallback')
     backend = os.environ.get('PGRF_BENCH_BACKEND', 'nccl')      # 'gloo' = test-only: ranks may then share one GPU
@@ -243,9 +300,14 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    force_dist = args.force_dist or os.environ.get('PGRF_FORCE_COLLECTIVES') == '1'
+    if force_dist:
+        os.environ['PGRF_FORCE_COLLECTIVES'] = '1'      # panogrf_amd.dist: do not short-cut the collectives at world size 1
+    distributed = world > 1 or force_dist
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -314,7 +376,7 @@ def main():
         return img, out
 
     def sync_all():
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -326,13 +388,13 @@ def main():
         img, out = step(True)
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     rays_per_s = H * W * args.steps / dt
     gather_diff = None
-    if world > 1 and rank == 0:
+    if distributed and rank == 0:
         # outside the timed region: the reassembled image against this rank rendering a sample of ALL pixels by itself
         # (rays are independent and every kernel is deterministic, so the all-gathered frame must match bit for bit)
         gsel = torch.randperm(H * W, generator=torch.Generator().manual_seed(11))[:1024].to(dev)
@@ -355,8 +417,8 @@ def main():
     # HBM-side traffic of the dominant kernel comes from rocprofv3 PMC passes of this same command (they cannot be
     # collected from inside the process): profiles/<round>_render_pass_pmc.txt, FETCH_SIZE doubled per the gfx950
     # note of MI355X_MICROARCH.md (wide coalesced reads are tallied at half), both counters in KiB.
-    traffic = None
-    if (H, W, V, dn, world) == (512, 1024, 2, 64, 1) and not args.fine:
+    traffic, traffic_source = None, None
+    if (H, W, V, dn, world) == (512, 1024, 2, 64, 1) and not args.fine and args.precision == 'f32':
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_render_pass_pmc.txt')))[-1:]:
             vals = {}
@@ -366,6 +428,8 @@ def main():
                     vals[t[1]] = float(t[2])
             if len(vals) == 2:
                 traffic = (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+                traffic_source = ('profiles/' + os.path.basename(f) + ': (2 x FETCH_SIZE + WRITE_SIZE) KiB of a rocprofv3 --pmc pass of '
+                                  'this command, NOT measured by this run (tools/profile_round.sh regenerates it)')
     res = {
         'metric': f'rendered rays/sec ({H}x{W} ERP, {dn} samples)', 'value': rays_per_s, 'unit': 'rays/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -374,9 +438,10 @@ def main():
                                + (' coarse + ' + str(dn) + ' fine' if args.fine else ', single pass')
                                + ' (BASELINE configs[1])' * (not args.fine and (H, W, V, dn) == (512, 1024, 2, 64)),
                    'rays_per_step': H * W, 'ray_tiles': world, 'parallelism': f'ray-tile x{world} + all-gather',
-                   'gathered_image_max_abs_diff_vs_unsharded': gather_diff},
+                   'gathered_image_max_abs_diff_vs_unsharded': gather_diff,
+                   'collectives': (None if not distributed else backend + (', forced at world size 1' if world == 1 else ''))},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
-                     'frac': achieved / peak_tf, 'traffic': traffic,
+                     'frac': achieved / peak_tf, 'traffic': traffic, 'traffic_source': traffic_source,
                      'kernel': 'render_pass_kernel', 'kernel_ms': k_ms / launches,
                      'flop_per_ray': flop_per_ray(V, dn, 1), 'rays_per_launch': rn},
     }
@@ -396,7 +461,19 @@ def main():
         eg['psnr_hip_vs_eager_db'] = 10 * math.log10(1.0 / max(mse, 1e-20))
         eg['value_ray_batch_4096'] = eg4['value']
         eg['speedup_hip_over_eager'] = rays_per_s / max(eg['value'], eg4['value'])
-        res['torch_eager_gpu_baseline'] = eg
+        res['torch_eager_gpu_baseline_whole_frame'] = eg
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # driver-run denominator of the north star's '>= 10x the reference single-GPU PyTorch path': bounded strip, <= 20 s
+        es, eouts = eager_strip_baseline(case, dev)
+        if eouts is not None:
+            ec, parts = eouts
+            key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'
+            eimg = torch.cat([p_[key] for p_ in parts], 0)
+            eidx = (ec[:eimg.shape[0], 1].long() * W + ec[:eimg.shape[0], 0].long())
+            mse = float(((img[eidx].double() - eimg.double()) ** 2).mean())
+            es['psnr_hip_vs_eager_db'] = 10 * math.log10(1.0 / max(mse, 1e-20))
+        es['speedup_hip_over_eager'] = rays_per_s / es['value']
+        res['torch_eager_gpu_baseline'] = es
     if rank == 0 and world == 1 and not (args.no_end_to_end or args.no_cpu_baseline) and V == 2 and args.precision == 'f32' and H % 64 == 0 and W % 64 == 0:
         res['end_to_end'] = end_to_end_frames(H, W, V, dn, args.fine, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -426,7 +503,7 @@ def main():
             'rays': int(idx.numel())}
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if distributed:
         torch.distributed.destroy_process_group()
 
 

@@ -33,7 +33,10 @@ extern "C" {
 #define PGRF_MAX_DN 128
 
 const char* pgrf_last_error(void);
-/* library / kernel ABI version, bumped when struct layouts change */
+/* library / kernel ABI version, bumped when struct layouts change (5: PgrfPassOut.render_uncert, pgrf_instnorm scratch).
+ * A NEGATIVE value marks a library linked from experiment objects (timing ablations etc., csrc/pgrf_experiments.h):
+ * it must never be used as the product; panogrf_amd/_lib.py refuses it unless PGRF_ALLOW_ABLATION_LIB=1. */
+#define PGRF_ABI_VERSION 5
 int pgrf_abi_version(void);
 
 /* ------------------------------------------------------------------ per-frame source maps -- */
@@ -111,6 +114,8 @@ typedef struct PgrfPassOut {   /* any pointer may be NULL = not wanted */
                                 * reference stops in ipdb there (renderer.py:264-265,459-462; render_ops.py:251-252);
                                 * the library never blocks or prints.  NaNs in the source FEATURE maps can be absorbed inside
                                 * the MLPs (ELU/ReLU are v_med3/v_max, which return the non-NaN operand) */
+  float* render_uncert;        /* [rn]       'render_uncert' = sum_i hit_prob_i (z_i - render_depth)^2 + 1e-5
+                                * (cfg render_uncert, network/renderer.py:305-312,507-514); needs render_depth and hit_prob */
 } PgrfPassOut;
 
 typedef struct PgrfPassDebug { /* intermediate tensors for stage-level parity tests; NULL = skip */
@@ -295,7 +300,7 @@ int pgrf_maxpool3s2_wrap(const float* in, int in_cs, int in_coff, int C, int N, 
                          void* stream);
 /* nn.InstanceNorm2d(C, affine=True, track_running_stats=False) + activation (0 none, 1 ReLU, 2 ELU), with an optional
  * residual added BEFORE the activation (BasicBlock: relu(bn2(conv2) + shortcut), network/ops.py:127-196).  gamma/beta
- * may be NULL.  `partial`: caller-owned scratch of N * pgrf_instnorm_chunks(HW) * C * 2 floats.  In place is allowed
+ * may be NULL.  `partial`: caller-owned scratch of N * pgrf_instnorm_chunks(HW) * C * 4 floats (16-byte aligned).  In place is allowed
  * (out == x). */
 int pgrf_instnorm_chunks(int HW);
 int pgrf_instnorm(const float* x, int cs, int coff, int C, int N, int HW, const float* gamma, const float* beta, float eps,

@@ -420,6 +420,8 @@ def render_pass(weights, dd_pre, agg_pre, frame, coords, depth, cfg, want_debug=
     hitq, pixel, rdepth = composite(density, colors, depth)
     res = {'pixel_colors_nr': pixel, 'hit_prob_nr': hitq, 'colors_nr': colors, 'density_nr': density,
            'render_depth': rdepth}
+    if cfg.get('render_uncert'):
+        res['render_uncert'] = depth_uncertainty(depth, rdepth, hitq)
     if want_debug:
         res['dbg'] = dict(px=px.reshape(rfn, rn, dn, 2), depth_v=dv.reshape(rfn, rn, dn), ddiff=dd,
                           ray_feats=rf.reshape(rfn, rn, dn, 32), rgb=rgb.reshape(rfn, rn, dn, 3),
@@ -428,7 +430,12 @@ def render_pass(weights, dd_pre, agg_pre, frame, coords, depth, cfg, want_debug=
     return res
 
 
-def merge_c2f_all(coarse_depth, coarse, fine_depth, fine):
+def depth_uncertainty(depth, rdepth, hit):
+    """cfg render_uncert: variance of the sample depths under the hit probabilities, + 1e-5.  renderer.py:305-312."""
+    return ((depth - rdepth.unsqueeze(-1)).pow(2) * hit).sum(-1) + 1e-5
+
+
+def merge_c2f_all(coarse_depth, coarse, fine_depth, fine, uncert=False):
     """`render_c2f_all`: one composite over the union of coarse and fine samples.
     renderer.py:484-518."""
     z = torch.cat([coarse_depth, fine_depth], -1)
@@ -438,8 +445,11 @@ def merge_c2f_all(coarse_depth, coarse, fine_depth, fine):
     col = torch.gather(col, -2, idx.unsqueeze(-1).expand_as(col))
     den = torch.gather(den, -1, idx)
     hit, pixel, rdepth = composite(den, col, z)
-    return {'pixel_colors_nr': pixel, 'hit_prob_nr': hit, 'colors_nr': col, 'density_nr': den,
-            'render_depth': rdepth}
+    res = {'pixel_colors_nr': pixel, 'hit_prob_nr': hit, 'colors_nr': col, 'density_nr': den,
+           'render_depth': rdepth}
+    if uncert:
+        res['render_uncert'] = depth_uncertainty(z, rdepth, hit)
+    return res
 
 
 def render_rays(weights, frame, coords, cfg, want_debug=False, jitter=None, u=None):
@@ -448,7 +458,8 @@ def render_rays(weights, frame, coords, cfg, want_debug=False, jitter=None, u=No
     rn = coords.shape[0]
     dn = cfg['depth_sample_num']
     depth = sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn, cfg.get('use_disp', True), coords.device, jitter)
-    ccfg = {'use_vis': cfg.get('dist_decoder_cfg', {}).get('use_vis', True)}
+    unc = bool(cfg.get('render_uncert', False))
+    ccfg = {'use_vis': cfg.get('dist_decoder_cfg', {}).get('use_vis', True), 'render_uncert': unc}
     out = render_pass(weights, 'dist_decoder', 'agg_net', frame, coords, depth, ccfg, want_debug)
     out['depth'] = depth
     if cfg.get('use_hierarchical_sampling', False):
@@ -456,7 +467,7 @@ def render_rays(weights, frame, coords, cfg, want_debug=False, jitter=None, u=No
         fd = sample_fine_depth(depth, out['hit_prob_nr'], frame['que_depth_range'], fdn, cfg.get('use_disp', True), u)
         if cfg.get('fine_depth_use_all', False):
             fd = torch.sort(torch.cat([depth, fd], -1), -1)[0]
-        fcfg = {'use_vis': cfg.get('fine_dist_decoder_cfg', {}).get('use_vis', True)}
+        fcfg = {'use_vis': cfg.get('fine_dist_decoder_cfg', {}).get('use_vis', True), 'render_uncert': unc}
         # quirk kept: the fine pass evaluates compute_prob through the COARSE decoder object,
         # i.e. with the coarse decoder's use_vis flag (renderer.py:128)
         fcfg_prob = dict(fcfg)
@@ -465,7 +476,7 @@ def render_rays(weights, frame, coords, cfg, want_debug=False, jitter=None, u=No
         else:
             fine = render_pass(weights, 'fine_dist_decoder', 'fine_agg_net', frame, coords, fd, fcfg_prob, want_debug)
         if cfg.get('render_c2f_all', False):
-            fine.update(merge_c2f_all(depth, out, fd, fine))
+            fine.update(merge_c2f_all(depth, out, fd, fine, unc))
         fine['depth'] = fd
         for k, v in fine.items():
             out[k + '_fine'] = v

@@ -33,7 +33,7 @@ DATASETS = {'m3d': 0, 'replica_test': 1, 'residential': 2, 'CoffeeArea': 3}
 
 class PgrfPassOut(C.Structure):
     _fields_ = [("pixel_colors", C.c_void_p), ("render_depth", C.c_void_p), ("hit_prob", C.c_void_p),
-                ("colors", C.c_void_p), ("density", C.c_void_p), ("nan_flag", C.c_void_p)]
+                ("colors", C.c_void_p), ("density", C.c_void_p), ("nan_flag", C.c_void_p), ("render_uncert", C.c_void_p)]
 
 
 class PgrfPassDebug(C.Structure):
@@ -46,6 +46,8 @@ class PgrfRenderCfg(C.Structure):
                 ("fdn", C.c_int), ("hierarchical", C.c_int), ("fine_use_all", C.c_int), ("c2f_all", C.c_int),
                 ("use_vis_coarse", C.c_int), ("use_vis_fine", C.c_int), ("precision", C.c_int)]
 
+
+ABI_VERSION = 5      # PGRF_ABI_VERSION of include/panogrf_hip.h (struct layouts below)
 
 # every symbol include/panogrf_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
@@ -130,6 +132,13 @@ class _Lib:
                 fn = getattr(dll, name)   # AttributeError if the .so lacks a declared symbol
                 fn.restype = res
                 fn.argtypes = args
+            ver = dll.pgrf_abi_version()
+            if ver < 0 and os.environ.get("PGRF_ALLOW_ABLATION_LIB") != "1":
+                raise PgrfError(f"{path} was built from experiment objects (ablation / timing switches, pgrf_abi_version() = {ver}): "
+                                f"not the product library.  Profiling tools set PGRF_ALLOW_ABLATION_LIB=1 to load it on purpose.")
+            if abs(ver) != ABI_VERSION:
+                raise PgrfError(f"{path} has ABI version {ver}, this package binds version {ABI_VERSION}: rebuild with "
+                                f"`make -C panogrf_amd/csrc -j8`")
             self._dll = dll
         return self._dll
 

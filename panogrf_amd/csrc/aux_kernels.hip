@@ -1,4 +1,5 @@
 // Small HBM-bound kernels around the fused render pass: map re-layout, depth samplers, c2f merge.
+#include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -443,6 +444,7 @@ __global__ void __launch_bounds__(256) merge_c2f_kernel(const float* __restrict_
     carry *= __shfl(incl, 63, 64);
     if (!in) continue;
     const float hitp = s_a[wv][i] * T;
+    s_a[wv][i] = hitp;                                   // kept for the uncertainty epilogue (only this lane reads slot i)
     const size_t pt = (size_t)ray * total + i;
     if (ok) {
       if (o.hit_prob) o.hit_prob[pt] = hitp;
@@ -460,6 +462,38 @@ __global__ void __launch_bounds__(256) merge_c2f_kernel(const float* __restrict_
     if (o.pixel_colors) { o.pixel_colors[(size_t)ray * 3] = acc[0]; o.pixel_colors[(size_t)ray * 3 + 1] = acc[1]; o.pixel_colors[(size_t)ray * 3 + 2] = acc[2]; }
     if (o.render_depth) o.render_depth[ray] = acc[3];
   }
+  if (o.render_uncert) {      // sum_i w_i (z_i - depth)^2 + 1e-5 over the merged samples (renderer.py:507-514)
+    float u = 0.f;
+    for (int i = lane; i < total; i += 64) { const float d = s_sz[wv][i] - acc[3]; u = fmaf(d * d, s_a[wv][i], u); }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) u += __shfl_xor(u, off, 64);
+    if (ok && lane == 0) o.render_uncert[ray] = u + 1e-5f;
+  }
+}
+
+// cfg render_uncert for a network pass (renderer.py:305-312): sum_i hit_prob_i (z_i - render_depth)^2 + 1e-5, one wave per
+// ray over the pass's own outputs (the composite inside the render kernel is not touched: the key is off in every shipped
+// configuration, and 0.27 GB of reads per 512x1024x64 frame are ~40 us)
+__global__ void __launch_bounds__(256) render_uncert_kernel(const float* __restrict__ depth, const float* __restrict__ hit,
+                                                            const float* __restrict__ rdepth, int rn, int dn, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= rn) return;
+  const float mu = rdepth[ray];
+  float u = 0.f;
+  for (int i = lane; i < dn; i += 64) {
+    const float d = depth[(size_t)ray * dn + i] - mu;
+    u = fmaf(d * d, hit[(size_t)ray * dn + i], u);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) u += __shfl_xor(u, off, 64);
+  if (lane == 0) out[ray] = u + 1e-5f;
+}
+
+int launch_render_uncert(const float* depth, const float* hit, const float* rdepth, int rn, int dn, float* out, void* stream) {
+  hipLaunchKernelGGL(render_uncert_kernel, dim3((rn + 3) / 4), dim3(256), 0, (hipStream_t)stream, depth, hit, rdepth, rn, dn, out);
+  PGRF_CHECK_LAUNCH("render_uncert");
+  return PGRF_OK;
 }
 
 int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,

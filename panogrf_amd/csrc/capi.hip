@@ -30,6 +30,8 @@ int launch_fine_depth(const float* depth, const float* hit, float qnear, float q
 int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
                      const float* denf, int dnf, int rn, const PgrfPassOut& o, void* stream);
 
+int launch_render_uncert(const float* depth, const float* hit, const float* rdepth, int rn, int dn, float* out, void* stream);
+
 static const char* kRawNames[R_COUNT] = {
     "dist_decoder.mean_decoder.0.weight", "dist_decoder.mean_decoder.0.bias", "dist_decoder.mean_decoder.2.weight",
     "dist_decoder.mean_decoder.2.bias", "dist_decoder.mean_decoder.4.weight", "dist_decoder.mean_decoder.4.bias",
@@ -99,6 +101,8 @@ static int do_render_pass(const PgrfFrame* frame, const float* blob, int flags, 
   if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_render_pass: rn=%d < 0", rn);
   if (dn != 32 && dn != 64 && dn != 128)
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass: dn=%d unsupported (32, 64 or 128 samples per ray)", dn);
+  if (out->render_uncert && (!out->render_depth || !out->hit_prob))
+    return set_error(PGRF_ERR_ARG, "pgrf_render_pass: render_uncert needs the render_depth and hit_prob outputs as well");
   if (rn == 0) return PGRF_OK;
   if (!workspace || ws_bytes < pass_ws_bytes(frame))
     return set_error(PGRF_ERR_ARG, "pgrf_render_pass: workspace too small (%zu < %zu bytes)", ws_bytes, pass_ws_bytes(frame));
@@ -132,7 +136,9 @@ static int do_render_pass(const PgrfFrame* frame, const float* blob, int flags, 
   a.out_pixel = out->pixel_colors; a.out_depth = out->render_depth; a.out_hit = out->hit_prob;
   a.out_colors = out->colors; a.out_density = out->density; a.nan_flag = out->nan_flag;
   if (dbg) a.dbg = *dbg;
-  return launch_render_pass(a, frame->rfn, dn, dbg != nullptr, precision, stream);
+  rc = launch_render_pass(a, frame->rfn, dn, dbg != nullptr, precision, stream);
+  if (rc || !out->render_uncert) return rc;
+  return launch_render_uncert(depth, out->hit_prob, out->render_depth, rn, dn, out->render_uncert, stream);
 }
 
 }  // namespace pgrf
@@ -142,7 +148,9 @@ using namespace pgrf;
 extern "C" {
 
 const char* pgrf_last_error(void) { return g_err; }
-int pgrf_abi_version(void) { return 4; }
+// negative when any object of this library was compiled as an experiment (pgrf_experiments.h): never loadable as the product
+extern "C" __attribute__((weak)) int pgrf_ablation_marker;
+int pgrf_abi_version(void) { return &pgrf_ablation_marker ? -PGRF_ABI_VERSION : PGRF_ABI_VERSION; }
 
 int pgrf_pack_map(const float* src, int n, int C, int h, int w, float* dst, void* stream) {
   if (!src || !dst) return set_error(PGRF_ERR_ARG, "pgrf_pack_map: null pointer");

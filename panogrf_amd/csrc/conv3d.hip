@@ -8,6 +8,7 @@
 // bytes (its voxel, its half of the channel chunk) straight into the B operand registers — no LDS
 // staging: the 27 taps re-read the same lines from L1/L2.  Output channels sit on the MFMA rows
 // (accumulator registers), so a lane writes 4 consecutive channels per 16-byte store.
+#include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -26,10 +26,12 @@
 // issued behind them would wait for them.
 // Accuracy: fp32 throughout; the transforms add ~1e-6 relative round-off (tests compare with the direct kernel and with
 // the oracle at the regulariser tolerances).
+#include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -456,6 +458,8 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
 
 using namespace pgrf;
 
+static constexpr int kMaxDevices = 64;
+
 extern "C" {
 
 size_t pgrf_conv3d_wino_packed_floats(int Cout, int Cin) {
@@ -546,18 +550,26 @@ int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* ou
   const long long nrows_ll = (long long)B * (D / 2) * (H / (2 * ty)) * (W / (2 * tx)) * (a.cot_total / 2);
   if (nrows_ll >= (1ll << 31)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino: too many tile rows");
   const int nrows = (int)nrows_ll;
-  static int ncu = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeom<false>::kLdsBytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeom<true>::kLdsBytes) != hipSuccess)
-      return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot reserve %d bytes of LDS", WinoGeom<true>::kLdsBytes);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot query the device");
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    attr_done = true;
+  // per DEVICE (a process may drive several GPUs): the LDS reservation is a per-device function attribute and the
+  // persistent grid is sized from that device's CU count
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+    return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot query the current device");
+  int ncu;
+  {
+    static std::mutex mu;
+    static int ncu_of[kMaxDevices] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (ncu_of[dev] == 0) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeom<false>::kLdsBytes) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WinoGeom<true>::kLdsBytes) != hipSuccess)
+        return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot reserve %d bytes of LDS", WinoGeom<true>::kLdsBytes);
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return set_error(PGRF_ERR_LAUNCH, "pgrf_conv3d_wino: cannot query the device");
+      ncu_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    ncu = ncu_of[dev];
   }
   // persistent: one workgroup (8 MFMA waves + 8 loader waves) per CU (the ~140 KB LDS block allows no more), each loops over rows
   int wgs = ncu;

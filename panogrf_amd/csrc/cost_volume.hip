@@ -6,6 +6,7 @@
 // Geometry (back-projection, two 3x3 transforms, atan2/acos, tap setup) is computed ONCE per voxel
 // by one lane and handed to the C/4 lanes that move that voxel's channels through wave shuffles,
 // instead of being recomputed per channel group.
+#include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -7,6 +7,7 @@
 // All maps are channel-last [N,H,W,Cs] with (cs, coff) slices like the 3-D volumes.  These layers run once per frame
 // on a few MB: they are launch/latency bound, so the point is few, fused launches (MIOpen + torch elementwise needs
 // ~250 launches per frame for the same work), not roofline.
+#include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
 
 #include "pgrf_internal.h"
@@ -99,10 +100,12 @@ __global__ void __launch_bounds__(256) conv2d_direct_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// InstanceNorm2d statistics: block (n, chunk) sums x and x^2 of its pixel range for every channel.
-// Thread layout: C/4 channel quads x 256/(C/4) pixel lanes; pixel lanes are combined through LDS.
+// InstanceNorm2d statistics: block (n, chunk) reduces its pixel range to (mean, M2 = sum of squared deviations) per channel.
+// Sums are taken of x - shift with shift = the chunk's first pixel (the "shifted data" algorithm): E[x^2] - mean^2 on raw
+// fp32 sums loses log2(mean^2/var) bits when a channel carries a large offset (biased conv outputs ahead of the norm).
+// Thread layout: C/4 channel quads x 256/(C/4) pixel lanes; pixel lanes are combined through LDS in double.
 __global__ void __launch_bounds__(256) instnorm_stats_kernel(const float* __restrict__ x, int cs, int coff, int C, int HW,
-                                                             int nchunk, float* __restrict__ partial /* [N][nchunk][C][2] */) {
+                                                             int nchunk, float* __restrict__ partial /* [N][nchunk][C][4]: mean hi, mean lo, M2, - */) {
   __shared__ float s_red[256 * 8];
   const int quads = C / 4, plan = 256 / quads;             // C <= 256, a multiple of 4 and dividing 1024
   const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
@@ -110,10 +113,12 @@ __global__ void __launch_bounds__(256) instnorm_stats_kernel(const float* __rest
   const int per = (HW + nchunk - 1) / nchunk;
   const int p0 = chunk * per, p1 = min(p0 + per, HW);
   float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
-  if (pl < plan) {
+  if (pl < plan && p0 < p1) {
     const float* xp = x + (size_t)n * HW * cs + coff + q * 4;
+    const float4 sh = *reinterpret_cast<const float4*>(xp + (size_t)p0 * cs);
     for (int p = p0 + pl; p < p1; p += plan) {
-      const float4 v = *reinterpret_cast<const float4*>(xp + (size_t)p * cs);
+      float4 v = *reinterpret_cast<const float4*>(xp + (size_t)p * cs);
+      v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
       s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
       ss[0] = fmaf(v.x, v.x, ss[0]); ss[1] = fmaf(v.y, v.y, ss[1]); ss[2] = fmaf(v.z, v.z, ss[2]); ss[3] = fmaf(v.w, v.w, ss[3]);
     }
@@ -122,40 +127,63 @@ __global__ void __launch_bounds__(256) instnorm_stats_kernel(const float* __rest
   for (int i = 0; i < 4; ++i) { s_red[threadIdx.x * 8 + i] = s[i]; s_red[threadIdx.x * 8 + 4 + i] = ss[i]; }
   __syncthreads();
   if (threadIdx.x < quads) {
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    double a[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
     for (int l = 0; l < plan; ++l)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] += s_red[(l * quads + threadIdx.x) * 8 + i];
-    float* pp = partial + (((size_t)n * nchunk + chunk) * C + threadIdx.x * 4) * 2;
+      for (int i = 0; i < 8; ++i) a[i] += (double)s_red[(l * quads + threadIdx.x) * 8 + i];
+    float4* pp = reinterpret_cast<float4*>(partial) + ((size_t)n * nchunk + chunk) * C + threadIdx.x * 4;
+    const int cnt = p1 - p0;
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cnt > 0) {
+      const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * HW + p0) * cs + coff + threadIdx.x * 4);
+      sh[0] = v.x; sh[1] = v.y; sh[2] = v.z; sh[3] = v.w;
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { pp[2 * i] = a[i]; pp[2 * i + 1] = a[4 + i]; }
+    for (int i = 0; i < 4; ++i) {
+      const double m = cnt > 0 ? a[i] / (double)cnt : 0.0;
+      const double mean = (double)sh[i] + m;                           // chunk mean, kept as a float pair
+      const float hi = (float)mean;
+      pp[i] = make_float4(hi, (float)(mean - (double)hi), (float)fmax(a[4 + i] - a[i] * m, 0.0) /* chunk M2 */, 0.f);
+    }
   }
 }
 
 // y = act((x - mean) * rstd * gamma + beta [+ residual]); act: 0 none, 1 ReLU, 2 ELU.  Biased variance, as
-// nn.InstanceNorm2d(track_running_stats=False) computes it; the partial sums are combined in double.
+// nn.InstanceNorm2d(track_running_stats=False) computes it; the chunk statistics are combined in double.
 __global__ void __launch_bounds__(256) instnorm_apply_kernel(const float* __restrict__ x, int cs, int coff, int C, int N, int HW,
                                                              const float* __restrict__ partial, int nchunk,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int act, const float* __restrict__ residual, int res_cs,
                                                              int res_coff, float* __restrict__ out, int out_cs, int out_coff) {
-  __shared__ float s_scale[256], s_shift[256];
+  __shared__ float s_scale[256], s_mean[256], s_mlo[256], s_beta[256];
   const int n = blockIdx.y;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double s = 0.0, ss = 0.0;
-    const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)n * nchunk * C + c;
+    // chunk (mean, M2) pairs -> instance mean and variance (Chan et al. pairwise update, in double)
+    const float4* pp = reinterpret_cast<const float4*>(partial) + (size_t)n * nchunk * C + c;
+    const int per = (HW + nchunk - 1) / nchunk;
+    double s = 0.0, m2 = 0.0;
 #pragma unroll 8
     for (int k = 0; k < nchunk; ++k) {           // independent loads, issued together
-      const float2 v = pp[(size_t)k * C];
-      s += (double)v.x; ss += (double)v.y;
+      const float4 v = pp[(size_t)k * C];
+      const int cnt = min(per, HW - k * per);
+      if (cnt > 0) { s += (double)cnt * ((double)v.x + (double)v.y); m2 += (double)v.z; }
     }
     const double mean = s / (double)HW;
-    double var = ss / (double)HW - mean * mean;
+#pragma unroll 8
+    for (int k = 0; k < nchunk; ++k) {
+      const int cnt = min(per, HW - k * per);
+      if (cnt > 0) { const float4 v = pp[(size_t)k * C]; const double d = ((double)v.x + (double)v.y) - mean; m2 += (double)cnt * d * d; }
+    }
+    double var = m2 / (double)HW;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     s_scale[c] = rstd * g;
-    s_shift[c] = b - (float)mean * rstd * g;
+    // (x - mean) first, as PyTorch does (x*scale - mean*scale cancels for |mean| >> std); the mean as a float pair: x - hi
+    // is exact for x near the mean (Sterbenz), so the result carries the double mean's accuracy
+    s_mean[c] = (float)mean;
+    s_mlo[c] = (float)(mean - (double)s_mean[c]);
+    s_beta[c] = b;
   }
   __syncthreads();
   const int quads = C / 4;
@@ -166,7 +194,7 @@ __global__ void __launch_bounds__(256) instnorm_apply_kernel(const float* __rest
     const float4 v = *reinterpret_cast<const float4*>(x + p * cs + coff + q * 4);
     float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = fmaf(r[k], s_scale[q * 4 + k], s_shift[q * 4 + k]);
+    for (int k = 0; k < 4; ++k) r[k] = fmaf((r[k] - s_mean[q * 4 + k]) - s_mlo[q * 4 + k], s_scale[q * 4 + k], s_beta[q * 4 + k]);
     if (residual) {
       const float4 rv = *reinterpret_cast<const float4*>(residual + p * res_cs + res_coff + q * 4);
       r[0] += rv.x; r[1] += rv.y; r[2] += rv.z; r[3] += rv.w;

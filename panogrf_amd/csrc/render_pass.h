@@ -12,6 +12,7 @@
 //
 // Reference semantics (file:line into /root/reference) are cited at each stage.
 #pragma once
+#include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
 
 #include "pgrf_internal.h"

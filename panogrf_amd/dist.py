@@ -5,8 +5,20 @@ tile [g*H/G, (g+1)*H/G) with NO data-path collective; one all-gather (RCCL over 
 backend is "nccl") reassembles the final image.  The reference has no multi-GPU inference at all
 (train/trainer.py:232-234): this is new, not a translation.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _world(group=None):
+    """World size the collectives act on; 1 = nothing to gather.  With PGRF_FORCE_COLLECTIVES=1 a single-rank process
+    group is NOT short-cut (-1 is returned: 'one rank, but run the collective'), so that the RCCL calls themselves
+    execute on a one-GPU box (bench.py --force-dist, tests/mp_nccl_one_rank.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    w = dist.get_world_size(group)
+    return -1 if (w == 1 and os.environ.get('PGRF_FORCE_COLLECTIVES') == '1') else w
 
 
 def tile_rows(rank, world, H):
@@ -27,9 +39,10 @@ def tile_coords(rank, world, H, W, device='cpu'):
 def allgather_rows(shard, H, W, group=None):
     """shard [rows_g*W, C] of every rank -> full [H*W, C] on every rank.  Equal tiles use one
     all_gather_into_tensor (a single ncclAllGather); ragged tiles fall back to padded gather."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    world = _world(group)
     if world == 1:
         return shard
+    world = abs(world)
     C = shard.shape[1]
     if dist.get_backend(group) == 'gloo' and shard.is_cuda:
         # test-only path (several ranks sharing one GPU cannot use RCCL): stage through host memory
@@ -62,9 +75,10 @@ def view_shard(rank, world, n_views):
 def allgather_views(local, n_views, group=None):
     """local [len(view_shard(rank)), ...] of every rank -> [n_views, ...] in view order on every rank.  Ranks own
     different numbers of views (including none), so every rank contributes ceil(n_views/world) padded slots."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    world = _world(group)
     if world == 1:
         return local
+    world = abs(world)
     if dist.get_backend(group) == 'gloo' and local.is_cuda:      # test-only: ranks sharing one GPU
         return allgather_views(local.cpu(), n_views, group).to(local.device)
     slots = -(-n_views // world)
@@ -90,9 +104,10 @@ def ray_shard(rank, world, n):
 def allgather_rays(local, n, dim=1, group=None):
     """local [..., n_rank, ...] (this rank's chunk of ray_shard along `dim`) -> [..., n, ...] on every rank, in ray order.
     Chunks differ by at most one ray: every rank contributes ceil(n / world) padded slots to ONE all-gather."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    world = _world(group)
     if world == 1:
         return local
+    world = abs(world)
     if dist.get_backend(group) == 'gloo' and local.is_cuda:      # test-only: ranks sharing one GPU
         return allgather_rays(local.cpu(), n, dim, group).to(local.device)
     was_bool = local.dtype == torch.bool

@@ -71,7 +71,8 @@ class HipEncoders:
         _require_gpu()
         self.ie, self.ve, self.device = image_encoder, vis_encoder, torch.device(device)
         self._packed, self._key = None, None
-        self._partial = torch.empty(2 * 32 * 256 * 2, dtype=torch.float32, device=self.device)
+        self._partial = torch.empty(2 * 32 * 256 * 4, dtype=torch.float32, device=self.device)
+        self._nrm = {}
 
     # ------------------------------------------------------------------ weights
     def _state_key(self):
@@ -136,13 +137,27 @@ class HipEncoders:
                                   int(residual_first), _stream()))
         return out
 
+    def _norm_wb(self, norm):
+        """gamma / beta of a norm module as fp32, contiguous tensors ON self.device (the kernel dereferences raw pointers:
+        a module still on the CPU, on another GPU or in half precision must never reach it as it is).  Parameters that
+        already qualify are used in place; the copy of any other is refreshed when its version counter moves."""
+        w, b = norm.weight, norm.bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        cache = self.__dict__.setdefault('_nrm', {})
+        ent = cache.get(id(norm))
+        if ent is None or ent[0] != key:
+            f = lambda t: t.detach().to(self.device, torch.float32).contiguous()
+            ent = cache[id(norm)] = (key, f(w), f(b))
+        return ent[1], ent[2]
+
     def _norm(self, x, norm, act, out=None, residual=None):
         """InstanceNorm2d(affine) + activation ('none' | 'relu' | 'elu'), residual added before the activation."""
         out = x if out is None else out
-        need = x.N * lib.pgrf_instnorm_chunks(x.H * x.W) * x.C * 2
+        gamma, beta = self._norm_wb(norm)
+        need = x.N * lib.pgrf_instnorm_chunks(x.H * x.W) * x.C * 4
         if self._partial.numel() < need:
             self._partial = torch.empty(need, dtype=torch.float32, device=self.device)
-        lib.check(lib.pgrf_instnorm(_ptr(x.buf), x.cs, x.coff, x.C, x.N, x.H * x.W, _ptr(norm.weight), _ptr(norm.bias),
+        lib.check(lib.pgrf_instnorm(_ptr(x.buf), x.cs, x.coff, x.C, x.N, x.H * x.W, _ptr(gamma), _ptr(beta),
                                     float(norm.eps), {'none': 0, 'relu': 1, 'elu': 2}[act],
                                     _ptr(residual.buf) if residual is not None else None,
                                     residual.cs if residual is not None else 0, residual.coff if residual is not None else 0,

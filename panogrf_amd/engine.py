@@ -37,7 +37,7 @@ def host_floats(t, n):
     panogrf_amd.imgs_info.imgs_info_to_torch moved to the GPU carries its host values (`_pgrf_host`), so no device->host copy
     and no host sync happens; any other GPU tensor is read back."""
     mirror = getattr(t, '_pgrf_host', None)
-    if mirror is not None and mirror[1] == t._version and mirror[0].numel() >= n:
+    if mirror is not None and not t.is_inference() and mirror[1] == t._version and mirror[0].numel() >= n:
         return [float(x) for x in mirror[0][:n]]
     return [float(x) for x in _f32c(t, 'cpu').reshape(-1)[:n]]
 
@@ -176,26 +176,30 @@ def sample_fine_depth(depth, hit_prob, que_depth_range, fdn, use_disp=True, use_
     return out
 
 
-def _alloc_out(rn, dn, dev, nan_flag=None):
+def _alloc_out(rn, dn, dev, nan_flag=None, uncert=False):
     t = dict(pixel_colors_nr=torch.empty(rn, 3, device=dev), render_depth=torch.empty(rn, device=dev),
              hit_prob_nr=torch.empty(rn, dn, device=dev), colors_nr=torch.empty(rn, dn, 3, device=dev),
              density_nr=torch.empty(rn, dn, device=dev))
+    if uncert:
+        t['render_uncert'] = torch.empty(rn, device=dev)
     o = PgrfPassOut(t['pixel_colors_nr'].data_ptr(), t['render_depth'].data_ptr(), t['hit_prob_nr'].data_ptr(),
                     t['colors_nr'].data_ptr(), t['density_nr'].data_ptr(),
-                    nan_flag.data_ptr() if nan_flag is not None else None)
+                    nan_flag.data_ptr() if nan_flag is not None else None,
+                    t['render_uncert'].data_ptr() if uncert else None)
     return t, o
 
 
 PRECISIONS = {'f32': 0, 'f16x3': 1}
 
 
-def render_pass(frame, blob_dev, use_vis, coords, depth, debug=False, precision='f32'):
+def render_pass(frame, blob_dev, use_vis, coords, depth, debug=False, precision='f32', uncert=False):
     """One network pass; returns dict of [rn,...] CUDA tensors (reference key names without the
-    leading qn axis).  `debug=True` also returns the intermediate tensors under 'dbg'."""
+    leading qn axis).  `debug=True` also returns the intermediate tensors under 'dbg'; `uncert=True` adds
+    'render_uncert' (cfg render_uncert, renderer.py:305-312)."""
     _require_gpu()
     coords, depth = _f32c(coords, frame.device), _f32c(depth, frame.device)
     rn, dn = depth.shape
-    t, o = _alloc_out(rn, dn, frame.device)
+    t, o = _alloc_out(rn, dn, frame.device, uncert=uncert)
     dbg_t, dbg_s = None, None
     if debug:
         dbg_t = {k: torch.zeros(*f(frame.rfn, rn, dn), device=frame.device) for k, f in _DEBUG_SHAPES.items()}
@@ -276,12 +280,13 @@ class RayRenderer:
         # cfg['hip_check_nan']: the reference drops into ipdb when a NaN shows up (renderer.py:264-265,459-462); here the
         # kernels raise a device flag and the host turns it into an exception (costs one device->host sync per call)
         flag = torch.zeros(1, dtype=torch.int32, device=self.device) if self.cfg.get('hip_check_nan') else None
-        tc, oc = _alloc_out(rn, c.dn, self.device, flag)
+        unc = bool(self.cfg.get('render_uncert', False))
+        tc, oc = _alloc_out(rn, c.dn, self.device, flag, unc)
         out = dict(tc)
         of = None
         fd = None
         if c.hierarchical:
-            tf, of = _alloc_out(rn, dn_f_out, self.device, flag)
+            tf, of = _alloc_out(rn, dn_f_out, self.device, flag, unc)
             fd = torch.empty(rn, fdn_eff, device=self.device)
             for k, v in tf.items():
                 out[k + '_fine'] = v

@@ -48,7 +48,7 @@ def imgs_info_to_torch(info, device=None):
         if torch.is_tensor(v) and device is not None:
             host = v
             v = v.to(device)
-            if v is not host and host.numel() <= 64:
+            if v is not host and host.numel() <= 64 and not v.is_inference():
                 # poses, intrinsics and depth ranges become BY-VALUE kernel arguments (PgrfFrame.que_c2w, ...): keep the host
                 # values next to the device copy so that panogrf_amd.engine.host_floats does not read them back (a
                 # device->host copy = one host sync per frame); valid while the device tensor's version counter stands

@@ -38,26 +38,31 @@ def psnr_float(pred, ref, max_val=1.0):
     return 10 * np.log10(max_val * max_val / max(mse, 1e-30))
 
 
+def erp_row_weights(height):
+    """Solid-angle weight of every ERP row: a pixel of row i (centre at polar angle (i + 1/2) pi / H) covers an area of the
+    sphere proportional to the sine of that angle.  float64 [H]."""
+    return np.sin((np.arange(height, dtype=np.float64) + 0.5) * (np.pi / height))
+
+
 class WSPSNR:
-    """Weighted-to-spherical PSNR: an ERP row covers a band of the sphere proportional to sin(polar angle)."""
+    """Weighted-to-spherical PSNR on ERP images: the squared error of every pixel counts with its row's solid angle
+    (interface of the reference's evaluator, network/metrics.py:118-171: get_weights / calculate_wsmse / ws_psnr)."""
 
     def __init__(self):
-        self.weight_cache = {}
+        self._rows = {}
 
     def get_weights(self, height=1080, width=1920):
-        key = (height, width)
-        if key not in self.weight_cache:
-            v = np.sin((np.arange(0, height) + 0.5) * (np.pi / height)).reshape(height, 1)
-            self.weight_cache[key] = np.broadcast_to(v, (height, width)).copy()
-        return self.weight_cache[key]
+        """[height, width] weight map (every column is erp_row_weights(height))."""
+        if height not in self._rows:
+            self._rows[height] = erp_row_weights(height)
+        return np.repeat(self._rows[height][:, None], width, axis=1)
 
     def calculate_wsmse(self, reconstructed, reference):
-        """[B,H,W,C] tensors -> [B] weighted MSE."""
-        batch_size, height, width, channels = reconstructed.shape
-        weights = torch.tensor(self.get_weights(height, width), device=reconstructed.device, dtype=reconstructed.dtype)
-        weights = weights.view(1, height, width, 1).expand(batch_size, -1, -1, channels)
-        squared_error = torch.pow(reconstructed - reference, 2.0)
-        return torch.sum(weights * squared_error, dim=(1, 2, 3)) / torch.sum(weights, dim=(1, 2, 3))
+        """[B,H,W,C] image batches -> [B]: sum_y w_y * err^2 / (W * C * sum_y w_y), evaluated per row first."""
+        H, W, C = reconstructed.shape[1:]
+        w = torch.as_tensor(self.get_weights(H, 1)[:, 0], dtype=reconstructed.dtype, device=reconstructed.device)
+        row_err = ((reconstructed - reference) ** 2).sum(dim=(2, 3))          # [B,H]
+        return (row_err * w).sum(1) / (w.sum() * (W * C))
 
     def ws_psnr(self, y_pred, y_true, max_val=1.0):
         return 10 * torch.log10(max_val * max_val / self.calculate_wsmse(y_pred, y_true))
@@ -66,7 +71,7 @@ class WSPSNR:
     def ws_psnr_rays(pred, ref, rows, height, max_val=1.0):
         """The same metric on a SUBSET of an ERP image's pixels ([n,3] colours, their row indices): what bench.py can
         evaluate against the CPU oracle, which renders a sample of the frame's rays only."""
-        w = torch.sin((torch.as_tensor(rows).double() + 0.5) * (np.pi / height)).view(-1, 1)
+        w = torch.as_tensor(erp_row_weights(height))[torch.as_tensor(rows).long().cpu()].view(-1, 1)
         a = torch.as_tensor(pred).double().cpu()
         b = torch.as_tensor(ref).double().cpu()
         wmse = float((w * (a - b) ** 2).sum() / (w.sum() * a.shape[1]))

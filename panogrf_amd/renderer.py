@@ -121,13 +121,17 @@ class _SphHolder(nn.Module):
 
 def _snapshot(named):
     """[(name, value)] -> the same with each tensor's version counter: what `_unchanged` compares the next frame's inputs to.
-    Holds the tensors themselves (no copies): an in-place write bumps the counter and invalidates the snapshot."""
+    Holds the tensors themselves (no copies): an in-place write bumps the counter and invalidates the snapshot.  Returns
+    None when an input is an inference tensor (torch.inference_mode: no version counter, so nothing can be kept)."""
+    if any(torch.is_tensor(v) and v.is_inference() for _, v in named):
+        return None
     return [(k, v, v._version if torch.is_tensor(v) else None) for k, v in named]
 
 
-def _unchanged(snap, named):
-    """True when every input equals the snapshot's: the same tensor object at the same version counter (no device work), or
-    a tensor of equal contents (one device compare and a host sync per tensor that is a new object)."""
+def _unchanged(snap, named, compare_contents=False):
+    """True when every input is the snapshot's: the same tensor object at the same version counter (no device work).  With
+    `compare_contents` a NEW tensor object of equal contents also counts (one device compare and a host sync per such
+    tensor: cfg['hip_reuse_source_maps']='equal'); by default a new object means new data."""
     named = list(named)
     if snap is None or len(snap) != len(named):
         return False
@@ -138,10 +142,13 @@ def _unchanged(snap, named):
             if v0 is not v and not np.array_equal(np.asarray(v0), np.asarray(v)):
                 return False
             continue
-        if v0._version != ver0:
+        if v.is_inference() or v0._version != ver0:
             return False
-        if v is not v0 and (v.shape != v0.shape or v.dtype != v0.dtype or v.device != v0.device or not torch.equal(v, v0)):
-            return False
+        if v is not v0:
+            if not compare_contents:
+                return False
+            if v.shape != v0.shape or v.dtype != v0.dtype or v.device != v0.device or not torch.equal(v, v0):
+                return False
     return True
 
 
@@ -171,9 +178,11 @@ class NeuralRayBaseRenderer(nn.Module):
         if c.get('dataset_name', 'm3d') not in E.DATASETS:
             raise PgrfError(f"dataset_name {c.get('dataset_name')!r}: spherical convention not implemented "
                             f"(have {sorted(E.DATASETS)}; network/spt_utils.py)")
-        for key in ('debug', 'diner_depth_guided_sampling', 'render_uncert', 'autoencoder'):
+        for key in ('debug', 'diner_depth_guided_sampling', 'autoencoder'):
             if c.get(key):
                 raise PgrfError(f"cfg['{key}'] is not implemented on the HIP path")
+        if c.get('render_uncert') and not c['render_depth']:
+            raise PgrfError("cfg['render_uncert'] needs cfg['render_depth'] (the reference reads outputs['render_depth'], renderer.py:312)")
         if c.get('local_feature_type') == 'ERP+TP':
             raise PgrfError('ERP+TP image encoder is out of scope')
         self.vis_encoder = DefaultVisEncoder(c)
@@ -243,6 +252,8 @@ class NeuralRayBaseRenderer(nn.Module):
                 res['ray_mask' + suffix] = torch.full((1, rn), bool(ok), dtype=torch.bool, device=dev)
             if c['render_depth']:
                 res['render_depth' + suffix] = out['render_depth' + suffix].unsqueeze(0)
+            if c.get('render_uncert'):       # sum_i w_i (z_i - depth)^2 + 1e-5 (renderer.py:305-312)
+                res['render_uncert' + suffix] = out['render_uncert' + suffix].unsqueeze(0)
         return res
 
     def _torch_encoders(self, imgs, ray_feats):
@@ -325,8 +336,16 @@ class NeuralRayBaseRenderer(nn.Module):
         SAME source views (render.py:248-278 rebuilds identical ref/src infos for every frame), and everything in front of
         the per-ray kernel -- MVS stage, 2-D encoders: 8.5 of 84 ms at the shipped configuration -- depends on the source
         views and the weights only.  With cfg['hip_reuse_source_maps'] (default on; eval, GPU, no autograd) those results
-        are kept and returned again while the inputs are unchanged (`_unchanged`) and the weights' version counters are."""
-        return bool(self.cfg.get('hip_reuse_source_maps', True)) and imgs.is_cuda and not is_train and not torch.is_grad_enabled()
+        are kept and returned again while the inputs are unchanged (`_unchanged`) and the weights' version counters are.
+        True (default) recognises the SAME tensor objects at the same version counters only -- no device work, no host
+        sync; 'equal' additionally accepts new tensors of equal contents (a caller that rebuilds identical infos per
+        frame, at one torch.equal = one sync per tensor and frame); False recomputes always.  Off under
+        torch.inference_mode(): inference tensors have no version counter to watch."""
+        return (bool(self.cfg.get('hip_reuse_source_maps', True)) and imgs.is_cuda and not is_train
+                and not torch.is_grad_enabled() and not torch.is_inference_mode_enabled())
+
+    def _reuse_by_contents(self):
+        return self.cfg.get('hip_reuse_source_maps', True) == 'equal'
 
     def _encode_reusing(self, imgs, ray_feats, is_train):
         if not self._reuse_enabled(imgs, is_train):
@@ -334,11 +353,13 @@ class NeuralRayBaseRenderer(nn.Module):
         named = [('imgs', imgs), ('ray_feats', ray_feats)]
         wver = self._weights_version((self.image_encoder, self.vis_encoder))
         c = self.__dict__.get('_enc_cache')
-        if (c is not None and c['wver'] == wver and all(o._version == ver for o, ver in c['outs']) and _unchanged(c['snap'], named)):
+        if (c is not None and c['wver'] == wver and all(o._version == ver for o, ver in c['outs']) and
+                _unchanged(c['snap'], named, self._reuse_by_contents())):
             self.__dict__.pop('_early_feats', None)
             return c['outs'][0][0], c['outs'][1][0]
         outs = self._encode(imgs, ray_feats)
-        self.__dict__['_enc_cache'] = dict(snap=_snapshot(named), wver=wver, outs=[(o, o._version) for o in outs])
+        snap = _snapshot(named)
+        self.__dict__['_enc_cache'] = None if snap is None else dict(snap=snap, wver=wver, outs=[(o, o._version) for o in outs])
         return outs
 
     def _encode_images_early(self, imgs):
@@ -389,6 +410,8 @@ class NeuralRayBaseRenderer(nn.Module):
         # tensors (colors_nr, density_nr, hit_prob_nr: hundreds of MB per frame), the default 'image' returns per-ray keys only.
         shard = self._ray_shard_world()
         n_all = coords.shape[1]
+        if shard is not None and n_all < shard[1]:
+            shard = None        # fewer rays than ranks: a rank without rays would produce no keys to gather -> every rank renders all
         if shard is not None:
             from . import dist as D
             r0, r1 = D.ray_shard(shard[0], shard[1], n_all)
@@ -407,7 +430,7 @@ class NeuralRayBaseRenderer(nn.Module):
                 parts.setdefault(k, []).append(v)
         out = {k: torch.cat(v, 1) if len(v) > 1 else v[0] for k, v in parts.items()}
         if shard is not None:
-            per_ray = ('pixel_colors', 'render_depth', 'ray_mask')
+            per_ray = ('pixel_colors', 'render_depth', 'render_uncert', 'ray_mask')
             keep = out if self.cfg.get('hip_gather', 'image') == 'all' else {k: v for k, v in out.items() if k.startswith(per_ray)}
             out = {k: D.allgather_rays(v, n_all, 1) for k, v in keep.items()}
         return out
@@ -466,12 +489,13 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
             wver = self._weights_version((self.init_net,)) if isinstance(self.init_net, nn.Module) else None
             c = self.__dict__.get('_init_cache')
             if (c is not None and wver is not None and c['wver'] == wver and all(o._version == ver for o, ver in c['outs']) and
-                    _unchanged(c['snap'], named)):
+                    _unchanged(c['snap'], named, self._reuse_by_contents())):
                 return dict(c['ret'])
         self._encode_images_early(ref['imgs'])
         ret = self._run_init_net_sharded(ref, src, is_train)
-        if reuse and wver is not None:
-            self.__dict__['_init_cache'] = dict(snap=_snapshot(named), wver=wver, ret=dict(ret),
+        snap = _snapshot(named) if (reuse and wver is not None) else None
+        if snap is not None:
+            self.__dict__['_init_cache'] = dict(snap=snap, wver=wver, ret=dict(ret),
                                                 outs=[(o, o._version) for o in ret.values() if torch.is_tensor(o)])
         return ret
 

@@ -194,3 +194,39 @@ def test_host_mirror_of_small_pose_tensors():
     dev['c2w'].mul_(2.0)                                               # in-place write: the mirror is stale -> read back
     with pytest.raises((NotImplementedError, RuntimeError)):
         E.host_floats(dev['c2w'], 12)
+
+
+def test_product_library_is_not_an_experiment_build():
+    """pgrf_abi_version(): the header's PGRF_ABI_VERSION, positive (negative = linked from ablation / timing objects,
+    csrc/pgrf_experiments.h) -- and a kernel source given an experiment switch without -DPGRF_ABLATION_BUILD does not compile,
+    so the product Makefile can never ship one."""
+    import subprocess
+    from panogrf_amd._lib import lib, ABI_VERSION
+    hdr = open(os.path.join(ROOT, 'include', 'panogrf_hip.h')).read()
+    assert int(re.search(r'#define PGRF_ABI_VERSION (\d+)', hdr).group(1)) == ABI_VERSION
+    assert lib.pgrf_abi_version() == ABI_VERSION
+    src = os.path.join(ROOT, 'panogrf_amd', 'csrc')
+    r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-fsyntax-only', '--cuda-host-only',
+                        '-I' + os.path.join(ROOT, 'include'), '-DPGRF_NO_BARRIER', '-DPGRF_KT=2', '-DPGRF_V=2', '-DPGRF_DBG=0',
+                        '-DPGRF_PREC=0', os.path.join(src, 'render_pass_inst.hip')], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'PGRF_ABLATION_BUILD' in r.stderr
+    guarded = 0
+    for f in os.listdir(src):
+        if f.endswith('.hip') and f not in ('capi.hip', 'render_pass_inst.hip'):
+            assert '#include "pgrf_experiments.h"' in open(os.path.join(src, f)).read(), f
+            guarded += 1
+    assert guarded >= 5 and '#include "pgrf_experiments.h"' in open(os.path.join(src, 'render_pass.h')).read()
+
+
+def test_plain_bench_gpus_n_becomes_a_launcher():
+    """`python bench.py --gpus 2` without torchrun must start child ranks (here they stop at 'needs a ROCm GPU'), not refuse
+    with a launch hint; on a GPU box tests/test_gpu_bench_multirank.py runs the same command to completion."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: covered by the -m gpu test')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'needs a ROCm GPU' in r.stderr and 'launch N>1 as' not in r.stderr

@@ -59,3 +59,41 @@ def test_renderer_module_shards_rays_and_views():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert r.stdout.count('sharded == unsharded') == 2
+
+
+def test_rccl_collectives_execute_with_one_rank():
+    """backend = nccl (RCCL) on this one GPU: panogrf_amd.dist's all-gathers, the barrier and the MAX all-reduce really run
+    (PGRF_FORCE_COLLECTIVES=1 stops them from being short-cut at world size 1)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29525', os.path.join(ROOT, 'tests', 'mp_nccl_one_rank.py')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert 'rccl one-rank collectives ok' in r.stdout
+
+
+def test_bench_distributed_path_on_rccl_with_one_rank():
+    """bench.py itself with backend nccl, world size 1 and --force-dist: process group on RCCL, tile all-gather through
+    all_gather_into_tensor, barrier + MAX all-reduce around the timed region, gathered-frame check."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29527', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+           '--height', '64', '--width', '128', '--samples', '32', '--force-dist', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0
+    assert d['config']['gathered_image_max_abs_diff_vs_unsharded'] == 0.0
+    assert d['config']['collectives'] == 'nccl, forced at world size 1'
+
+
+def test_plain_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (no torchrun, WORLD_SIZE unset): bench.py starts the ranks itself as child
+    processes (gloo here: two ranks share this one GPU) and relays rank 0's JSON line; exit code 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['PGRF_BENCH_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '64',
+           '--width', '128', '--samples', '32']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['config']['ray_tiles'] == 2
+    assert d['config']['gathered_image_max_abs_diff_vs_unsharded'] == 0.0

@@ -628,3 +628,57 @@ def test_training_mode_forward_vs_reference():
     # the fp32 cdf (measured: 3 of 1536 draws off by more than 1e-5): compare in inverse depth, the sampler's own space
     err = (1.0 / fd.cpu() - 1.0 / want).abs()
     assert float((err > 1e-5).float().mean()) < 0.01 and float(err.median()) < 1e-6 and float(err.max()) < 1e-2
+
+
+# ---- round 3: cfg keys of SURVEY 8(b) that had no reference vector (tests/golden/make_round3_fixtures.py)
+@pytest.mark.parametrize('name', ['render_r3_uncert', 'render_r3_uncert_c2f', 'render_r3_nodisp'])
+def test_render_uncert_and_linear_depth_sampling_vs_reference(name):
+    """render_uncert (renderer.py:305-312; over the merged samples with render_c2f_all, :507-514) and use_disp=False
+    (render_ops.py:303-318, :423-424) through pgrf_render_rays, against the reference's own render_impl outputs."""
+    E = _engine()
+    frame, w, cfg, g = FX.load(name)
+    gold = g['out']
+    fr = _frame(E, frame)
+    rn, dn = frame['coords'].shape[0], cfg['depth_sample_num']
+    cd = E.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn, use_disp=cfg['use_disp'])
+    assert FX.max_abs(cd.cpu(), gold['coarse_depth']) < 2e-6
+    fd = E.sample_fine_depth(gold['coarse_depth'].cuda(), gold['hit_prob_nr'].cuda(), frame['que_depth_range'],
+                             cfg['fine_depth_sample_num'], use_disp=cfg['use_disp'])
+    assert FX.max_abs(fd.cpu(), torch.sort(gold['fine_depth_unsorted'], -1)[0]) < 1e-4 * 15.0
+    rr = E.RayRenderer(cfg, w)
+    out = rr.render_rays(fr, frame['coords'])
+    assert FX.max_abs(out['pixel_colors_nr'].cpu(), gold['pixel_colors_nr']) < 2e-5
+    assert FX.max_abs(out['render_depth'].cpu(), gold['render_depth']) < 5e-5
+    assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), gold['pixel_colors_nr_fine']) > 70.0
+    assert FX.max_abs(out['render_depth_fine'].cpu(), gold['render_depth_fine']) < 1e-2
+    if cfg.get('render_uncert'):
+        assert FX.max_abs(out['render_uncert'].cpu(), gold['render_uncert']) < 1e-5
+        assert FX.max_abs(out['render_uncert_fine'].cpu(), gold['render_uncert_fine']) < 1e-3
+        assert float(out['render_uncert'].min()) >= 1e-5
+        # the single-pass entry point computes it too
+        blob = E.pack_pass_weights(w, 'dist_decoder', 'agg_net', cfg['dist_decoder_cfg']['use_vis']).cuda()
+        one = E.render_pass(fr, blob, cfg['dist_decoder_cfg']['use_vis'], frame['coords'], gold['coarse_depth'], uncert=True)
+        assert FX.max_abs(one['render_uncert'].cpu(), gold['render_uncert']) < 1e-5
+    else:
+        assert 'render_uncert' not in out
+
+
+def test_render_uncert_through_the_module():
+    """cfg['render_uncert'] on the drop-in module: same keys as the reference returns ('render_uncert', 'render_uncert_fine'),
+    refused without render_depth (the reference reads outputs['render_depth'] there)."""
+    from panogrf_amd.renderer import name2network
+    from panogrf_amd import PgrfError
+    frame, w, cfg, g = FX.load('render_r3_uncert')
+    net = name2network['neuray_base'](dict(cfg))
+    net.load_state_dict(w, strict=False)
+    net = net.cuda().eval()
+    que = {'c2w': frame['que_c2w'][None].cuda(), 'coords': frame['coords'][None].cuda(), 'depth_range': frame['que_depth_range'][None].cuda()}
+    ref = {'imgs': frame['imgs'].cuda(), 'w2c': frame['w2c'].cuda(), 'depth_range': frame['ref_depth_range'].cuda(),
+           'ray_feats': frame['ray_feats'].cuda(), 'img_feats': frame['img_feats'].cuda()}
+    with torch.no_grad():
+        out = net.render_impl(que, ref, False)
+    for k in ('render_uncert', 'render_uncert_fine'):
+        assert out[k].shape == (1, frame['coords'].shape[0])
+    assert FX.max_abs(out['render_uncert'][0].cpu(), g['out']['render_uncert']) < 1e-5
+    with pytest.raises(PgrfError):
+        name2network['neuray_base'](dict(cfg, render_depth=False))

@@ -164,9 +164,16 @@ def test_source_maps_are_reused_only_while_inputs_and_weights_are_unchanged():
         a0 = frame(que[0], ref, src)
         a1 = frame(que[1], ref, src)                  # same tensor objects: no compare, no MVS stage
         assert len(calls) == 1
-        ref2, src2 = mk(imgs)                         # new tensors, equal contents (what render.py's loop builds per frame)
+        ref2, src2 = mk(imgs)                         # new tensors, equal contents (what the reference's render.py loop builds per frame)
+        net.cfg['hip_reuse_source_maps'] = 'equal'    # opt-in: compare contents (one torch.equal = one host sync per tensor)
         a1b = frame(que[1], ref2, src2)
         assert len(calls) == 1 and torch.equal(a1[key], a1b[key])
+        net.cfg['hip_reuse_source_maps'] = True       # default: identity + version counter only -> new objects recompute
+        ref2b, src2b = mk(imgs)
+        a1c = frame(que[1], ref2b, src2b)
+        assert len(calls) == 2 and torch.equal(a1[key], a1c[key])
+        frame(que[1], ref, src)
+        calls.clear(); calls.append(1)
         net.cfg['hip_reuse_source_maps'] = False
         b0, b1 = frame(que[0], ref, src), frame(que[1], ref, src)
         assert len(calls) == 3
@@ -183,6 +190,7 @@ def test_source_maps_are_reused_only_while_inputs_and_weights_are_unchanged():
         imgs3[0, :, 10:20, 30:50] = 0.25
         ref3, src3 = mk(imgs3)
         src3['imgs'] = src['imgs']                    # sources as in the previous frame, reference = the edited pixels
+        net.cfg['hip_reuse_source_maps'] = 'equal'
         c0b = frame(que[0], ref3, src3)               # equal contents again
         assert len(calls) == n + 1 and torch.equal(c0[key], c0b[key])
         src3['trans'] = src3['trans'] * 1.5           # a pose change
@@ -199,6 +207,16 @@ def test_source_maps_are_reused_only_while_inputs_and_weights_are_unchanged():
         next(net.image_encoder.parameters()).mul_(1.5)          # encoder weights: MVS result stays, encoders rerun
         d1 = frame(que[1], ref3, src3)
         assert len(calls) == n + 3 and not torch.equal(d0[key], d1[key])
+        net.cfg['hip_reuse_source_maps'] = True
+    # torch.inference_mode(): inference tensors carry no version counter -> nothing is kept, nothing raises
+    with torch.inference_mode():
+        ref4, src4 = mk(imgs)
+        q4 = imgs_info_to_torch(build_render_imgs_info(pose(0.0), (H, W), [0.5, 15.0]), 'cuda')
+        n = len(calls)
+        e0 = frame(q4, ref4, src4)
+        e1 = frame(q4, ref4, src4)
+        assert len(calls) == n + 2 and torch.equal(e0[key], e1[key])
+    assert torch.isfinite(e0[key]).all()
 
 
 @pytest.mark.gpu

@@ -121,3 +121,30 @@ def test_training_mode_forward_vs_reference():
     assert FX.max_abs(dj, gold['jittered_depth']) < 2e-6
     # the jitter really moved the samples, and never past the neighbouring bin
     assert float((dj - d0).abs().max()) > 1e-3 and bool((dj[:, 1:] > dj[:, :-1]).all())
+
+
+# ---- round 3: cfg keys of SURVEY 8(b) that had no reference vector (tests/golden/make_round3_fixtures.py)
+@pytest.mark.parametrize('name', ['render_r3_uncert', 'render_r3_uncert_c2f', 'render_r3_nodisp'])
+def test_render_uncert_and_linear_depth_sampling_vs_reference(name):
+    """render_uncert (renderer.py:305-312; over the merged samples with render_c2f_all, :507-514) and use_disp=False
+    (render_ops.py:303-318 linear-depth coarse samples, :423-424 importance sampling without the inverse-depth map)."""
+    torch.set_num_threads(1)
+    frame, w, cfg, g = FX.load(name)
+    gold = g['out']
+    rn, dn = frame['coords'].shape[0], cfg['depth_sample_num']
+    cd = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rn, dn, cfg['use_disp'])
+    assert FX.max_abs(cd, gold['coarse_depth']) < 2e-6
+    fd = O.sample_fine_depth(gold['coarse_depth'], gold['hit_prob_nr'], frame['que_depth_range'], cfg['fine_depth_sample_num'], cfg['use_disp'])
+    assert FX.max_abs(fd, torch.sort(gold['fine_depth_unsorted'], -1)[0]) < 1e-4 * 15.0
+    out = O.render_rays(w, frame, frame['coords'], cfg)
+    assert FX.max_abs(out['pixel_colors_nr'], gold['pixel_colors_nr']) < 2e-5
+    assert FX.max_abs(out['render_depth'], gold['render_depth']) < 2e-4
+    assert FX.psnr(out['pixel_colors_nr_fine'], gold['pixel_colors_nr_fine']) > 80.0
+    assert FX.max_abs(out['render_depth_fine'], gold['render_depth_fine']) < 5e-3
+    if cfg.get('render_uncert'):
+        assert FX.max_abs(out['render_uncert'], gold['render_uncert']) < 2e-6
+        assert FX.max_abs(out['render_uncert_fine'], gold['render_uncert_fine']) < 2e-5
+        assert float(gold['render_uncert'].min()) >= 1e-5
+    else:
+        assert 'render_uncert' not in out and not cfg['use_disp']
+        assert float((cd[:, 1:] - cd[:, :-1]).std()) < 1e-5          # linear in depth: equal steps

@@ -1,7 +1,7 @@
 """Per-stage wave cycles of the render-pass kernel (experiment build with -DPGRF_STAGE_TIMING).
 
     tools/build_variant.sh st "-DPGRF_STAGE_TIMING" 2 2 0 0
-    PANOGRF_HIP_LIB=$PWD/panogrf_amd/libpanogrf_hip_st.so python tools/stage_timing.py [--precision f16x3]
+    PANOGRF_HIP_LIB=$PWD/panogrf_amd/libpanogrf_hip_st.so PGRF_ALLOW_ABLATION_LIB=1 python tools/stage_timing.py [--precision f16x3]
 """
 import argparse, ctypes, os, sys
 import torch

@@ -1,5 +1,5 @@
 """Per-phase cycle breakdown of the Winograd kernel's MFMA wave 0 (needs a -DPGRF_WINO_TIMING build of conv3d_wino.hip,
-selected with PANOGRF_HIP_LIB): python tools/wino_timing.py"""
+selected with PANOGRF_HIP_LIB, PGRF_ALLOW_ABLATION_LIB=1): python tools/wino_timing.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
