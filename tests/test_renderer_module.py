@@ -198,10 +198,11 @@ def test_render_script_rejects_mismatched_checkpoint():
 
 
 def test_bench_refuses_gpu_count_mismatch():
-    """`python bench.py --gpus 8` without torchrun must not silently run (and report) a 1-GPU number."""
+    """A launcher that started a different number of ranks than --gpus says must not silently report the wrong GPU count
+    (plain `python bench.py --gpus N` starts its own ranks: tests/test_cabi_and_host.py, tests/test_gpu_bench_multirank.py)."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], capture_output=True, text=True,
                        timeout=300, cwd=root, env=env)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
