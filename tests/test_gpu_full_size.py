@@ -191,12 +191,7 @@ def test_config3_regulariser_128x256x64_winograd_vs_direct_and_oracle_slab(reg, 
         assert 0.0 < d < 1e-4 * scale, (d, scale)        # different kernels (transforms add ~1e-6 relative round-off), same function
     else:
         assert d == 0.0                                  # CostRegNet's narrow layers never take the Winograd kernel
-    # translation equivariance along W (circular padding): rolling the input by 64 voxels rolls the output
-    with torch.no_grad():
-        rolled = net.forward_ndhwc(torch.roll(vol, 64, dims=3).contiguous())
-    assert a.shape == (1, D, H, W, 1)
-    assert max_abs(rolled, torch.roll(a, 64, dims=3)) < 1e-4 * scale
-    del outs, rolled
+    del outs
     # oracle slab: same W, cropped D and H
     Ds, Hs = 32, 64
     slab = vol[:, :Ds, :Hs].contiguous()
