@@ -730,6 +730,77 @@ __global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, con
   }
 }
 
+// Cout == 1 from EIGHT input channels (CostRegNet's prob head, models/cost_reg.py:165-172, at full resolution): the general
+// kernel above issues 54 16-byte loads per output voxel (27 taps x 2) and ran at 143 us for 64x128x256 -- 67 MB in, 8 MB out.
+// Here a thread owns YB = 4 consecutive outputs along y of one (b, z, x): an input row (dz, y0 - 1 + r, dx) is loaded once
+// and feeds the up to three outputs whose 3-tap window covers it, 27 loads per output instead of 54; consecutive lanes are
+// consecutive x, so a wave load covers 64 voxels x 16 B of one row.  Weights [27][8] (+ bias) sit in LDS.
+constexpr int kC8YB = 4;
+__global__ void __launch_bounds__(256) conv3d_cout1_c8_kernel(const ConvArgs a, const float* __restrict__ wlin, int has_bias) {
+  __shared__ __attribute__((aligned(16))) float s_w[27 * 8 + 8];
+  for (int i = threadIdx.x; i < 27 * 8 + 1; i += 256) s_w[i] = (i < 216 || has_bias) ? wlin[i] : 0.f;
+  __syncthreads();
+  const int ygroups = (a.Ho + kC8YB - 1) / kC8YB;
+  const long long nthreads = (long long)a.B * a.Do * ygroups * a.Wo;
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nthreads) return;
+  const int x = (int)(t % a.Wo); t /= a.Wo;
+  const int yg = (int)(t % ygroups); t /= ygroups;
+  const int z = (int)(t % a.Do); const int b = (int)(t / a.Do);
+  const int y0 = yg * kC8YB;
+  int xs[3];
+  bool xok[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    int xi = x + dx - 1;
+    xok[dx] = a.wrap_w || (xi >= 0 && xi < a.W);
+    xs[dx] = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
+  }
+  float s[kC8YB];
+#pragma unroll
+  for (int o = 0; o < kC8YB; ++o) s[o] = 0.f;
+  for (int dz = 0; dz < 3; ++dz) {
+    const int zi = z + dz - 1;
+    if (zi < 0 || zi >= a.D) continue;
+#pragma unroll
+    for (int r = 0; r < kC8YB + 2; ++r) {
+      const int yi = y0 + r - 1;
+      if (yi < 0 || yi >= a.H) continue;
+      const float* rowp = a.in + (((long long)b * a.D + zi) * a.H + yi) * a.W * a.in_cs + a.in_coff;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (!xok[dx]) continue;
+        const float4 v0 = *reinterpret_cast<const float4*>(rowp + (long long)xs[dx] * a.in_cs);
+        const float4 v1 = *reinterpret_cast<const float4*>(rowp + (long long)xs[dx] * a.in_cs + 4);
+#pragma unroll
+        for (int o = 0; o < kC8YB; ++o) {
+          const int ky = r - o;                          // this row is tap ky of output o
+          if (ky < 0 || ky > 2) continue;
+          const float4 w0 = *reinterpret_cast<const float4*>(&s_w[((dz * 3 + ky) * 3 + dx) * 8]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&s_w[((dz * 3 + ky) * 3 + dx) * 8 + 4]);
+          float acc = s[o];
+          acc = fmaf(v0.x, w0.x, acc); acc = fmaf(v0.y, w0.y, acc); acc = fmaf(v0.z, w0.z, acc); acc = fmaf(v0.w, w0.w, acc);
+          acc = fmaf(v1.x, w1.x, acc); acc = fmaf(v1.y, w1.y, acc); acc = fmaf(v1.z, w1.z, acc); acc = fmaf(v1.w, w1.w, acc);
+          s[o] = acc;
+        }
+      }
+    }
+  }
+  const float bias = s_w[216];
+#pragma unroll
+  for (int o = 0; o < kC8YB; ++o) {
+    const int y = y0 + o;
+    if (y >= a.Ho) break;
+    const long long ov = (((long long)b * a.Do + z) * a.Ho + y) * a.Wo + x;
+    float v = s[o] + bias;
+    const float rr = a.residual ? a.residual[ov * a.res_cs + a.res_coff] : 0.f;
+    if (a.res_first) v += rr;
+    v = conv_act(a, v);
+    if (!a.res_first) v += rr;
+    a.out[ov * a.out_cs + a.out_coff] = v;
+  }
+}
+
 // Second half of the Cout == 1 convolution: out[p] = act(bias + sum_tap y[tap][p + tap]) where y[tap][q] =
 // <w[:, tap], x[q, :]> was produced by the pointwise MFMA pass in tap-major order (so a wave reads 64 consecutive
 // voxels of one row per tap; the channel-last form touched one 128-byte line per lane and tap: 975 -> ~100 us).
@@ -921,6 +992,13 @@ static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, fl
   if (Cout == 1) {
     const int lpv = ((Cin & 3) == 0 && Cin >= 32) ? 8 : 1;
     const float* wlin = packed + a_floats + a.cot_total * 32;
+    if (Cin == 8 && stride == 1 && !getenv("PGRF_CONV_NO_C8")) {
+      const long long threads = (long long)B * a.Do * ((a.Ho + kC8YB - 1) / kC8YB) * a.Wo;
+      hipLaunchKernelGGL(conv3d_cout1_c8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, wlin,
+                         has_bias ? 1 : 0);
+      PGRF_CHECK_LAUNCH("conv3d_cout1_c8");
+      return PGRF_OK;
+    }
     const long long threads = nvox * lpv;
     hipLaunchKernelGGL(conv3d_cout1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, wlin,
                        has_bias ? 1 : 0, lpv);

@@ -111,7 +111,11 @@ constexpr bool kSmall = false;
 constexpr bool kSmall = (kPrec == 0);
 #endif
 // not with 4 views: the padded tiles cost less there than the registers the 4x4 path adds (260 -> 162 spilled, 79.8 -> 78.3 ms)
+#ifdef PGRF_SMALL_V4
+template <int V> constexpr bool kSmallV = kSmall;
+#else
 template <int V> constexpr bool kSmallV = kSmall && V != 4;
+#endif
 
 // which LDS image a kernel instance uses (pgrf_layout.h)
 #ifdef PGRF_NO_FULL_IMG
@@ -141,7 +145,17 @@ template <int V> constexpr bool kRecomputeNf = kTwoWave<V> && V > 3;
 #ifndef PGRF_KT
 #define PGRF_KT 2
 #endif
-template <int V> constexpr bool kSlimImg = (PGRF_KT == 2) && (V == 2 || V == 3);
+// Experiment (-DPGRF_LDS_STATE, off by default): 4 views at two waves (f32) with the per-view state of one view PAIR in LDS
+// while the other pair is worked on (see "kLdsState" in render_pass_kernel) -- that needs the LDS the first weight chunks
+// would take, so those kernels then carry the slim image.  Measured in round 3 (profiles/r03_views4_lds_state.txt): spilled
+// registers 157 -> 57, HBM-side traffic of the launch 90 -> 41 GB, and the frame 78.3 -> 79.2 ms: the scratch traffic was
+// never the limiter (0.5 TB/s, absorbed next to a pipe that is issue-bound), the extra LDS instructions cost what it saved.
+#ifdef PGRF_LDS_STATE
+template <int V> constexpr bool kLdsState = (V == 4) && kTwoWave<V> && (kPrec == 0);
+#else
+template <int V> constexpr bool kLdsState = false;
+#endif
+template <int V> constexpr bool kSlimImg = ((PGRF_KT == 2) && (V == 2 || V == 3)) || kLdsState<V>;
 template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (kTwoWave<V> ? (kSlimImg<V> ? 3 : 0) : 2);
 // no image in the split-f16 mode (see above).  (Tried for > 2 views at two waves: image dropped in favour of parking the
 // first view group's prob_embed features through stage B — the register allocator answered with MORE spills, 170 -> 289.)
@@ -1073,19 +1087,6 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
   if constexpr (kHasImg<V>) __syncthreads();
   PGRF_TICK(0);   // ray generation
 
-  // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
-  stage_front<V, 0, kNT0<V>, DBG, GEN>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
-#ifdef PGRF_STAGE_TIMING
-                                           , t_prev
-#endif
-  );
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (V > kNT0<V>) stage_front<V, 2, V - 2, DBG, GEN>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
-#ifdef PGRF_STAGE_TIMING
-                                           , t_prev
-#endif
-  );
-  PGRF_TICK(1);   // stage A
   // Two-wave kernels: the direction differences and source colours of every view (7 registers per view) are next
   // needed in stage E; parked in LDS in between they free enough registers that NOTHING spills any more
   // (36 -> 0 spilled registers, 12 GB less scratch traffic per frame, 41.1 -> 38.6 ms).  -DPGRF_NO_PARK disables.
@@ -1094,16 +1095,55 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
 #else
   constexpr bool kPark = kTwoWave<V>;
 #endif
-  __shared__ float lds_park[kPark ? V * 7 : 1][256];
-  if constexpr (kPark) {
+  // (kLdsState: both lane halves hold the same values here, so one column per POINT is enough -- half the LDS)
+  constexpr int kParkCols = kLdsState<V> ? 128 : 256;
+  const int park_col = kLdsState<V> ? (wave * 32 + pl) : (int)threadIdx.x;
+  __shared__ float lds_park[kPark ? V * 7 : 1][kParkCols];
+  auto park_views = [&](int v0, int v1) {
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
+    for (int v = v0; v < v1; ++v) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) lds_park[v * 7 + c][threadIdx.x] = vs[v].dd[c];
+      for (int c = 0; c < 4; ++c) lds_park[v * 7 + c][park_col] = vs[v].dd[c];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) lds_park[v * 7 + 4 + c][threadIdx.x] = vs[v].rgb[c];
+      for (int c = 0; c < 3; ++c) lds_park[v * 7 + 4 + c][park_col] = vs[v].rgb[c];
     }
+  };
+  // ---- stage A: per-view front end, views in groups of <= 2 sharing the weight operand
+  stage_front<V, 0, kNT0<V>, DBG, GEN>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                           , t_prev
+#endif
+  );
+  // kLdsState (4 views, two waves per SIMD): between its production in stage A and its consumption in stages B / C the
+  // 16-register feature tile `fa` of a view pair is kept in LDS, and so is the pair's stage-C output until stages D / E read
+  // it -- the kernel then never holds more than ONE pair's tiles in registers, as the 2-view kernel does.  The compiler's
+  // own answer to the same pressure was 157-163 spilled registers = 616-640 B of scratch per lane, written and re-read once
+  // per wave: ~40 KB x 1 M waves per 512x1024 frame through L2 / the fabric.
+  //   stage A(pair 0) -> LDS | stage A(pair 1) | stage B reads pair 0 from LDS | stage C(pair 1) | pair 0 LDS -> registers,
+  //   pair 1's outputs -> the same LDS rows | stage C(pair 0) | stages D, E read pair 1 from LDS
+  __shared__ float lds_state[kLdsState<V> ? 32 : 1][kLdsState<V> ? 256 : 1];
+  if constexpr (kLdsState<V>) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) lds_state[v * 16 + j][threadIdx.x] = vs[v].fa[j];
+    if constexpr (kPark) park_views(0, 2);           // (and its directions / colours: not carried through pair 1's stage A)
   }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (V > kNT0<V>) stage_front<V, 2, V - 2, DBG, GEN>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                           , t_prev
+#endif
+  );
+  PGRF_TICK(1);   // stage A
+  if constexpr (kPark) park_views(kLdsState<V> ? 2 : 0, V);
+  // feature j of view v's tile: from the registers, or (kLdsState) from the LDS rows of the pair that is parked there
+  auto fa_at = [&](int v, int j, int parked_pair) -> float {
+    if constexpr (kLdsState<V>) {
+      if ((v >> 1) == parked_pair) return *(volatile float*)&lds_state[(v & 1) * 16 + j][threadIdx.x];
+    }
+    return vs[v].fa[j];
+  };
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage B: view statistics (ibrnet.py:112-116,339-342) and the view-shared part of base_fc.0
@@ -1129,7 +1169,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
     for (int j = 0; j < 17; ++j) {
       float xv[V];
 #pragma unroll
-      for (int v = 0; v < V; ++v) xv[v] = (j < 16) ? vs[v].fa[j < 16 ? j : 0] : (half ? vs[v].fb[1] : vs[v].fb[0]);
+      for (int v = 0; v < V; ++v) xv[v] = (j < 16) ? fa_at(v, j < 16 ? j : 0, 0) : (half ? vs[v].fb[1] : vs[v].fb[0]);
       float m0, v0, m1, v1;
       stats(xv, w0a, m0, v0);
       stats(xv, w1a, m1, v1);
@@ -1148,9 +1188,23 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
   // ---- stage C: per-view base_fc / vis_fc / vis_fc2
+  if constexpr (kLdsState<V>) {
+    stage_mid<V, 2, 2, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);          // pair 1 first: its inputs are in registers
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        vs[v].fa[j] = *(volatile float*)&lds_state[v * 16 + j][threadIdx.x];     // pair 0's inputs back into registers ...
+        *(volatile float*)&lds_state[v * 16 + j][threadIdx.x] = vs[2 + v].fa[j]; // ... pair 1's outputs into their rows
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_mid<V, 0, 2, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
+  } else {
   stage_mid<V, 0, kNT0<V>, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (V > kNT0<V>) stage_mid<V, 2, V - 2, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
+  }
   PGRF_TICK(3);   // stage C
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
@@ -1169,12 +1223,15 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
     float b33[1][33];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      float xr[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) xr[v] = fa_at(v, r, 1);
       float m = 0.f;
 #pragma unroll
-      for (int v = 0; v < V; ++v) m += vs[v].fa[r] * w2[v];
+      for (int v = 0; v < V; ++v) m += xr[v] * w2[v];
       float var = 0.f;
 #pragma unroll
-      for (int v = 0; v < V; ++v) { const float d = vs[v].fa[r] - m; var += w2[v] * (d * d); }
+      for (int v = 0; v < V; ++v) { const float d = xr[v] - m; var += w2[v] * (d * d); }
       b33[0][r] = m;
       b33[0][16 + r] = var;
     }
@@ -1347,12 +1404,19 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
 #pragma unroll
       for (int v = 0; v < V; ++v) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) vs[v].dd[c] = *(volatile float*)&lds_park[v * 7 + c][threadIdx.x];
+        for (int c = 0; c < 4; ++c) vs[v].dd[c] = *(volatile float*)&lds_park[v * 7 + c][park_col];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vs[v].rgb[c] = *(volatile float*)&lds_park[v * 7 + 4 + c][threadIdx.x];
+        for (int c = 0; c < 3; ++c) vs[v].rgb[c] = *(volatile float*)&lds_park[v * 7 + 4 + c][park_col];
       }
     }
     stage_rgb<V, 0, kNT0<V>>(p, LI, vs, lane, logit);
+    if constexpr (kLdsState<V>) {        // pair 1's stage-C outputs come back from LDS only now
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vs[2 + v].fa[j] = *(volatile float*)&lds_state[v * 16 + j][threadIdx.x];
+    }
     if constexpr (V > kNT0<V>) stage_rgb<V, 2, V - 2>(p, LI, vs, lane, logit);
     float mx = logit[0];
 #pragma unroll
