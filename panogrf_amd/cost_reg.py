@@ -269,5 +269,7 @@ class UNet2Reg(_RegBase):
 def build_unet3d(args, in_channels=32):
     """The `unet3d` branch of models/test_models.py:95-146."""
     if args.get('use_new_reg3dnet', False):
+        # (models/test_models.py:95-100: 64 input channels without group_wise -- the reference's default there never matches its
+        #  32-channel cost volume; the caller passes the channel count its volume really has)
         return CostRegNet(args, in_channels=in_channels)
     return UNet2Reg(in_channels=in_channels, cnn3d_num_layer=args.get('cnn3d_num_layer', 3))

@@ -163,14 +163,21 @@ class MVSDepthNet(nn.Module):
         for key, want in (('net', 'Equi'), ('contain_dnet', True)):
             if a.get(key, want) != want:
                 raise PgrfError(f"MVSDepthNet mirrors args['{key}'] = {want!r} only (got {a.get(key)!r})")
-        for key in ('mono_uncertainty', 'mono_uncert_tune', 'change_input', 'with_sin', 'wo_hdh', 'revise_range', 'group_wise',
-                    'mvs_uncertainty', 'wo_mono_feat'):
+        for key in ('mono_uncert_tune', 'change_input', 'with_sin', 'wo_hdh', 'mvs_uncertainty', 'wo_mono_feat'):
+            # (wo_hdh leaves the 5 guided planes alone: a D = 5 volume cannot pass the regularisers' three 2x poolings, in the
+            #  reference either -- it is not a runnable configuration)
             if a.get(key):
                 raise PgrfError(f"args['{key}'] is not implemented (no shipped configuration sets it)")
         if not a.get('use_depth_sampling', True) or a.get('out_type', 'depth') != 'depth':
             raise PgrfError("only use_depth_sampling=True, out_type='depth' are implemented")
         self.unet = Equi()
-        self.unet3d = build_unet3d(a)
+        # group_wise (pipeline3_model.py:849-853): the C = 32 cost channels are averaged in G groups before the regulariser,
+        # which the reference then builds for 64 // group_num input channels (models/test_models.py:95-100, CostRegNet only)
+        self.G = int(a['group_num']) if a.get('group_wise') and int(a.get('group_num', 1)) > 1 else 1
+        if a.get('group_wise') and a.get('use_new_reg3dnet'):
+            self.unet3d = build_unet3d(a, in_channels=64 // int(a['group_num']))
+        else:
+            self.unet3d = build_unet3d(a)
         self.decoders1 = _ConvBlock1x1(64, 1)
         self.decoders2 = nn.ModuleList([_ConvBlock2(64 + 32, 32, True, True), _ConvBlock2(32, 16, True, True),
                                         _ConvBlock2(16, 1, False, False)])
@@ -206,13 +213,22 @@ class MVSDepthNet(nn.Module):
             x = F.interpolate(x, (a['mono_height'], a['mono_width']), mode=a.get('interpolation_mode', 'bilinear'), align_corners=False)
             with torch.no_grad():
                 mono = self.d_net((x - self._im_mean) / self._im_std, self._cube_input(x), dnet=True)
-        mu = F.interpolate(mono['pred_depth'], [h, w], mode='bilinear').detach()
+        # mono_uncertainty: the mono net's 'pred' = [depth, sigma] takes the place of 'pred_depth' (pipeline3_model.py:660-663)
+        gm = F.interpolate(mono['pred'] if self.args.get('mono_uncertainty') else mono['pred_depth'], [h, w], mode='bilinear').detach()
         x_d3 = F.interpolate(mono['mono_feat'], [h, w], mode='bilinear')
-        return mu[:B, :1], x_d3[:B]
+        self.__dict__['_ref_sigma'] = gm[:B, 1:] if self.args.get('mono_uncertainty') else None
+        return gm[:B, :1], x_d3[:B]
+
+    def _regularise(self, cost_volume):
+        """channel-last cost volume [B,D,h,w,C] -> regularised [B,D,h,w,1] (pipeline3_model.py:847-856)."""
+        if self.args.get('group_wise'):                                   # mean over each group of C // G channels (:849-853)
+            Bv, Dv, hv, wv, Cv = cost_volume.shape
+            cost_volume = cost_volume.view(Bv, Dv, hv, wv, self.G, Cv // self.G).mean(-1)
+        return self.unet3d.forward_ndhwc(cost_volume)
 
     def _tail(self, cost_volume, x_d3, ref_mu, H, W):
         """3-D regulariser -> decoders -> depth (pipeline3_model.py:847-949)."""
-        reg = self.unet3d.forward_ndhwc(cost_volume)                      # [B,D,h,w,1]
+        reg = self._regularise(cost_volume)                               # [B,D,h,w,1]
         cost_reg = reg[..., 0]                                            # [B,D,h,w]: depth planes as channels
         d1 = F.interpolate(self.decoders1(cost_reg), scale_factor=4, mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
         x = torch.cat([cost_reg, x_d3], 1)
@@ -231,7 +247,28 @@ class MVSDepthNet(nn.Module):
         # guided planes are clamped to args min/max depth, the uniform planes span the call's range (:732, :799)
         if float(a['min_depth']) != float(min_depth) or float(a['max_depth']) != float(max_depth):
             raise PgrfError('args min_depth/max_depth must equal the mvs depth range of the call (as in every shipped cfg)')
-        return CV.build_depth_volume(ref_mu, self.k_list, float(a.get('fixed_sigma', 0.5)), float(min_depth), float(max_depth), 64)
+        if not (a.get('mono_uncertainty') or a.get('revise_range')):
+            return CV.build_depth_volume(ref_mu, self.k_list, float(a.get('fixed_sigma', 0.5)), float(min_depth), float(max_depth), 64)
+        # Switches no shipped configuration sets: the hypothesis set as the reference's own tensor expressions
+        # (pipeline3_model.py:718-733 guided planes with the mono net's sigma; :781-796 per-pixel uniform range), then the
+        # same concat + sort (:809-815).  The fused kernel above covers the shipped flags only.
+        lo, hi = float(a['min_depth']), float(a['max_depth'])
+        if a.get('mono_uncertainty'):
+            sig = torch.clamp(self.__dict__['_ref_sigma'], min=float(a['basic_sigma']))
+            planes = [torch.clamp(ref_mu + sig * float(k), min=lo, max=hi) for k in self.k_list]
+        else:
+            planes = [torch.clamp(ref_mu + float(k * a.get('fixed_sigma', 0.5)), min=lo, max=hi) for k in self.k_list]
+        n_depths = 64 - len(self.k_list)
+        B, _, h, w = ref_mu.shape
+        if a.get('revise_range'):
+            d_min = torch.clamp(ref_mu - float(a['fixed_dist']), min=lo)
+            d_max = torch.clamp(ref_mu + float(a['fixed_dist']), max=hi)
+            interval = (d_max - d_min) / (n_depths - 1)
+            vals = torch.arange(0, n_depths - 1, device=ref_mu.device).reshape(1, n_depths - 1, 1, 1)
+            d_centers = torch.cat([d_min, d_min + interval * vals], 1)    # (as the reference: d_min twice, d_max never reached)
+        else:
+            d_centers = torch.linspace(float(min_depth), float(max_depth), n_depths, device=ref_mu.device).reshape(1, n_depths, 1, 1).repeat(B, 1, h, w)
+        return torch.sort(torch.cat(planes + [d_centers], 1), dim=1)[0].contiguous()
 
     def estimate_depth_using_cost_volume(self, panos, rots, trans, min_depth=2.0, max_depth=100, mono=None):
         """panos [B,2,H,W,3] with index 0 = source, 1 = reference (pipeline3_model.py:571-590, :602-949)."""

@@ -150,7 +150,7 @@ class HipInitNet:
             dv = dn._hypotheses(ref_mu.contiguous(), c['mvs_min_depth'], c['mvs_max_depth'])
             feats = self.equi(pair.reshape(B * 2, 3, dh, dw)).view(B, 2, h, w, 32)
             vol = CV.calculate_cost_volume_erp(dn.args, feats, None, trans, rots, depth_volume=dv, cost_type='abs_diff')
-        reg = dn.unet3d.forward_ndhwc(vol)                                       # [B,D,h,w,1]
+        reg = dn._regularise(vol)                                                # [B,D,h,w,1]
         cat96 = _Map.empty(B, h, w, 96, d)
         cat96.buf[..., :64] = reg[..., 0].permute(0, 2, 3, 1)                    # depth planes become channels
         cat96.buf[..., 64:] = pack_map(x_d3)

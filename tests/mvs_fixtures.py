@@ -36,6 +36,20 @@ class StubMono(nn.Module):
         return {'pred_depth': 1.0 + 6.0 * torch.sigmoid(self.c3(h)), 'mono_feat': self.c2(h)}
 
 
+class StubMonoUncert(StubMono):
+    """The same stand-in with the output of a mono net trained with uncertainty (args mono_uncertainty):
+    'pred' = [depth, sigma] (pipeline3_model.py:660-661, :718-719)."""
+
+    def __init__(self):
+        super().__init__()
+        self.c4 = nn.Conv2d(8, 1, 3, 1, 1)
+
+    def forward(self, erp, cube=None, dnet=True):
+        h = torch.tanh(self.c1(erp))
+        depth = 1.0 + 6.0 * torch.sigmoid(self.c3(h))
+        return {'pred_depth': depth, 'pred': torch.cat([depth, 0.02 + 0.6 * torch.sigmoid(self.c4(h))], 1), 'mono_feat': self.c2(h)}
+
+
 def seeded_state(shapes, seed):
     """Deterministic values for every entry of a state_dict given as [(name, shape)], in order."""
     g = torch.Generator().manual_seed(seed)
@@ -67,8 +81,8 @@ def key_shapes(blob):
     return res
 
 
-def load():
-    z = np.load(os.path.join(GOLDEN, 'mvs_fixtures.npz'))
+def load(name='mvs_fixtures'):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
     out = {}
     for k in z.files:
         grp, name = k.split('.', 1)

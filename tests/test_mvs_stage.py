@@ -280,3 +280,28 @@ def test_hip_init_net_multiview_vs_reference():
     assert any(k[0] == 'init_net_hip' for k in net._graphs)
     assert max_abs(got['ray_feats'], out['ray_feats']) < 1e-5 * max(1.0, float(tor['ray_feats'].abs().max()))
     assert max_abs(got['mvs_depth'], out['mvs_depth']) < 1e-5 * max(1.0, float(want.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,extra,mono', [('gw', dict(group_wise=True, group_num=8, use_new_reg3dnet=True), 'plain'),
+                                            ('rr', dict(revise_range=True, fixed_dist=1.0), 'plain'),
+                                            ('mu', dict(mono_uncertainty=True, basic_sigma=0.1, relaxation_factor=1.0), 'uncert')])
+def test_unshipped_mvs_switches_vs_reference(tag, extra, mono):
+    """group_wise / revise_range / mono_uncertainty (SURVEY.md 8(b) key list; pipeline3_model.py:849-853, :781-796, :718-731)
+    against the reference's own estimate_depth_using_cost_volume_v3_erp (tests/golden/make_mvs_flag_fixtures.py)."""
+    from panogrf_amd.mvs import MVSDepthNet
+    fx = MF.load('mvs_flag_fixtures')
+    t, inp = fx[tag], fx['in']
+    args = dict(_args(), inplace_abn=False, use_wrap_padding=True, **extra)
+    net = MVSDepthNet(args, d_net=MF.StubMonoUncert() if mono == 'uncert' else MF.StubMono()).eval()
+    shapes = MF.key_shapes(t['keys'])
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == dict(shapes)       # reference key names and shapes
+    net.load_state_dict(MF.seeded_state(shapes, int(t['seed'][0])), strict=True)
+    net = net.cuda()
+    with torch.no_grad():
+        ret = net.estimate_depth_using_cost_volume_v3_erp(inp['panos'].cuda(), inp['rots'].cuda(), inp['trans'].cuda(),
+                                                          args['mvs_min_depth'], args['mvs_max_depth'])
+    assert max_abs(ret['mono_depth_ref'].cpu(), t['mono_depth_ref']) < 1e-5
+    cr = t['cost_reg']
+    assert max_abs(ret['cost_reg'].cpu(), cr) < 1e-4 * max(1.0, float(cr.abs().max()))
+    assert max_abs(ret['depth'].cpu(), t['depth']) < 1e-3 * max(1.0, float(t['depth'].abs().max()))
