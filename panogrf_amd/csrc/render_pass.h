@@ -147,7 +147,7 @@ template <int V> constexpr bool kRecomputeNf = kTwoWave<V> && V > 3;
 #endif
 // Experiment (-DPGRF_LDS_STATE, off by default): 4 views at two waves (f32) with the per-view state of one view PAIR in LDS
 // while the other pair is worked on (see "kLdsState" in render_pass_kernel) -- that needs the LDS the first weight chunks
-// would take, so those kernels then carry the slim image.  Measured in round 3 (profiles/r03_views4_lds_state.txt): spilled
+// would take, so those kernels then carry the slim image.  Measured in round 3 (profiles/r03_dead_ends.txt): spilled
 // registers 157 -> 57, HBM-side traffic of the launch 90 -> 41 GB, and the frame 78.3 -> 79.2 ms: the scratch traffic was
 // never the limiter (0.5 TB/s, absorbed next to a pipe that is issue-bound), the extra LDS instructions cost what it saved.
 #ifdef PGRF_LDS_STATE
