@@ -66,21 +66,29 @@ def allgather_rows(shard, H, W, group=None):
 # ---- MVS stage: one cost volume per reference view (network/init_net.py:164-171 builds B = rfn pairs), each
 # independent of the others -> shard BY REFERENCE VIEW, then all-gather the per-view result.
 
-def view_shard(rank, world, n_views):
-    """Reference views handled by `rank`: round-robin, so 2 or 4 views spread over the first 2 or 4 ranks and the
-    remaining ranks (a node has 8) idle through the MVS stage."""
-    return list(range(rank, n_views, world))
+def view_shard(rank, world, n_views, offset=0):
+    """Reference views handled by `rank`: view v belongs to rank (v + offset) % world -- round-robin, so 2 or 4 views spread
+    over 2 or 4 ranks and the remaining ranks (a node has 8) idle through that stage.  `offset` moves the owners: the
+    per-frame image encoder is dealt with offset = n_views, i.e. to the ranks the MVS stage leaves idle (encoder_offset)."""
+    return [v for v in range(n_views) if (v + offset) % world == rank]
 
 
-def allgather_views(local, n_views, group=None):
-    """local [len(view_shard(rank)), ...] of every rank -> [n_views, ...] in view order on every rank.  Ranks own
-    different numbers of views (including none), so every rank contributes ceil(n_views/world) padded slots."""
+def encoder_offset(world, n_views):
+    """Owner offset of the per-frame image encoder's views: the MVS stage occupies ranks 0..n_views-1 (one cost volume per
+    reference view), so with at least 2 * n_views ranks the encoder images go to ranks n_views..2*n_views-1 and both stages
+    run side by side; with fewer ranks they share the MVS ranks (offset 0)."""
+    return n_views if world >= 2 * n_views else 0
+
+
+def allgather_views(local, n_views, group=None, offset=0):
+    """local [len(view_shard(rank, offset=offset)), ...] of every rank -> [n_views, ...] in view order on every rank.  Ranks
+    own different numbers of views (including none), so every rank contributes ceil(n_views/world) padded slots."""
     world = _world(group)
     if world == 1:
         return local
     world = abs(world)
     if dist.get_backend(group) == 'gloo' and local.is_cuda:      # test-only: ranks sharing one GPU
-        return allgather_views(local.cpu(), n_views, group).to(local.device)
+        return allgather_views(local.cpu(), n_views, group, offset).to(local.device)
     slots = -(-n_views // world)
     pad = torch.zeros((slots,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
@@ -89,7 +97,7 @@ def allgather_views(local, n_views, group=None):
     full = full.view((world, slots) + tuple(local.shape[1:]))
     out = [None] * n_views
     for g in range(world):
-        for i, v in enumerate(view_shard(g, world, n_views)):
+        for i, v in enumerate(view_shard(g, world, n_views, offset)):
             out[v] = full[g, i]
     return torch.stack(out, 0)
 

@@ -305,10 +305,68 @@ class NeuralRayBaseRenderer(nn.Module):
         g.replay()
         return tuple(o.clone() for o in outs)
 
+    def _enc_shard(self, imgs):
+        """Multi-GPU: the image encoder runs once per SOURCE view, each independent of the others, so under a
+        process group the views are dealt to the ranks -- to the ranks the MVS stage leaves idle when the node has at least
+        2 * rfn of them (panogrf_amd.dist.encoder_offset), so that the two stages run side by side -- and the feature maps
+        (4 MB per 512x1024 view) are all-gathered; the small visibility encoder stays replicated.  -> (mine, offset) or None.
+        cfg['hip_shard_encoders']=False keeps every rank on all views."""
+        import torch.distributed as tdist
+        if not (self.cfg.get('hip_shard_encoders', True) and imgs.is_cuda and not torch.is_grad_enabled() and
+                tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1 and imgs.shape[0] > 1):
+            return None
+        from . import dist as D
+        rank, world, n = tdist.get_rank(), tdist.get_world_size(), imgs.shape[0]
+        off = D.encoder_offset(world, n)
+        return D.view_shard(rank, world, n, off), off
+
+    def _encode_sharded(self, imgs, ray_feats, shard):
+        """Image encoder on this rank's views only (started early on a side stream when the MVS stage runs in front), one
+        all-gather of the feature maps, visibility encoder on every rank."""
+        from . import dist as D
+        mine, off = shard
+        dev = imgs.device
+        n, _, H, W = imgs.shape
+        enc = self._encoder_fn(imgs)
+        hip = enc != self._torch_encoders
+        early = self.__dict__.pop('_early_feats', None)
+        if early is not None and early[0] is imgs:
+            local, side = early[1], early[2]
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+                if local.numel():
+                    local.record_stream(torch.cuda.current_stream(dev))
+        else:
+            local = self._encode_local_views(imgs, mine)
+        feats = D.allgather_views(local.contiguous(), n, offset=off)
+        use_graph = self.cfg.get('hip_graph_encoders', True)
+        vis = (lambda rf, f: (enc.vis_encoder(rf, f.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2),)) if hip else \
+              (lambda rf, f: (self.vis_encoder(rf, f),))
+        if use_graph:
+            return feats, self._graphed('enc_vis_hip' if hip else 'enc_vis_torch', vis, (ray_feats.contiguous(), feats), modules=(self.vis_encoder,))[0]
+        return feats, vis(ray_feats.contiguous(), feats)[0]
+
+    def _encode_local_views(self, imgs, mine):
+        """image_encoder(imgs[mine]) -> [len(mine),32,H/4,W/4] (contiguous NCHW; an empty tensor for a rank without views)."""
+        dev = imgs.device
+        n, _, H, W = imgs.shape
+        if not mine:
+            return torch.zeros(0, 32, H // 4, W // 4, device=dev)
+        enc = self._encoder_fn(imgs)
+        hip = enc != self._torch_encoders
+        sub = imgs[torch.as_tensor(mine, device=dev)].contiguous()
+        img_fn = (lambda x: (enc.image_encoder(x).permute(0, 3, 1, 2).contiguous(),)) if hip else (lambda x: (self.image_encoder(x),))
+        if self.cfg.get('hip_graph_encoders', True):
+            return self._graphed('enc_img_hip_l' if hip else 'enc_img_torch_l', img_fn, (sub,), modules=(self.image_encoder,))[0]
+        return img_fn(sub)[0]
+
     def _encode(self, imgs, ray_feats):
         """The two per-frame 2-D encoders (network/renderer.py:639-642).  On a GPU their ~70 small kernels are
         launch-bound (3.4 ms eager for 2x512x1024), so the launch sequence is captured once per input shape into a
         hipGraph and replayed (1.9 ms); cfg['hip_graph_encoders']=False keeps eager launches."""
+        shard = self._enc_shard(imgs)
+        if shard is not None:
+            return self._encode_sharded(imgs, ray_feats, shard)
         enc = self._encoder_fn(imgs)
         if not (imgs.is_cuda and self.cfg.get('hip_graph_encoders', True)) or torch.is_grad_enabled():
             return enc(imgs, ray_feats)
@@ -367,6 +425,20 @@ class NeuralRayBaseRenderer(nn.Module):
         produces, and both are chains of small launches: start the encoder's hipGraph on a side stream so that it runs next
         to the MVS stage; _encode() joins it.  (GPU, no autograd, graphs enabled; otherwise a no-op.)"""
         if not (imgs.is_cuda and self.cfg.get('hip_graph_encoders', True) and self.cfg.get('hip_overlap_encoders', True)) or torch.is_grad_enabled():
+            return
+        shard = self._enc_shard(imgs)
+        if shard is not None:       # multi-GPU: this rank's share of the views only (none on the ranks busy with the MVS stage)
+            dev = imgs.device
+            if not shard[0]:
+                self.__dict__['_early_feats'] = (imgs, self._encode_local_views(imgs, []), None)
+                return
+            side = self.__dict__.get('_enc_stream')
+            if side is None or side.device != dev:
+                side = self.__dict__['_enc_stream'] = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                local = self._encode_local_views(imgs, shard[0])
+            self.__dict__['_early_feats'] = (imgs, local, side)
             return
         enc = self._encoder_fn(imgs)
         hip = enc != self._torch_encoders

@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_bench_multirank.py::test_renderer_module_shards_rays_and_views: launched by torch.distributed.run
 with 2 ranks over gloo on ONE GPU; renders through the renderer MODULE with ray / view sharding and compares, on every rank,
-with the same call under cfg hip_shard_rays / hip_shard_views = False."""
+with the same call under cfg hip_shard_rays / hip_shard_views / hip_shard_encoders = False.  With 4 ranks the image-encoder
+views go to ranks 2 and 3 (the MVS stage keeps 0 and 1 busy) and ranks render a quarter of the rays each."""
 import os
 import sys
 
@@ -34,7 +35,7 @@ def main():
                   imgs_info_to_torch(build_render_imgs_info(pose(0.0), (H, W), [0.5, 15.0]), 'cuda'))
     outs = {}
     for sharded in (True, False):
-        net.cfg['hip_shard_rays'] = net.cfg['hip_shard_views'] = sharded
+        net.cfg['hip_shard_rays'] = net.cfg['hip_shard_views'] = net.cfg['hip_shard_encoders'] = sharded
         ref, src, que = mk()
         with torch.no_grad():
             outs[sharded] = net({'que_imgs_info': que, 'ref_imgs_info': ref, 'src_imgs_info': src, 'eval': True})

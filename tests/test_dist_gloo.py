@@ -53,24 +53,24 @@ def test_allgather_equal_tiles_world4():
     _run(4, 16, 5)
 
 
-def _view_worker(rank, world, port, n_views, ret):
+def _view_worker(rank, world, port, n_views, ret, offset=0):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from panogrf_amd import dist as D
-    mine = D.view_shard(rank, world, n_views)
+    mine = D.view_shard(rank, world, n_views, offset)
     local = torch.stack([torch.full((3, 4), float(v)) + torch.arange(4.0) for v in mine], 0) if mine else torch.zeros(0, 3, 4)
-    full = D.allgather_views(local, n_views)
+    full = D.allgather_views(local, n_views, offset=offset)
     exp = torch.stack([torch.full((3, 4), float(v)) + torch.arange(4.0) for v in range(n_views)], 0)
     ret[rank] = torch.equal(full, exp)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run_views(world, n_views):
+def _run_views(world, n_views, offset=0):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_view_worker, args=(world, _free_port(), n_views, ret), nprocs=world, join=True)
+    mp.spawn(_view_worker, args=(world, _free_port(), n_views, ret, offset), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)), dict(ret)
 
 
@@ -119,3 +119,23 @@ def test_allgather_rays_world2_ragged_and_bool():
         assert all(ret[r] for r in range(2)), dict(ret)
     from panogrf_amd import dist as D
     assert [D.ray_shard(g, 3, 10) for g in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+def test_encoder_views_go_to_the_ranks_the_mvs_stage_leaves_idle():
+    """panogrf_amd.dist.encoder_offset / view_shard(offset): with >= 2 * rfn ranks the image-encoder views land on ranks
+    rfn..2*rfn-1 (disjoint from the MVS stage's ranks 0..rfn-1), otherwise they share them; always a partition."""
+    from panogrf_amd import dist as D
+    for world in (2, 3, 4, 8):
+        for nv in (2, 4):
+            off = D.encoder_offset(world, nv)
+            owners = {v: [r for r in range(world) if v in D.view_shard(r, world, nv, off)] for v in range(nv)}
+            assert all(len(o) == 1 for o in owners.values()), (world, nv, owners)
+            mvs = {v: [r for r in range(world) if v in D.view_shard(r, world, nv)][0] for v in range(nv)}
+            if world >= 2 * nv:
+                assert off == nv and not set(mvs.values()) & {o[0] for o in owners.values()}, (world, nv)
+            else:
+                assert off == 0
+
+
+def test_allgather_views_world4_with_owner_offset():
+    _run_views(4, 2, offset=2)       # views owned by ranks 2 and 3; ranks 0 and 1 contribute empty shards

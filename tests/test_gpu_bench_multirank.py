@@ -51,14 +51,16 @@ def test_bench_two_ranks_cost_volume_sharded_by_view():
     assert d['cost_volume_stage']['view_shards'] == 2 and d['cost_volume_stage']['ms_per_step'] > 0
 
 
-def test_renderer_module_shards_rays_and_views():
+@pytest.mark.parametrize('ranks', [2, 4])
+def test_renderer_module_shards_rays_and_views(ranks):
     """`renderer(data)` under a process group: rays split over the ranks + one all-gather per output, the MVS stage split by
-    reference view -- the same result as the unsharded call (tests/mp_render_shard.py, 2 ranks, gloo)."""
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29521', os.path.join(ROOT, 'tests', 'mp_render_shard.py')]
+    reference view, the image encoder by source view on the ranks the MVS stage leaves idle -- the same
+    result as the unsharded call (tests/mp_render_shard.py, 2 and 4 ranks, gloo, one GPU)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
+           '--master-port', str(29521 + ranks), os.path.join(ROOT, 'tests', 'mp_render_shard.py')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
-    assert r.stdout.count('sharded == unsharded') == 2
+    assert r.stdout.count('sharded == unsharded') == ranks
 
 
 def test_rccl_collectives_execute_with_one_rank():
