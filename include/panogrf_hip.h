@@ -155,6 +155,35 @@ int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int flags, const
                      const float* depth, int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ training: backward of one pass --- */
+/* Upstream gradients of one pass's outputs (any pointer may be NULL = zero): what the reference's losses differentiate
+ * (network/loss.py: RenderLoss on pixel_colors_nr, DepthLoss on render_depth, the consistency terms on hit_prob_nr). */
+typedef struct PgrfPassGrad {
+  const float* pixel_colors;   /* [rn,3]    */
+  const float* render_depth;   /* [rn]      */
+  const float* hit_prob;       /* [rn,dn]   */
+  const float* colors;         /* [rn,dn,3] */
+  const float* density;        /* [rn,dn]   */
+} PgrfPassGrad;
+
+/* Bytes of scratch pgrf_render_pass_backward needs (every activation of a staged forward + its gradient: ~9 KB per
+ * (ray, sample, source view)). */
+size_t pgrf_render_pass_backward_workspace_bytes(int rfn, int rn, int dn);
+
+/* Backward of pgrf_render_pass (network/renderer.py:223-304 under autograd, as the reference's trainer runs it): the forward is
+ * REMATERIALISED stage by stage (the fused kernel keeps no activations), then differentiated in reverse.
+ *   raw_dev    pgrf_raw_count() DEVICE pointers to the pass's weights in the reference's state_dict layout ([out,in] row-major
+ *              Linear weights, biases; order = pgrf_raw_name(i); vis_decoder entries may be NULL without use_vis)
+ *   g_raw_dev  the same table for the gradients, ACCUMULATED (+=) into caller-zeroed buffers; NULL entries are skipped
+ *   g_img_feats / g_ray_feats   gradients of the channel-last source maps of `frame` ([rfn,hf,wf,32] / [rfn,hr,wr,32]),
+ *              accumulated; NULL = not wanted.  Depths, poses and source colours get no gradient (the reference detaches the
+ *              importance sampler's inputs, renderer.py:437).
+ *   fwd_out    optional: the staged forward's own outputs (must equal pgrf_render_pass's to round-off; used by the tests) */
+int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_dev, int n_raw, int use_vis, const float* coords,
+                              const float* depth, int rn, int dn, const PgrfPassGrad* grad, float* const* g_raw_dev,
+                              float* g_img_feats, float* g_ray_feats, const PgrfPassOut* fwd_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* `render_c2f_all` (network/renderer.py:484-518): one composite over the sorted union of the
  * coarse and fine samples.  Inputs [rn,dn_c]/[rn,dn_f]; outputs sized dn_c+dn_f. */
 int pgrf_merge_c2f(const float* depth_c, const float* colors_c, const float* density_c, int dn_c,

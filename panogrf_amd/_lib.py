@@ -36,6 +36,11 @@ class PgrfPassOut(C.Structure):
                 ("colors", C.c_void_p), ("density", C.c_void_p), ("nan_flag", C.c_void_p), ("render_uncert", C.c_void_p)]
 
 
+class PgrfPassGrad(C.Structure):
+    _fields_ = [("pixel_colors", C.c_void_p), ("render_depth", C.c_void_p), ("hit_prob", C.c_void_p),
+                ("colors", C.c_void_p), ("density", C.c_void_p)]
+
+
 class PgrfPassDebug(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("px", "depth_v", "ddiff", "vis", "hit", "ray_feats", "rgb", "img_feats",
                                           "neuray", "base_x", "geo", "attn")]
@@ -67,6 +72,10 @@ SYMBOLS = {
     "pgrf_render_pass": (C.c_int, [C.POINTER(PgrfFrame), _P, C.c_int, _P, _P, C.c_int, C.c_int,
                                    C.POINTER(PgrfPassOut), C.POINTER(PgrfPassDebug), _P, C.c_size_t, _P]),
     "pgrf_merge_c2f": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.POINTER(PgrfPassOut), _P]),
+    "pgrf_render_pass_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "pgrf_render_pass_backward": (C.c_int, [C.POINTER(PgrfFrame), C.POINTER(_P), C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
+                                            C.POINTER(PgrfPassGrad), C.POINTER(_P), _P, _P, C.POINTER(PgrfPassOut), _P,
+                                            C.c_size_t, _P]),
     "pgrf_depth_hypotheses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, _P,
                                         C.c_int, _P, _P]),
     "pgrf_cost_volume_erp": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

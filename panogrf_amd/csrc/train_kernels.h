@@ -1,0 +1,562 @@
+// Device kernels of the training-mode backward pass (train_pass.hip): generic row-major GEMMs for the Linear layers, the
+// activation derivatives, and forward / backward kernels of every non-Linear stage of one network pass.  Plain fp32 VALU
+// code, one thread (or one wave) per sample point: training batches are 512-2048 rays, three orders of magnitude below the
+// inference frame the fused kernel (render_pass.h) is built for, so clarity wins over MFMA tiling here.
+//
+// Reference semantics: network/dist_decoder.py:6-51,109-140 (compute_prob), network/ibrnet.py:7-27,52-116,315-373,
+// network/aggregate_net.py:41-89, network/renderer.py:210-219,291-304; every kernel cites what it differentiates.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ray_dir.h"
+
+namespace pgrf {
+namespace train {
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[M,N] (=|+=) op(A)[M,K] * op(B)[K,N], row-major with leading dimensions; 64x64 tile per 256-thread block, 4x4 per thread.
+//   TA: A is stored [K,M] (lda = row stride of that storage); TB: B is stored [N,K].
+//   Split over K by gridDim.z with atomicAdd (ATOMIC) for the weight gradients, whose K is the number of sample points.
+template <bool TA, bool TB, bool ATOMIC>
+__global__ void __launch_bounds__(256) gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                   float* __restrict__ C, int ldc, int M, int N, int K, int accumulate, int kchunk) {
+  __shared__ float sA[16][64 + 1], sB[16][64 + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  float acc[4][4] = {};
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+      const int kk = TA ? i / 64 : i % 16, mm = TA ? i % 64 : i / 16;      // coalesced along the storage's fast axis
+      const int gm = m0 + mm, gk = k0 + kk;
+      sA[kk][mm] = (gm < M && gk < kend) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
+    }
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+      const int kk = TB ? i % 16 : i / 64, nn = TB ? i / 16 : i % 64;
+      const int gn = n0 + nn, gk = k0 + kk;
+      sB[kk][nn] = (gn < N && gk < kend) ? (TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = sA[kk][ty * 4 + i]; b[i] = sB[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gm = m0 + ty * 4 + i, gn = n0 + tx * 4 + j;
+      if (gm < M && gn < N) {
+        float* c = C + (size_t)gm * ldc + gn;
+        if (ATOMIC) atomicAdd(c, acc[i][j]);
+        else *c = accumulate ? *c + acc[i][j] : acc[i][j];
+      }
+    }
+}
+
+// activations of the per-point MLPs; the derivative is written in terms of the OUTPUT y (nothing else is stored)
+enum Act { ACT_NONE = 0, ACT_ELU, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SOFTPLUS_B };   // _B: softplus + 0.05 (AddBias)
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case ACT_RELU: return fmaxf(x, 0.f);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    case ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+    case ACT_SOFTPLUS_B: return (x > 20.f ? x : log1pf(expf(x))) + 0.05f;
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_grad(float y, int act) {
+  switch (act) {
+    case ACT_ELU: return y > 0.f ? 1.f : y + 1.f;                 // d/dx (e^x - 1) = e^x = y + 1
+    case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case ACT_SIGMOID: return y * (1.f - y);
+    case ACT_SOFTPLUS: return 1.f - expf(-y);                      // sigmoid(x) = 1 - e^{-softplus(x)}
+    case ACT_SOFTPLUS_B: return 1.f - expf(-(y - 0.05f));
+    default: return 1.f;
+  }
+}
+
+// Y[r, c] = act(Y[r, c] + bias[c])  (epilogue of the forward GEMM)
+__global__ void bias_act_kernel(float* __restrict__ Y, int ldy, const float* __restrict__ bias, long rows, int cols, int act) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols; const int c = (int)(i % cols);
+    float* y = Y + r * ldy + c;
+    *y = act_fwd(*y + (bias ? bias[c] : 0.f), act);
+  }
+}
+// dY[r, c] *= act'(Y[r, c]);  gbias[c] += sum_r dY[r, c]   (block partial sums, then atomics)
+__global__ void __launch_bounds__(256) act_bwd_kernel(float* __restrict__ dY, int lddy, const float* __restrict__ Y, int ldy, long rows,
+                                                      int cols, int act, float* __restrict__ gbias) {
+  __shared__ float s_b[256];
+  for (int c = threadIdx.x; c < cols && c < 256; c += blockDim.x) s_b[c] = 0.f;
+  __syncthreads();
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols; const int c = (int)(i % cols);
+    const float d = dY[r * lddy + c] * act_grad(Y[r * ldy + c], act);
+    dY[r * lddy + c] = d;
+    if (gbias) atomicAdd(&s_b[c], d);
+  }
+  __syncthreads();
+  if (gbias)
+    for (int c = threadIdx.x; c < cols && c < 256; c += blockDim.x)
+      if (s_b[c] != 0.f) atomicAdd(&gbias[c], s_b[c]);
+}
+
+// dst[r, dc + c] (=|+=) src[r, sc + c] * scale  for c < cols: column-slice copies between concatenated buffers
+__global__ void slice_kernel(float* __restrict__ dst, int ldd, int dc, const float* __restrict__ src, int lds, int sc, long rows, int cols,
+                             int accumulate) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols; const int c = (int)(i % cols);
+    const float v = src[r * lds + sc + c];
+    float* d = dst + r * ldd + dc + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// geometry of every (point, view): projection into the source ERP (render_ops.py:158-209, spt_utils.py:128-192), bilinear tap
+// setups (ops.py:32-52, grid_sample border padding), ray-direction difference (aggregate_net.py:8-14), gathered source colour,
+// and per point the interval half-widths in normalised inverse depth (render_ops.py:110-122).  Constants w.r.t. every
+// trainable quantity: computed once, used by the forward recompute and by the gather backward.
+struct Taps { int o[4]; float w[4]; };
+__device__ __forceinline__ Taps tap_setup(float xn, float yn, int fh, int fw, bool align) {
+  float ix, iy;
+  if (align) { ix = (xn + 1.f) / 2.f * (float)(fw - 1); iy = (yn + 1.f) / 2.f * (float)(fh - 1); }
+  else { ix = ((xn + 1.f) * (float)fw - 1.f) / 2.f; iy = ((yn + 1.f) * (float)fh - 1.f) / 2.f; }
+  ix = fminf(fmaxf(ix, 0.f), (float)(fw - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(fh - 1));
+  const float fx0 = floorf(ix), fy0 = floorf(iy), fx1 = fx0 + 1.f, fy1 = fy0 + 1.f;
+  Taps t;
+  t.w[0] = (fx1 - ix) * (fy1 - iy); t.w[1] = (ix - fx0) * (fy1 - iy); t.w[2] = (fx1 - ix) * (iy - fy0); t.w[3] = (ix - fx0) * (iy - fy0);
+  const int x0 = (int)fx0, y0 = (int)fy0, x1 = min(x0 + 1, fw - 1), y1 = min(y0 + 1, fh - 1);
+  t.o[0] = y0 * fw + x0; t.o[1] = y0 * fw + x1; t.o[2] = y1 * fw + x0; t.o[3] = y1 * fw + x1;
+  return t;
+}
+
+struct GeomOut {
+  int* tap_rf_o; float* tap_rf_w;     // [PV,4] each
+  int* tap_if_o; float* tap_if_w;
+  float* rgb;                          // [PV,3]
+  float* dd;                           // [PV,4]
+  float* depth_v;                      // [PV]
+  float* hw;                           // [P,2] near / far half width
+};
+
+__global__ void geometry_kernel(const PassArgs a, int dn, int V, GeomOut o) {
+  const long PV = (long)a.rn * dn * V;
+  const long pv = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pv >= PV) return;
+  const int v = (int)(pv % V);
+  const long p = pv / V;
+  const int ray = (int)(p / dn), s = (int)(p % dn);
+  float wx, wy, wz;
+  ray_direction<true>(a, ray, wx, wy, wz);
+  const float* drow = a.depth + (size_t)ray * dn;
+  const float td = drow[s];
+  const float P0 = a.c2w[3] + wx * td, P1 = a.c2w[7] + wy * td, P2 = a.c2w[11] + wz * td;
+  const float wn = sqrtf(wx * wx + wy * wy + wz * wz);
+  const float q0 = -wx / wn, q1 = -wy / wn, q2 = -wz / wn;
+  if (v == 0) {
+    const float qn = -1.f / a.que_near, qf = -1.f / a.que_far;
+    const float d_c = (-1.f / td - qn) / (qf - qn);
+    const float d_p = (-1.f / drow[max(s - 1, 0)] - qn) / (qf - qn);
+    const float d_n = (-1.f / drow[min(s + 1, dn - 1)] - qn) / (qf - qn);
+    const float dist_c = (s == dn - 1) ? 1e6f : d_n - d_c;
+    const float dist_p = (s == 0) ? dist_c : d_c - d_p;
+    o.hw[p * 2] = dist_p / 2.f;
+    o.hw[p * 2 + 1] = dist_c / 2.f;
+  }
+  const float* M = a.w2c + v * 12;
+  const float cx = M[0] * P0 + M[1] * P1 + M[2] * P2 + M[3];
+  const float cy = M[4] * P0 + M[5] * P1 + M[6] * P2 + M[7];
+  const float cz = M[8] * P0 + M[9] * P1 + M[10] * P2 + M[11];
+  const float r = sqrtf(cx * cx + cy * cy + cz * cz);
+  float px, py;
+  if (a.dataset == PGRF_DATASET_M3D) {
+    float th = atan2f(cz, cx) + PGRF_HALF_PI_F;
+    if (th < 0.f) th += PGRF_TWO_PI_F;
+    const float ph = acosf(cy / (r + 1e-5f));
+    px = th / PGRF_TWO_PI_F * (float)(a.W - 1);
+    py = ph / PGRF_PI_F * (float)(a.H - 1);
+  } else if (a.dataset == PGRF_DATASET_REPLICA_TEST) {
+    const float th = atan2f(cx, cz), ph = -asinf(cy / r);
+    px = (float)((double)(a.W - 1) / (2.0 * 3.14159265358979323846)) * (th + PGRF_PI_F);
+    py = (float)((double)(a.H - 1) / 3.14159265358979323846) * (-ph + PGRF_HALF_PI_F);
+  } else if (a.dataset == PGRF_DATASET_RESIDENTIAL) {
+    float th = -atan2f(-cz, cx);
+    const float ph = asinf(cy / r);
+    if (th > PGRF_HALF_PI_F && th <= PGRF_TWO_PI_F) th -= PGRF_TWO_PI_F;
+    px = (0.15915494309189535f * th + 0.75f) * (float)(a.W - 1);
+    py = (0.5f - ph / PGRF_PI_F) * (float)(a.H - 1);
+  } else {
+    float th = atan2f(cy, cx);
+    const float ph = acosf(cz / r);
+    if (th < 0.f) th += PGRF_TWO_PI_F;
+    px = (float)(a.W - 1) * (1.f - th / PGRF_TWO_PI_F);
+    py = ph * (float)(a.H - 1) / PGRF_PI_F;
+  }
+  o.depth_v[pv] = r;
+  const float ccx = -(M[0] * M[3] + M[4] * M[7] + M[8] * M[11]);
+  const float ccy = -(M[1] * M[3] + M[5] * M[7] + M[9] * M[11]);
+  const float ccz = -(M[2] * M[3] + M[6] * M[7] + M[10] * M[11]);
+  float dx = P0 - ccx, dy = P1 - ccy, dz = P2 - ccz;
+  const float dn_ = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-5f);
+  dx = -dx / dn_; dy = -dy / dn_; dz = -dz / dn_;
+  o.dd[pv * 4 + 0] = dx - q0; o.dd[pv * 4 + 1] = dy - q1; o.dd[pv * 4 + 2] = dz - q2;
+  o.dd[pv * 4 + 3] = dx * q0 + dy * q1 + dz * q2;
+  const float xn = px / (float)(a.W - 1) * 2.f - 1.f, yn = py / (float)(a.H - 1) * 2.f - 1.f;
+  const Taps trf = tap_setup(xn, yn, a.hr, a.wr, a.hr == a.H && a.wr == a.W);
+  const Taps tif = tap_setup(xn, yn, a.hf, a.wf, a.hf == a.H && a.wf == a.W);
+  const Taps tim = tap_setup(xn, yn, a.H, a.W, true);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o.tap_rf_o[pv * 4 + i] = trf.o[i]; o.tap_rf_w[pv * 4 + i] = trf.w[i];
+    o.tap_if_o[pv * 4 + i] = tif.o[i]; o.tap_if_w[pv * 4 + i] = tif.w[i];
+  }
+  const float* ib = a.imgs + (size_t)v * a.H * a.W * 4;
+  float c[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 t = *reinterpret_cast<const float4*>(ib + (size_t)tim.o[i] * 4);
+    c[0] += t.x * tim.w[i]; c[1] += t.y * tim.w[i]; c[2] += t.z * tim.w[i];
+  }
+  o.rgb[pv * 3] = c[0]; o.rgb[pv * 3 + 1] = c[1]; o.rgb[pv * 3 + 2] = c[2];
+}
+
+// out[pv, dc + c] = sum_t w_t * map[v][o_t][c]  for a 32-channel channel-last map (render_ops.py:243-245)
+__global__ void gather32_kernel(const float* __restrict__ map, long view_stride, const int* __restrict__ to, const float* __restrict__ tw,
+                                long PV, int V, float* __restrict__ out, int ldo, int dc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PV * 8) return;
+  const long pv = i / 8; const int q = (int)(i % 8);
+  const float* mb = map + (pv % V) * view_stride + q * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float4 m = *reinterpret_cast<const float4*>(mb + (size_t)to[pv * 4 + t] * 32);
+    const float w = tw[pv * 4 + t];
+    s.x += m.x * w; s.y += m.y * w; s.z += m.z * w; s.w += m.w * w;
+  }
+  *reinterpret_cast<float4*>(out + pv * ldo + dc + q * 4) = s;
+}
+// gmap[v][o_t][c] += w_t * g[pv, c]   (transpose of the gather: scatter-add with atomics)
+__global__ void gather32_bwd_kernel(float* __restrict__ gmap, long view_stride, const int* __restrict__ to, const float* __restrict__ tw,
+                                    long PV, int V, const float* __restrict__ g, int ldg, int gc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PV * 32) return;
+  const long pv = i / 32; const int c = (int)(i % 32);
+  const float gv = g[pv * ldg + gc + c];
+  if (gv == 0.f) return;
+  float* mb = gmap + (pv % V) * view_stride + c;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float w = tw[pv * 4 + t];
+    if (w != 0.f) atomicAdd(mb + (size_t)to[pv * 4 + t] * 32, gv * w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// compute_prob (dist_decoder.py:6-51 is_ref branch, :109-140): mixture of two logistics -> visibility, hit probability
+struct ProbIO {
+  const float* depth_v;  // [PV]
+  const float* hw;       // [P,2]
+  const float* ref_dr;   // [V,2]
+  const float *mean, *var, *aw, *visp;   // [PV,2] each; aw / visp use column 0 only (visp null without use_vis)
+  float *vis, *hit;      // [PV]
+};
+__device__ __forceinline__ float logistic2(float d) { return 1.f / (1.f + expf(-2.f * d)); }      // 0.5 + 0.5 tanh(d)
+__global__ void prob_kernel(ProbIO io, long PV, int V, float* __restrict__ pe_in /* [PV,34]: columns 32, 33 written */) {
+  const long pv = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pv >= PV) return;
+  const int v = (int)(pv % V); const long p = pv / V;
+  const float rn_ = -1.f / io.ref_dr[2 * v], rf_ = -1.f / io.ref_dr[2 * v + 1];
+  const float z = (-1.f / fmaxf(io.depth_v[pv], 1e-5f) - rn_) / (rf_ - rn_);
+  const float nearp = z - io.hw[p * 2], farp = z + io.hw[p * 2 + 1];
+  const float aw = io.aw[pv * 2], u = io.visp ? io.visp[pv * 2] : 1.f;
+  float vis = 0.f, hit = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float m = io.mean[pv * 2 + k], s = io.var[pv * 2 + k];
+    const float c0 = logistic2((nearp - m) * s) * u, c1 = logistic2((farp - m) * s) * u;
+    const float mix = k == 0 ? aw : 1.f - aw;
+    vis += (1.f - c0) * mix; hit += (c1 - c0) * mix;
+  }
+  io.vis[pv] = vis; io.hit[pv] = hit;
+  pe_in[pv * 34 + 32] = (hit - 0.5f) * 2.f;
+  pe_in[pv * 34 + 33] = (vis - 0.5f) * 2.f;
+}
+struct ProbGrad { const float* g_pe_in; /* [PV,34] */ float *g_mean, *g_var, *g_aw, *g_visp; /* [PV,2] each, column 0 for aw / visp */ };
+__global__ void prob_bwd_kernel(ProbIO io, ProbGrad gr, long PV, int V) {
+  const long pv = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pv >= PV) return;
+  const int v = (int)(pv % V); const long p = pv / V;
+  const float ghit = 2.f * gr.g_pe_in[pv * 34 + 32], gvis = 2.f * gr.g_pe_in[pv * 34 + 33];
+  const float rn_ = -1.f / io.ref_dr[2 * v], rf_ = -1.f / io.ref_dr[2 * v + 1];
+  const float z = (-1.f / fmaxf(io.depth_v[pv], 1e-5f) - rn_) / (rf_ - rn_);
+  const float nearp = z - io.hw[p * 2], farp = z + io.hw[p * 2 + 1];
+  const float aw = io.aw[pv * 2], u = io.visp ? io.visp[pv * 2] : 1.f;
+  float gaw = 0.f, gu = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float m = io.mean[pv * 2 + k], s = io.var[pv * 2 + k];
+    const float r0 = logistic2((nearp - m) * s), r1 = logistic2((farp - m) * s);
+    const float c0 = r0 * u, c1 = r1 * u;
+    const float mix = k == 0 ? aw : 1.f - aw;
+    const float gmix = (1.f - c0) * gvis + (c1 - c0) * ghit;
+    gaw += k == 0 ? gmix : -gmix;
+    const float gc0 = -mix * (gvis + ghit), gc1 = mix * ghit;
+    gu += gc0 * r0 + gc1 * r1;
+    const float ga0 = gc0 * u * 2.f * r0 * (1.f - r0), ga1 = gc1 * u * 2.f * r1 * (1.f - r1);
+    gr.g_mean[pv * 2 + k] = -s * (ga0 + ga1);
+    gr.g_var[pv * 2 + k] = (nearp - m) * ga0 + (farp - m) * ga1;
+  }
+  gr.g_aw[pv * 2] = gaw;
+  if (gr.g_visp) gr.g_visp[pv * 2] = gu;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weighted mean / variance over the views of a point (ibrnet.py:112-116): mean = sum_v w x, var = sum_v w (x - mean)^2
+// x [PV, ldx] (columns xc .. xc+F), w [PV] -> out [P, ldo]: mean at column mc, var at column vc
+__global__ void stats_kernel(const float* __restrict__ x, int ldx, int xc, const float* __restrict__ w, int V, int F, long P,
+                             float* __restrict__ out, int ldo, int mc, int vc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * F) return;
+  const long p = i / F; const int j = (int)(i % F);
+  float m = 0.f;
+  for (int v = 0; v < V; ++v) m += x[(p * V + v) * ldx + xc + j] * w[p * V + v];
+  float var = 0.f;
+  for (int v = 0; v < V; ++v) { const float d = x[(p * V + v) * ldx + xc + j] - m; var += w[p * V + v] * (d * d); }
+  out[p * ldo + mc + j] = m;
+  out[p * ldo + vc + j] = var;
+}
+// gx[PV, .] += ..., gw[PV] += ...   (one thread per (point, view): loops over the F features)
+__global__ void stats_bwd_kernel(const float* __restrict__ x, int ldx, int xc, const float* __restrict__ w, int V, int F, long P,
+                                 const float* __restrict__ stat, int lds, int mc, int vc, const float* __restrict__ g, int ldg, int gmc,
+                                 int gvc, float* __restrict__ gx, int ldgx, int gxc, float* __restrict__ gw) {
+  const long pv = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pv >= P * V) return;
+  const long p = pv / V;
+  const float wv = w[pv];
+  float gwv = 0.f;
+  for (int j = 0; j < F; ++j) {
+    const float m = stat[p * lds + mc + j];
+    const float gm = g[p * ldg + gmc + j], gvar = g[p * ldg + gvc + j];
+    float S = 0.f;                                   // sum_u w_u (x_u - m): zero only when the weights sum to one
+    for (int u = 0; u < V; ++u) S += w[p * V + u] * (x[(p * V + u) * ldx + xc + j] - m);
+    const float gmt = gm - 2.f * S * gvar;           // total gradient reaching the mean
+    const float xv = x[pv * ldx + xc + j], d = xv - m;
+    gx[pv * ldgx + gxc + j] += wv * gmt + 2.f * wv * d * gvar;
+    gwv += xv * gmt + d * d * gvar;
+  }
+  if (gw) gw[pv] += gwv;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ray attention (ibrnet.py:7-27,52-102): 4 heads of dimension 4 over the dn samples of a ray, temperature 2; for ONE
+// source view the reference's mask makes every logit equal (uniform weights).  q, k, v, o: [P,16] with head h at columns 4h..
+// One thread per (ray, head, query sample); the probabilities are recomputed in the backward (never stored).
+__global__ void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vv, int rn, int dn,
+                                int uniform, float* __restrict__ o) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rn * 4 * dn) return;
+  const int s = (int)(i % dn), h = (int)((i / dn) % 4), ray = (int)(i / (4L * dn));
+  const float* kb = k + (size_t)ray * dn * 16 + h * 4;
+  const float* vb = vv + (size_t)ray * dn * 16 + h * 4;
+  const float* qp = q + ((size_t)ray * dn + s) * 16 + h * 4;
+  const float q0 = qp[0] * 0.5f, q1 = qp[1] * 0.5f, q2 = qp[2] * 0.5f, q3 = qp[3] * 0.5f;
+  float mx = -3.0e38f;
+  if (!uniform)
+    for (int t = 0; t < dn; ++t) mx = fmaxf(mx, q0 * kb[t * 16] + q1 * kb[t * 16 + 1] + q2 * kb[t * 16 + 2] + q3 * kb[t * 16 + 3]);
+  float l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int t = 0; t < dn; ++t) {
+    const float e = uniform ? 1.f : expf(q0 * kb[t * 16] + q1 * kb[t * 16 + 1] + q2 * kb[t * 16 + 2] + q3 * kb[t * 16 + 3] - mx);
+    l += e;
+    a0 += e * vb[t * 16]; a1 += e * vb[t * 16 + 1]; a2 += e * vb[t * 16 + 2]; a3 += e * vb[t * 16 + 3];
+  }
+  float* op = o + ((size_t)ray * dn + s) * 16 + h * 4;
+  op[0] = a0 / l; op[1] = a1 / l; op[2] = a2 / l; op[3] = a3 / l;
+}
+// per query sample s: P_st = softmax_t(S_st); gP_st = <go_s, v_t>; gS_st = P_st (gP_st - <go_s, o_s>);
+//   gq_s = 0.5 * sum_t gS_st k_t;  gk_t += 0.5 * gS_st q_s;  gv_t += P_st go_s   (atomics across the queries of the ray)
+__global__ void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vv,
+                                const float* __restrict__ o, const float* __restrict__ go, int rn, int dn, int uniform,
+                                float* __restrict__ gq, float* __restrict__ gk, float* __restrict__ gv) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rn * 4 * dn) return;
+  const int s = (int)(i % dn), h = (int)((i / dn) % 4), ray = (int)(i / (4L * dn));
+  const size_t base = (size_t)ray * dn * 16 + h * 4, me = ((size_t)ray * dn + s) * 16 + h * 4;
+  const float* kb = k + base; const float* vb = vv + base;
+  const float qs[4] = {q[me], q[me + 1], q[me + 2], q[me + 3]};
+  const float g[4] = {go[me], go[me + 1], go[me + 2], go[me + 3]};
+  const float dot_go_o = g[0] * o[me] + g[1] * o[me + 1] + g[2] * o[me + 2] + g[3] * o[me + 3];
+  float mx = -3.0e38f, l = 0.f;
+  if (!uniform) {
+    for (int t = 0; t < dn; ++t)
+      mx = fmaxf(mx, 0.5f * (qs[0] * kb[t * 16] + qs[1] * kb[t * 16 + 1] + qs[2] * kb[t * 16 + 2] + qs[3] * kb[t * 16 + 3]));
+    for (int t = 0; t < dn; ++t)
+      l += expf(0.5f * (qs[0] * kb[t * 16] + qs[1] * kb[t * 16 + 1] + qs[2] * kb[t * 16 + 2] + qs[3] * kb[t * 16 + 3]) - mx);
+  } else {
+    l = (float)dn;
+  }
+  float gqa[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < dn; ++t) {
+    const float pst = uniform ? 1.f / l
+                              : expf(0.5f * (qs[0] * kb[t * 16] + qs[1] * kb[t * 16 + 1] + qs[2] * kb[t * 16 + 2] + qs[3] * kb[t * 16 + 3]) - mx) / l;
+    const float gp = g[0] * vb[t * 16] + g[1] * vb[t * 16 + 1] + g[2] * vb[t * 16 + 2] + g[3] * vb[t * 16 + 3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) atomicAdd(&gv[base + (size_t)t * 16 + c], pst * g[c]);
+    if (!uniform) {                                   // masked logits are constants: no gradient reaches q or k
+      const float gs = pst * (gp - dot_go_o);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { gqa[c] += 0.5f * gs * kb[t * 16 + c]; atomicAdd(&gk[base + (size_t)t * 16 + c], 0.5f * gs * qs[c]); }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) gq[me + c] += gqa[c];
+}
+
+// LayerNorm(16, eps 1e-6) (ibrnet.py:101): y = (x - mean) * rstd * gamma + beta
+__global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, long P,
+                                 float* __restrict__ y) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float m = 0.f;
+  for (int c = 0; c < 16; ++c) m += x[p * 16 + c];
+  m *= 0.0625f;
+  float sq = 0.f;
+  for (int c = 0; c < 16; ++c) { const float d = x[p * 16 + c] - m; sq += d * d; }
+  const float rstd = rsqrtf(sq * 0.0625f + 1e-6f);
+  for (int c = 0; c < 16; ++c) y[p * 16 + c] = (x[p * 16 + c] - m) * rstd * gamma[c] + beta[c];
+}
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ gy,
+                                                            long P, float* __restrict__ gx, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+  __shared__ float s_g[16], s_b[16];
+  if (threadIdx.x < 16) { s_g[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
+  __syncthreads();
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) {
+    float m = 0.f;
+    for (int c = 0; c < 16; ++c) m += x[p * 16 + c];
+    m *= 0.0625f;
+    float sq = 0.f;
+    for (int c = 0; c < 16; ++c) { const float d = x[p * 16 + c] - m; sq += d * d; }
+    const float rstd = rsqrtf(sq * 0.0625f + 1e-6f);
+    float a = 0.f, b = 0.f;            // mean of g*gamma, mean of g*gamma*xhat
+    for (int c = 0; c < 16; ++c) {
+      const float xh = (x[p * 16 + c] - m) * rstd, gg = gy[p * 16 + c] * gamma[c];
+      a += gg; b += gg * xh;
+      atomicAdd(&s_g[c], gy[p * 16 + c] * xh);
+      atomicAdd(&s_b[c], gy[p * 16 + c]);
+    }
+    a *= 0.0625f; b *= 0.0625f;
+    for (int c = 0; c < 16; ++c) {
+      const float xh = (x[p * 16 + c] - m) * rstd, gg = gy[p * 16 + c] * gamma[c];
+      gx[p * 16 + c] = rstd * (gg - a - xh * b);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) { atomicAdd(&ggamma[threadIdx.x], s_g[threadIdx.x]); atomicAdd(&gbeta[threadIdx.x], s_b[threadIdx.x]); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// colour blending over the views (ibrnet.py:364-370): blend = softmax_v(logit), colors = sum_v rgb_v * blend_v
+__global__ void blend_kernel(const float* __restrict__ logit, const float* __restrict__ rgb, long P, int V, float* __restrict__ blend,
+                             float* __restrict__ colors) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float mx = logit[p * V];
+  for (int v = 1; v < V; ++v) mx = fmaxf(mx, logit[p * V + v]);
+  float es = 0.f;
+  for (int v = 0; v < V; ++v) es += expf(logit[p * V + v] - mx);
+  float c[3] = {0.f, 0.f, 0.f};
+  for (int v = 0; v < V; ++v) {
+    const float b = expf(logit[p * V + v] - mx) / es;
+    blend[p * V + v] = b;
+    c[0] += rgb[(p * V + v) * 3] * b; c[1] += rgb[(p * V + v) * 3 + 1] * b; c[2] += rgb[(p * V + v) * 3 + 2] * b;
+  }
+  colors[p * 3] = c[0]; colors[p * 3 + 1] = c[1]; colors[p * 3 + 2] = c[2];
+}
+__global__ void blend_bwd_kernel(const float* __restrict__ blend, const float* __restrict__ rgb, const float* __restrict__ gcol, long P, int V,
+                                 float* __restrict__ glogit) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float dot = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float gb = gcol[p * 3] * rgb[(p * V + v) * 3] + gcol[p * 3 + 1] * rgb[(p * V + v) * 3 + 1] + gcol[p * 3 + 2] * rgb[(p * V + v) * 3 + 2];
+    dot += blend[p * V + v] * gb;
+  }
+  for (int v = 0; v < V; ++v) {
+    const float gb = gcol[p * 3] * rgb[(p * V + v) * 3] + gcol[p * 3 + 1] * rgb[(p * V + v) * 3 + 1] + gcol[p * 3 + 2] * rgb[(p * V + v) * 3 + 2];
+    glogit[p * V + v] = blend[p * V + v] * (gb - dot);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// alpha compositing along a ray (renderer.py:210-219,291-304; render_ops.py:145-153), one thread per ray:
+//   alpha = 1 - exp(-relu(sigma)), T_i = prod_{j<i} (1 - alpha_j + 1e-10), hit_i = alpha_i T_i
+// backward: with G_i = d/d hit_i (own gradient + through the pixel colour and the depth) and B_i = sum_{k>i} G_k hit_k:
+//   d/d alpha_i = T_i G_i - B_i / (1 - alpha_i + 1e-10),  d/d sigma_i = (1 - alpha_i) d/d alpha_i,  d/d colour_i = hit_i g_pixel
+__global__ void composite_kernel(const float* __restrict__ sigma, const float* __restrict__ colors, const float* __restrict__ depth, int rn,
+                                 int dn, float* __restrict__ hit, float* __restrict__ pixel, float* __restrict__ rdepth) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= rn) return;
+  float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dd = 0.f;
+  for (int i = 0; i < dn; ++i) {
+    const size_t p = (size_t)ray * dn + i;
+    const float alpha = 1.f - expf(-fmaxf(sigma[p], 0.f));
+    const float h = alpha * T;
+    if (hit) hit[p] = h;
+    c0 += h * colors[p * 3]; c1 += h * colors[p * 3 + 1]; c2 += h * colors[p * 3 + 2];
+    dd += h * depth[p];
+    T *= 1.f - alpha + 1e-10f;
+  }
+  if (pixel) { pixel[ray * 3] = c0; pixel[ray * 3 + 1] = c1; pixel[ray * 3 + 2] = c2; }
+  if (rdepth) rdepth[ray] = dd;
+}
+__global__ void composite_bwd_kernel(const float* __restrict__ sigma, const float* __restrict__ colors, const float* __restrict__ depth, int rn,
+                                     int dn, const float* __restrict__ g_pixel, const float* __restrict__ g_depth, const float* __restrict__ g_hit,
+                                     const float* __restrict__ g_colors, const float* __restrict__ g_density, float* __restrict__ gsigma,
+                                     float* __restrict__ gcol) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= rn) return;
+  const float gp0 = g_pixel ? g_pixel[ray * 3] : 0.f, gp1 = g_pixel ? g_pixel[ray * 3 + 1] : 0.f, gp2 = g_pixel ? g_pixel[ray * 3 + 2] : 0.f;
+  const float gd = g_depth ? g_depth[ray] : 0.f;
+  float Ts[PGRF_MAX_DN];                              // T_i = prod_{j<i} f_j, built forwards (dividing back would blow up at alpha = 1)
+  {
+    float T = 1.f;
+    for (int i = 0; i < dn; ++i) {
+      Ts[i] = T;
+      T *= 1.f - (1.f - expf(-fmaxf(sigma[(size_t)ray * dn + i], 0.f))) + 1e-10f;
+    }
+  }
+  float B = 0.f;
+  for (int i = dn - 1; i >= 0; --i) {
+    const size_t p = (size_t)ray * dn + i;
+    const float alpha = 1.f - expf(-fmaxf(sigma[p], 0.f));
+    const float f = 1.f - alpha + 1e-10f;
+    const float T = Ts[i];
+    const float h = alpha * T;
+    const float G = (g_hit ? g_hit[p] : 0.f) + gp0 * colors[p * 3] + gp1 * colors[p * 3 + 1] + gp2 * colors[p * 3 + 2] + gd * depth[p];
+    const float galpha = T * G - B / f;
+    gsigma[p] = (sigma[p] > 0.f ? (1.f - alpha) * galpha : 0.f) + (g_density ? g_density[p] : 0.f);
+    gcol[p * 3] = h * gp0 + (g_colors ? g_colors[p * 3] : 0.f);
+    gcol[p * 3 + 1] = h * gp1 + (g_colors ? g_colors[p * 3 + 1] : 0.f);
+    gcol[p * 3 + 2] = h * gp2 + (g_colors ? g_colors[p * 3 + 2] : 0.f);
+    B += G * h;
+  }
+}
+
+}  // namespace train
+}  // namespace pgrf

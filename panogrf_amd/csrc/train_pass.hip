@@ -1,0 +1,427 @@
+// Backward pass of ONE network pass of the per-ray renderer: gradients of the reference's
+// training losses (network/loss.py: functions of pixel_colors_nr, render_depth, hit_prob_nr; optionally of colors_nr /
+// density_nr) with respect to every per-ray network weight (dist decoder + aggregation net, reference state_dict layout) and
+// to the two source feature maps (img_feats, ray_feats: from there torch autograd carries on into the 2-D encoders).
+//
+// The forward the gradients belong to is the fused kernel (render_pass.h), which keeps no activations.  The backward
+// REMATERIALISES: one staged forward over the batch's (point, view) rows with every activation kept in a caller-owned
+// workspace, then the reverse sweep stage by stage.  Linear layers are plain row-major fp32 GEMMs (train_kernels.h), the
+// other stages have hand-written forward / backward kernels.  Sample depths, poses and source colours are constants (the
+// reference detaches the importance-sampling inputs, renderer.py:437: hit_prob.detach()), so no gradient flows into geometry.
+//
+// Rows: P = rn * dn points (ray-major), PV = P * V (point-major, views innermost).  Concatenated layer inputs are real
+// buffers whose producers write column slices: pe_in [PV,34] = [ray_feats 32 | hit | vis], xin [PV,207] = [view statistics 140 |
+// rgb_feat 35 | neuray 32], xr [PV,37] = [x 32 | vis 1 | ray_diff 4], gin [P,65] = [mean 32 | var 32 | weight mean 1].
+#include "pgrf_experiments.h"
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "pgrf_internal.h"
+#include "pgrf_layout.h"
+#include "render_pass_args.h"
+#include "train_kernels.h"
+
+namespace pgrf {
+namespace train {
+
+#define PGRF_TCHECK(what)                                                                              \
+  do {                                                                                                \
+    const hipError_t e__ = hipGetLastError();                                                         \
+    if (e__ != hipSuccess) return set_error(PGRF_ERR_LAUNCH, what " launch failed: %s", hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- small glue kernels ----------------------------------------------------------------------------------------------
+// dst[r, dc + c] = src[r / div, sc + c]   (per-point values repeated for the views of the point)
+__global__ void bcast_kernel(float* __restrict__ dst, int ldd, int dc, const float* __restrict__ src, int lds, int sc, long rows, int div,
+                             int cols) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols; const int c = (int)(i % cols);
+    dst[r * ldd + dc + c] = src[(r / div) * lds + sc + c];
+  }
+}
+// dst[p, dc + c] (=|+=) sum_v src[p * V + v, sc + c]
+__global__ void reduce_views_kernel(float* __restrict__ dst, int ldd, int dc, const float* __restrict__ src, int lds, int sc, long P, int V,
+                                    int cols, int accumulate) {
+  const long n = P * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / cols; const int c = (int)(i % cols);
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += src[(p * V + v) * lds + sc + c];
+    float* d = dst + p * ldd + dc + c;
+    *d = accumulate ? *d + s : s;
+  }
+}
+// y[r, yc + c] = x[r, xc + c] * (s ? s[r * sstride] : cst)
+__global__ void rowscale_kernel(float* __restrict__ y, int ldy, int yc, const float* __restrict__ x, int ldx, int xc, const float* __restrict__ s,
+                                int sstride, float cst, long rows, int cols) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols; const int c = (int)(i % cols);
+    y[r * ldy + yc + c] = x[r * ldx + xc + c] * (s ? s[r * sstride] : cst);
+  }
+}
+// gx[r, gxc + c] += gy[r, gyc + c] * scale_r ;  gs[r] (=) sum_c gy[r, gyc + c] * x[r, xc + c]
+__global__ void rowscale_bwd_kernel(const float* __restrict__ gy, int ldgy, int gyc, const float* __restrict__ x, int ldx, int xc,
+                                    const float* __restrict__ s, int sstride, float cst, long rows, int cols, float* __restrict__ gx, int ldgx,
+                                    int gxc, float* __restrict__ gs) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float sc = s ? s[r * sstride] : cst;
+  float acc = 0.f;
+  for (int c = 0; c < cols; ++c) {
+    const float g = gy[r * ldgy + gyc + c];
+    gx[r * ldgx + gxc + c] += g * sc;
+    acc += g * x[r * ldx + xc + c];
+  }
+  if (gs) gs[r] = acc;
+}
+// rgb_feat = [rgb | img_feats] + dir_feat  (ibrnet.py:325-327) -> xin[:, 140:175]
+__global__ void rgbfeat_kernel(const float* __restrict__ rgb, const float* __restrict__ imf, const float* __restrict__ dfeat, long PV,
+                               float* __restrict__ xin) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PV * 35) return;
+  const long pv = i / 35; const int c = (int)(i % 35);
+  xin[pv * 207 + 140 + c] = (c < 3 ? rgb[pv * 3 + c] : imf[pv * 32 + c - 3]) + dfeat[pv * 35 + c];
+}
+// x2 = x + x_res, v1 = sigmoid(xv[32])  (ibrnet.py:347-350); x2 -> xr[:, 0:32]
+__global__ void visfc_post_kernel(const float* __restrict__ x, const float* __restrict__ xv, long PV, float* __restrict__ xr, float* __restrict__ v1) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PV * 33) return;
+  const long pv = i / 33; const int c = (int)(i % 33);
+  if (c < 32) xr[pv * 37 + c] = x[pv * 32 + c] + xv[pv * 33 + c];
+  else v1[pv] = 1.f / (1.f + expf(-xv[pv * 33 + 32]));
+}
+// backward of the line above: gx = gxr[:, :32]; gxv[:, :32] = gxr[:, :32]; gxv[:, 32] = gv1 * v1 (1 - v1)
+__global__ void visfc_post_bwd_kernel(const float* __restrict__ gxr, const float* __restrict__ gv1, const float* __restrict__ v1, long PV,
+                                      float* __restrict__ gx, float* __restrict__ gxv) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PV * 33) return;
+  const long pv = i / 33; const int c = (int)(i % 33);
+  if (c < 32) { const float g = gxr[pv * 37 + c]; gx[pv * 32 + c] = g; gxv[pv * 33 + c] = g; }
+  else gxv[pv * 33 + 32] = gv1[pv] * v1[pv] * (1.f - v1[pv]);
+}
+// wgt2 = v2 / (sum_v v2 + 1e-8);  gin[:, 64] = mean_v wgt2   (ibrnet.py:352-355); v2 lives in xr[:, 32]
+__global__ void wgt2_kernel(const float* __restrict__ xr, long P, int V, float* __restrict__ wgt2, float* __restrict__ gin) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float S = 0.f;
+  for (int v = 0; v < V; ++v) S += xr[(p * V + v) * 37 + 32];
+  float m = 0.f;
+  for (int v = 0; v < V; ++v) { const float w = xr[(p * V + v) * 37 + 32] / (S + 1e-8f); wgt2[p * V + v] = w; m += w; }
+  gin[p * 65 + 64] = m / (float)V;
+}
+// gv2_v += gw_v / (S + e) - sum_u gw_u v2_u / (S + e)^2, with gw_u = gwgt2_u + ggin[:, 64] / V
+__global__ void wgt2_bwd_kernel(const float* __restrict__ xr, const float* __restrict__ gwgt2, const float* __restrict__ ggin, long P, int V,
+                                float* __restrict__ gxr) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float S = 0.f;
+  for (int v = 0; v < V; ++v) S += xr[(p * V + v) * 37 + 32];
+  const float den = S + 1e-8f, gm = ggin[p * 65 + 64] / (float)V;
+  float dot = 0.f;
+  for (int v = 0; v < V; ++v) dot += (gwgt2[p * V + v] + gm) * xr[(p * V + v) * 37 + 32];
+  for (int v = 0; v < V; ++v) gxr[(p * V + v) * 37 + 32] += (gwgt2[p * V + v] + gm) / den - dot / (den * den);
+}
+// gp = g2 + positional encoding of the sample index (ibrnet.py:356-358); pos [dn,16]
+__global__ void posenc_kernel(const float* __restrict__ g2, const float* __restrict__ pos, long P, int dn, float* __restrict__ gp) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * 16) return;
+  const long p = i / 16; const int c = (int)(i % 16);
+  gp[i] = g2[i] + pos[(p % dn) * 16 + c];
+}
+__global__ void fill_kernel(float* __restrict__ x, float v, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
+}
+__global__ void posenc_table_kernel(float* __restrict__ pos, int dn) {     // ibrnet.py:305-313, evaluated in double like numpy
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dn * 16) return;
+  const int s = i / 16, j = i % 16;
+  const double ang = (double)s / pow(10000.0, 2.0 * (double)(j / 2) / 16.0);
+  pos[i] = (float)((j & 1) ? cos(ang) : sin(ang));
+}
+
+static inline unsigned nblk(long n, int per = 256) { const long b = (n + per - 1) / per; return (unsigned)(b < 1 ? 1 : (b > 65535L * 16 ? 65535L * 16 : b)); }
+
+// ---- workspace ------------------------------------------------------------------------------------------------------
+struct Ws {
+  // constants
+  int *tap_rf_o, *tap_if_o;
+  float *tap_rf_w, *tap_if_w, *rgb, *dd, *depth_v, *hw, *w1, *pos;
+  // forward activations
+  float *pe_in, *imf;
+  float *dh1[4], *dh2[4], *dout[4];
+  float *vis, *hit, *pe_h, *d1, *dfeat, *n1, *nfs, *w0, *glob, *xin, *b1, *x, *xw, *v1h, *xv, *v1, *xr, *xv1, *f1, *wgt2;
+  float *gin, *g1, *g2, *gp, *q, *k, *v, *o, *fo, *ln, *og1, *sigma, *r1, *r2, *logit, *blend, *colors;
+  // gradients
+  float *gsigma, *gcol, *glogit, *gr2, *gr1, *gxr, *gog1, *gln, *gfo, *go, *gq, *gk, *gv, *ggp, *gg1, *ggin, *gwgt2, *gf1, *gxv1, *gv1,
+      *gx, *gxv, *gv1h, *gxw, *gb1, *gxin, *gglob, *gw0, *gn1, *gdfeat, *gd1, *gpe_h, *gpe_in, *gdout[4], *gdh2[4], *gdh1[4];
+};
+
+static size_t plan(Ws& w, long P, int V, int dn, char* base) {
+  size_t off = 0;
+  auto take = [&](long floats) -> float* {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += ((size_t)floats * 4 + 255) & ~(size_t)255;
+    return p;
+  };
+  const long PV = P * V;
+  w.tap_rf_o = (int*)take(PV * 4); w.tap_if_o = (int*)take(PV * 4);
+  w.tap_rf_w = take(PV * 4); w.tap_if_w = take(PV * 4);
+  w.rgb = take(PV * 3); w.dd = take(PV * 4); w.depth_v = take(PV); w.hw = take(P * 2); w.w1 = take(PV); w.pos = take((long)dn * 16);
+  w.pe_in = take(PV * 34); w.imf = take(PV * 32);
+  for (int m = 0; m < 4; ++m) { w.dh1[m] = take(PV * 32); w.dh2[m] = take(PV * 32); w.dout[m] = take(PV * 2); }
+  w.vis = take(PV); w.hit = take(PV); w.pe_h = take(PV * 32); w.d1 = take(PV * 16); w.dfeat = take(PV * 35); w.n1 = take(PV * 8);
+  w.nfs = take(PV); w.w0 = take(PV); w.glob = take(P * 140); w.xin = take(PV * 207); w.b1 = take(PV * 64); w.x = take(PV * 32);
+  w.xw = take(PV * 32); w.v1h = take(PV * 32); w.xv = take(PV * 33); w.v1 = take(PV); w.xr = take(PV * 37); w.xv1 = take(PV * 32);
+  w.f1 = take(PV * 32); w.wgt2 = take(PV);
+  w.gin = take(P * 65); w.g1 = take(P * 64); w.g2 = take(P * 16); w.gp = take(P * 16); w.q = take(P * 16); w.k = take(P * 16);
+  w.v = take(P * 16); w.o = take(P * 16); w.fo = take(P * 16); w.ln = take(P * 16); w.og1 = take(P * 16); w.sigma = take(P);
+  w.r1 = take(PV * 16); w.r2 = take(PV * 8); w.logit = take(PV); w.blend = take(PV); w.colors = take(P * 3);
+  w.gsigma = take(P); w.gcol = take(P * 3); w.glogit = take(PV); w.gr2 = take(PV * 8); w.gr1 = take(PV * 16); w.gxr = take(PV * 37);
+  w.gog1 = take(P * 16); w.gln = take(P * 16); w.gfo = take(P * 16); w.go = take(P * 16); w.gq = take(P * 16); w.gk = take(P * 16);
+  w.gv = take(P * 16); w.ggp = take(P * 16); w.gg1 = take(P * 64); w.ggin = take(P * 65); w.gwgt2 = take(PV); w.gf1 = take(PV * 32);
+  w.gxv1 = take(PV * 32); w.gv1 = take(PV); w.gx = take(PV * 32); w.gxv = take(PV * 33); w.gv1h = take(PV * 32); w.gxw = take(PV * 32);
+  w.gb1 = take(PV * 64); w.gxin = take(PV * 207); w.gglob = take(P * 140); w.gw0 = take(PV); w.gn1 = take(PV * 8);
+  w.gdfeat = take(PV * 35); w.gd1 = take(PV * 16); w.gpe_h = take(PV * 32); w.gpe_in = take(PV * 34);
+  for (int m = 0; m < 4; ++m) { w.gdout[m] = take(PV * 2); w.gdh2[m] = take(PV * 32); w.gdh1[m] = take(PV * 32); }
+  return off;
+}
+
+struct Ctx {
+  hipStream_t st;
+  const float* const* raw;     // device pointers, reference layouts
+  float* const* graw;          // device pointers (accumulated), entries may be null = not wanted
+};
+
+static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float* Y, int ldy, long rows, int IN, int OUT, int act) {
+  dim3 grid((OUT + 63) / 64, (unsigned)((rows + 63) / 64), 1);
+  hipLaunchKernelGGL((gemm_kernel<false, true, false>), grid, dim3(256), 0, c.st, X, ldx, c.raw[rw], IN, Y, ldy, (int)rows, OUT, IN, 0, IN);
+  if (rb >= 0 || act != ACT_NONE)
+    hipLaunchKernelGGL(bias_act_kernel, dim3(nblk(rows * OUT)), dim3(256), 0, c.st, Y, ldy, rb >= 0 ? c.raw[rb] : nullptr, rows, OUT, act);
+  PGRF_TCHECK("train linear forward");
+  return PGRF_OK;
+}
+// dY (a [rows, OUT] slice, ld lddy) is overwritten by delta = dY * act'(Y); then gW += delta^T X, gb += colsum(delta),
+// dX (=|+=) delta W
+static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ldy, float* dY, int lddy, int rw, int rb, float* dX, int lddx,
+                   int acc_dx, long rows, int IN, int OUT, int act) {
+  float* gb = (rb >= 0) ? c.graw[rb] : nullptr;
+  if (act != ACT_NONE || gb)
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(rows * OUT) > 2048 ? 2048 : nblk(rows * OUT)), dim3(256), 0, c.st, dY, lddy, Y, ldy, rows, OUT,
+                       act, gb);
+  if (c.graw[rw]) {
+    const int kchunk = 4096;
+    dim3 grid((IN + 63) / 64, (OUT + 63) / 64, (unsigned)((rows + kchunk - 1) / kchunk));
+    hipLaunchKernelGGL((gemm_kernel<true, false, true>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], IN, OUT, IN, (int)rows, 1, kchunk);
+  }
+  if (dX) {
+    dim3 grid((IN + 63) / 64, (unsigned)((rows + 63) / 64), 1);
+    hipLaunchKernelGGL((gemm_kernel<false, false, false>), grid, dim3(256), 0, c.st, dY, lddy, c.raw[rw], IN, dX, lddx, (int)rows, IN, OUT, acc_dx, OUT);
+  }
+  PGRF_TCHECK("train linear backward");
+  return PGRF_OK;
+}
+
+}  // namespace train
+}  // namespace pgrf
+
+using namespace pgrf;
+using namespace pgrf::train;
+
+extern "C" {
+
+size_t pgrf_render_pass_backward_workspace_bytes(int rfn, int rn, int dn) {
+  if (rfn < 1 || rn < 1 || dn < 1) return 0;
+  Ws w;
+  return plan(w, (long)rn * dn, rfn, dn, nullptr);
+}
+
+int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_dev, int n_raw, int use_vis, const float* coords,
+                              const float* depth, int rn, int dn, const PgrfPassGrad* grad, float* const* g_raw_dev, float* g_img_feats,
+                              float* g_ray_feats, const PgrfPassOut* fwd_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (rn == 0) return PGRF_OK;             // empty batch: nothing to add to the gradients
+  if (!frame || !raw_dev || !coords || !depth || !grad || !g_raw_dev) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: null pointer");
+  if (n_raw != R_COUNT) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: expected %d raw tensors, got %d", R_COUNT, n_raw);
+  if (frame->rfn < 1 || frame->rfn > PGRF_MAX_VIEWS) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: rfn=%d not in [1,%d]", frame->rfn, PGRF_MAX_VIEWS);
+  if (dn < 3 || dn > PGRF_MAX_DN) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass_backward: dn=%d outside [3,%d]", dn, PGRF_MAX_DN);
+  if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: rn < 0");
+  if (frame->dataset < PGRF_DATASET_M3D || frame->dataset > PGRF_DATASET_COFFEEAREA)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass_backward: dataset convention %d unknown", frame->dataset);
+  for (int i = 0; i < R_COUNT; ++i) {
+    const bool is_vis = i >= R_DD_VIS_0_W && i <= R_DD_VIS_4_B;
+    if (!raw_dev[i] && !(is_vis && !use_vis)) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: raw weight %d is null", i);
+  }
+  const int V = frame->rfn;
+  const long P = (long)rn * dn, PV = P * V;
+  if ((double)PV * 207.0 >= 2147483648.0) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass_backward: batch too large (rn * dn * rfn * 207 >= 2^31)");
+  Ws w;
+  const size_t need = plan(w, P, V, dn, nullptr);
+  if (!workspace || workspace_bytes < need)
+    return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+  plan(w, P, V, dn, (char*)workspace);
+  Ctx c{(hipStream_t)stream, raw_dev, g_raw_dev};
+  hipStream_t st = c.st;
+  const int NM = use_vis ? 4 : 3;
+  static const int kDD[4][6] = {{R_DD_MEAN_0_W, R_DD_MEAN_0_B, R_DD_MEAN_2_W, R_DD_MEAN_2_B, R_DD_MEAN_4_W, R_DD_MEAN_4_B},
+                                {R_DD_VAR_0_W, R_DD_VAR_0_B, R_DD_VAR_2_W, R_DD_VAR_2_B, R_DD_VAR_4_W, R_DD_VAR_4_B},
+                                {R_DD_AW_0_W, R_DD_AW_0_B, R_DD_AW_2_W, R_DD_AW_2_B, R_DD_AW_4_W, R_DD_AW_4_B},
+                                {R_DD_VIS_0_W, R_DD_VIS_0_B, R_DD_VIS_2_W, R_DD_VIS_2_B, R_DD_VIS_4_W, R_DD_VIS_4_B}};
+  static const int kDDout[4] = {2, 2, 1, 1};
+  static const int kDDact[4] = {ACT_SOFTPLUS, ACT_SOFTPLUS_B, ACT_SIGMOID, ACT_SIGMOID};
+  const float wgt = 1.f / ((float)V + 1e-8f);
+  int rc;
+#define L(expr) do { rc = (expr); if (rc) return rc; } while (0)
+
+  // ------------------------------------------------------------------ constants: geometry, taps, source colours
+  PassArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.imgs = frame->imgs; a.img_feats = frame->img_feats; a.ray_feats = frame->ray_feats; a.w2c = frame->w2c; a.ref_dr = frame->ref_depth_range;
+  std::memcpy(a.c2w, frame->que_c2w, sizeof(a.c2w));
+  a.que_near = frame->que_depth_range[0]; a.que_far = frame->que_depth_range[1];
+  a.dataset = frame->dataset; a.perspective = frame->perspective ? 1 : 0;
+  std::memcpy(a.kinv, frame->que_kinv, sizeof(a.kinv));
+  a.H = frame->H; a.W = frame->W; a.hf = frame->hf; a.wf = frame->wf; a.hr = frame->hr; a.wr = frame->wr;
+  a.coords = coords; a.depth = depth; a.rn = rn;
+  GeomOut go{w.tap_rf_o, w.tap_rf_w, w.tap_if_o, w.tap_if_w, w.rgb, w.dd, w.depth_v, w.hw};
+  hipLaunchKernelGGL(geometry_kernel, dim3(nblk(PV)), dim3(256), 0, st, a, dn, V, go);
+  hipLaunchKernelGGL(fill_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w1, wgt, PV);
+  hipLaunchKernelGGL(posenc_table_kernel, dim3(nblk((long)dn * 16)), dim3(256), 0, st, w.pos, dn);
+  const long rf_stride = (long)frame->hr * frame->wr * 32, if_stride = (long)frame->hf * frame->wf * 32;
+  hipLaunchKernelGGL(gather32_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.pe_in, 34, 0);
+  hipLaunchKernelGGL(gather32_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.imf, 32, 0);
+  PGRF_TCHECK("train geometry");
+
+  // ------------------------------------------------------------------ forward, every activation kept
+  for (int m = 0; m < NM; ++m) {        // dist decoder MLPs on the gathered ray feature (dist_decoder.py:53-107)
+    L(lin_fwd(c, w.pe_in, 34, kDD[m][0], kDD[m][1], w.dh1[m], 32, PV, 32, 32, ACT_ELU));
+    L(lin_fwd(c, w.dh1[m], 32, kDD[m][2], kDD[m][3], w.dh2[m], 32, PV, 32, 32, ACT_ELU));
+    L(lin_fwd(c, w.dh2[m], 32, kDD[m][4], kDD[m][5], w.dout[m], 2, PV, 32, kDDout[m], kDDact[m]));
+  }
+  ProbIO pio{w.depth_v, w.hw, frame->ref_depth_range, w.dout[0], w.dout[1], w.dout[2], use_vis ? w.dout[3] : nullptr, w.vis, w.hit};
+  hipLaunchKernelGGL(prob_kernel, dim3(nblk(PV)), dim3(256), 0, st, pio, PV, V, w.pe_in);
+  PGRF_TCHECK("train compute_prob");
+  L(lin_fwd(c, w.pe_in, 34, R_PE_0_W, R_PE_0_B, w.pe_h, 32, PV, 34, 32, ACT_RELU));                 // prob_embed (aggregate_net.py:53-61)
+  L(lin_fwd(c, w.pe_h, 32, R_PE_2_W, R_PE_2_B, w.xin + 175, 207, PV, 32, 32, ACT_NONE));            //   -> neuray feature, xin[:, 175:207]
+  L(lin_fwd(c, w.dd, 4, R_RD_0_W, R_RD_0_B, w.d1, 16, PV, 4, 16, ACT_ELU));                          // ray_dir_fc
+  L(lin_fwd(c, w.d1, 16, R_RD_2_W, R_RD_2_B, w.dfeat, 35, PV, 16, 35, ACT_ELU));
+  hipLaunchKernelGGL(rgbfeat_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.rgb, w.imf, w.dfeat, PV, w.xin);
+  L(lin_fwd(c, w.xin + 175, 207, R_NF_0_W, R_NF_0_B, w.n1, 8, PV, 32, 8, ACT_ELU));                  // neuray_fc -> weight0 (ibrnet.py:337-338)
+  L(lin_fwd(c, w.n1, 8, R_NF_2_W, R_NF_2_B, w.nfs, 1, PV, 8, 1, ACT_SIGMOID));
+  hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w0, 1, 0, w.nfs, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
+  hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35);
+  hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105);
+  hipLaunchKernelGGL(bcast_kernel, dim3(nblk(PV * 140)), dim3(256), 0, st, w.xin, 207, 0, w.glob, 140, 0, PV, V, 140);
+  PGRF_TCHECK("train view statistics");
+  L(lin_fwd(c, w.xin, 207, R_BASE_0_W, R_BASE_0_B, w.b1, 64, PV, 207, 64, ACT_ELU));                 // base_fc
+  L(lin_fwd(c, w.b1, 64, R_BASE_2_W, R_BASE_2_B, w.x, 32, PV, 64, 32, ACT_ELU));
+  hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32);
+  L(lin_fwd(c, w.xw, 32, R_VF_0_W, R_VF_0_B, w.v1h, 32, PV, 32, 32, ACT_ELU));                       // vis_fc
+  L(lin_fwd(c, w.v1h, 32, R_VF_2_W, R_VF_2_B, w.xv, 33, PV, 32, 33, ACT_ELU));
+  hipLaunchKernelGGL(visfc_post_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.x, w.xv, PV, w.xr, w.v1);
+  hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32);
+  L(lin_fwd(c, w.xv1, 32, R_V2_0_W, R_V2_0_B, w.f1, 32, PV, 32, 32, ACT_ELU));                       // vis_fc2 -> xr[:, 32]
+  L(lin_fwd(c, w.f1, 32, R_V2_2_W, R_V2_2_B, w.xr + 32, 37, PV, 32, 1, ACT_SIGMOID));
+  hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 4)), dim3(256), 0, st, w.xr, 37, 33, w.dd, 4, 0, PV, 4, 0);
+  hipLaunchKernelGGL(wgt2_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, P, V, w.wgt2, w.gin);
+  hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 32)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32);
+  PGRF_TCHECK("train pooled geometry feature");
+  L(lin_fwd(c, w.gin, 65, R_GEO_0_W, R_GEO_0_B, w.g1, 64, P, 65, 64, ACT_ELU));                      // geometry_fc
+  L(lin_fwd(c, w.g1, 64, R_GEO_2_W, R_GEO_2_B, w.g2, 16, P, 64, 16, ACT_ELU));
+  hipLaunchKernelGGL(posenc_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.g2, w.pos, P, dn, w.gp);
+  L(lin_fwd(c, w.gp, 16, R_ATT_Q_W, -1, w.q, 16, P, 16, 16, ACT_NONE));                              // ray attention
+  L(lin_fwd(c, w.gp, 16, R_ATT_K_W, -1, w.k, 16, P, 16, 16, ACT_NONE));
+  L(lin_fwd(c, w.gp, 16, R_ATT_V_W, -1, w.v, 16, P, 16, 16, ACT_NONE));
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk((long)rn * 4 * dn)), dim3(256), 0, st, w.q, w.k, w.v, rn, dn, V <= 1 ? 1 : 0, w.o);
+  L(lin_fwd(c, w.o, 16, R_ATT_FC_W, -1, w.fo, 16, P, 16, 16, ACT_NONE));
+  hipLaunchKernelGGL(slice_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.fo, 16, 0, w.gp, 16, 0, P, 16, 1);           // + residual
+  hipLaunchKernelGGL(layernorm_kernel, dim3(nblk(P)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], raw_dev[R_ATT_LN_B], P, w.ln);
+  L(lin_fwd(c, w.ln, 16, R_OG_0_W, R_OG_0_B, w.og1, 16, P, 16, 16, ACT_ELU));                        // out_geometry_fc -> density
+  L(lin_fwd(c, w.og1, 16, R_OG_2_W, R_OG_2_B, w.sigma, 1, P, 16, 1, ACT_RELU));
+  L(lin_fwd(c, w.xr, 37, R_RGB_0_W, R_RGB_0_B, w.r1, 16, PV, 37, 16, ACT_ELU));                      // rgb_fc -> blending logits
+  L(lin_fwd(c, w.r1, 16, R_RGB_2_W, R_RGB_2_B, w.r2, 8, PV, 16, 8, ACT_ELU));
+  L(lin_fwd(c, w.r2, 8, R_RGB_4_W, R_RGB_4_B, w.logit, 1, PV, 8, 1, ACT_NONE));
+  hipLaunchKernelGGL(blend_kernel, dim3(nblk(P)), dim3(256), 0, st, w.logit, w.rgb, P, V, w.blend, w.colors);
+  PGRF_TCHECK("train forward tail");
+  if (fwd_out) {      // the staged forward's own outputs (tests: must equal the fused kernel's to round-off)
+    hipLaunchKernelGGL(composite_kernel, dim3(nblk(rn, 64)), dim3(64), 0, st, w.sigma, w.colors, depth, rn, dn, fwd_out->hit_prob,
+                       fwd_out->pixel_colors, fwd_out->render_depth);
+    if (fwd_out->density) (void)hipMemcpyAsync(fwd_out->density, w.sigma, P * 4, hipMemcpyDeviceToDevice, st);
+    if (fwd_out->colors) (void)hipMemcpyAsync(fwd_out->colors, w.colors, P * 12, hipMemcpyDeviceToDevice, st);
+  }
+
+  // ------------------------------------------------------------------ backward
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(nblk(rn, 64)), dim3(64), 0, st, w.sigma, w.colors, depth, rn, dn, grad->pixel_colors,
+                     grad->render_depth, grad->hit_prob, grad->colors, grad->density, w.gsigma, w.gcol);
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.blend, w.rgb, w.gcol, P, V, w.glogit);
+  PGRF_TCHECK("train composite backward");
+  L(lin_bwd(c, w.r2, 8, w.logit, 1, w.glogit, 1, R_RGB_4_W, R_RGB_4_B, w.gr2, 8, 0, PV, 8, 1, ACT_NONE));
+  L(lin_bwd(c, w.r1, 16, w.r2, 8, w.gr2, 8, R_RGB_2_W, R_RGB_2_B, w.gr1, 16, 0, PV, 16, 8, ACT_ELU));
+  L(lin_bwd(c, w.xr, 37, w.r1, 16, w.gr1, 16, R_RGB_0_W, R_RGB_0_B, w.gxr, 37, 0, PV, 37, 16, ACT_ELU));       // gxr written (=)
+  L(lin_bwd(c, w.og1, 16, w.sigma, 1, w.gsigma, 1, R_OG_2_W, R_OG_2_B, w.gog1, 16, 0, P, 16, 1, ACT_RELU));
+  L(lin_bwd(c, w.ln, 16, w.og1, 16, w.gog1, 16, R_OG_0_W, R_OG_0_B, w.gln, 16, 0, P, 16, 16, ACT_ELU));
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], w.gln, P, w.gfo,
+                     g_raw_dev[R_ATT_LN_W] ? g_raw_dev[R_ATT_LN_W] : w.gq /* scratch sink */, g_raw_dev[R_ATT_LN_B] ? g_raw_dev[R_ATT_LN_B] : w.gq);
+  (void)hipMemcpyAsync(w.ggp, w.gfo, P * 64, hipMemcpyDeviceToDevice, st);                                            // residual branch
+  L(lin_bwd(c, w.o, 16, w.fo, 16, w.gfo, 16, R_ATT_FC_W, -1, w.go, 16, 0, P, 16, 16, ACT_NONE));
+  (void)hipMemsetAsync(w.gq, 0, P * 64, st); (void)hipMemsetAsync(w.gk, 0, P * 64, st); (void)hipMemsetAsync(w.gv, 0, P * 64, st);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk((long)rn * 4 * dn)), dim3(256), 0, st, w.q, w.k, w.v, w.o, w.go, rn, dn, V <= 1 ? 1 : 0, w.gq,
+                     w.gk, w.gv);
+  PGRF_TCHECK("train attention backward");
+  L(lin_bwd(c, w.gp, 16, w.q, 16, w.gq, 16, R_ATT_Q_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
+  L(lin_bwd(c, w.gp, 16, w.k, 16, w.gk, 16, R_ATT_K_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
+  L(lin_bwd(c, w.gp, 16, w.v, 16, w.gv, 16, R_ATT_V_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
+  L(lin_bwd(c, w.g1, 64, w.g2, 16, w.ggp, 16, R_GEO_2_W, R_GEO_2_B, w.gg1, 64, 0, P, 64, 16, ACT_ELU));           // d(gp)/d(g2) = 1
+  L(lin_bwd(c, w.gin, 65, w.g1, 64, w.gg1, 64, R_GEO_0_W, R_GEO_0_B, w.ggin, 65, 0, P, 65, 64, ACT_ELU));
+  (void)hipMemsetAsync(w.gwgt2, 0, PV * 4, st);
+  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32, w.ggin, 65, 0, 32, w.gxr,
+                     37, 0, w.gwgt2);
+  hipLaunchKernelGGL(wgt2_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, w.gwgt2, w.ggin, P, V, w.gxr);
+  PGRF_TCHECK("train pooled geometry backward");
+  L(lin_bwd(c, w.f1, 32, w.xr + 32, 37, w.gxr + 32, 37, R_V2_2_W, R_V2_2_B, w.gf1, 32, 0, PV, 32, 1, ACT_SIGMOID));
+  L(lin_bwd(c, w.xv1, 32, w.f1, 32, w.gf1, 32, R_V2_0_W, R_V2_0_B, w.gxv1, 32, 0, PV, 32, 32, ACT_ELU));
+  hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gxv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32, w.gxr, 37, 0, w.gv1);
+  hipLaunchKernelGGL(visfc_post_bwd_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.gxr, w.gv1, w.v1, PV, w.gx, w.gxv);
+  L(lin_bwd(c, w.v1h, 32, w.xv, 33, w.gxv, 33, R_VF_2_W, R_VF_2_B, w.gv1h, 32, 0, PV, 32, 33, ACT_ELU));
+  L(lin_bwd(c, w.xw, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, w.gxw, 32, 0, PV, 32, 32, ACT_ELU));
+  hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gxw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32, w.gx, 32, 0,
+                     (float*)nullptr);
+  PGRF_TCHECK("train visibility backward");
+  L(lin_bwd(c, w.b1, 64, w.x, 32, w.gx, 32, R_BASE_2_W, R_BASE_2_B, w.gb1, 64, 0, PV, 64, 32, ACT_ELU));
+  L(lin_bwd(c, w.xin, 207, w.b1, 64, w.gb1, 64, R_BASE_0_W, R_BASE_0_B, w.gxin, 207, 0, PV, 207, 64, ACT_ELU));
+  hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 140)), dim3(256), 0, st, w.gglob, 140, 0, w.gxin, 207, 0, P, V, 140, 0);
+  (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
+  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35, w.gglob, 140, 0, 35,
+                     w.gxin, 207, 140, w.gw0);
+  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105, w.gglob, 140, 70, 105,
+                     w.gxin, 207, 140, (float*)nullptr);
+  PGRF_TCHECK("train view statistics backward");
+  // weight0 = sigmoid(neuray_fc) * wgt: the gradient enters the sigmoid output scaled by wgt
+  hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gw0, 1, 0, w.gw0, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
+  L(lin_bwd(c, w.n1, 8, w.nfs, 1, w.gw0, 1, R_NF_2_W, R_NF_2_B, w.gn1, 8, 0, PV, 8, 1, ACT_SIGMOID));
+  L(lin_bwd(c, w.xin + 175, 207, w.n1, 8, w.gn1, 8, R_NF_0_W, R_NF_0_B, w.gxin + 175, 207, 1, PV, 32, 8, ACT_ELU));    // += onto the neuray columns
+  hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.gdfeat, 35, 0, w.gxin, 207, 140, PV, 35, 0);
+  if (g_img_feats)
+    hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, g_img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.gxin, 207, 143);
+  L(lin_bwd(c, w.d1, 16, w.dfeat, 35, w.gdfeat, 35, R_RD_2_W, R_RD_2_B, w.gd1, 16, 0, PV, 16, 35, ACT_ELU));
+  L(lin_bwd(c, w.dd, 4, w.d1, 16, w.gd1, 16, R_RD_0_W, R_RD_0_B, (float*)nullptr, 0, 0, PV, 4, 16, ACT_ELU));
+  L(lin_bwd(c, w.pe_h, 32, w.xin + 175, 207, w.gxin + 175, 207, R_PE_2_W, R_PE_2_B, w.gpe_h, 32, 0, PV, 32, 32, ACT_NONE));
+  L(lin_bwd(c, w.pe_in, 34, w.pe_h, 32, w.gpe_h, 32, R_PE_0_W, R_PE_0_B, w.gpe_in, 34, 0, PV, 34, 32, ACT_RELU));
+  // compute_prob: gradients of (hit, vis) -> mixture parameters
+  ProbGrad pg{w.gpe_in, w.gdout[0], w.gdout[1], w.gdout[2], use_vis ? w.gdout[3] : nullptr};
+  hipLaunchKernelGGL(prob_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, pio, pg, PV, V);
+  PGRF_TCHECK("train compute_prob backward");
+  for (int m = 0; m < NM; ++m) {
+    L(lin_bwd(c, w.dh2[m], 32, w.dout[m], 2, w.gdout[m], 2, kDD[m][4], kDD[m][5], w.gdh2[m], 32, 0, PV, 32, kDDout[m], kDDact[m]));
+    L(lin_bwd(c, w.dh1[m], 32, w.dh2[m], 32, w.gdh2[m], 32, kDD[m][2], kDD[m][3], w.gdh1[m], 32, 0, PV, 32, 32, ACT_ELU));
+    L(lin_bwd(c, w.pe_in, 34, w.dh1[m], 32, w.gdh1[m], 32, kDD[m][0], kDD[m][1], w.gpe_in, 34, 1, PV, 32, 32, ACT_ELU));       // += onto the ray feature
+  }
+  if (g_ray_feats)
+    hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, g_ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.gpe_in, 34, 0);
+  PGRF_TCHECK("train gather backward");
+#undef L
+  return PGRF_OK;
+}
+
+}  // extern "C"

@@ -302,3 +302,54 @@ class RayRenderer:
         if flag is not None and int(flag.item()):
             raise PgrfError('NaN in the rendered samples (density / colour / hit probability)')
         return out
+
+
+# ------------------------------------------------------------------------------------------------ training (backward)
+def raw_weight_tensors(state_dict, dd_prefix, agg_prefix, use_vis, device):
+    """The pass's weights as fp32 contiguous DEVICE tensors in pgrf_raw_name order (None for an absent vis_decoder)."""
+    out = []
+    for n in raw_names():
+        key = (dd_prefix + n[len('dist_decoder'):]) if n.startswith('dist_decoder.') else (agg_prefix + n[len('agg_net'):])
+        if key not in state_dict:
+            if '.vis_decoder.' in key and not use_vis:
+                out.append(None)
+                continue
+            raise PgrfError(f"state_dict lacks '{key}'")
+        out.append(state_dict[key].detach().to(device, torch.float32).contiguous())
+    return out
+
+
+def render_pass_backward(frame, raw, use_vis, coords, depth, grads, want_maps=True, want_forward=False):
+    """Backward of one network pass (pgrf_render_pass_backward).  raw: list from raw_weight_tensors; grads: dict with any of
+    'pixel_colors_nr' [rn,3], 'render_depth' [rn], 'hit_prob_nr' [rn,dn], 'colors_nr' [rn,dn,3], 'density_nr' [rn,dn].
+    -> (list of weight gradients in raw order (None where raw is None), g_img_feats [rfn,32,hf,wf], g_ray_feats [rfn,32,hr,wr]
+    (NCHW, or None), forward outputs of the staged recompute when want_forward)."""
+    from ._lib import PgrfPassGrad
+    _require_gpu()
+    dev = frame.device
+    coords, depth = _f32c(coords, dev), _f32c(depth, dev)
+    rn, dn = depth.shape
+    g = {k: (_f32c(v, dev) if v is not None else None) for k, v in grads.items()}
+    pg = PgrfPassGrad(*[(g[k].data_ptr() if g.get(k) is not None else None)
+                        for k in ('pixel_colors_nr', 'render_depth', 'hit_prob_nr', 'colors_nr', 'density_nr')])
+    n = len(raw)
+    raw_arr, g_arr = (C.c_void_p * n)(), (C.c_void_p * n)()
+    g_raw = []
+    for i, t in enumerate(raw):
+        raw_arr[i] = None if t is None else t.data_ptr()
+        gt = None if t is None else torch.zeros_like(t)
+        g_raw.append(gt)
+        g_arr[i] = None if gt is None else gt.data_ptr()
+    fs = frame.c_struct()
+    g_if = torch.zeros_like(frame.img_feats) if want_maps else None         # channel-last, like the frame's maps
+    g_rf = torch.zeros_like(frame.ray_feats) if want_maps else None
+    fwd_t, fwd_s = None, None
+    if want_forward:
+        fwd_t, fwd_s = _alloc_out(rn, dn, dev)
+    nws = lib.pgrf_render_pass_backward_workspace_bytes(frame.rfn, rn, dn)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    lib.check(lib.pgrf_render_pass_backward(C.byref(fs), raw_arr, n, int(bool(use_vis)), _ptr(coords), _ptr(depth), rn, dn,
+                                            C.byref(pg), g_arr, _ptr(g_if), _ptr(g_rf), C.byref(fwd_s) if want_forward else None,
+                                            _ptr(ws), C.c_size_t(nws), _stream()))
+    to_nchw = lambda t: None if t is None else t.permute(0, 3, 1, 2)
+    return g_raw, to_nchw(g_if), to_nchw(g_rf), fwd_t

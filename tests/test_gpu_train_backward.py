@@ -1,0 +1,109 @@
+"""Backward pass of one network pass (pgrf_render_pass_backward) against torch.autograd THROUGH THE ORACLE
+(oracle/render_oracle.py is pinned to the reference's stage tensors by tests/test_oracle_render.py, so its autograd graph is the
+reference's: network/renderer.py:223-304 as the trainer differentiates it).  Inputs: the reference stage fixtures -- 1, 2, 3
+and 4 source views, 32 and 64 samples, with and without the visibility decoder.  -m gpu"""
+import pytest
+import torch
+
+from tests import fixtures as FX
+
+pytestmark = pytest.mark.gpu
+
+STAGE_FIXTURES = ['render_stages_v2_dn32', 'render_stages_v2_dn64', 'render_stages_v4_dn32', 'render_stages_v3_vis',
+                  'render_stages_v2_randinit', 'render_stages_v1_dn32']
+
+
+def _frame(E, frame):
+    return E.Frame(frame['imgs'], frame['img_feats'], frame['ray_feats'], frame['w2c'], frame['ref_depth_range'],
+                   frame['que_c2w'], frame['que_depth_range'])
+
+
+def _upstream(rn, dn, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {'pixel_colors_nr': torch.randn(rn, 3, generator=g), 'render_depth': 0.1 * torch.randn(rn, generator=g),
+            'hit_prob_nr': torch.randn(rn, dn, generator=g), 'colors_nr': 0.05 * torch.randn(rn, dn, 3, generator=g),
+            'density_nr': 0.05 * torch.randn(rn, dn, generator=g)}
+
+
+def _oracle_grads(w, dd, ag, frame, coords, depth, use_vis, up):
+    from oracle import render_oracle as O
+    torch.set_num_threads(8)
+    keys = [k for k in w if k.startswith(dd + '.') or k.startswith(ag + '.')]
+    wl = {k: (w[k].clone().requires_grad_(True) if k in keys else w[k]) for k in w}
+    fr = dict(frame)
+    fr['img_feats'] = frame['img_feats'].clone().requires_grad_(True)
+    fr['ray_feats'] = frame['ray_feats'].clone().requires_grad_(True)
+    out = O.render_pass(wl, dd, ag, fr, coords, depth, {'use_vis': use_vis})
+    loss = sum((out[k] * up[k]).sum() for k in up)
+    leaves = [wl[k] for k in keys] + [fr['img_feats'], fr['ray_feats']]
+    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    gw = {k: g for k, g in zip(keys, grads[:len(keys)])}
+    return gw, grads[-2], grads[-1], {k: out[k].detach() for k in up}
+
+
+def _close(a, b, rel, floor):
+    scale = max(float(b.abs().max()), floor)
+    return float((a - b).abs().max()) / scale
+
+
+@pytest.mark.parametrize('name', STAGE_FIXTURES)
+def test_backward_vs_autograd_through_the_oracle(name):
+    from panogrf_amd import engine as E
+    frame, w, cfg, g = FX.load(name)
+    fr = _frame(E, frame)
+    use_vis = cfg['dist_decoder_cfg']['use_vis']
+    coords = frame['coords']
+    for tag, dd, ag, seed in [('coarse', 'dist_decoder', 'agg_net', 1), ('fine', 'fine_dist_decoder', 'fine_agg_net', 2)]:
+        depth = g[tag]['depth']
+        rn, dn = depth.shape
+        up = _upstream(rn, dn, seed)
+        gw_ref, gif_ref, grf_ref, out_ref = _oracle_grads(w, dd, ag, frame, coords, depth, use_vis, up)
+        raw = E.raw_weight_tensors(w, dd, ag, use_vis, fr.device)
+        g_raw, g_if, g_rf, fwd = E.render_pass_backward(fr, raw, use_vis, coords, depth, up, want_forward=True)
+        # the rematerialised forward is the fused kernel's forward (and the reference's)
+        blob = E.pack_pass_weights(w, dd, ag, use_vis).cuda()
+        fused = E.render_pass(fr, blob, use_vis, coords, depth)
+        for k in ('pixel_colors_nr', 'hit_prob_nr', 'density_nr', 'colors_nr', 'render_depth'):
+            assert FX.max_abs(fwd[k].cpu(), fused[k].cpu()) < 2e-5 * max(1.0, float(fused[k].abs().max())), (name, tag, k)
+            assert FX.max_abs(fwd[k].cpu(), out_ref[k]) < 1e-4 * max(1.0, float(out_ref[k].abs().max())), (name, tag, k)
+        # weight gradients, in the reference's state_dict layout
+        names = E.raw_names()
+        checked = 0
+        for n_, gt in zip(names, g_raw):
+            key = (dd + n_[len('dist_decoder'):]) if n_.startswith('dist_decoder.') else (ag + n_[len('agg_net'):])
+            if gt is None:
+                assert '.vis_decoder.' in key and not use_vis
+                continue
+            ref = gw_ref[key]
+            ref = torch.zeros_like(w[key]) if ref is None else ref
+            assert gt.shape == ref.shape, (key, gt.shape, ref.shape)
+            # (floor: rgb_fc.4.bias has an exactly zero gradient -- a softmax over the views ignores a common shift -- so both
+            #  sides hold round-off of ~1e-7 there)
+            err = _close(gt.cpu(), ref, 1e-3, 1e-3)
+            assert err < 2e-3, (name, tag, key, err, float(ref.abs().max()))
+            checked += 1
+        assert checked >= 62
+        # feature-map gradients (scatter-add of the bilinear gathers)
+        assert _close(g_if.cpu(), gif_ref, 1e-3, 1e-6) < 2e-3, (name, tag, 'img_feats')
+        assert _close(g_rf.cpu(), grf_ref, 1e-3, 1e-6) < 2e-3, (name, tag, 'ray_feats')
+        assert float(grf_ref.abs().max()) > 0 and float(gif_ref.abs().max()) > 0
+
+
+def test_backward_argument_validation():
+    import ctypes as C
+    from panogrf_amd import engine as E
+    from panogrf_amd._lib import lib, PgrfError, PgrfPassGrad
+    frame, w, cfg, g = FX.load('render_stages_v2_dn32')
+    fr = _frame(E, frame)
+    raw = E.raw_weight_tensors(w, 'dist_decoder', 'agg_net', False, fr.device)
+    depth = g['coarse']['depth']
+    with pytest.raises(PgrfError):          # a missing non-optional weight
+        E.render_pass_backward(fr, [None] + raw[1:], False, frame['coords'], depth, {})
+    with pytest.raises(PgrfError):          # unsupported sample count
+        E.render_pass_backward(fr, raw, False, frame['coords'], torch.ones(frame['coords'].shape[0], 2), {})
+    assert lib.pgrf_render_pass_backward_workspace_bytes(2, 0, 32) == 0
+    need = lib.pgrf_render_pass_backward_workspace_bytes(2, 12, 32)
+    assert need > 12 * 32 * 2 * 4000
+    # empty batch: a no-op
+    g_raw, g_if, g_rf, _ = E.render_pass_backward(fr, raw, False, torch.zeros(0, 2), torch.zeros(0, 32), {})
+    assert all(float(t.abs().max()) == 0.0 for t in g_raw if t is not None) and float(g_if.abs().max()) == 0.0
