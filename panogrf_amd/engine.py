@@ -353,3 +353,48 @@ def render_pass_backward(frame, raw, use_vis, coords, depth, grads, want_maps=Tr
                                             _ptr(ws), C.c_size_t(nws), _stream()))
     to_nchw = lambda t: None if t is None else t.permute(0, 3, 1, 2)
     return g_raw, to_nchw(g_if), to_nchw(g_rf), fwd_t
+
+
+class RenderPassFunction(torch.autograd.Function):
+    """One network pass under torch.autograd: forward = the fused HIP kernel (pgrf_render_pass), backward =
+    pgrf_render_pass_backward (rematerialising).  Differentiable inputs: img_feats, ray_feats (NCHW, the 2-D encoders'
+    outputs) and the pass's weights in pgrf_raw_name order; everything else (source images, poses, sample depths) is a
+    constant, as in the reference's training graph (the importance sampler's inputs are detached, renderer.py:437)."""
+
+    @staticmethod
+    def forward(ctx, meta, coords, depth, img_feats, ray_feats, *raw):
+        imgs, w2c, ref_dr, que_c2w, que_dr, use_vis, precision, frame_kw = meta
+        frame = Frame(imgs, img_feats.detach(), ray_feats.detach(), w2c, ref_dr, que_c2w, que_dr, device=imgs.device, **frame_kw)
+        names = raw_names()
+        host = {n: (t.detach() if t is not None else None) for n, t in zip(names, raw)}
+        blob = pack_pass_weights({k: v for k, v in host.items() if v is not None}, 'dist_decoder', 'agg_net', use_vis).to(frame.device)
+        out = render_pass(frame, blob, use_vis, coords, depth, precision=precision)
+        ctx.frame, ctx.use_vis = frame, use_vis
+        ctx.coords, ctx.depth = coords.detach(), depth.detach()
+        ctx.raw = [None if t is None else t.detach().to(frame.device, torch.float32).contiguous() for t in raw]
+        ctx.need_maps = img_feats.requires_grad or ray_feats.requires_grad
+        return out['pixel_colors_nr'], out['render_depth'], out['hit_prob_nr'], out['colors_nr'], out['density_nr']
+
+    @staticmethod
+    def backward(ctx, g_pixel, g_depth, g_hit, g_colors, g_density):
+        grads = {'pixel_colors_nr': g_pixel, 'render_depth': g_depth, 'hit_prob_nr': g_hit, 'colors_nr': g_colors, 'density_nr': g_density}
+        g_raw, g_if, g_rf, _ = render_pass_backward(ctx.frame, ctx.raw, ctx.use_vis, ctx.coords, ctx.depth, grads, want_maps=ctx.need_maps)
+        return (None, None, None, g_if, g_rf) + tuple(g_raw)
+
+
+def render_pass_autograd(imgs, img_feats, ray_feats, w2c, ref_depth_range, que_c2w, que_depth_range, named_params, dd_prefix,
+                         agg_prefix, use_vis, coords, depth, precision='f32', **frame_kw):
+    """named_params: name -> Parameter (the module's own, so the gradients land on them).  -> dict like render_pass()."""
+    names = raw_names()
+    raw = []
+    for n in names:
+        key = (dd_prefix + n[len('dist_decoder'):]) if n.startswith('dist_decoder.') else (agg_prefix + n[len('agg_net'):])
+        if key not in named_params:
+            if '.vis_decoder.' in key and not use_vis:
+                raw.append(None)
+                continue
+            raise PgrfError(f"module lacks parameter '{key}'")
+        raw.append(named_params[key])
+    meta = (imgs.detach(), w2c.detach(), ref_depth_range.detach(), que_c2w, que_depth_range, bool(use_vis), precision, frame_kw)
+    px, rd, hit, col, den = RenderPassFunction.apply(meta, coords, depth, img_feats, ray_feats, *raw)
+    return {'pixel_colors_nr': px, 'render_depth': rd, 'hit_prob_nr': hit, 'colors_nr': col, 'density_nr': den}

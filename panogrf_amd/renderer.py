@@ -218,12 +218,15 @@ class NeuralRayBaseRenderer(nn.Module):
             self._rr_key = key
         return self._rr
 
-    @staticmethod
-    def _check_train(is_train):
-        """Training mode is FORWARD ONLY: jittered stratified sampling, random importance samples and
-        the hit_prob_* outputs as in the reference; the HIP kernels have no backward pass, so autograd must be off."""
+    def _check_train(self, is_train):
+        """Training mode: the reference's random importance samples and hit_prob_* outputs; with autograd
+        enabled the per-ray passes run as torch.autograd Functions whose backward is pgrf_render_pass_backward
+        (panogrf_amd.engine.RenderPassFunction) and the 2-D encoders stay on torch.  What has no backward is refused."""
         if is_train and torch.is_grad_enabled():
-            raise NotImplementedError('training-mode forward runs under torch.no_grad() only: the HIP path has no backward pass')
+            if self.cfg.get('render_c2f_all'):
+                raise NotImplementedError("cfg['render_c2f_all'] has no backward pass (pgrf_merge_c2f is forward only)")
+            if self.cfg.get('hip_precision', 'f32') != 'f32':
+                raise NotImplementedError("training runs in exact fp32 (cfg['hip_precision']='f32')")
 
     # ------------------------------------------------------------------ reference interface
     def render_impl(self, que_imgs_info, ref_imgs_info, is_train, is_perspec=False):
@@ -233,10 +236,13 @@ class NeuralRayBaseRenderer(nn.Module):
         imgs = ref_imgs_info['imgs']
         dev = imgs.device
         rr = self._engine(dev)
-        frame = ref_imgs_info.get('_pgrf_frame')
-        if frame is None:
-            frame = self._make_frame(que_imgs_info, ref_imgs_info, is_perspec)
-        out = rr.render_rays(frame, que_imgs_info['coords'][0], is_train=bool(is_train))
+        if is_train and torch.is_grad_enabled():
+            out = self._render_rays_autograd(que_imgs_info, ref_imgs_info, is_perspec)
+        else:
+            frame = ref_imgs_info.get('_pgrf_frame')
+            if frame is None:
+                frame = self._make_frame(que_imgs_info, ref_imgs_info, is_perspec)
+            out = rr.render_rays(frame, que_imgs_info['coords'][0], is_train=bool(is_train))
         c = self.cfg
         res = {}
         rn = que_imgs_info['coords'].shape[1]
@@ -255,6 +261,46 @@ class NeuralRayBaseRenderer(nn.Module):
             if c.get('render_uncert'):       # sum_i w_i (z_i - depth)^2 + 1e-5 (renderer.py:305-312)
                 res['render_uncert' + suffix] = out['render_uncert' + suffix].unsqueeze(0)
         return res
+
+    def _render_rays_autograd(self, que, ref, is_perspec):
+        """render_impl's per-ray part under autograd (network/renderer.py:567-633 as the trainer runs it): deterministic
+        coarse depths (:607 passes random_sample=False), coarse pass, importance sampling from the DETACHED hit
+        probabilities with torch.rand draws (:437, render_ops.py:449), fine pass.  Gradients reach the module's own
+        parameters and ref['img_feats'] / ref['ray_feats'] (the torch encoders' outputs)."""
+        c = self.cfg
+        imgs = ref['imgs']
+        dev = imgs.device
+        coords = que['coords'][0].detach().to(dev, torch.float32).contiguous()
+        rn, dn = coords.shape[0], int(c['depth_sample_num'])
+        params = dict(self.named_parameters())
+        kw = dict(dataset_name=c.get('dataset_name', 'm3d'))
+        que_c2w = None
+        if is_perspec:
+            kw.update(que_pose=que['poses'], que_K=que['Ks'])
+        else:
+            que_c2w = que['c2w']
+        use_disp = bool(c.get('use_disp', True))
+        depth = E.sample_coarse_depth(c['min_depth'], c['max_depth'], rn, dn, use_disp=use_disp, device=dev)
+        common = (imgs, ref['img_feats'], ref['ray_feats'], ref['w2c'], ref['depth_range'], que_c2w, que['depth_range'], params)
+        out = E.render_pass_autograd(*common, 'dist_decoder', 'agg_net', self.dist_decoder.cfg['use_vis'], coords, depth, **kw)
+        out['depth'] = depth
+        if c['use_hierarchical_sampling']:
+            fdn = int(c['fine_depth_sample_num'])
+            u = torch.rand([1, rn, fdn])[0].to(dev)
+            fd = E.sample_fine_depth(depth, out['hit_prob_nr'].detach(), E.host_floats(que['depth_range'], 2), fdn, use_disp=use_disp,
+                                     use_all=bool(c['fine_depth_use_all']), u=u)
+            if c.get('one_mlp', False):
+                pre, vis_f = ('dist_decoder', 'agg_net'), self.dist_decoder.cfg['use_vis']
+            else:
+                pre, vis_f = ('fine_dist_decoder', 'fine_agg_net'), self.fine_dist_decoder.cfg['use_vis']
+            fine = E.render_pass_autograd(*common, pre[0], pre[1], vis_f, coords, fd, **kw)
+            fine['depth'] = fd
+            for k, v in fine.items():
+                out[k + '_fine'] = v
+        if c.get('render_uncert'):        # renderer.py:305-312, in torch so that it stays differentiable
+            for sfx in [''] + (['_fine'] if c['use_hierarchical_sampling'] else []):
+                out['render_uncert' + sfx] = ((out['depth' + sfx] - out['render_depth' + sfx].unsqueeze(-1)).pow(2) * out['hit_prob_nr' + sfx]).sum(-1) + 1e-5
+        return out
 
     def _torch_encoders(self, imgs, ray_feats):
         feats = self.image_encoder(imgs)
@@ -474,7 +520,8 @@ class NeuralRayBaseRenderer(nn.Module):
         ref_imgs_info['img_feats'] = ref_img_feats
         ref_imgs_info['ray_feats'] = ray_feats
         ref = dict(ref_imgs_info)
-        ref['_pgrf_frame'] = self._make_frame(que_imgs_info, ref, is_perspec)
+        if not (is_train and torch.is_grad_enabled()):
+            ref['_pgrf_frame'] = self._make_frame(que_imgs_info, ref, is_perspec)
         coords = que_imgs_info['coords']
         # Multi-GPU (new, the reference is single-GPU): under an initialised process group every rank renders a
         # contiguous chunk of the rays (whole row tiles for a full panorama) and ONE all-gather per output reassembles them.
@@ -510,8 +557,8 @@ class NeuralRayBaseRenderer(nn.Module):
     def _ray_shard_world(self):
         """(rank, world) when rays are to be sharded over the default process group, else None."""
         import torch.distributed as tdist
-        if not (self.cfg.get('hip_shard_rays', True) and tdist.is_available() and tdist.is_initialized()):
-            return None
+        if not (self.cfg.get('hip_shard_rays', True) and tdist.is_available() and tdist.is_initialized()) or torch.is_grad_enabled():
+            return None          # (under autograd every rank renders its own batch: data parallelism is the trainer's, not ours)
         world = tdist.get_world_size()
         return (tdist.get_rank(), world) if world > 1 else None
 

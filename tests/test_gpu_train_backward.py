@@ -107,3 +107,92 @@ def test_backward_argument_validation():
     # empty batch: a no-op
     g_raw, g_if, g_rf, _ = E.render_pass_backward(fr, raw, False, torch.zeros(0, 2), torch.zeros(0, 32), {})
     assert all(float(t.abs().max()) == 0.0 for t in g_raw if t is not None) and float(g_if.abs().max()) == 0.0
+
+
+def test_module_training_step_matches_autograd_through_the_oracle():
+    """renderer(data) WITHOUT 'eval' under autograd (the reference's training call, network/renderer.py:777-786): coarse + fine
+    pass as autograd Functions on the HIP kernels, encoders on torch.  One loss, backward, and every gradient -- per-ray
+    networks, image encoder, visibility encoder -- compared with the same graph built from the oracle's torch ops on the
+    SAME encoder modules and the same importance-sampling draws."""
+    import numpy as np
+    from oracle import render_oracle as O
+    from panogrf_amd.renderer import name2network
+    frame, _, cfg, g = FX.load('render_full_v2_dn32')
+    z = np.load(FX.GOLDEN + '/render_full_v2_dn32.npz')
+    shapes = []
+    for ln in bytes(z['state.keys']).decode().split('\n'):
+        k, s_ = ln.split(':')
+        shapes.append((k, tuple(int(t) for t in s_.split(',')) if s_ else ()))
+    net = name2network['neuray_base'](dict(cfg))
+    net.load_state_dict(FX.seeded_renderer_state(shapes, 800))
+    net = net.cuda().train()
+    H, W = frame['imgs'].shape[-2:]
+    gsel = torch.Generator().manual_seed(3)
+    idx = torch.randperm(H * W, generator=gsel)[:96]
+    coords = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+    target = torch.rand(96, 3, generator=gsel).cuda()
+    que = {'c2w': frame['que_c2w'][None].cuda(), 'coords': coords[None].cuda(), 'depth_range': frame['que_depth_range'][None].cuda()}
+    mk_ref = lambda: {'imgs': frame['imgs'].cuda(), 'w2c': frame['w2c'].cuda(), 'depth_range': frame['ref_depth_range'].cuda(),
+                      'ray_feats': frame['ray_feats'].cuda()}
+
+    def loss_of(out):
+        return ((out['pixel_colors_nr_fine'] - target) ** 2).mean() + 0.5 * ((out['pixel_colors_nr'] - target) ** 2).mean() + \
+            0.01 * out['render_depth_fine'].mean() + 0.1 * (out['hit_prob_nr'] ** 2).sum(-1).mean()
+
+    # ---- HIP path
+    net.zero_grad()
+    torch.manual_seed(11)                      # the importance sampler's torch.rand draws
+    out = net({'que_imgs_info': dict(que), 'ref_imgs_info': mk_ref()})          # no 'eval': training mode
+    assert out['pixel_colors_nr_fine'].requires_grad and 'hit_prob_nr_fine' in out
+    loss = loss_of({k: v[0] for k, v in out.items() if v.dtype == torch.float32})
+    loss.backward()
+    mine = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    assert any(k.startswith('image_encoder.') for k in mine) and any(k.startswith('vis_encoder.') for k in mine)
+    assert all(bool(torch.isfinite(v).all()) for v in mine.values())
+
+    # ---- the same graph from the oracle's torch ops (GPU tensors, same modules, same draws)
+    net.zero_grad()
+    torch.manual_seed(11)
+    u = torch.rand([1, 96, cfg['fine_depth_sample_num']])[0].cuda()
+    ref = mk_ref()
+    feats, rf = net._torch_encoders(ref['imgs'], ref['ray_feats'])
+    w = {k: p for k, p in net.named_parameters()}
+    fr = dict(imgs=ref['imgs'], img_feats=feats, ray_feats=rf, w2c=ref['w2c'], ref_depth_range=ref['depth_range'],
+              que_c2w=frame['que_c2w'].cuda(), que_depth_range=frame['que_depth_range'].cuda())
+    # sample depths are constants of the graph: take the fine depths the HIP sampler drew from the HIP coarse pass (the oracle's
+    # own inverse CDF lands ~1e-4 away, which white-noise feature maps turn into per-cent level gradient differences)
+    from panogrf_amd import engine as E
+    dn = cfg['depth_sample_num']
+    depth_c = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], 96, dn, cfg.get('use_disp', True), 'cuda')
+    fd = E.sample_fine_depth(depth_c, out['hit_prob_nr'][0].detach(), frame['que_depth_range'], cfg['fine_depth_sample_num'],
+                             use_disp=cfg.get('use_disp', True), u=u)
+    uv = cfg['dist_decoder_cfg']['use_vis']
+    oc = O.render_pass(w, 'dist_decoder', 'agg_net', fr, coords.cuda(), depth_c, {'use_vis': uv})
+    of = O.render_pass(w, 'fine_dist_decoder', 'fine_agg_net', fr, coords.cuda(), fd, {'use_vis': cfg['fine_dist_decoder_cfg']['use_vis']})
+    oout = dict(oc, **{k + '_fine': v for k, v in of.items()})
+    oloss = loss_of(oout)
+    oloss.backward()
+    theirs = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-5 * max(1.0, abs(float(oloss.detach())))
+    assert set(mine) == set(theirs)
+    worst = 0.0
+    for k in theirs:
+        a, b = mine[k].double().flatten(), theirs[k].double().flatten()
+        nb = float(b.norm())
+        if nb < 1e-7:
+            assert float(a.norm()) < 1e-5, k
+            continue
+        rel = float((a - b).norm()) / nb
+        worst = max(worst, rel)
+        assert rel < 3e-3, (k, rel)
+    assert worst > 0.0
+    # an optimiser step through the module's own parameters works (and invalidates the packed inference weights)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    for k, p in net.named_parameters():
+        p.grad = mine.get(k)
+    before = float(loss.detach())
+    opt.step()
+    torch.manual_seed(11)
+    out2 = net({'que_imgs_info': dict(que), 'ref_imgs_info': mk_ref()})
+    after = float(loss_of({k: v[0] for k, v in out2.items() if v.dtype == torch.float32}).detach())
+    assert after < before, (before, after)

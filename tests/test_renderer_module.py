@@ -51,9 +51,7 @@ def test_render_end_to_end_vs_reference():
     assert FX.psnr(out['pixel_colors_nr'].cpu(), gold['pixel_colors_nr']) > 80
     assert FX.psnr(out['pixel_colors_nr_fine'].cpu(), gold['pixel_colors_nr_fine']) > 60
     assert torch.equal(out['ray_mask_fine'].cpu(), gold['ray_mask_fine'])
-    # training mode is forward-only: refused while autograd is on (there is no backward pass) ...
-    with pytest.raises(NotImplementedError):
-        net({'que_imgs_info': que, 'ref_imgs_info': ref})
+    # training mode with autograd on runs the per-ray passes as autograd Functions (tests/test_gpu_train_backward.py) ...
     # ... and under no_grad it returns the reference's training outputs: hit_prob_* kept (renderer.py:675), random
     # importance samples -> a different fine image, the same deterministic coarse image
     ref2 = {'imgs': frame['imgs'].cuda(), 'w2c': frame['w2c'].cuda(), 'depth_range': frame['ref_depth_range'].cuda(),
