@@ -155,6 +155,20 @@ int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int flags, const
                      const float* depth, int rn, int dn, const PgrfPassOut* out, const PgrfPassDebug* dbg,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ multi-GPU: image all-gather over RCCL --- */
+/* For hosts WITHOUT torch.distributed (the Python host uses `panogrf_amd.dist`, i.e. torch.distributed on RCCL): the one
+ * collective of the ray-tile split -- every rank renders H/G rows, one ncclAllGather reassembles the image.
+ * RCCL is resolved at run time (dlopen; a copy already in the process is reused).  The reference has no counterpart
+ * (train/trainer.py:232-234: single GPU).
+ *   rank 0: pgrf_comm_unique_id(&id) -> send `id` to the other ranks (any side channel) -> every rank: pgrf_comm_init ->
+ *   per frame: pgrf_allgather_image(comm, my_rows, whole_image, floats_per_rank, stream) -> pgrf_comm_destroy */
+typedef struct PgrfUniqueId { char internal[128]; } PgrfUniqueId;      /* = ncclUniqueId */
+int pgrf_comm_unique_id(PgrfUniqueId* id);
+int pgrf_comm_init(const PgrfUniqueId* id, int rank, int nranks, void** comm);
+/* shard: `count` floats of this rank; full: nranks * count floats, rank-major (equal shards: H % nranks == 0) */
+int pgrf_allgather_image(void* comm, const float* shard, float* full, size_t count, void* stream);
+int pgrf_comm_destroy(void* comm);
+
 /* ------------------------------------------------------------------ training: backward of one pass --- */
 /* Upstream gradients of one pass's outputs (any pointer may be NULL = zero): what the reference's losses differentiate
  * (network/loss.py: RenderLoss on pixel_colors_nr, DepthLoss on render_depth, the consistency terms on hit_prob_nr). */

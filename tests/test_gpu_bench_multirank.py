@@ -99,3 +99,31 @@ def test_plain_bench_gpus_2_launches_its_own_ranks():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert d['n_gpus'] == 2 and d['config']['ray_tiles'] == 2
     assert d['config']['gathered_image_max_abs_diff_vs_unsharded'] == 0.0
+
+
+def test_cabi_rccl_image_allgather_one_rank():
+    """The C-ABI collective entry points (include/panogrf_hip.h: pgrf_comm_unique_id / pgrf_comm_init / pgrf_allgather_image /
+    pgrf_comm_destroy) for hosts without torch.distributed: a one-rank communicator on this GPU, the image
+    all-gather through ncclAllGather, in a fresh process (RCCL resolved by dlopen)."""
+    code = r'''
+import ctypes as C, torch
+from panogrf_amd._lib import lib
+torch.cuda.set_device(0)
+uid = (C.c_char * 128)()
+lib.check(lib.pgrf_comm_unique_id(C.cast(uid, C.c_void_p)))
+comm = C.c_void_p()
+lib.check(lib.pgrf_comm_init(C.cast(uid, C.c_void_p), 0, 1, C.byref(comm)))
+assert comm.value
+shard = torch.rand(64 * 128, 3, device='cuda')
+full = torch.zeros_like(shard)
+st = torch.cuda.current_stream().cuda_stream
+lib.check(lib.pgrf_allgather_image(comm, C.c_void_p(shard.data_ptr()), C.c_void_p(full.data_ptr()), shard.numel(), C.c_void_p(st)))
+torch.cuda.synchronize()
+assert torch.equal(full, shard)
+assert lib.pgrf_allgather_image(None, C.c_void_p(shard.data_ptr()), C.c_void_p(full.data_ptr()), 4, None) != 0
+lib.check(lib.pgrf_comm_destroy(comm))
+print('cabi rccl allgather ok')
+'''
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2500:])
+    assert 'cabi rccl allgather ok' in r.stdout
