@@ -388,43 +388,66 @@ __global__ void attn_fwd_kernel(const float* __restrict__ q, const float* __rest
   float* op = o + ((size_t)ray * dn + s) * 16 + h * 4;
   op[0] = a0 / l; op[1] = a1 / l; op[2] = a2 / l; op[3] = a3 / l;
 }
-// per query sample s: P_st = softmax_t(S_st); gP_st = <go_s, v_t>; gS_st = P_st (gP_st - <go_s, o_s>);
-//   gq_s = 0.5 * sum_t gS_st k_t;  gk_t += 0.5 * gS_st q_s;  gv_t += P_st go_s   (atomics across the queries of the ray)
-__global__ void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vv,
-                                const float* __restrict__ o, const float* __restrict__ go, int rn, int dn, int uniform,
-                                float* __restrict__ gq, float* __restrict__ gk, float* __restrict__ gv) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)rn * 4 * dn) return;
-  const int s = (int)(i % dn), h = (int)((i / dn) % 4), ray = (int)(i / (4L * dn));
-  const size_t base = (size_t)ray * dn * 16 + h * 4, me = ((size_t)ray * dn + s) * 16 + h * 4;
-  const float* kb = k + base; const float* vb = vv + base;
-  const float qs[4] = {q[me], q[me + 1], q[me + 2], q[me + 3]};
-  const float g[4] = {go[me], go[me + 1], go[me + 2], go[me + 3]};
-  const float dot_go_o = g[0] * o[me] + g[1] * o[me + 1] + g[2] * o[me + 2] + g[3] * o[me + 3];
-  float mx = -3.0e38f, l = 0.f;
-  if (!uniform) {
-    for (int t = 0; t < dn; ++t)
-      mx = fmaxf(mx, 0.5f * (qs[0] * kb[t * 16] + qs[1] * kb[t * 16 + 1] + qs[2] * kb[t * 16 + 2] + qs[3] * kb[t * 16 + 3]));
-    for (int t = 0; t < dn; ++t)
-      l += expf(0.5f * (qs[0] * kb[t * 16] + qs[1] * kb[t * 16 + 1] + qs[2] * kb[t * 16 + 2] + qs[3] * kb[t * 16 + 3]) - mx);
-  } else {
-    l = (float)dn;
-  }
-  float gqa[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < dn; ++t) {
-    const float pst = uniform ? 1.f / l
-                              : expf(0.5f * (qs[0] * kb[t * 16] + qs[1] * kb[t * 16 + 1] + qs[2] * kb[t * 16 + 2] + qs[3] * kb[t * 16 + 3]) - mx) / l;
-    const float gp = g[0] * vb[t * 16] + g[1] * vb[t * 16 + 1] + g[2] * vb[t * 16 + 2] + g[3] * vb[t * 16 + 3];
+// Backward of the attention of ONE (ray, head) per workgroup, thread = sample index (dn <= 128), no atomics:
+//   P_st = softmax_t(q_s k_t / 2);  gP_st = <go_s, v_t>;  gS_st = P_st (gP_st - <go_s, o_s>)
+//   phase 1 (thread = query s): row maximum / sum, <go_s, o_s>, and gq_s = 0.5 sum_t gS_st k_t
+//   phase 2 (thread = key t):   gk_t = 0.5 sum_s gS_st q_s,  gv_t = sum_s P_st go_s   (P_st recomputed from the row statistics)
+// gq / gk / gv are ACCUMULATED (+=) into zero-initialised buffers.
+__global__ void __launch_bounds__(128) attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vv,
+                                                       const float* __restrict__ o, const float* __restrict__ go, int rn, int dn, int uniform,
+                                                       float* __restrict__ gq, float* __restrict__ gk, float* __restrict__ gv) {
+  __shared__ float s_q[PGRF_MAX_DN][4], s_k[PGRF_MAX_DN][4], s_v[PGRF_MAX_DN][4], s_go[PGRF_MAX_DN][4];
+  __shared__ float s_mx[PGRF_MAX_DN], s_l[PGRF_MAX_DN], s_dot[PGRF_MAX_DN];
+  const int ray = blockIdx.x >> 2, h = blockIdx.x & 3, t = threadIdx.x;
+  const size_t base = (size_t)ray * dn * 16 + h * 4;
+  if (t < dn) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) atomicAdd(&gv[base + (size_t)t * 16 + c], pst * g[c]);
-    if (!uniform) {                                   // masked logits are constants: no gradient reaches q or k
-      const float gs = pst * (gp - dot_go_o);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { gqa[c] += 0.5f * gs * kb[t * 16 + c]; atomicAdd(&gk[base + (size_t)t * 16 + c], 0.5f * gs * qs[c]); }
+    for (int c = 0; c < 4; ++c) {
+      s_q[t][c] = q[base + (size_t)t * 16 + c]; s_k[t][c] = k[base + (size_t)t * 16 + c];
+      s_v[t][c] = vv[base + (size_t)t * 16 + c]; s_go[t][c] = go[base + (size_t)t * 16 + c];
     }
   }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) gq[me + c] += gqa[c];
+  __syncthreads();
+  if (t < dn) {          // phase 1: query t
+    const float q0 = 0.5f * s_q[t][0], q1 = 0.5f * s_q[t][1], q2 = 0.5f * s_q[t][2], q3 = 0.5f * s_q[t][3];
+    float mx = -3.0e38f, l = 0.f;
+    if (!uniform) {
+      for (int u = 0; u < dn; ++u) mx = fmaxf(mx, q0 * s_k[u][0] + q1 * s_k[u][1] + q2 * s_k[u][2] + q3 * s_k[u][3]);
+      for (int u = 0; u < dn; ++u) l += expf(q0 * s_k[u][0] + q1 * s_k[u][1] + q2 * s_k[u][2] + q3 * s_k[u][3] - mx);
+    } else {
+      mx = 0.f; l = (float)dn;
+    }
+    const size_t me = base + (size_t)t * 16;
+    const float dot = s_go[t][0] * o[me] + s_go[t][1] * o[me + 1] + s_go[t][2] * o[me + 2] + s_go[t][3] * o[me + 3];
+    s_mx[t] = mx; s_l[t] = l; s_dot[t] = dot;
+    if (!uniform) {      // masked logits are constants: no gradient reaches q or k
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int u = 0; u < dn; ++u) {
+        const float p = expf(q0 * s_k[u][0] + q1 * s_k[u][1] + q2 * s_k[u][2] + q3 * s_k[u][3] - mx) / l;
+        const float gp = s_go[t][0] * s_v[u][0] + s_go[t][1] * s_v[u][1] + s_go[t][2] * s_v[u][2] + s_go[t][3] * s_v[u][3];
+        const float gs = 0.5f * p * (gp - dot);
+        a0 += gs * s_k[u][0]; a1 += gs * s_k[u][1]; a2 += gs * s_k[u][2]; a3 += gs * s_k[u][3];
+      }
+      gq[me] += a0; gq[me + 1] += a1; gq[me + 2] += a2; gq[me + 3] += a3;
+    }
+  }
+  __syncthreads();
+  if (t < dn) {          // phase 2: key t
+    float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    for (int s = 0; s < dn; ++s) {
+      const float p = uniform ? 1.f / s_l[s]
+                              : expf(0.5f * (s_q[s][0] * s_k[t][0] + s_q[s][1] * s_k[t][1] + s_q[s][2] * s_k[t][2] + s_q[s][3] * s_k[t][3]) - s_mx[s]) / s_l[s];
+      v0 += p * s_go[s][0]; v1 += p * s_go[s][1]; v2 += p * s_go[s][2]; v3 += p * s_go[s][3];
+      if (!uniform) {
+        const float gp = s_go[s][0] * s_v[t][0] + s_go[s][1] * s_v[t][1] + s_go[s][2] * s_v[t][2] + s_go[s][3] * s_v[t][3];
+        const float gs = 0.5f * p * (gp - s_dot[s]);
+        k0 += gs * s_q[s][0]; k1 += gs * s_q[s][1]; k2 += gs * s_q[s][2]; k3 += gs * s_q[s][3];
+      }
+    }
+    const size_t me = base + (size_t)t * 16;
+    gv[me] += v0; gv[me + 1] += v1; gv[me + 2] += v2; gv[me + 3] += v3;
+    gk[me] += k0; gk[me + 1] += k1; gk[me + 2] += k2; gk[me + 3] += k3;
+  }
 }
 
 // LayerNorm(16, eps 1e-6) (ibrnet.py:101): y = (x - mean) * rstd * gamma + beta

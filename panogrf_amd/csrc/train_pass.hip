@@ -212,7 +212,11 @@ static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ld
     hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(rows * OUT) > 2048 ? 2048 : nblk(rows * OUT)), dim3(256), 0, c.st, dY, lddy, Y, ldy, rows, OUT,
                        act, gb);
   if (c.graw[rw]) {
-    const int kchunk = 4096;
+    // the reduction runs over the ROWS (sample points x views): split it so that the launch has ~2048 workgroups even when
+    // the weight matrix is one 64x64 tile (atomics into at most 207 x 64 outputs: no contention to speak of)
+    const long tiles = (long)((IN + 63) / 64) * ((OUT + 63) / 64);
+    long kc = (rows * tiles / 2048 + 15) / 16 * 16;
+    const int kchunk = (int)(kc < 128 ? 128 : kc);
     dim3 grid((IN + 63) / 64, (OUT + 63) / 64, (unsigned)((rows + kchunk - 1) / kchunk));
     hipLaunchKernelGGL((gemm_kernel<true, false, true>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], IN, OUT, IN, (int)rows, 1, kchunk);
   }
@@ -366,8 +370,8 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   (void)hipMemcpyAsync(w.ggp, w.gfo, P * 64, hipMemcpyDeviceToDevice, st);                                            // residual branch
   L(lin_bwd(c, w.o, 16, w.fo, 16, w.gfo, 16, R_ATT_FC_W, -1, w.go, 16, 0, P, 16, 16, ACT_NONE));
   (void)hipMemsetAsync(w.gq, 0, P * 64, st); (void)hipMemsetAsync(w.gk, 0, P * 64, st); (void)hipMemsetAsync(w.gv, 0, P * 64, st);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk((long)rn * 4 * dn)), dim3(256), 0, st, w.q, w.k, w.v, w.o, w.go, rn, dn, V <= 1 ? 1 : 0, w.gq,
-                     w.gk, w.gv);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)rn * 4), dim3(dn <= 64 ? 64 : 128), 0, st, w.q, w.k, w.v, w.o, w.go, rn, dn,
+                     V <= 1 ? 1 : 0, w.gq, w.gk, w.gv);
   PGRF_TCHECK("train attention backward");
   L(lin_bwd(c, w.gp, 16, w.q, 16, w.gq, 16, R_ATT_Q_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(lin_bwd(c, w.gp, 16, w.k, 16, w.gk, 16, R_ATT_K_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
