@@ -1,13 +1,14 @@
 #!/bin/bash
-# Collect the round's rocprof evidence on the GPU box:  bash tools/profile_round.sh r01
-# outputs under gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/
+# Collect the round's rocprof evidence on the GPU box from the FINAL binary, in one go:  bash tools/profile_round.sh r03
+# outputs under gpurun_out/profiles_<tag>/ ; then, back in the build container:
+#   bash tools/install_profiles.sh r03       (copies them to profiles/<tag>_* and regenerates the number blocks of DESIGN.md / README.md)
 TAG=$1
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. plain bench line (incl. cpu + eager baselines)
-python3 $R/bench.py --eager-baseline > $OUT/bench.json 2> $OUT/bench.err
+# 1. plain bench line as the driver runs it (cpu baseline, bounded eager strip, end-to-end frames, PSNR block)
+python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 2000 $OUT/bench.json
 # 2. kernel trace + stats of the bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
@@ -45,7 +46,7 @@ python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --views 4 > $OUT/benc
 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --precision f16x3 > $OUT/bench_f16x3.json 2>/dev/null
 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --with-cost-volume > $OUT/bench_config3.json 2>/dev/null
 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --with-cost-volume --reg costregnet > $OUT/bench_config3_costregnet.json 2>/dev/null
-python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --views 4 --height 1024 --width 2048 > $OUT/bench_config5_1gpu.json 2>/dev/null
+python3 $R/bench.py --steps 3 --warmup 1 --views 4 --height 1024 --width 2048 > $OUT/bench_config5_1gpu.json 2>/dev/null      # with the PSNR block
 # 6. per-frame 2-D encoders and the MVS stage (init net)
 python3 $R/tools/time_encoders.py 2>&1 | grep -E "ms|err" > $OUT/encoders_timing.txt
 python3 $R/tools/time_mvs.py 256 512 2>&1 | grep -E "ms|err" > $OUT/mvs_stage_timing_256x512.txt
@@ -53,5 +54,13 @@ python3 $R/tools/time_mvs.py 512 1024 2>&1 | grep -E "ms|err" > $OUT/mvs_stage_t
 # 7. Winograd vs direct 3-D convolution per UNet2 layer shape, and the per-dispatch durations of one UNet2 forward
 python3 $R/tools/check_wino.py time 2>&1 | grep "winograd" > $OUT/winograd_vs_direct_layers.txt
 bash $R/tools/layer_trace.sh unet2 128 256 2>&1 | grep -E "dur_us|sum_us" > $OUT/unet2_layer_trace_128x256.txt
+# 8. whole frames: one GPU (overlap / reuse), per-rank shares of the 8-GPU split, row tiles; training step
+python3 $R/tools/time_frame.py 2>&1 | grep -E "renderer\(data\)|max \|" > $OUT/frame_timing.txt
+python3 $R/tools/time_frame_shares.py 8 2>&1 | grep -vE "amdgpu.ids" | tail -7 > $OUT/whole_frame_rank_shares.txt
+python3 $R/tools/time_tiles.py 8 2>&1 | grep -vE "amdgpu.ids" | tail -8 > $OUT/row_tiles_per_rank.txt
+python3 $R/tools/train_demo.py 30 1024 2>&1 | grep -E "step|rays x" > $OUT/train_demo.txt
+# 9. memory-side counters of the 4-view kernel and the CostRegNet layer trace
+bash $R/tools/pmc_mem.sh v4 --views 4 2>&1 | grep "per-launch" > $OUT/views4_mem_pmc.txt
+bash $R/tools/trace_costreg.sh $TAG 128 256 2>&1 | grep -E " us$|sum " > $OUT/costregnet_layer_trace_128x256.txt
 rm -rf $OUT/pmc[0-9] $OUT/bench_trace $OUT/cv_trace
 ls $OUT
