@@ -303,6 +303,18 @@ int pgrf_pack_conv3d_small(const float* w_host, const float* bias_host, int Cout
 int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                       const float* packed, int has_bias, int nshift, int B, int D, int H, int W, int stride, float lrelu_slope,
                       const float* residual, int res_cs, int res_coff, void* stream);
+
+/* Trilinear x2 up-sampling (align_corners=False) FUSED into the wrap-padded 3x3x3 convolution behind it -- CostRegNet's decoder
+ * layers (models/cost_reg.py:58-94,136-158: conv9 32->16, conv11 16->8): evaluated on the LOW-resolution tensor as an 8-parity
+ * convolution (8 * Cout output rows share one operand; the up-sampled volume is never materialised), with per-position-class
+ * folded kernels for the border voxels.  in: [B,D,H,W,Cin-slice] low-res; out / residual: [B,2D,2H,2W,.] high-res;
+ * epilogue LeakyReLU(slope) then + residual.  Cin in {16, 32}, Cout in {8, 16}, D, H, W >= 2.  The packed block depends on
+ * (D, H, W) only through the border classes of axes of length 2. */
+size_t pgrf_conv3d_upfused_packed_floats(int Cout, int Cin);
+int pgrf_pack_conv3d_upfused(const float* w_host, const float* bias_host, int Cout, int Cin, int D, int H, int W, float* packed_host);
+int pgrf_conv3d_upfused(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                        const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                        int res_cs, int res_coff, void* stream);
 /* Fast path of the same convolution for Cout == 1 and wide inputs (UNet2's last block, 128 -> 1): a pointwise MFMA
  * pass projects every voxel onto the 27 tap vectors (y[B,D,H,W,32], caller-owned scratch), a 27-tap gather finishes
  * (bias, LeakyReLU, residual).  `packed` is the block made by pgrf_pack_conv3d(Cout=1). */

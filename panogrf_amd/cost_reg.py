@@ -50,6 +50,32 @@ class _PackedConv:
         return self._small[nshift]
 
 
+    def upfused(self, D, H, W):
+        """Packed block of the up-sampling-fused kernel (pgrf_conv3d_upfused) for a LOW-resolution input of D x H x W: 27
+        position classes of interpolation-folded kernels, built on first use per size."""
+        key = ('up', D, H, W)
+        if key not in self._small:
+            n = lib.pgrf_conv3d_upfused_packed_floats(self.cout, self.cin)
+            host = torch.empty(n, dtype=torch.float32)
+            lib.check(lib.pgrf_pack_conv3d_upfused(_ptr(self._w), _ptr(self._b), self.cout, self.cin, D, H, W, _ptr(host)))
+            self._small[key] = host.to(self._device)
+        return self._small[key]
+
+
+def _upconv(pc, x, out, up_scratch, slope=0.01, residual=None):
+    """conv(interpolate(x, scale_factor=2, mode='trilinear')) + LeakyReLU (+ residual) -> `out` (high resolution): CostRegNet's
+    decoder step (models/cost_reg.py:58-94).  Fused into ONE launch on the low-resolution tensor where the kernel applies
+    (Cin 16 | 32, Cout 8 | 16; PANOGRF_CONV_UPFUSE=0 disables); otherwise up-sample into `up_scratch()` and convolve."""
+    if (os.environ.get('PANOGRF_CONV_UPFUSE', '1') != '0' and pc.cin in (16, 32) and pc.cout in (8, 16) and min(x.D, x.H, x.W) >= 2):
+        lib.check(lib.pgrf_conv3d_upfused(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                          _ptr(pc.upfused(x.D, x.H, x.W)), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope),
+                                          _ptr(residual.buf) if residual is not None else None,
+                                          residual.cs if residual is not None else 0,
+                                          residual.coff if residual is not None else 0, _stream()))
+        return out
+    return _conv(pc, _up(x, up_scratch()), out, slope=slope, residual=residual)
+
+
 class _Vol:
     """channel-last volume view: buffer [B,D,H,W,cs] + channel slice [coff, coff+C)"""
 
@@ -197,9 +223,9 @@ class CostRegNet(_RegBase):
         c2 = _conv(pk['conv2'], _conv(pk['conv1'], c0, E(2, 16), stride=2), E(2, 16))
         c4 = _conv(pk['conv4'], _conv(pk['conv3'], c2, E(4, 32), stride=2), E(4, 32))
         t = _conv(pk['conv6'], _conv(pk['conv5'], c4, E(8, 64), stride=2), E(8, 64))
-        t = _conv(pk['conv7'], _up(t, E(4, 64)), E(4, 32), residual=c4)        # conv4 + conv7(x)
-        t = _conv(pk['conv9'], _up(t, E(2, 32)), E(2, 16), residual=c2)
-        t = _conv(pk['conv11'], _up(t, E(1, 16)), E(1, 8), residual=c0)
+        t = _upconv(pk['conv7'], t, E(4, 32), lambda: E(4, 64), residual=c4)   # conv4 + conv7(up(x))
+        t = _upconv(pk['conv9'], t, E(2, 16), lambda: E(2, 32), residual=c2)
+        t = _upconv(pk['conv11'], t, E(1, 8), lambda: E(1, 16), residual=c0)
         return _conv(pk['prob'], t, E(1, 1), slope=1.0).buf
 
 

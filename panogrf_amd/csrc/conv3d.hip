@@ -11,9 +11,11 @@
 #include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "conv3d_common.h"
 
@@ -687,6 +689,152 @@ __global__ void __launch_bounds__(256) conv3d_small_kernel(const SmallArgs sa) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Trilinear x2 up-sampling FUSED into the convolution that follows it (CostRegNet's decoder: models/cost_reg.py:58-94,
+// 136-158: `conv(interpolate(x, scale_factor=2, mode='trilinear'))` for conv7 / conv9 / conv11).  The composition is linear in
+// the LOW-resolution tensor t: the output voxel (2i + p) -- p in {0,1}^3 its parity -- depends on the 3x3x3 neighbourhood of low-res
+// voxel i only,   out[2i + p] = sum_{n in {-1,0,1}^3} K_p[n] t[i + n],   K_p = the 3x3x3 kernel folded with the interpolation
+// weights of the up to three up-sampled taps per axis.  So the 8 parities x Cout output channels of one low-res voxel are 8*Cout
+// ROWS of one GEMM that share a single B operand: Cout = 8 fills two whole 32-row MFMA tiles (the depth-shift packing of
+// conv3d_small_kernel wastes half of its rows), the up-sampled volume is never written or read, and the operand loads come
+// from a tensor an eighth of the size.
+// Borders: the interpolation clamps at the volume faces and the convolution pads the UP-SAMPLED volume (zeros along D and H,
+// circular along W), so the folded kernel of a voxel depends on its position class per axis -- first / interior / last --
+// 27 combinations, each with its own packed weight block (pgrf_pack_conv3d_upfused).  Work items enumerate the voxels of one
+// class box at a time, so the A operand stays wave-uniform.
+struct UpArgs {
+  ConvArgs c;                 // in = low-res tensor (D, H, W = its dims), out / residual = high-res (Do = 2D, ...)
+  const float* bias4;         // [Cout] plain
+  int nsteps, combo_stride;   // 32-deep reduction steps; floats per class block
+  int item_start[28];         // prefix sums of wave items per class box
+  int lo[27][3], n[27][3];    // box origin / extent per class (z, y, x)
+};
+
+template <int CIN, int MT, int NT>
+__global__ void __launch_bounds__(256) conv3d_upfused_kernel(const UpArgs ua) {
+  const ConvArgs& a = ua.c;
+  constexpr int TPH = CIN >= 16 ? 1 : 16 / CIN;
+  constexpr int QPT = CIN >= 16 ? 4 : CIN / 4;
+  constexpr int COUT = MT * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, kk = lane >> 5;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= ua.item_start[27]) return;
+  int cls = 0;
+#pragma unroll 1
+  for (int c = 1; c < 27; ++c) cls = (item >= ua.item_start[c]) ? c : cls;
+  cls = __builtin_amdgcn_readfirstlane(cls);
+  const int nz = ua.n[cls][0], ny = ua.n[cls][1], nx = ua.n[cls][2];
+  const long long nbox = (long long)a.B * nz * ny * nx;
+  const long long tile0 = (long long)(item - ua.item_start[cls]) * NT;
+  int vb[NT], vz[NT], vy[NT], vx[NT], cen[NT];
+  bool vok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    long long v = (tile0 + t) * 32 + j;
+    vok[t] = v < nbox;
+    if (!vok[t]) v = nbox - 1;
+    vx[t] = ua.lo[cls][2] + (int)(v % nx); v /= nx;
+    vy[t] = ua.lo[cls][1] + (int)(v % ny); v /= ny;
+    vz[t] = ua.lo[cls][0] + (int)(v % nz); vb[t] = (int)(v / nz);
+    cen[t] = ((vb[t] * a.D + vz[t]) * a.H + vy[t]) * a.W;
+  }
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
+  const float* wcls = ua.c.wpk + (size_t)cls * ua.combo_stride;
+  struct Step {
+    float4 bv[NT][4];
+    float4 av[MT][4];
+  };
+  auto issue = [&](Step& st, int step) {
+#pragma unroll
+    for (int u = 0; u < TPH; ++u) {
+      const int tap = CIN == 32 ? step : (CIN == 16 ? 2 * step + kk : 4 * step + 2 * kk + u);
+      const bool tap_ok = tap < 27;
+      const int tp = tap_ok ? tap : 13;
+      const int dz = tp / 9 - 1, dy = (tp / 3) % 3 - 1, dx = tp % 3 - 1;
+      const int c0 = CIN == 32 ? kk * 16 : 0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        int xi = vx[t] + dx;
+        xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
+        const bool ok = vok[t] && tap_ok && (unsigned)(vz[t] + dz) < (unsigned)a.D && (unsigned)(vy[t] + dy) < (unsigned)a.H;
+        const int lin = ok ? cen[t] + (dz * a.H + dy) * a.W + xi : cen[t] + vx[t];
+        const float* ip = a.in + (long long)lin * a.in_cs + a.in_coff + c0;
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+          float4 v = *reinterpret_cast<const float4*>(ip + q * 4);
+          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);       // (their folded weights are zero as well; this keeps NaNs out)
+          st.bv[t][u * QPT + q] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4* ap = reinterpret_cast<const float4*>(wcls) + ((size_t)m * ua.nsteps + step) * 256 + lane;
+      st.av[m][0] = ap[0]; st.av[m][1] = ap[64]; st.av[m][2] = ap[128]; st.av[m][3] = ap[192];
+    }
+  };
+  auto compute = [&](Step& st) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float4 aq = st.av[m][s4];
+          const float as = (jj == 0) ? aq.x : (jj == 1) ? aq.y : (jj == 2) ? aq.z : aq.w;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float4 bq = st.bv[t][s4];
+            const float bs = (jj == 0) ? bq.x : (jj == 1) ? bq.y : (jj == 2) ? bq.z : bq.w;
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs, acc[t][m], 0, 0, 0);
+          }
+        }
+  };
+  Step P, Q;
+  int step = 0;
+  issue(P, step++);
+  while (true) {
+    const bool hasQ = step < ua.nsteps;
+    if (hasQ) issue(Q, step++);
+    compute(P);
+    if (!hasQ) break;
+    const bool hasP = step < ua.nsteps;
+    if (hasP) issue(P, step++);
+    compute(Q);
+    if (!hasP) break;
+  }
+  // epilogue: row = m*32 + q*8 + kk*4 + i = parity * COUT + channel -> high-res voxel 2i + parity
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (!vok[t]) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m * 32 + q * 8 + kk * 4;
+        const int par = row / COUT, c = row % COUT;
+        const int oz = 2 * vz[t] + (par >> 2), oy = 2 * vy[t] + ((par >> 1) & 1), ox = 2 * vx[t] + (par & 1);
+        const long long ov = (((long long)vb[t] * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+        const float4 b4 = ua.bias4 ? *reinterpret_cast<const float4*>(ua.bias4 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(acc[t][m][q * 4] + b4.x, acc[t][m][q * 4 + 1] + b4.y, acc[t][m][q * 4 + 2] + b4.z, acc[t][m][q * 4 + 3] + b4.w);
+        v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+        v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+        if (a.residual) {
+          const float4 rr = *reinterpret_cast<const float4*>(a.residual + ov * a.res_cs + a.res_coff + c);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
+      }
+  }
+}
+
 // Cout == 1 (UNet2's last block, CostRegNet's prob head): VALU dot products, LPV lanes per voxel.
 // wlin: [27][Cin] (tap-major), bias scalar.
 __global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, const float* __restrict__ wlin, int has_bias, int lpv) {
@@ -1164,6 +1312,141 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
 #undef PGRF_LS_NS
 #undef PGRF_LS
   PGRF_CHECK_LAUNCH("conv3d_small");
+  return PGRF_OK;
+}
+
+// ---- up-sampling fused into the following convolution (conv3d_upfused_kernel) ----------------------------------------
+// packed block: [27 classes][Cout/4 tiles][steps][4][64 lanes][4] A operands | [Cout] bias
+static int upfused_steps(int Cin) { return (27 * Cin + 31) / 32; }
+static bool upfused_ok(int Cout, int Cin) { return (Cin == 16 || Cin == 32) && (Cout == 8 || Cout == 16); }
+
+size_t pgrf_conv3d_upfused_packed_floats(int Cout, int Cin) {
+  if (!upfused_ok(Cout, Cin)) return 0;
+  return (size_t)27 * (Cout / 4) * upfused_steps(Cin) * 1024 + (size_t)Cout;
+}
+
+// interpolation-folded 1-D operator of one axis: E[cls][par][nb + 1][tap] = weight of low-res neighbour nb of voxel i (of class
+// cls) in up-sampled tap (tap - 1) of output 2i + par.  F.interpolate(scale_factor=2, mode='trilinear', align_corners=False):
+// src = max((j + 0.5) / 2 - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, n - 1).  Padding of the UP-SAMPLED axis: zeros or circular.
+static void upfused_axis(int n, bool circular, double E[3][2][3][3]) {
+  std::memset(E, 0, sizeof(double) * 54);
+  const int N = 2 * n;
+  for (int cls = 0; cls < 3; ++cls) {
+    const int i = cls == 0 ? 0 : (cls == 1 ? 1 : n - 1);
+    if (cls == 1 && n < 3) continue;                       // no interior voxel
+    for (int par = 0; par < 2; ++par)
+      for (int tap = 0; tap < 3; ++tap) {
+        int jx = 2 * i + par + tap - 1;
+        if (jx < 0 || jx >= N) {
+          if (!circular) continue;
+          jx = (jx + N) % N;
+        }
+        double src = (jx + 0.5) / 2.0 - 0.5;
+        if (src < 0) src = 0;
+        const int i0 = (int)std::floor(src), i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+        const double lam = src - i0;
+        const int ms[2] = {i0, i1};
+        const double ws[2] = {1.0 - lam, lam};
+        for (int e = 0; e < 2; ++e) {
+          int d = ms[e] - i;
+          if (circular) { d = ((d % n) + n) % n; if (d == n - 1 && n > 2) d = -1; }       // n == 2: the other voxel counts as +1
+          if (d < -1 || d > 1) continue;                   // cannot happen for the taps above; guards degenerate sizes
+          E[cls][par][d + 1][tap] += ws[e];
+        }
+      }
+  }
+}
+
+int pgrf_pack_conv3d_upfused(const float* w_host, const float* bias_host, int Cout, int Cin, int D, int H, int W, float* packed_host) {
+  if (!w_host || !packed_host) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d_upfused: null pointer");
+  if (!upfused_ok(Cout, Cin)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv3d_upfused: Cin %d (16 | 32), Cout %d (8 | 16)", Cin, Cout);
+  if (D < 2 || H < 2 || W < 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv3d_upfused: low-res dims must be >= 2");
+  const int steps = upfused_steps(Cin), MT = Cout / 4;
+  const size_t combo = (size_t)MT * steps * 1024;
+  std::memset(packed_host, 0, sizeof(float) * pgrf_conv3d_upfused_packed_floats(Cout, Cin));
+  double Ez[3][2][3][3], Ey[3][2][3][3], Ex[3][2][3][3];
+  upfused_axis(D, false, Ez); upfused_axis(H, false, Ey); upfused_axis(W, true, Ex);
+  std::vector<double> K((size_t)8 * Cout * 27 * Cin);
+  for (int cz = 0; cz < 3; ++cz)
+    for (int cy = 0; cy < 3; ++cy)
+      for (int cx = 0; cx < 3; ++cx) {
+        std::fill(K.begin(), K.end(), 0.0);
+        for (int par = 0; par < 8; ++par) {
+          const int pz = par >> 2, py = (par >> 1) & 1, px = par & 1;
+          for (int nb = 0; nb < 27; ++nb) {
+            const int bz = nb / 9, by = (nb / 3) % 3, bx = nb % 3;
+            for (int tp = 0; tp < 27; ++tp) {
+              const double f = Ez[cz][pz][bz][tp / 9] * Ey[cy][py][by][(tp / 3) % 3] * Ex[cx][px][bx][tp % 3];
+              if (f == 0.0) continue;
+              for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < Cin; ++ci)
+                  K[(((size_t)par * Cout + co) * 27 + nb) * Cin + ci] += f * (double)w_host[((size_t)co * Cin + ci) * 27 + tp];
+            }
+          }
+        }
+        float* blk = packed_host + (size_t)((cz * 3 + cy) * 3 + cx) * combo;
+        for (int m = 0; m < MT; ++m)
+          for (int st = 0; st < steps; ++st)
+            for (int s = 0; s < 16; ++s)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int row = m * 32 + (lane & 31), kk = lane >> 5;
+                const int k = st * 32 + kk * 16 + s;
+                const int tap = k / Cin, ci = k % Cin;
+                if (tap >= 27) continue;
+                blk[((((size_t)m * steps + st) * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3)] = (float)K[((size_t)row * 27 + tap) * Cin + ci];
+              }
+      }
+  float* bv = packed_host + (size_t)27 * combo;
+  for (int co = 0; co < Cout; ++co) bv[co] = bias_host ? bias_host[co] : 0.f;
+  return PGRF_OK;
+}
+
+int pgrf_conv3d_upfused(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                        const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                        int res_cs, int res_coff, void* stream) {
+  if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_upfused: null pointer");
+  if (!upfused_ok(Cout, Cin)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upfused: Cin %d (16 | 32), Cout %d (8 | 16)", Cin, Cout);
+  if (B < 1 || D < 2 || H < 2 || W < 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upfused: low-res dims must be >= 2");
+  if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upfused: channel strides/offsets must be multiples of 4");
+  if ((double)B * D * H * W * in_cs * 4.0 >= 2147483648.0 || (double)B * D * H * W * 8.0 >= 2147483648.0)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upfused: tensor too large for 32-bit voxel indices");
+  UpArgs ua;
+  std::memset(&ua, 0, sizeof(ua));
+  ConvArgs& a = ua.c;
+  a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff; a.Cout = Cout;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.Do = 2 * D; a.Ho = 2 * H; a.Wo = 2 * W; a.stride = 1; a.slope = lrelu_slope;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wrap_w = 1;
+  const int steps = upfused_steps(Cin), MT = Cout / 4;
+  ua.nsteps = steps; ua.combo_stride = MT * steps * 1024;
+  a.wpk = packed;
+  ua.bias4 = has_bias ? packed + (size_t)27 * ua.combo_stride : nullptr;
+  const int NT = MT == 2 ? 2 : 1;
+  const int dims[3] = {D, H, W};
+  int total = 0;
+  for (int c = 0; c < 27; ++c) {
+    const int cl[3] = {c / 9, (c / 3) % 3, c % 3};
+    long long vox = B;
+    for (int ax = 0; ax < 3; ++ax) {
+      const int n = dims[ax];
+      ua.lo[c][ax] = cl[ax] == 0 ? 0 : (cl[ax] == 1 ? 1 : n - 1);
+      ua.n[c][ax] = cl[ax] == 1 ? (n > 2 ? n - 2 : 0) : 1;
+      vox *= ua.n[c][ax];
+    }
+    ua.item_start[c] = total;
+    const long long tiles = (vox + 31) / 32;
+    total += (int)((tiles + NT - 1) / NT);
+  }
+  ua.item_start[27] = total;
+  for (int c = 0; c < 27; ++c)       // empty boxes: extent 1 keeps the index arithmetic away from a division by zero
+    for (int ax = 0; ax < 3; ++ax) if (ua.n[c][ax] == 0) { ua.n[c][ax] = 1; }
+  // (an empty box has zero items, so no wave ever decodes a voxel of it)
+  dim3 grid((unsigned)((total + 3) / 4));
+  if (Cin == 16 && MT == 2) hipLaunchKernelGGL((conv3d_upfused_kernel<16, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, ua);
+  else if (Cin == 32 && MT == 2) hipLaunchKernelGGL((conv3d_upfused_kernel<32, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, ua);
+  else if (Cin == 16 && MT == 4) hipLaunchKernelGGL((conv3d_upfused_kernel<16, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, ua);
+  else hipLaunchKernelGGL((conv3d_upfused_kernel<32, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, ua);
+  PGRF_CHECK_LAUNCH("conv3d_upfused");
   return PGRF_OK;
 }
 

@@ -196,3 +196,34 @@ def test_unet2_winograd_equals_direct(monkeypatch):
             outs.append(net(x).clone())
     d = max_abs(outs[0], outs[1])
     assert 0.0 < d < 1e-4 * max(1.0, float(outs[1].abs().max()))
+
+
+@pytest.mark.parametrize('cin,cout,B,D,H,W', [(16, 8, 1, 4, 6, 40), (32, 16, 2, 3, 5, 33), (16, 8, 1, 2, 2, 2), (16, 16, 1, 6, 4, 64),
+                                              (32, 8, 1, 5, 3, 7)])
+def test_upsample_fused_conv_vs_oracle(cin, cout, B, D, H, W, monkeypatch):
+    """pgrf_conv3d_upfused (trilinear x2 folded into the 3x3x3 conv, 27 position classes) against the oracle's
+    F.interpolate + F.conv3d, with the LeakyReLU + residual epilogue and channel-sliced buffers; ragged class boxes, several
+    workgroups per box, the W seam and axes of length 2.  And against the unfused two-launch path."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    g = torch.Generator().manual_seed(cin * 17 + cout + D * 3 + H * 5 + W)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5, 'c.bias': torch.randn(cout, generator=g) * 0.1}
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode='trilinear', align_corners=False)
+    conv = O._conv3(w, 'c', up)
+    res = torch.randn(conv.shape, generator=g)
+    ref = torch.nn.functional.leaky_relu(conv, 0.01) + res
+    pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
+    wide_in = torch.full((B, D, H, W, cin + 8), 3.0, device='cuda')
+    wide_in[..., 4:4 + cin] = R._to_ndhwc(x.cuda())
+    resv = R._Vol(res.cuda().permute(0, 2, 3, 4, 1).contiguous(), 0, cout)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PANOGRF_CONV_UPFUSE', flag)
+        wide_out = R._Vol.empty(B, 2 * D, 2 * H, 2 * W, cout + 8, 'cuda')
+        wide_out.buf.fill_(7.0)
+        o = R._upconv(pc, R._Vol(wide_in, 4, cin), wide_out.slice(4, cout), lambda: R._Vol.empty(B, 2 * D, 2 * H, 2 * W, cin, 'cuda'), residual=resv)
+        outs[flag] = o.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
+        assert bool((o.buf[..., :4] == 7.0).all()) and bool((o.buf[..., 4 + cout:] == 7.0).all())
+        assert max_abs(outs[flag], ref) < 2e-5 * max(1.0, float(ref.abs().max())), flag
+    assert 0.0 < max_abs(outs['1'], outs['0']) < 2e-5 * max(1.0, float(ref.abs().max()))        # two different evaluations
