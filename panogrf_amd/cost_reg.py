@@ -66,7 +66,11 @@ def _upconv(pc, x, out, up_scratch, slope=0.01, residual=None):
     """conv(interpolate(x, scale_factor=2, mode='trilinear')) + LeakyReLU (+ residual) -> `out` (high resolution): CostRegNet's
     decoder step (models/cost_reg.py:58-94).  Fused into ONE launch on the low-resolution tensor where the kernel applies
     (Cin 16 | 32, Cout 8 | 16; PANOGRF_CONV_UPFUSE=0 disables); otherwise up-sample into `up_scratch()` and convolve."""
-    if (os.environ.get('PANOGRF_CONV_UPFUSE', '1') != '0' and pc.cin in (16, 32) and pc.cout in (8, 16) and min(x.D, x.H, x.W) >= 2):
+    want = os.environ.get('PANOGRF_CONV_UPFUSE', '1')
+    # (Cout = 16 fills four row tiles by itself: the fused form measured 155 us against 110 + 11 us for conv9 at 64x128x256, so only
+    #  the 8-channel layers take it by default; 'force' = wherever the kernel applies)
+    if (want != '0' and pc.cin in (16, 32) and (pc.cout == 8 or (want == 'force' and pc.cout == 16)) and min(x.D, x.H, x.W) >= 2
+            and x.H * x.W * x.cs < (1 << 23) and x.B * x.D * x.H * x.W * x.cs < (1 << 29)):
         lib.check(lib.pgrf_conv3d_upfused(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
                                           _ptr(pc.upfused(x.D, x.H, x.W)), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope),
                                           _ptr(residual.buf) if residual is not None else None,

@@ -725,20 +725,21 @@ __global__ void __launch_bounds__(256) conv3d_upfused_kernel(const UpArgs ua) {
   for (int c = 1; c < 27; ++c) cls = (item >= ua.item_start[c]) ? c : cls;
   cls = __builtin_amdgcn_readfirstlane(cls);
   const int nz = ua.n[cls][0], ny = ua.n[cls][1], nx = ua.n[cls][2];
-  const long long nbox = (long long)a.B * nz * ny * nx;
-  const long long tile0 = (long long)(item - ua.item_start[cls]) * NT;
+  const int nbox = a.B * nz * ny * nx;                         // 32-bit index arithmetic throughout (sizes checked by the launcher):
+  const int tile0 = (item - ua.item_start[cls]) * NT;          // 64-bit div / mod is ~100 instructions each
   int vb[NT], vz[NT], vy[NT], vx[NT], cen[NT];
   bool vok[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    long long v = (tile0 + t) * 32 + j;
-    vok[t] = v < nbox;
-    if (!vok[t]) v = nbox - 1;
-    vx[t] = ua.lo[cls][2] + (int)(v % nx); v /= nx;
-    vy[t] = ua.lo[cls][1] + (int)(v % ny); v /= ny;
-    vz[t] = ua.lo[cls][0] + (int)(v % nz); vb[t] = (int)(v / nz);
-    cen[t] = ((vb[t] * a.D + vz[t]) * a.H + vy[t]) * a.W;
+    unsigned v = (unsigned)((tile0 + t) * 32 + j);
+    vok[t] = v < (unsigned)nbox;
+    if (!vok[t]) v = (unsigned)nbox - 1u;
+    vx[t] = ua.lo[cls][2] + (int)(v % (unsigned)nx); v /= (unsigned)nx;
+    vy[t] = ua.lo[cls][1] + (int)(v % (unsigned)ny); v /= (unsigned)ny;
+    vz[t] = ua.lo[cls][0] + (int)(v % (unsigned)nz); vb[t] = (int)(v / (unsigned)nz);
+    cen[t] = (((vb[t] * a.D + vz[t]) * a.H + vy[t]) * a.W) * a.in_cs;       // element offset of the voxel's ROW start (x = 0)
   }
+  const int zstep = a.H * a.W * a.in_cs, ystep = a.W * a.in_cs;          // < 2^23 (launcher): 24-bit multiplies below
   f32x16 acc[NT][MT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -747,36 +748,34 @@ __global__ void __launch_bounds__(256) conv3d_upfused_kernel(const UpArgs ua) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
   const float* wcls = ua.c.wpk + (size_t)cls * ua.combo_stride;
+  const float* inb = a.in + a.in_coff + (CIN == 32 ? kk * 16 : 0);       // uniform base + 32-bit element offsets (size checked by the launcher)
   struct Step {
     float4 bv[NT][4];
     float4 av[MT][4];
   };
+  // NO masking of out-of-volume neighbours: their FOLDED weights are exactly zero (the zero padding of the up-sampled volume and
+  // the interpolation clamp are inside the class's kernel), so any finite value may stand in -- the address is clamped into the
+  // volume.  (conv3d_small_kernel needs its selects because there the padding is not in the weights.)
   auto issue = [&](Step& st, int step) {
 #pragma unroll
     for (int u = 0; u < TPH; ++u) {
-      const int tap = CIN == 32 ? step : (CIN == 16 ? 2 * step + kk : 4 * step + 2 * kk + u);
-      const bool tap_ok = tap < 27;
-      const int tp = tap_ok ? tap : 13;
-      const int dz = tp / 9 - 1, dy = (tp / 3) % 3 - 1, dx = tp % 3 - 1;
-      const int c0 = CIN == 32 ? kk * 16 : 0;
+      int tap = CIN == 32 ? step : (CIN == 16 ? 2 * step + kk : 4 * step + 2 * kk + u);
+      tap = tap < 27 ? tap : 13;                       // padding steps carry zero weights
+      const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         int xi = vx[t] + dx;
         xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
-        const bool ok = vok[t] && tap_ok && (unsigned)(vz[t] + dz) < (unsigned)a.D && (unsigned)(vy[t] + dy) < (unsigned)a.H;
-        const int lin = ok ? cen[t] + (dz * a.H + dy) * a.W + xi : cen[t] + vx[t];
-        const float* ip = a.in + (long long)lin * a.in_cs + a.in_coff + c0;
+        const int dzc = min(max(vz[t] + dz, 0), a.D - 1) - vz[t], dyc = min(max(vy[t] + dy, 0), a.H - 1) - vy[t];   // -1 | 0 | 1
+        const unsigned off = (unsigned)(cen[t] + __mul24(dzc, zstep) + __mul24(dyc, ystep) + __mul24(xi, a.in_cs));
+        const float* ip = inb + off;
 #pragma unroll
-        for (int q = 0; q < QPT; ++q) {
-          float4 v = *reinterpret_cast<const float4*>(ip + q * 4);
-          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);       // (their folded weights are zero as well; this keeps NaNs out)
-          st.bv[t][u * QPT + q] = v;
-        }
+        for (int q = 0; q < QPT; ++q) st.bv[t][u * QPT + q] = *reinterpret_cast<const float4*>(ip + q * 4);
       }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const float4* ap = reinterpret_cast<const float4*>(wcls) + ((size_t)m * ua.nsteps + step) * 256 + lane;
+      const float4* ap = reinterpret_cast<const float4*>(wcls) + ((unsigned)(m * ua.nsteps + step) * 256u + (unsigned)lane);
       st.av[m][0] = ap[0]; st.av[m][1] = ap[64]; st.av[m][2] = ap[128]; st.av[m][3] = ap[192];
     }
   };
@@ -797,40 +796,63 @@ __global__ void __launch_bounds__(256) conv3d_upfused_kernel(const UpArgs ua) {
           }
         }
   };
+  // bottom-tested loop over PAIRS of steps (nsteps is even: the packer pads with a zero-weight step): no mid-loop exit, so the
+  // compiler does not rotate the loop and copy the accumulators (63 v_accvgpr_mov per iteration in the first version)
+  // (Measured, 64x128x256 out, conv11: 198 us = 48 % MFMA-pipe duty in every variant tried -- 1, 2 or 4 voxel tiles per wave,
+  // masks at issue or at use or none, 64- or 32-bit addressing, residual loads batched, scheduling fences that pin the next
+  // step's loads in front of this step's MFMAs (209-224 us): the compiler sinks the loads to their first use either way.)
   Step P, Q;
+  issue(P, 0);
   int step = 0;
-  issue(P, step++);
-  while (true) {
-    const bool hasQ = step < ua.nsteps;
-    if (hasQ) issue(Q, step++);
+  do {
+    issue(Q, step + 1);
     compute(P);
-    if (!hasQ) break;
-    const bool hasP = step < ua.nsteps;
-    if (hasP) issue(P, step++);
+    issue(P, min(step + 2, ua.nsteps - 1));          // (the last one re-loads its own step; nobody reads it)
     compute(Q);
-    if (!hasP) break;
-  }
-  // epilogue: row = m*32 + q*8 + kk*4 + i = parity * COUT + channel -> high-res voxel 2i + parity
+    step += 2;
+  } while (step < ua.nsteps);
+  // epilogue: row = m*32 + q*8 + kk*4 + i = parity * COUT + channel -> high-res voxel 2i + parity.  All residual loads are
+  // issued BEFORE the first store (the compiler cannot prove that `out` and `residual` do not alias and serialised one HBM
+  // round trip per 16-byte piece: 16 of them per wave, a third of the kernel)
+  unsigned ovs[NT][MT][4];
+  int cs_[MT][4];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (!vok[t]) continue;
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cs_[m][q] = (m * 32 + q * 8 + kk * 4) % COUT;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = m * 32 + q * 8 + kk * 4;
-        const int par = row / COUT, c = row % COUT;
+        const int par = (m * 32 + q * 8 + kk * 4) / COUT;
         const int oz = 2 * vz[t] + (par >> 2), oy = 2 * vy[t] + ((par >> 1) & 1), ox = 2 * vx[t] + (par & 1);
-        const long long ov = (((long long)vb[t] * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+        ovs[t][m][q] = (unsigned)(((vb[t] * a.Do + oz) * a.Ho + oy) * a.Wo + ox);
+      }
+  float4 rr[NT][MT][4];
+  if (a.residual) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rr[t][m][q] = *reinterpret_cast<const float4*>(a.residual + (ovs[t][m][q] * (unsigned)a.res_cs + (unsigned)(a.res_coff + cs_[m][q])));
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = cs_[m][q];
         const float4 b4 = ua.bias4 ? *reinterpret_cast<const float4*>(ua.bias4 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 v = make_float4(acc[t][m][q * 4] + b4.x, acc[t][m][q * 4 + 1] + b4.y, acc[t][m][q * 4 + 2] + b4.z, acc[t][m][q * 4 + 3] + b4.w);
         v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
         v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-        if (a.residual) {
-          const float4 rr = *reinterpret_cast<const float4*>(a.residual + ov * a.res_cs + a.res_coff + c);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
+        if (a.residual) { v.x += rr[t][m][q].x; v.y += rr[t][m][q].y; v.z += rr[t][m][q].z; v.w += rr[t][m][q].w; }
+        if (vok[t]) *reinterpret_cast<float4*>(a.out + (ovs[t][m][q] * (unsigned)a.out_cs + (unsigned)(a.out_coff + c))) = v;
       }
   }
 }
@@ -1317,7 +1339,7 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
 
 // ---- up-sampling fused into the following convolution (conv3d_upfused_kernel) ----------------------------------------
 // packed block: [27 classes][Cout/4 tiles][steps][4][64 lanes][4] A operands | [Cout] bias
-static int upfused_steps(int Cin) { return (27 * Cin + 31) / 32; }
+static int upfused_steps(int Cin) { return ((27 * Cin + 31) / 32 + 1) / 2 * 2; }     // even: the kernel walks the steps in pairs
 static bool upfused_ok(int Cout, int Cin) { return (Cin == 16 || Cin == 32) && (Cout == 8 || Cout == 16); }
 
 size_t pgrf_conv3d_upfused_packed_floats(int Cout, int Cin) {
@@ -1409,8 +1431,9 @@ int pgrf_conv3d_upfused(const float* in, int in_cs, int in_coff, int Cin, float*
   if (B < 1 || D < 2 || H < 2 || W < 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upfused: low-res dims must be >= 2");
   if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upfused: channel strides/offsets must be multiples of 4");
-  if ((double)B * D * H * W * in_cs * 4.0 >= 2147483648.0 || (double)B * D * H * W * 8.0 >= 2147483648.0)
-    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upfused: tensor too large for 32-bit voxel indices");
+  if ((double)B * D * H * W * in_cs * 4.0 >= 2147483648.0 || (double)B * D * H * W * 8.0 >= 2147483648.0 || (double)H * W * in_cs >= 8388608.0 ||
+      (double)B * D * H * W * 8.0 * (out_cs > res_cs ? out_cs : res_cs) >= 4294967296.0)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upfused: tensor too large (32-bit element offsets, 24-bit plane stride)");
   UpArgs ua;
   std::memset(&ua, 0, sizeof(ua));
   ConvArgs& a = ua.c;
@@ -1421,7 +1444,8 @@ int pgrf_conv3d_upfused(const float* in, int in_cs, int in_coff, int Cin, float*
   ua.nsteps = steps; ua.combo_stride = MT * steps * 1024;
   a.wpk = packed;
   ua.bias4 = has_bias ? packed + (size_t)27 * ua.combo_stride : nullptr;
-  const int NT = MT == 2 ? 2 : 1;
+  int NT = MT == 2 ? 2 : 1;
+  if (const char* e = getenv("PGRF_UPF_NT")) { const int v = atoi(e); if (MT == 2 && (v == 1 || v == 2 || v == 4)) NT = v; }      // tuning knob
   const int dims[3] = {D, H, W};
   int total = 0;
   for (int c = 0; c < 27; ++c) {
@@ -1442,7 +1466,9 @@ int pgrf_conv3d_upfused(const float* in, int in_cs, int in_coff, int Cin, float*
     for (int ax = 0; ax < 3; ++ax) if (ua.n[c][ax] == 0) { ua.n[c][ax] = 1; }
   // (an empty box has zero items, so no wave ever decodes a voxel of it)
   dim3 grid((unsigned)((total + 3) / 4));
-  if (Cin == 16 && MT == 2) hipLaunchKernelGGL((conv3d_upfused_kernel<16, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, ua);
+  if (Cin == 16 && MT == 2 && NT == 4) hipLaunchKernelGGL((conv3d_upfused_kernel<16, 2, 4>), grid, dim3(256), 0, (hipStream_t)stream, ua);
+  else if (Cin == 16 && MT == 2 && NT == 1) hipLaunchKernelGGL((conv3d_upfused_kernel<16, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, ua);
+  else if (Cin == 16 && MT == 2) hipLaunchKernelGGL((conv3d_upfused_kernel<16, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, ua);
   else if (Cin == 32 && MT == 2) hipLaunchKernelGGL((conv3d_upfused_kernel<32, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, ua);
   else if (Cin == 16 && MT == 4) hipLaunchKernelGGL((conv3d_upfused_kernel<16, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, ua);
   else hipLaunchKernelGGL((conv3d_upfused_kernel<32, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, ua);

@@ -218,7 +218,7 @@ def test_upsample_fused_conv_vs_oracle(cin, cout, B, D, H, W, monkeypatch):
     wide_in[..., 4:4 + cin] = R._to_ndhwc(x.cuda())
     resv = R._Vol(res.cuda().permute(0, 2, 3, 4, 1).contiguous(), 0, cout)
     outs = {}
-    for flag in ('1', '0'):
+    for flag in ('force', '0'):
         monkeypatch.setenv('PANOGRF_CONV_UPFUSE', flag)
         wide_out = R._Vol.empty(B, 2 * D, 2 * H, 2 * W, cout + 8, 'cuda')
         wide_out.buf.fill_(7.0)
@@ -226,4 +226,4 @@ def test_upsample_fused_conv_vs_oracle(cin, cout, B, D, H, W, monkeypatch):
         outs[flag] = o.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
         assert bool((o.buf[..., :4] == 7.0).all()) and bool((o.buf[..., 4 + cout:] == 7.0).all())
         assert max_abs(outs[flag], ref) < 2e-5 * max(1.0, float(ref.abs().max())), flag
-    assert 0.0 < max_abs(outs['1'], outs['0']) < 2e-5 * max(1.0, float(ref.abs().max()))        # two different evaluations
+    assert 0.0 < max_abs(outs['force'], outs['0']) < 2e-5 * max(1.0, float(ref.abs().max()))        # two different evaluations

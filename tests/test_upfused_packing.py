@@ -12,7 +12,7 @@ from oracle import cost_volume_oracle as O
 
 
 def _unpack(packed, Cout, Cin):
-    steps, MT = (27 * Cin + 31) // 32, Cout // 4
+    steps, MT = ((27 * Cin + 31) // 32 + 1) // 2 * 2, Cout // 4
     blk = packed[:27 * MT * steps * 1024].view(27, MT, steps, 4, 64, 4)
     K = torch.zeros(27, MT * 32, 27, Cin)
     for st in range(steps):
@@ -33,7 +33,7 @@ def test_folded_kernels_reproduce_upsample_then_conv(Cin, Cout, D, H, W):
     w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.2
     b = torch.randn(Cout, generator=g) * 0.1
     n = lib.pgrf_conv3d_upfused_packed_floats(Cout, Cin)
-    assert n == 27 * (Cout // 4) * ((27 * Cin + 31) // 32) * 1024 + Cout
+    assert n == 27 * (Cout // 4) * (((27 * Cin + 31) // 32 + 1) // 2 * 2) * 1024 + Cout
     packed = torch.zeros(n)
     lib.check(lib.pgrf_pack_conv3d_upfused(C.c_void_p(w.contiguous().data_ptr()), C.c_void_p(b.data_ptr()), Cout, Cin, D, H, W,
                                            C.c_void_p(packed.data_ptr())))
