@@ -767,7 +767,11 @@ __global__ void __launch_bounds__(256) conv3d_upfused_kernel(const UpArgs ua) {
         int xi = vx[t] + dx;
         xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
         const int dzc = min(max(vz[t] + dz, 0), a.D - 1) - vz[t], dyc = min(max(vy[t] + dy, 0), a.H - 1) - vy[t];   // -1 | 0 | 1
+#if defined(PGRF_UPF_ABL) && (PGRF_UPF_ABL & 2)      // timing experiment: every B operand from one resident line
+        const unsigned off = (unsigned)(lane * 4 + 0 * (dzc + dyc + xi + cen[t] + zstep + ystep));
+#else
         const unsigned off = (unsigned)(cen[t] + __mul24(dzc, zstep) + __mul24(dyc, ystep) + __mul24(xi, a.in_cs));
+#endif
         const float* ip = inb + off;
 #pragma unroll
         for (int q = 0; q < QPT; ++q) st.bv[t][u * QPT + q] = *reinterpret_cast<const float4*>(ip + q * 4);
@@ -775,7 +779,11 @@ __global__ void __launch_bounds__(256) conv3d_upfused_kernel(const UpArgs ua) {
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+#if defined(PGRF_UPF_ABL) && (PGRF_UPF_ABL & 1)      // timing experiment: every A operand from the same 4 KB
+      const float4* ap = reinterpret_cast<const float4*>(wcls) + ((unsigned)(m * 0 + (step & 1)) * 256u + (unsigned)lane);
+#else
       const float4* ap = reinterpret_cast<const float4*>(wcls) + ((unsigned)(m * ua.nsteps + step) * 256u + (unsigned)lane);
+#endif
       st.av[m][0] = ap[0]; st.av[m][1] = ap[64]; st.av[m][2] = ap[128]; st.av[m][3] = ap[192];
     }
   };
@@ -852,7 +860,12 @@ __global__ void __launch_bounds__(256) conv3d_upfused_kernel(const UpArgs ua) {
         v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
         v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
         if (a.residual) { v.x += rr[t][m][q].x; v.y += rr[t][m][q].y; v.z += rr[t][m][q].z; v.w += rr[t][m][q].w; }
-        if (vok[t]) *reinterpret_cast<float4*>(a.out + (ovs[t][m][q] * (unsigned)a.out_cs + (unsigned)(a.out_coff + c))) = v;
+#if defined(PGRF_UPF_ABL) && (PGRF_UPF_ABL & 4)      // timing experiment: no output stores
+        if (vok[t] && v.x == -12345.f)
+#else
+        if (vok[t])
+#endif
+          *reinterpret_cast<float4*>(a.out + (ovs[t][m][q] * (unsigned)a.out_cs + (unsigned)(a.out_coff + c))) = v;
       }
   }
 }

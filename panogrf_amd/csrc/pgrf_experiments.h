@@ -14,7 +14,7 @@
     defined(PGRF_FENCE_MASK) || defined(PGRF_GROUP_FENCE) || defined(PGRF_LDS_STATE) || defined(PGRF_SMALL_V4) ||                                                              \
     defined(PGRF_CONV_ABL_A) || defined(PGRF_CONV_ABL_B) || defined(PGRF_CONV_ABL_NOISSUE) ||                                 \
     defined(PGRF_CONV_ABL_NOREFILL_A) || defined(PGRF_CONV_ABL_NOREFILL_B) || defined(PGRF_CONV_NO_FAST) ||                   \
-    defined(PGRF_CONV_NO_FUSE) || defined(PGRF_CONV_SPREAD_REFILL) || defined(PGRF_CONV_WAVES) ||                             \
+    defined(PGRF_CONV_NO_FUSE) || defined(PGRF_CONV_SPREAD_REFILL) || defined(PGRF_UPF_ABL) || defined(PGRF_CONV_WAVES) ||                             \
     defined(PGRF_CV_ABL_GATHER) || defined(PGRF_CV_ABL_GEOM) || defined(PGRF_CV_ABL_STORE) || defined(PGRF_CV_MINITEMS) ||    \
     defined(PGRF_CV_WAVES) ||                                                                                                \
     defined(PGRF_WINO_ABL_NOA) || defined(PGRF_WINO_ABL_NOADD) || defined(PGRF_WINO_ABL_NOALOAD) ||                           \
