@@ -304,6 +304,15 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
                       const float* packed, int has_bias, int nshift, int B, int D, int H, int W, int stride, float lrelu_slope,
                       const float* residual, int res_cs, int res_coff, void* stream);
 
+/* The same narrow layers on the 16-row MFMA tile (v_mfma_f32_16x16x4_f32): Cout = 8 with nshift = 2 (4 input planes per 2
+ * output planes: 75 % useful products against 50 % of pgrf_conv3d_small's nshift = 4), or Cout = 16 with nshift = 1 (100 %).
+ * Same arguments and epilogue as pgrf_conv3d_small. */
+size_t pgrf_conv3d_small16_packed_floats(int Cout, int Cin, int nshift);
+int pgrf_pack_conv3d_small16(const float* w_host, const float* bias_host, int Cout, int Cin, int nshift, float* packed_host);
+int pgrf_conv3d_small16(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                        const float* packed, int has_bias, int nshift, int B, int D, int H, int W, int stride, float lrelu_slope,
+                        const float* residual, int res_cs, int res_coff, void* stream);
+
 /* Trilinear x2 up-sampling (align_corners=False) FUSED into the wrap-padded 3x3x3 convolution behind it -- CostRegNet's decoder
  * layers (models/cost_reg.py:58-94,136-158: conv9 32->16, conv11 16->8): evaluated on the LOW-resolution tensor as an 8-parity
  * convolution (8 * Cout output rows share one operand; the up-sampled volume is never materialised), with per-position-class

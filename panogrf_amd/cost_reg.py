@@ -50,6 +50,16 @@ class _PackedConv:
         return self._small[nshift]
 
 
+    def small16(self, nshift):
+        """Packed block of the 16-row narrow-layer kernel (pgrf_conv3d_small16), built on first use per depth-shift count."""
+        key = ('s16', nshift)
+        if key not in self._small:
+            n = lib.pgrf_conv3d_small16_packed_floats(self.cout, self.cin, nshift)
+            host = torch.empty(n, dtype=torch.float32)
+            lib.check(lib.pgrf_pack_conv3d_small16(_ptr(self._w), _ptr(self._b), self.cout, self.cin, nshift, _ptr(host)))
+            self._small[key] = host.to(self._device)
+        return self._small[key]
+
     def upfused(self, D, H, W):
         """Packed block of the up-sampling-fused kernel (pgrf_conv3d_upfused) for a LOW-resolution input of D x H x W: 27
         position classes of interpolation-folded kernels, built on first use per size."""
@@ -109,6 +119,17 @@ def _small_shift(pc, x, stride):
     return 1 if pc.cin < 32 else 0
 
 
+def _small16_shift(pc, x, stride):
+    """Depth-shift count for the 16-row narrow-layer kernel (v_mfma_f32_16x16x4_f32 tiles), or 0: 8 output channels x 2
+    shifts (75 % useful products against the 32-row kernel's 50 %) or 16 channels unshifted (100 % against 67 %).
+    PANOGRF_CONV_SMALL16=0 disables."""
+    if os.environ.get('PANOGRF_CONV_SMALL16', '1') == '0' or pc.cin not in (8, 16, 32):
+        return 0
+    if pc.cout == 8 and stride == 1 and x.D % 2 == 0:
+        return 2
+    return 1 if pc.cout == 16 else 0
+
+
 def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
     if pc.cout == 1 and pc.cin >= 64 and pc.cin % 4 == 0 and stride == 1:
         # wide-input single-channel conv: pointwise MFMA projection onto the 27 tap vectors + 27-tap gather
@@ -119,6 +140,14 @@ def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
                                                _ptr(residual.buf) if residual is not None else None,
                                                residual.cs if residual is not None else 0,
                                                residual.coff if residual is not None else 0, _stream()))
+        return out
+    ns = _small16_shift(pc, x, stride)
+    if ns:
+        lib.check(lib.pgrf_conv3d_small16(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                          _ptr(pc.small16(ns)), int(pc.has_bias), ns, x.B, x.D, x.H, x.W, stride, float(slope),
+                                          _ptr(residual.buf) if residual is not None else None,
+                                          residual.cs if residual is not None else 0,
+                                          residual.coff if residual is not None else 0, _stream()))
         return out
     ns = _small_shift(pc, x, stride)
     if ns:

@@ -549,6 +549,7 @@ struct SmallArgs {
   ConvArgs c;
   int ns;        // depth shifts packed on the rows
   int nsteps;    // ceil((ns + 2) * 9 * Cin / 32)
+  unsigned in_bytes;          // conv3d_brick16_kernel: extent of the input behind in + in_coff (buffer descriptor)
 };
 
 template <int CIN, int NS, int NT>
@@ -685,6 +686,290 @@ __global__ void __launch_bounds__(256) conv3d_small_kernel(const SmallArgs sa) {
         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       }
       *reinterpret_cast<float4*>(a.out + ov * a.out_cs + a.out_coff + c) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow layers on the 16-row tile (v_mfma_f32_16x16x4_f32: same FLOP rate as the 32x32x2 form, half the rows).  With 32 rows
+// conv3d_small_kernel needs NS = 32 / Cout depth shifts to fill the tile and pays (NS + 2) / (3 NS) useful products: 50 % at
+// Cout = 8.  Sixteen rows are filled by NS = 2 shifts of 8 channels (4 input planes for 2 outputs: 75 % useful; 288 instead of
+// 432 MFMA cycles per output voxel) or by 16 channels with no shift at all (100 %).  Columns = 16 voxels per tile, NT tiles per
+// wave share the A operand; the reduction index k = tap * CIN + c is cut into groups of 16 (4 MFMAs of depth 4): lane group
+// g = lane / 16 supplies k = 16 G + 4 g + m to MFMA m, i.e. one 16-byte load per lane feeds four MFMAs.  Accumulators are 4
+// registers per tile, so eight tiles fit next to a double-buffered operand set at three waves per SIMD.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+// 16-byte load through a buffer descriptor (offsets past num_records read zeros); the clang builtin of this toolchain lowers its
+// b128 form to a one-dword load, so the LLVM intrinsic is bound directly
+__device__ f32x4v pgrf_buffer_load_x4(i32x4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+template <int CIN, int NS, int NT>
+__global__ void __launch_bounds__(256) conv3d_small16_kernel(const SmallArgs sa) {
+  const ConvArgs& a = sa.c;
+  constexpr int NTAP = (NS + 2) * 9;
+  constexpr int NG = ((NTAP * CIN + 15) / 16 + 1) & ~1;    // groups of 16 reduction indices, padded to a pair (zero A rows)
+  constexpr int RPS = 16 / NS;                             // rows per shift = channels carried
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int Dq = a.Do / NS;
+  const unsigned nbase = (unsigned)(a.B * Dq * a.Ho * a.Wo);
+  const unsigned tile0 = (unsigned)((blockIdx.x * 4 + wave) * NT);
+  if (tile0 * 16u >= nbase) return;
+  int zin[NT], yin[NT], xin[NT], cen[NT];
+  unsigned vflat[NT];
+  bool vok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    unsigned v = (tile0 + t) * 16u + j;
+    vok[t] = v < nbase;
+    if (!vok[t]) v = nbase - 1u;
+    vflat[t] = v;
+    const int vx = (int)(v % (unsigned)a.Wo); v /= (unsigned)a.Wo;
+    const int vy = (int)(v % (unsigned)a.Ho); v /= (unsigned)a.Ho;
+    const int vz = (int)(v % (unsigned)Dq) * NS, vb = (int)(v / (unsigned)Dq);
+    zin[t] = vz * a.stride; yin[t] = vy * a.stride; xin[t] = vx * a.stride;
+    cen[t] = (((vb * a.D + zin[t]) * a.H + yin[t]) * a.W) * a.in_cs;          // element offset of the row start (x = 0)
+  }
+  const int zstep = a.H * a.W * a.in_cs, ystep = a.W * a.in_cs;
+  const float* inb = a.in + a.in_coff;
+  f32x4v acc[NT];
+  {
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + g * 4);        // rows 4g..4g+3, plain order: bias[row % RPS]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){b4.x, b4.y, b4.z, b4.w};
+  }
+  struct Grp {
+    float4 bv[NT];
+    float4 av;
+    unsigned okmask;          // bit t: this lane's operand of tile t lies inside the volume
+    bool need_mask;
+  };
+  auto issue = [&](Grp& gr, int G) {
+    // reduction order: CIN >= 16 -> [16-channel chunk][tap][16 channels] (shared with the LDS-brick kernel below), CIN = 8 ->
+    // [tap][8 channels]; groups that pad the walk to a pair re-read the last tap against zero weights
+    const int k0 = G * 16 + 4 * g;
+    const int tap = CIN >= 16 ? min(G, NTAP * (CIN / 16) - 1) % NTAP : min(k0 / CIN, NTAP - 1);
+    const int c0 = CIN >= 16 ? 16 * (min(G, NTAP * (CIN / 16) - 1) / NTAP) + 4 * g : k0 % CIN;
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    unsigned okm = 0;
+    bool all = true;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      int xi = xin[t] + dx;
+      xi = xi < 0 ? xi + a.W : (xi >= a.W ? xi - a.W : xi);
+      const bool ok = vok[t] && (unsigned)(zin[t] + dz) < (unsigned)a.D && (unsigned)(yin[t] + dy) < (unsigned)a.H;
+      okm |= ok ? (1u << t) : 0u;
+      all = all && ok;
+      const unsigned off = ok ? (unsigned)(cen[t] + __mul24(dz, zstep) + __mul24(dy, ystep) + __mul24(xi, a.in_cs) + c0)
+                              : (unsigned)(cen[t] + __mul24(xin[t], a.in_cs) + c0);
+      gr.bv[t] = *reinterpret_cast<const float4*>(inb + off);
+    }
+    gr.okmask = okm;
+    gr.need_mask = !__all(all);
+    gr.av = reinterpret_cast<const float4*>(a.wpk)[(unsigned)G * 64u + (unsigned)lane];
+  };
+  auto compute = [&](Grp& gr) {
+    if (gr.need_mask)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (!((gr.okmask >> t) & 1u)) gr.bv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float av[4] = {gr.av.x, gr.av.y, gr.av.z, gr.av.w};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 bq = gr.bv[t];
+        const float bs = (m == 0) ? bq.x : (m == 1) ? bq.y : (m == 2) ? bq.z : bq.w;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bs, acc[t], 0, 0, 0);
+      }
+  };
+  Grp P, Q;
+  issue(P, 0);
+  int G = 0;
+  do {
+    issue(Q, G + 1);
+    compute(P);
+    issue(P, min(G + 2, NG - 1));
+    compute(Q);
+    G += 2;
+  } while (G < NG);
+  // epilogue: rows 4g..4g+3 -> shift delta = row / RPS, channels row % RPS .. +3
+  const int row = 4 * g, delta = row / RPS, c = row % RPS;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (!vok[t] || c + 4 > a.Cout) continue;
+    unsigned v = vflat[t];
+    const int vx = (int)(v % (unsigned)a.Wo); v /= (unsigned)a.Wo;
+    const int vy = (int)(v % (unsigned)a.Ho); v /= (unsigned)a.Ho;
+    const int vz = (int)(v % (unsigned)Dq) * NS, vb = (int)(v / (unsigned)Dq);
+    const unsigned ov = (unsigned)(((vb * a.Do + vz + delta) * a.Ho + vy) * a.Wo + vx);
+    float4 o = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
+    o.z = o.z > 0.f ? o.z : o.z * a.slope; o.w = o.w > 0.f ? o.w : o.w * a.slope;
+    if (a.residual) {
+      const float4 rr = *reinterpret_cast<const float4*>(a.residual + (ov * (unsigned)a.res_cs + (unsigned)(a.res_coff + c)));
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    *reinterpret_cast<float4*>(a.out + (ov * (unsigned)a.out_cs + (unsigned)(a.out_coff + c))) = o;
+  }
+}
+
+// The 8-channel x 2-shift case with the B operand staged through LDS.  From registers the kernel above is bound by the vector
+// memory path, not by the MFMA: a 16-row tile consumes 16 bytes per lane per 128 MFMA cycles, 32 B/clk/CU through the L1 for
+// four SIMDs (641 us for conv0 of CostRegNet whatever the tiles-per-wave, against 246 us of MFMA time).  Here a workgroup owns a
+// brick of 2 x 4 x 32 output voxels; the 4 x 6 x 34 input voxels it touches (zero padding in z / y and the wrap in x resolved
+// while filling) are copied once per 16-channel chunk into LDS and every tap is a ds_read_b128 at a compile-time offset -- no
+// masks, no address arithmetic, 3.2x instead of 36x input traffic through the L1.  A voxel is 64 bytes = four 16-byte slots; slot
+// s of the voxel in column px is stored at s ^ ((px >> 1) & 3), which puts the 16 lanes of every ds_read_b128 lane group
+// ({0-3, 12-15, 20-27}, ...: two channel quads x eight columns) on 16 different slots for every tap shift.  The next chunk travels global -> registers while the current one is multiplied.
+template <int CIN>
+__global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs sa) {
+  const ConvArgs& a = sa.c;
+  constexpr int NCH = CIN / 16, NTAP = 36;
+  constexpr int PX = 34, PY = 6, PZ = 4, VS = 16;          // brick extent in voxels, voxel pitch in floats
+  constexpr int NV = PX * PY * PZ, NQ = NV * 4, NPRE = (NQ + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float brick[NV * VS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  // brick of this workgroup: grid = (bricks along x, along y, z pairs x batch).  Workgroups go round-robin over the 8 XCDs in x-fastest
+  // order, so with W = 256 (8 bricks along x) an XCD owns one 32-column band of the volume and the y / z halos stay in its L2.
+  const int nbz = a.D >> 1;
+  const int vb = (int)blockIdx.z / nbz, bz = (int)blockIdx.z - vb * nbz;
+  const int x0 = (int)blockIdx.x * 32, y0 = (int)blockIdx.y * 4, z0 = bz * 2;
+  const float* inb = a.in + a.in_coff;
+  // fill plan (NPRE = 13 loads and ds_writes per thread and chunk, ~no address arithmetic): the brick is 24 rows (pz, py) of 34
+  // voxels x 4 channel quads.  Columns 0..31: thread -> (column, quad) = tid % 128, the two halves of the workgroup take 12 rows
+  // each; the row term of the address is wave-uniform (soffset of the buffer load, a compile-time ds offset) and rows in the zero
+  // padding are skipped by a uniform branch.  Columns 32, 33 (192 quads): one more load per thread, whose lanes in the padding
+  // carry an offset past the end of the buffer descriptor and read zeros.
+  const unsigned long long inb_bits = (unsigned long long)inb;
+  const i32x4v rsrc = {(int)(unsigned)inb_bits, (int)(unsigned)(inb_bits >> 32), (int)sa.in_bytes, 0x00020000};          // raw buffer, 32-bit data
+  const int half = __builtin_amdgcn_readfirstlane(wave >> 1);
+  auto wrap_x = [&](int x) { x %= a.W; return x < 0 ? x + a.W : x; };
+  const int ystep = a.W * a.in_cs, zstep = a.H * ystep;
+  const int row0 = ((vb * a.D + z0 - 1 + 2 * half) * a.H + y0 - 1) * ystep;              // element offset of row (pz = 2 half, py = 0), uniform
+  unsigned src_col, dst_col, src_x, dst_x;
+  {
+    const int cq = tid & 3, px = (tid & 127) >> 2;
+    src_col = (unsigned)(wrap_x(x0 - 1 + px) * a.in_cs + 4 * cq) * 4u;
+    dst_col = (unsigned)(((half * 12 * PX + px) * VS + 4 * (cq ^ ((px >> 1) & 3))) * 4);
+    const int row = tid >> 3, pxx = 32 + ((tid >> 2) & 1), pz = row / PY, py = row - pz * PY;
+    const int z = z0 - 1 + pz, y = y0 - 1 + py;
+    const bool ok = tid < 192 && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H;
+    src_x = ok ? (unsigned)((((vb * a.D + z) * a.H + y) * a.W + wrap_x(x0 - 1 + pxx)) * a.in_cs + 4 * cq) * 4u : 0x80000000u;
+    dst_x = (unsigned)(((row * PX + pxx) * VS + 4 * (cq ^ ((pxx >> 1) & 3))) * 4);
+  }
+  float4 pre[NPRE];
+  auto fetch_one = [&](int chunk, int i) {
+    if (i < 12) {
+      const int z = z0 - 1 + 2 * half + i / PY, y = y0 - 1 + i % PY;              // uniform
+      pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H) {
+        const f32x4v r = pgrf_buffer_load_x4(rsrc, (int)src_col, (row0 + (i / PY) * zstep + (i % PY) * ystep + 16 * chunk) * 4, 0);
+        pre[i] = make_float4(r.x, r.y, r.z, r.w);
+      }
+    } else {
+      const f32x4v r = pgrf_buffer_load_x4(rsrc, (int)src_x, 64 * chunk, 0);
+      pre[i] = make_float4(r.x, r.y, r.z, r.w);
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) *reinterpret_cast<float4*>(reinterpret_cast<char*>(brick) + dst_col + i * (PX * VS * 4)) = pre[i];
+    if (tid < 192) *reinterpret_cast<float4*>(reinterpret_cast<char*>(brick) + dst_x) = pre[12];
+  };
+  static_assert(NPRE == 13, "12 row loads + 1 for the two last columns");
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) fetch_one(0, i);
+  f32x4v acc[2];
+  {
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + g * 4);
+    acc[0] = acc[1] = (f32x4v){b4.x, b4.y, b4.z, b4.w};
+  }
+  // wave w multiplies row y0 + w: tiles x0 + j and x0 + 16 + j.  Per dx one LDS base at the (dz, dy) = (-1, -1) corner, so that every
+  // tap is that base + a non-negative immediate: voxel (pz = 0, py = w, px = j + dx + 1), this lane's (swizzled) channel quad
+  const float* bl[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) bl[d] = &brick[(wave * PX + j + d) * VS + 4 * (g ^ (((j + d) >> 1) & 3))];
+  const unsigned long long w_bits = (unsigned long long)a.wpk;
+  const i32x4v wrsrc = {(int)(unsigned)w_bits, (int)(unsigned)(w_bits >> 32), NCH * NTAP * 1024, 0x00020000};
+  park();
+  __syncthreads();
+#pragma unroll 1
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    // A operands (global, L2-resident: the 36 KB of a chunk cycle through the L1) run AD taps ahead of their MFMAs, B operands (LDS)
+    // one tap; the next chunk's fill is spread over the taps, one load each, so that the in-order vector-memory queue never puts a
+    // burst of slow loads in front of an A operand.  The scheduling barriers pin that order (left alone, the scheduler sinks every
+    // load to its use and chains four MFMAs on one accumulator).
+    constexpr int AD = 6;
+    float4 av[AD], bv[2][2];
+    auto issue_a = [&](int tap) {
+      const f32x4v r = pgrf_buffer_load_x4(wrsrc, lane * 16, (chunk * NTAP + tap) * 1024, 0);
+      av[tap % AD] = make_float4(r.x, r.y, r.z, r.w);
+    };
+    auto issue_b = [&](int slot, int tap) {
+      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+      const int off = (dz * PY + dy) * PX * VS;
+      bv[slot][0] = *reinterpret_cast<const float4*>(bl[dx] + off);
+      bv[slot][1] = *reinterpret_cast<const float4*>(bl[dx] + off + 16 * VS);          // 16 columns on: same (px >> 1) & 3
+    };
+    auto compute = [&](int slot, int tap) {
+      const float4 a4 = av[tap % AD];
+      const float aq[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float4 bq = bv[slot][t];
+          const float bs = (m == 0) ? bq.x : (m == 1) ? bq.y : (m == 2) ? bq.z : bq.w;
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m], bs, acc[t], 0, 0, 0);
+        }
+      }
+    };
+    const bool more = chunk + 1 < NCH;
+#pragma unroll
+    for (int tap = 0; tap < AD - 1; ++tap) issue_a(tap);
+    issue_b(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < NTAP; tap += 2) {
+      if (tap + AD - 1 < NTAP) issue_a(tap + AD - 1);
+      issue_b(1, tap + 1);
+      if (more && tap / 2 < NPRE) fetch_one(chunk + 1, tap / 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(0, tap);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + AD < NTAP) issue_a(tap + AD);
+      if (tap + 2 < NTAP) issue_b(0, tap + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(1, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(NPRE <= NTAP / 2, "one fill load per tap pair");
+    if (more) {
+      __syncthreads();
+      park();
+      __syncthreads();
+    }
+  }
+  // epilogue: rows 4g .. 4g+3 = shift g / 2, channels 4 (g % 2) .. + 3
+  const int delta = g >> 1, c = (g & 1) * 4;
+  const int y = y0 + wave, z = z0 + delta;
+  if (y < a.H) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int x = x0 + 16 * t + j;
+      if (x >= a.W) continue;
+      const unsigned ov = (unsigned)(((vb * a.D + z) * a.H + y) * a.W + x);
+      float4 o = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
+      o.z = o.z > 0.f ? o.z : o.z * a.slope; o.w = o.w > 0.f ? o.w : o.w * a.slope;
+      if (a.residual) {
+        const float4 rr = *reinterpret_cast<const float4*>(a.residual + (ov * (unsigned)a.res_cs + (unsigned)(a.res_coff + c)));
+        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+      }
+      *reinterpret_cast<float4*>(a.out + (ov * (unsigned)a.out_cs + (unsigned)(a.out_coff + c))) = o;
     }
   }
 }
@@ -1285,6 +1570,7 @@ int pgrf_pack_conv3d_small(const float* w_host, const float* bias_host, int Cout
         const int row = lane & 31, kk = lane >> 5;
         const int k = st * 32 + kk * 16 + s;             // reduction index = tap * Cin + channel
         const int tap = k / Cin, ci = k % Cin;
+        if (tap >= (nshift + 2) * 9) continue;             // padding of the last pair of groups
         const int delta = row / rps, co = row % rps;
         if (tap >= ntap || co >= Cout) continue;
         const int kz = tap / 9 - 1 - delta;               // which of the 3 depth taps of output (delta, co) this plane is
@@ -1347,6 +1633,100 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
 #undef PGRF_LS_NS
 #undef PGRF_LS
   PGRF_CHECK_LAUNCH("conv3d_small");
+  return PGRF_OK;
+}
+
+// ---- narrow layers on the 16-row tile (conv3d_small16_kernel) ------------------------------------------------------
+// packed block: [groups][64 lanes][4] A operands | [16] bias by row
+static bool small16_ok(int Cout, int Cin, int ns) {
+  return (Cin == 8 || Cin == 16 || Cin == 32) && ((ns == 2 && Cout == 8) || (ns == 1 && Cout == 16));
+}
+static int small16_groups(int Cin, int ns) { return (((ns + 2) * 9 * Cin + 15) / 16 + 1) & ~1; }
+
+size_t pgrf_conv3d_small16_packed_floats(int Cout, int Cin, int nshift) {
+  if (!small16_ok(Cout, Cin, nshift)) return 0;
+  return (size_t)small16_groups(Cin, nshift) * 256 + 16;
+}
+
+int pgrf_pack_conv3d_small16(const float* w_host, const float* bias_host, int Cout, int Cin, int nshift, float* packed_host) {
+  if (!w_host || !packed_host) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d_small16: null pointer");
+  if (!small16_ok(Cout, Cin, nshift))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv3d_small16: Cin %d (8 | 16 | 32), Cout %d with nshift %d (8 x 2 | 16 x 1)", Cin, Cout, nshift);
+  const int groups = small16_groups(Cin, nshift), rps = 16 / nshift;
+  std::memset(packed_host, 0, sizeof(float) * pgrf_conv3d_small16_packed_floats(Cout, Cin, nshift));
+  for (int G = 0; G < groups; ++G)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int m = 0; m < 4; ++m) {
+        const int row = lane & 15, g = lane >> 4;
+        // reduction order: Cin >= 16 -> group G = chunk * ntap + tap carries channels 16 chunk + 4 g + m; Cin = 8 -> k = tap * 8 + c
+        const int ntap = (nshift + 2) * 9;
+        const int k = G * 16 + 4 * g + m;
+        const int tap = Cin >= 16 ? G % ntap : k / Cin;
+        const int ci = Cin >= 16 ? 16 * (G / ntap) + 4 * g + m : k % Cin;
+        if (Cin >= 16 ? G >= ntap * (Cin / 16) : tap >= ntap) continue;          // padding of the last pair of groups
+        const int delta = row / rps, co = row % rps;
+        const int kz = tap / 9 - 1 - delta;                 // which of the 3 depth taps of output (delta, co) this plane is
+        if (kz < -1 || kz > 1) continue;
+        const int t27 = (kz + 1) * 9 + tap % 9;
+        packed_host[((size_t)G * 64 + lane) * 4 + m] = w_host[((size_t)co * Cin + ci) * 27 + t27];
+      }
+  float* bv = packed_host + (size_t)groups * 256;
+  for (int r = 0; r < 16; ++r) bv[r] = bias_host ? bias_host[r % rps] : 0.f;
+  return PGRF_OK;
+}
+
+int pgrf_conv3d_small16(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                        const float* packed, int has_bias, int nshift, int B, int D, int H, int W, int stride, float lrelu_slope,
+                        const float* residual, int res_cs, int res_coff, void* stream) {
+  if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_small16: null pointer");
+  if (stride != 1 && stride != 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: stride %d", stride);
+  if (!small16_ok(Cout, Cin, nshift))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: Cin %d (8 | 16 | 32), Cout %d with nshift %d (8 x 2 | 16 x 1)", Cin, Cout, nshift);
+  if (B < 1 || D < 1 || H < 1 || W < 2) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_small16: bad dims");
+  if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: channel strides/offsets must be multiples of 4");
+  SmallArgs sa;
+  std::memset(&sa, 0, sizeof(sa));
+  ConvArgs& a = sa.c;
+  a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff;
+  a.Cout = Cout; a.B = B; a.D = D; a.H = H; a.W = W; a.stride = stride; a.slope = lrelu_slope;
+  a.Do = (D - 1) / stride + 1; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wrap_w = 1;
+  if (nshift > 1 && (stride != 1 || a.Do % nshift))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: nshift %d needs stride 1 and D %% nshift == 0", nshift);
+  const int mcs = out_cs > res_cs ? out_cs : res_cs;
+  if ((double)B * D * H * W * in_cs >= 2147483648.0 || (double)H * W * in_cs >= 8388608.0 || (double)B * a.Do * a.Ho * a.Wo * (mcs > 1 ? mcs : 1) >= 4294967296.0)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: tensor too large (32-bit element offsets, 24-bit plane stride)");
+  sa.ns = nshift; sa.nsteps = small16_groups(Cin, nshift);
+  a.wpk = packed;
+  a.bias = has_bias ? packed + (size_t)sa.nsteps * 256 : nullptr;
+  static const bool no_brick = getenv("PGRF_CONV16_NO_BRICK") != nullptr;                   // A/B switch: B operand from registers
+  if (nshift == 2 && Cin >= 16 && !no_brick) {
+    // B operand staged through LDS: bricks of 2 x 4 x 32 output voxels
+    sa.in_bytes = (unsigned)(((size_t)B * D * H * W * in_cs - (size_t)in_coff) * sizeof(float));          // < 2^31 elements checked above: fits
+    if (sa.in_bytes >= 0x80000000u) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: input beyond 2 GB");
+    if ((long long)B * (D / 2) > 65535 || (H + 3) / 4 > 65535) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: grid too large");
+    const dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 3) / 4), (unsigned)(B * (D / 2)));
+    if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+    else hipLaunchKernelGGL((conv3d_brick16_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+    PGRF_CHECK_LAUNCH("conv3d_brick16");
+    return PGRF_OK;
+  }
+  const long long nbase = (long long)B * (a.Do / nshift) * a.Ho * a.Wo;
+  const long long tiles = (nbase + 15) / 16;
+  int nt = tiles >= 8LL * 4096 ? 8 : (tiles >= 4LL * 4096 ? 4 : 2);
+  if (const char* e = getenv("PGRF_CONV16_NT")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) nt = v; }       // tuning knob
+  dim3 grid((unsigned)((tiles + 4 * nt - 1) / (4 * nt)));
+#define PGRF_L16(CIN_, NS_)                                                                                                       \
+  do {                                                                                                                           \
+    if (nt == 8) hipLaunchKernelGGL((conv3d_small16_kernel<CIN_, NS_, 8>), grid, dim3(256), 0, (hipStream_t)stream, sa);          \
+    else if (nt == 4) hipLaunchKernelGGL((conv3d_small16_kernel<CIN_, NS_, 4>), grid, dim3(256), 0, (hipStream_t)stream, sa);     \
+    else hipLaunchKernelGGL((conv3d_small16_kernel<CIN_, NS_, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);                  \
+  } while (0)
+  if (nshift == 2) { if (Cin == 8) PGRF_L16(8, 2); else if (Cin == 16) PGRF_L16(16, 2); else PGRF_L16(32, 2); }
+  else { if (Cin == 8) PGRF_L16(8, 1); else if (Cin == 16) PGRF_L16(16, 1); else PGRF_L16(32, 1); }
+#undef PGRF_L16
+  PGRF_CHECK_LAUNCH("conv3d_small16");
   return PGRF_OK;
 }
 

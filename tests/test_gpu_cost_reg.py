@@ -59,12 +59,13 @@ def test_single_conv_vs_oracle(cin, cout, stride):
 @pytest.mark.parametrize('cin,cout,stride,D,ns', [(32, 8, 1, 8, 4), (16, 8, 1, 12, 4), (8, 8, 1, 4, 4), (16, 16, 1, 6, 2),
                                                   (32, 16, 1, 6, 2), (8, 16, 2, 6, 1), (16, 32, 2, 7, 1), (16, 8, 1, 6, 2),
                                                   (8, 4, 1, 5, 1)])
-def test_narrow_layer_kernel_vs_oracle(cin, cout, stride, D, ns):
+def test_narrow_layer_kernel_vs_oracle(cin, cout, stride, D, ns, monkeypatch):
     """pgrf_conv3d_small (taps packed along K, depth shifts packed along M) against F.conv3d of the oracle, with a
     residual, a channel-sliced output and a voxel count that is not a multiple of the tile; the dispatcher must
     pick the depth-shift count the layer shape allows."""
     from oracle import cost_volume_oracle as O
     from panogrf_amd import cost_reg as R
+    monkeypatch.setenv('PANOGRF_CONV_SMALL16', '0')               # this test is about the 32-row kernel
     g = torch.Generator().manual_seed(cin * 977 + cout * 13 + stride + D)
     B, H, W = 2, 5, 11
     x = torch.randn(B, cin, D, H, W, generator=g)
@@ -84,6 +85,50 @@ def test_narrow_layer_kernel_vs_oracle(cin, cout, stride, D, ns):
     got = out.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
     assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
     assert bool((out.buf[..., :4] == 7.0).all()) and bool((out.buf[..., 4 + cout:] == 7.0).all())
+
+
+@pytest.mark.parametrize('cin,cout,stride,D,ns,nt', [(32, 8, 1, 8, 2, 0), (16, 8, 1, 12, 2, 8), (8, 8, 1, 4, 2, 4), (16, 16, 1, 6, 1, 0),
+                                                     (32, 16, 1, 5, 1, 8), (8, 16, 2, 6, 1, 0), (8, 16, 2, 7, 1, 4), (16, 16, 2, 7, 1, 2),
+                                                     (32, 8, 1, 5, 0, 0), (16, 32, 1, 4, 0, 0)])
+def test_narrow_layer_16_row_kernel_vs_oracle(cin, cout, stride, D, ns, nt, monkeypatch):
+    """pgrf_conv3d_small16 (v_mfma_f32_16x16x4_f32 tiles: 8 channels x 2 depth shifts, or 16 channels) against F.conv3d of the
+    oracle, with a residual, a channel-sliced output, a ragged last tile, every tiles-per-wave instance, odd depths and the
+    zero-padded reduction tail of Cin = 8 / 16 (27 taps are not a whole number of 16-wide groups); ns == 0: the dispatcher
+    must leave the layer to the other kernels."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    if nt:
+        monkeypatch.setenv('PGRF_CONV16_NT', str(nt))
+    g = torch.Generator().manual_seed(cin * 877 + cout * 17 + stride + D)
+    B, H, W = 2, 5, 11
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5,
+         'c.bias': torch.randn(cout, generator=g) * 0.1}
+    conv = O._conv3(w, 'c', x, stride)
+    res = torch.randn(conv.shape, generator=g)
+    ref = torch.nn.functional.leaky_relu(conv, 0.01) + res
+    pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
+    xin = R._Vol(R._to_ndhwc(x.cuda()), 0, cin)
+    assert R._small16_shift(pc, xin, stride) == ns
+    Do, Ho, Wo = ref.shape[2:]
+    wide = R._Vol.empty(B, Do, Ho, Wo, cout + 8, 'cuda')
+    wide.buf.fill_(7.0)
+    resv = R._Vol(res.cuda().permute(0, 2, 3, 4, 1).contiguous(), 0, cout)
+    out = R._conv(pc, xin, wide.slice(4, cout), stride=stride, residual=resv)
+    got = out.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
+    assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert bool((out.buf[..., :4] == 7.0).all()) and bool((out.buf[..., 4 + cout:] == 7.0).all())
+
+
+def test_narrow_layer_16_row_kernel_rejects_what_it_cannot_do():
+    from panogrf_amd._lib import lib
+    import ctypes
+    assert lib.pgrf_conv3d_small16_packed_floats(8, 32, 2) == 72 * 256 + 16
+    assert lib.pgrf_conv3d_small16_packed_floats(16, 8, 1) == 14 * 256 + 16          # 13.5 groups padded to a pair
+    assert lib.pgrf_conv3d_small16_packed_floats(8, 32, 4) == 0 and lib.pgrf_conv3d_small16_packed_floats(32, 32, 1) == 0
+    buf = (ctypes.c_float * 16)()
+    assert lib.pgrf_pack_conv3d_small16(ctypes.cast(buf, ctypes.c_void_p), None, 16, 16, 2, ctypes.cast(buf, ctypes.c_void_p)) != 0
+    assert b'pgrf_pack_conv3d_small16' in lib.pgrf_last_error()
 
 
 def test_narrow_layer_kernel_rejects_what_it_cannot_do():
