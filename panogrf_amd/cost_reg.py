@@ -120,13 +120,14 @@ def _small_shift(pc, x, stride):
 
 
 def _small16_shift(pc, x, stride):
-    """Depth-shift count for the 16-row narrow-layer kernel (v_mfma_f32_16x16x4_f32 tiles), or 0: 8 output channels x 2
-    shifts (75 % useful products against the 32-row kernel's 50 %) or 16 channels unshifted (100 % against 67 %).
-    PANOGRF_CONV_SMALL16=0 disables."""
+    """Depth-shift count for the 16-row narrow-layer kernels (pgrf_conv3d_small16, v_mfma_f32_16x16x4_f32 tiles), or 0:
+    8 output channels x 2 shifts from 16 / 32 input channels (LDS-brick kernel, 75 % useful products against the 32-row
+    kernel's 50 %: conv0 of CostRegNet 573 -> 341 us) or 16 channels unshifted (100 % against 67 %; stride 1 from 16 / 32
+    channels on the LDS-brick kernel, everything else from registers).  PANOGRF_CONV_SMALL16=0 disables."""
     if os.environ.get('PANOGRF_CONV_SMALL16', '1') == '0' or pc.cin not in (8, 16, 32):
         return 0
-    if pc.cout == 8 and stride == 1 and x.D % 2 == 0:
-        return 2
+    if pc.cout == 8:
+        return 2 if pc.cin >= 16 and stride == 1 and x.D % 2 == 0 else 0
     return 1 if pc.cout == 16 else 0
 
 

@@ -823,10 +823,31 @@ __global__ void __launch_bounds__(256) conv3d_small16_kernel(const SmallArgs sa)
 // masks, no address arithmetic, 3.2x instead of 36x input traffic through the L1.  A voxel is 64 bytes = four 16-byte slots; slot
 // s of the voxel in column px is stored at s ^ ((px >> 1) & 3), which puts the 16 lanes of every ds_read_b128 lane group
 // ({0-3, 12-15, 20-27}, ...: two channel quads x eight columns) on 16 different slots for every tap shift.  The next chunk travels global -> registers while the current one is multiplied.
-template <int CIN>
+//   NS = 2 (Cout = 8): rows = 2 depth shifts x 8 channels, one tile pair (x halves) per wave, 36 plane taps.
+//   NS = 1 (Cout = 16): rows = 16 channels; the wave owns both output planes of its row (4 tiles).  Walking the 36 PLANE taps
+//   (pz, dy, dx) instead of the 27 kernel taps per output plane, one B operand serves output plane 0 (kernel tap dz = pz - 1) and
+//   output plane 1 (dz = pz - 2): the depth-shift reuse without a single structural zero (100 % useful products).
+struct Brick16 {
+  // A-operand stream of one chunk: which kernel tap the n-th A load fetches, and where step s (= plane tap) finds its operands
+  static constexpr int a_count(int ns, int s) { return ns == 2 ? 1 : (s / 9 <= 2) + (s / 9 >= 1); }
+  static constexpr int a_pos(int ns, int s) {
+    if (ns == 2) return s;
+    const int pz = s / 9, r = s % 9;
+    return pz == 0 ? r : pz == 1 ? 9 + 2 * r : pz == 2 ? 27 + 2 * r : 45 + r;
+  }
+  static constexpr int a_tap(int ns, int n) {
+    if (ns == 2) return n;
+    if (n < 9) return n;
+    if (n < 27) return (n - 9) % 2 == 0 ? 9 + (n - 9) / 2 : (n - 9) / 2;
+    if (n < 45) return (n - 27) % 2 == 0 ? 18 + (n - 27) / 2 : 9 + (n - 27) / 2;
+    return 18 + (n - 45);
+  }
+};
+template <int CIN, int NS>
 __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs sa) {
   const ConvArgs& a = sa.c;
-  constexpr int NCH = CIN / 16, NTAP = 36;
+  constexpr int NCH = CIN / 16, NSTEP = 36, NTAP = (NS + 2) * 9, NSTREAM = NS == 2 ? 36 : 54, NACC = NS == 2 ? 2 : 4;
+  constexpr int NGRP = NS == 2 ? NTAP * NCH : ((NTAP * NCH + 1) & ~1);          // groups in the packed block (padded to a pair)
   constexpr int PX = 34, PY = 6, PZ = 4, VS = 16;          // brick extent in voxels, voxel pitch in floats
   constexpr int NV = PX * PY * PZ, NQ = NV * 4, NPRE = (NQ + 255) / 256;
   __shared__ __attribute__((aligned(16))) float brick[NV * VS];
@@ -834,7 +855,7 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
   const int j = lane & 15, g = lane >> 4;
   // brick of this workgroup: grid = (bricks along x, along y, z pairs x batch).  Workgroups go round-robin over the 8 XCDs in x-fastest
   // order, so with W = 256 (8 bricks along x) an XCD owns one 32-column band of the volume and the y / z halos stay in its L2.
-  const int nbz = a.D >> 1;
+  const int nbz = (a.D + 1) >> 1;
   const int vb = (int)blockIdx.z / nbz, bz = (int)blockIdx.z - vb * nbz;
   const int x0 = (int)blockIdx.x * 32, y0 = (int)blockIdx.y * 4, z0 = bz * 2;
   const float* inb = a.in + a.in_coff;
@@ -882,11 +903,12 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
   static_assert(NPRE == 13, "12 row loads + 1 for the two last columns");
 #pragma unroll
   for (int i = 0; i < NPRE; ++i) fetch_one(0, i);
-  f32x4v acc[2];
+  f32x4v acc[NACC];                                       // NS = 2: [x half]; NS = 1: [output plane][x half]
   {
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + g * 4);
-    acc[0] = acc[1] = (f32x4v){b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = (f32x4v){b4.x, b4.y, b4.z, b4.w};
   }
   // wave w multiplies row y0 + w: tiles x0 + j and x0 + 16 + j.  Per dx one LDS base at the (dz, dy) = (-1, -1) corner, so that every
   // tap is that base + a non-negative immediate: voxel (pz = 0, py = w, px = j + dx + 1), this lane's (swizzled) channel quad
@@ -894,73 +916,88 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
 #pragma unroll
   for (int d = 0; d < 3; ++d) bl[d] = &brick[(wave * PX + j + d) * VS + 4 * (g ^ (((j + d) >> 1) & 3))];
   const unsigned long long w_bits = (unsigned long long)a.wpk;
-  const i32x4v wrsrc = {(int)(unsigned)w_bits, (int)(unsigned)(w_bits >> 32), NCH * NTAP * 1024, 0x00020000};
+  const i32x4v wrsrc = {(int)(unsigned)w_bits, (int)(unsigned)(w_bits >> 32), NGRP * 1024, 0x00020000};
   park();
   __syncthreads();
 #pragma unroll 1
   for (int chunk = 0; chunk < NCH; ++chunk) {
-    // A operands (global, L2-resident: the 36 KB of a chunk cycle through the L1) run AD taps ahead of their MFMAs, B operands (LDS)
-    // one tap; the next chunk's fill is spread over the taps, one load each, so that the in-order vector-memory queue never puts a
+    // A operands (global, L2-resident: the 36 KB of a chunk cycle through the L1) run AD loads ahead of their MFMAs, B operands (LDS)
+    // one step; the next chunk's fill is spread over the steps, one load each, so that the in-order vector-memory queue never puts a
     // burst of slow loads in front of an A operand.  The scheduling barriers pin that order (left alone, the scheduler sinks every
     // load to its use and chains four MFMAs on one accumulator).
-    constexpr int AD = 6;
-    float4 av[AD], bv[2][2];
-    auto issue_a = [&](int tap) {
-      const f32x4v r = pgrf_buffer_load_x4(wrsrc, lane * 16, (chunk * NTAP + tap) * 1024, 0);
-      av[tap % AD] = make_float4(r.x, r.y, r.z, r.w);
+    constexpr int AD = 6, RING = 8;
+    float4 av[RING], bv[2][2];
+    auto issue_a = [&](int n) {                            // n = position in the A stream
+      const f32x4v r = pgrf_buffer_load_x4(wrsrc, lane * 16, (chunk * NTAP + Brick16::a_tap(NS, n)) * 1024, 0);
+      av[n % RING] = make_float4(r.x, r.y, r.z, r.w);
     };
-    auto issue_b = [&](int slot, int tap) {
-      const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-      const int off = (dz * PY + dy) * PX * VS;
+    auto issue_a_upto = [&](int from, int to) {
+#pragma unroll
+      for (int n = from; n < to; ++n)
+        if (n < NSTREAM) issue_a(n);
+    };
+    auto a_limit = [](int s) {                             // A loads issued once step s has issued: everything up to AD - 1 beyond its own
+      return s < 0 ? AD - 1 : (s >= NSTEP ? NSTREAM : Brick16::a_pos(NS, s) + Brick16::a_count(NS, s) + AD - 1);
+    };
+    auto issue_b = [&](int slot, int s) {
+      const int pz = s / 9, dy = (s / 3) % 3, dx = s % 3;
+      const int off = (pz * PY + dy) * PX * VS;
       bv[slot][0] = *reinterpret_cast<const float4*>(bl[dx] + off);
       bv[slot][1] = *reinterpret_cast<const float4*>(bl[dx] + off + 16 * VS);          // 16 columns on: same (px >> 1) & 3
     };
-    auto compute = [&](int slot, int tap) {
-      const float4 a4 = av[tap % AD];
-      const float aq[4] = {a4.x, a4.y, a4.z, a4.w};
+    auto pick = [](const float4& q, int m) { return (m == 0) ? q.x : (m == 1) ? q.y : (m == 2) ? q.z : q.w; };
+    auto compute = [&](int slot, int s) {
+      const int n0 = Brick16::a_pos(NS, s);
+      if (NS == 2) {
+        const float4 a4 = av[n0 % RING];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const float4 bq = bv[slot][t];
-          const float bs = (m == 0) ? bq.x : (m == 1) ? bq.y : (m == 2) ? bq.z : bq.w;
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m], bs, acc[t], 0, 0, 0);
+          for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pick(a4, m), pick(bv[slot][t], m), acc[t], 0, 0, 0);
+      } else {
+        const int pz = s / 9;
+        const bool lo = pz <= 2, hi = pz >= 1;             // output plane 0 takes kernel tap dz = pz - 1, plane 1 takes dz = pz - 2
+        const float4 a_lo = av[n0 % RING], a_hi = av[(n0 + (lo ? 1 : 0)) % RING];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if (lo) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pick(a_lo, m), pick(bv[slot][t], m), acc[t], 0, 0, 0);
+          }
+          if (hi) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[2 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pick(a_hi, m), pick(bv[slot][t], m), acc[2 + t], 0, 0, 0);
+          }
         }
       }
     };
     const bool more = chunk + 1 < NCH;
-#pragma unroll
-    for (int tap = 0; tap < AD - 1; ++tap) issue_a(tap);
+    issue_a_upto(0, a_limit(-1));
     issue_b(0, 0);
 #pragma unroll
-    for (int tap = 0; tap < NTAP; tap += 2) {
-      if (tap + AD - 1 < NTAP) issue_a(tap + AD - 1);
-      issue_b(1, tap + 1);
-      if (more && tap / 2 < NPRE) fetch_one(chunk + 1, tap / 2);
+    for (int st = 0; st < NSTEP; ++st) {
+      issue_a_upto(a_limit(st - 1), a_limit(st));
+      if (st + 1 < NSTEP) issue_b((st + 1) & 1, st + 1);
+      if (more && (st & 1) == 0 && st / 2 < NPRE) fetch_one(chunk + 1, st / 2);
       __builtin_amdgcn_sched_barrier(0);
-      compute(0, tap);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tap + AD < NTAP) issue_a(tap + AD);
-      if (tap + 2 < NTAP) issue_b(0, tap + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(1, tap + 1);
+      compute(st & 1, st);
       __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(NPRE <= NTAP / 2, "one fill load per tap pair");
+    static_assert(NPRE <= NSTEP / 2, "one fill load per pair of steps");
     if (more) {
       __syncthreads();
       park();
       __syncthreads();
     }
   }
-  // epilogue: rows 4g .. 4g+3 = shift g / 2, channels 4 (g % 2) .. + 3
-  const int delta = g >> 1, c = (g & 1) * 4;
-  const int y = y0 + wave, z = z0 + delta;
+  // epilogue: rows 4g .. 4g+3 = (NS = 2) shift g / 2, channels 4 (g % 2) .. + 3 | (NS = 1) channels 4g .. 4g + 3 of the tile's plane
+  const int y = y0 + wave;
   if (y < a.H) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int x = x0 + 16 * t + j;
-      if (x >= a.W) continue;
+    for (int t = 0; t < NACC; ++t) {
+      const int x = x0 + 16 * (t & 1) + j;
+      const int z = z0 + (NS == 2 ? (g >> 1) : (t >> 1)), c = NS == 2 ? (g & 1) * 4 : 4 * g;
+      if (x >= a.W || z >= a.D) continue;
       const unsigned ov = (unsigned)(((vb * a.D + z) * a.H + y) * a.W + x);
       float4 o = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
       o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
@@ -1700,15 +1737,20 @@ int pgrf_conv3d_small16(const float* in, int in_cs, int in_coff, int Cin, float*
   sa.ns = nshift; sa.nsteps = small16_groups(Cin, nshift);
   a.wpk = packed;
   a.bias = has_bias ? packed + (size_t)sa.nsteps * 256 : nullptr;
-  static const bool no_brick = getenv("PGRF_CONV16_NO_BRICK") != nullptr;                   // A/B switch: B operand from registers
-  if (nshift == 2 && Cin >= 16 && !no_brick) {
+  const bool no_brick = getenv("PGRF_CONV16_NO_BRICK") != nullptr;                          // A/B switch: B operand from registers
+  if (Cin >= 16 && stride == 1 && !no_brick) {
     // B operand staged through LDS: bricks of 2 x 4 x 32 output voxels
     sa.in_bytes = (unsigned)(((size_t)B * D * H * W * in_cs - (size_t)in_coff) * sizeof(float));          // < 2^31 elements checked above: fits
     if (sa.in_bytes >= 0x80000000u) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: input beyond 2 GB");
-    if ((long long)B * (D / 2) > 65535 || (H + 3) / 4 > 65535) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: grid too large");
-    const dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 3) / 4), (unsigned)(B * (D / 2)));
-    if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, sa);
-    else hipLaunchKernelGGL((conv3d_brick16_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+    if ((long long)B * ((D + 1) / 2) > 65535 || (H + 3) / 4 > 65535) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: grid too large");
+    const dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 3) / 4), (unsigned)(B * ((D + 1) / 2)));
+    if (nshift == 2) {
+      if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+      else hipLaunchKernelGGL((conv3d_brick16_kernel<32, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+    } else {
+      if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+      else hipLaunchKernelGGL((conv3d_brick16_kernel<32, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+    }
     PGRF_CHECK_LAUNCH("conv3d_brick16");
     return PGRF_OK;
   }

@@ -87,18 +87,21 @@ def test_narrow_layer_kernel_vs_oracle(cin, cout, stride, D, ns, monkeypatch):
     assert bool((out.buf[..., :4] == 7.0).all()) and bool((out.buf[..., 4 + cout:] == 7.0).all())
 
 
-@pytest.mark.parametrize('cin,cout,stride,D,ns,nt', [(32, 8, 1, 8, 2, 0), (16, 8, 1, 12, 2, 8), (8, 8, 1, 4, 2, 4), (16, 16, 1, 6, 1, 0),
-                                                     (32, 16, 1, 5, 1, 8), (8, 16, 2, 6, 1, 0), (8, 16, 2, 7, 1, 4), (16, 16, 2, 7, 1, 2),
+@pytest.mark.parametrize('cin,cout,stride,D,ns,nt', [(32, 8, 1, 8, 2, 0), (16, 8, 1, 12, 2, 0), (32, 8, 1, 8, 2, 8), (16, 8, 1, 12, 2, 4),
+                                                     (8, 8, 1, 4, 0, 0), (16, 16, 1, 6, 1, 0), (32, 16, 1, 5, 1, 0), (32, 16, 1, 5, 1, 8),
+                                                     (16, 16, 1, 6, 1, 2), (8, 16, 2, 6, 1, 0), (8, 16, 2, 7, 1, 4), (16, 16, 2, 7, 1, 2),
                                                      (32, 8, 1, 5, 0, 0), (16, 32, 1, 4, 0, 0)])
 def test_narrow_layer_16_row_kernel_vs_oracle(cin, cout, stride, D, ns, nt, monkeypatch):
     """pgrf_conv3d_small16 (v_mfma_f32_16x16x4_f32 tiles: 8 channels x 2 depth shifts, or 16 channels) against F.conv3d of the
-    oracle, with a residual, a channel-sliced output, a ragged last tile, every tiles-per-wave instance, odd depths and the
-    zero-padded reduction tail of Cin = 8 / 16 (27 taps are not a whole number of 16-wide groups); ns == 0: the dispatcher
-    must leave the layer to the other kernels."""
+    oracle, with a residual, a channel-sliced output, ragged bricks / tiles (H = 5, W = 11: the brick is wider than the panorama),
+    odd depths and the zero-padded reduction tail of Cin = 8 / 16.  nt = 0: the dispatcher's choice (LDS-brick kernel for stride 1
+    from 16 / 32 channels); nt > 0: the register-path kernel with that many tiles per wave.  ns == 0: the dispatcher must leave
+    the layer to the other kernels."""
     from oracle import cost_volume_oracle as O
     from panogrf_amd import cost_reg as R
     if nt:
         monkeypatch.setenv('PGRF_CONV16_NT', str(nt))
+        monkeypatch.setenv('PGRF_CONV16_NO_BRICK', '1')
     g = torch.Generator().manual_seed(cin * 877 + cout * 17 + stride + D)
     B, H, W = 2, 5, 11
     x = torch.randn(B, cin, D, H, W, generator=g)
@@ -118,6 +121,26 @@ def test_narrow_layer_16_row_kernel_vs_oracle(cin, cout, stride, D, ns, nt, monk
     got = out.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
     assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
     assert bool((out.buf[..., :4] == 7.0).all()) and bool((out.buf[..., 4 + cout:] == 7.0).all())
+
+
+@pytest.mark.parametrize('cin,cout,ns,D,H,W', [(32, 8, 2, 6, 9, 70), (16, 16, 1, 5, 6, 40), (32, 16, 1, 4, 8, 64), (8, 8, 2, 4, 5, 19)])
+def test_narrow_layer_16_row_kernel_c_abi_shapes(cin, cout, ns, D, H, W):
+    """The C entry point itself on shapes with several bricks per axis (interior bricks, a ragged last brick in x and y, the
+    x wrap across the seam) and the Cin = 8 two-shift instance no dispatcher path reaches."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    from panogrf_amd._lib import lib
+    g = torch.Generator().manual_seed(cin + 3 * cout + D * H * W)
+    x = torch.randn(1, cin, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5, 'c.bias': torch.randn(cout, generator=g) * 0.1}
+    ref = torch.nn.functional.leaky_relu(O._conv3(w, 'c', x, 1), 0.01)
+    pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
+    xin = R._Vol(R._to_ndhwc(x.cuda()), 0, cin)
+    out = R._Vol.empty(1, D, H, W, cout, 'cuda')
+    lib.check(lib.pgrf_conv3d_small16(R._ptr(xin.buf), xin.cs, xin.coff, cin, R._ptr(out.buf), out.cs, out.coff, cout, R._ptr(pc.small16(ns)),
+                                      1, ns, 1, D, H, W, 1, 0.01, None, 0, 0, R._stream()))
+    got = out.buf.permute(0, 4, 1, 2, 3).cpu()
+    assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_narrow_layer_16_row_kernel_rejects_what_it_cannot_do():
