@@ -379,7 +379,7 @@ __device__ __forceinline__ Bilin bilin_setup(float xn, float yn, int fh, int fw,
 }
 
 // Gather one 32-channel NHWC map into the accumulator layout: register 4q+i of half h = channel 8q+4h+i.
-template <int STRIDE = 32>
+template <int STRIDE = 32, bool BATCH = false>
 __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const Bilin& b, int half) {
   f32x16 out;
 #ifdef PGRF_ABL_GATHER    // ablation (timing only): all taps read pixel 0
@@ -389,16 +389,39 @@ __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const 
 #else
   const float* base = map + half * 4;
 #endif
+  if constexpr (BATCH) {
+    // experiment (PGRF_BATCH_GATHER): all 16 loads of the gather in flight before the first blend, pinned by scheduling fences.
+    // In the second view pair of the 4-view kernels the scheduler falls back to its minimum-pressure order (the first pair's
+    // state is live across the region) -- four loads, wait, blend, four times per gather.
+    float4 t[4][4];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 a = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * STRIDE + q * 8);
-    const float4 c = *reinterpret_cast<const float4*>(base + (size_t)b.o01 * STRIDE + q * 8);
-    const float4 d = *reinterpret_cast<const float4*>(base + (size_t)b.o10 * STRIDE + q * 8);
-    const float4 e = *reinterpret_cast<const float4*>(base + (size_t)b.o11 * STRIDE + q * 8);
-    out[4 * q + 0] = a.x * b.wnw + c.x * b.wne + d.x * b.wsw + e.x * b.wse;
-    out[4 * q + 1] = a.y * b.wnw + c.y * b.wne + d.y * b.wsw + e.y * b.wse;
-    out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
-    out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
+    for (int q = 0; q < 4; ++q) {
+      t[q][0] = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * STRIDE + q * 8);
+      t[q][1] = *reinterpret_cast<const float4*>(base + (size_t)b.o01 * STRIDE + q * 8);
+      t[q][2] = *reinterpret_cast<const float4*>(base + (size_t)b.o10 * STRIDE + q * 8);
+      t[q][3] = *reinterpret_cast<const float4*>(base + (size_t)b.o11 * STRIDE + q * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      out[4 * q + 0] = t[q][0].x * b.wnw + t[q][1].x * b.wne + t[q][2].x * b.wsw + t[q][3].x * b.wse;
+      out[4 * q + 1] = t[q][0].y * b.wnw + t[q][1].y * b.wne + t[q][2].y * b.wsw + t[q][3].y * b.wse;
+      out[4 * q + 2] = t[q][0].z * b.wnw + t[q][1].z * b.wne + t[q][2].z * b.wsw + t[q][3].z * b.wse;
+      out[4 * q + 3] = t[q][0].w * b.wnw + t[q][1].w * b.wne + t[q][2].w * b.wsw + t[q][3].w * b.wse;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * STRIDE + q * 8);
+      const float4 c = *reinterpret_cast<const float4*>(base + (size_t)b.o01 * STRIDE + q * 8);
+      const float4 d = *reinterpret_cast<const float4*>(base + (size_t)b.o10 * STRIDE + q * 8);
+      const float4 e = *reinterpret_cast<const float4*>(base + (size_t)b.o11 * STRIDE + q * 8);
+      out[4 * q + 0] = a.x * b.wnw + c.x * b.wne + d.x * b.wsw + e.x * b.wse;
+      out[4 * q + 1] = a.y * b.wnw + c.y * b.wne + d.y * b.wsw + e.y * b.wse;
+      out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
+      out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
+    }
   }
 #ifdef PGRF_ABL_GATHER
 #undef b
@@ -486,6 +509,14 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #else
   constexpr bool kLazyTaps = (kTwoWave<V> && kPrec == 0 && V != 3);   // 3 views in one group: 118 -> 6 spilled registers and
                                                                        // 60.1 -> 55.3 ms WITHOUT it (allocator behaviour, measured)
+#endif
+  // gathers with all their loads in flight behind scheduling fences (see gather32): measured SLOWER for the second view pair of
+  // the 4-view kernel (78.4 -> 79.7 ms, both pairs 80.5 ms; 163 -> 187 spilled registers) although that pair's gathers are
+  // scheduled four loads at a time -- the other wave of the SIMD already hides those waits.  Off; experiment builds only.
+#ifdef PGRF_BATCH_GATHER
+  constexpr bool kBatchGather = ((PGRF_BATCH_GATHER) >> (V0 > 0 ? 1 : 0)) & 1;          // bit 0 = first group, bit 1 = later groups
+#else
+  constexpr bool kBatchGather = false;
 #endif
 #ifdef PGRF_NO_DEDUPE
   constexpr bool kDedupe = false;
@@ -611,7 +642,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     float b2[NT][16];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const f32x16 a1 = gather32<kPrjCh>(prj[t] + (m < 3 ? m : 4) * 32, brf[t], half);
+      const f32x16 a1 = gather32<kPrjCh, kBatchGather>(prj[t] + (m < 3 ? m : 4) * 32, brf[t], half);
 #pragma unroll
       for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[s]);
     }
@@ -702,7 +733,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
                                  : reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const f32x16 pe = gather32<kPrjCh>(prj[t] + 3 * 32, brf[t], half);
+      const f32x16 pe = gather32<kPrjCh, kBatchGather>(prj[t] + 3 * 32, brf[t], half);
       const float hv = hvs[t];
       if constexpr (kRecomputeNf<V>) { vs[V0 + t].hv = hv; vs[V0 + t].xn = pxy[t][0]; vs[V0 + t].yn = pxy[t][1]; }
       a1[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a16, hv, pe, 0, 0, 0);
@@ -802,7 +833,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
         bfeat[t] = bfeat_e[t];
         bimg[t] = bimg_e[t];
       }
-      const f32x16 imf = gather32(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
+      const f32x16 imf = gather32<32, kBatchGather>(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
       const float* ib = p.imgs + (size_t)v * p.H * p.W * 4;
       const float4 c00 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o00 * 4);
       const float4 c01 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o01 * 4);
