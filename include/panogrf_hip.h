@@ -304,6 +304,15 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
                       const float* packed, int has_bias, int nshift, int B, int D, int H, int W, int stride, float lrelu_slope,
                       const float* residual, int res_cs, int res_coff, void* stream);
 
+/* pgrf_conv3d_upfused's step for Cin = 16 -> Cout = 8 on 16-row MFMA tiles with the low-resolution brick staged in LDS (z / y
+ * position classes select the weight block per brick / wave; the two seam columns of the circular axis get a corrected B operand
+ * under the interior x weights).  Same arguments as pgrf_conv3d_upfused; low-res D, H >= 2 and W >= 33. */
+size_t pgrf_conv3d_upbrick_packed_floats(int Cout, int Cin);
+int pgrf_pack_conv3d_upbrick(const float* w_host, const float* bias_host, int Cout, int Cin, int D, int H, int W, float* packed_host);
+int pgrf_conv3d_upbrick(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                        const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                        int res_cs, int res_coff, void* stream);
+
 /* The same narrow layers on the 16-row MFMA tile (v_mfma_f32_16x16x4_f32): Cout = 8 with nshift = 2 (4 input planes per 2
  * output planes: 75 % useful products against 50 % of pgrf_conv3d_small's nshift = 4), or Cout = 16 with nshift = 1 (100 %).
  * Same arguments and epilogue as pgrf_conv3d_small. */

@@ -72,6 +72,17 @@ class _PackedConv:
         return self._small[key]
 
 
+    def upbrick(self, D, H, W):
+        """Packed block of pgrf_conv3d_upbrick (16-row tiles over the low-res brick in LDS), per low-res size."""
+        key = ('upb', D, H, W)
+        if key not in self._small:
+            n = lib.pgrf_conv3d_upbrick_packed_floats(self.cout, self.cin)
+            host = torch.empty(n, dtype=torch.float32)
+            lib.check(lib.pgrf_pack_conv3d_upbrick(_ptr(self._w), _ptr(self._b), self.cout, self.cin, D, H, W, _ptr(host)))
+            self._small[key] = host.to(self._device)
+        return self._small[key]
+
+
 def _upconv(pc, x, out, up_scratch, slope=0.01, residual=None):
     """conv(interpolate(x, scale_factor=2, mode='trilinear')) + LeakyReLU (+ residual) -> `out` (high resolution): CostRegNet's
     decoder step (models/cost_reg.py:58-94).  Fused into ONE launch on the low-resolution tensor where the kernel applies
@@ -79,8 +90,16 @@ def _upconv(pc, x, out, up_scratch, slope=0.01, residual=None):
     want = os.environ.get('PANOGRF_CONV_UPFUSE', '1')
     # (Cout = 16 fills four row tiles by itself: the fused form measured 155 us against 110 + 11 us for conv9 at 64x128x256, so only
     #  the 8-channel layers take it by default; 'force' = wherever the kernel applies)
-    if (want != '0' and pc.cin in (16, 32) and (pc.cout == 8 or (want == 'force' and pc.cout == 16)) and min(x.D, x.H, x.W) >= 2
-            and x.H * x.W * x.cs < (1 << 23) and x.B * x.D * x.H * x.W * x.cs < (1 << 29)):
+    fits = (min(x.D, x.H, x.W) >= 2 and x.H * x.W * x.cs < (1 << 23) and x.B * x.D * x.H * x.W * x.cs < (1 << 29))
+    if want != '0' and fits and pc.cin == 16 and pc.cout == 8 and x.W >= 33 and os.environ.get('PANOGRF_CONV_UPBRICK', '1') != '0':
+        # 16-row tiles over the low-res brick in LDS (conv11 of CostRegNet)
+        lib.check(lib.pgrf_conv3d_upbrick(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                          _ptr(pc.upbrick(x.D, x.H, x.W)), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope),
+                                          _ptr(residual.buf) if residual is not None else None,
+                                          residual.cs if residual is not None else 0,
+                                          residual.coff if residual is not None else 0, _stream()))
+        return out
+    if want != '0' and fits and pc.cin in (16, 32) and (pc.cout == 8 or (want == 'force' and pc.cout == 16)):
         lib.check(lib.pgrf_conv3d_upfused(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
                                           _ptr(pc.upfused(x.D, x.H, x.W)), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope),
                                           _ptr(residual.buf) if residual is not None else None,

@@ -1421,6 +1421,188 @@ static int grid_for(long long total) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same fused step (up-sampling x2 + 3x3x3 convolution, Cin = 16 -> Cout = 8: conv11 of CostRegNet) on 16-row MFMA tiles with
+// the LOW-resolution input brick in LDS (the scheme of conv3d_brick16_kernel).  Rows = 2 z parities x 8 channels; the four (y, x)
+// parities of a low-res voxel are four accumulators fed by the SAME B operand and their own folded weights, so every product is
+// useful (3.4 MFMAs per high-res voxel against 4.5 for the direct form on the up-sampled volume and a 64-row tile pair per 32
+// voxels for conv3d_upfused_kernel, whose waves quantise badly: 4112 items on 2048 slots).
+// Position classes: a brick is ONE low-res z plane (class of the plane = block-uniform) and a wave owns ONE low-res row (y class =
+// wave-uniform); the class only selects the weight block (scalar offset).  Along x every column is multiplied with the INTERIOR
+// weights.  The two seam columns (x = 0 and W - 1: clamped interpolation next to the circular wrap) get a corrected B operand
+// instead: with r0, r1, r2 the three x neighbours a seam lane reads and E the interior operator of the axis, the values
+//     left  seam, d = (r0 - r1) / 2:   x parity 0: (r0 + d, r1 - d, r2 + 3d)    parity 1: (r0 - 2d, r1, r2)
+//     right seam, e = (r2 - r1) / 2:   x parity 0: (r0, r1, r2 - 2e)            parity 1: (r0 + 3e, r1 - e, r2 + e)
+// satisfy E^T b = E_seam^T r for every filter tap, i.e. the interior weights applied to them give exactly the seam voxel's
+// result.  d (or e) is formed once per brick row in LDS; the seam tile of a seam brick reads it per tap and adds c * d with a
+// per-lane coefficient that is zero off the seam (8 FMAs per tap in the bricks that hold a seam, nothing elsewhere).
+struct UpBrickArgs {
+  ConvArgs c;                 // in = low-res tensor (D, H, W = its dims), out / residual = high-res (2D, 2H, 2W)
+  unsigned in_bytes;
+};
+
+__global__ void __launch_bounds__(256, 4) conv3d_upbrick_kernel(const UpBrickArgs ua) {
+  const ConvArgs& a = ua.c;
+  constexpr int NTAP = 27, NSET = 4, NSTREAM = NTAP * NSET;
+  constexpr int PX = 34, PY = 6, PZ = 3, VS = 16;
+  constexpr int NV = PX * PY * PZ, NROW = PY * PZ;
+  __shared__ __attribute__((aligned(16))) float brick[NV * VS + NROW * VS];     // 39 168 B + 1 152 B seam deltas: four workgroups per CU
+  float* seamv = brick + NV * VS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int vb = (int)blockIdx.z / a.D, iz = (int)blockIdx.z - vb * a.D;
+  const int x0 = (int)blockIdx.x * 32, y0 = (int)blockIdx.y * 4;
+  const float* inb = a.in + a.in_coff;
+  const unsigned long long inb_bits = (unsigned long long)inb;
+  const i32x4v rsrc = {(int)(unsigned)inb_bits, (int)(unsigned)(inb_bits >> 32), (int)ua.in_bytes, 0x00020000};
+  // fill: 18 rows (pz, py) of 34 voxels x 4 channel quads.  Columns 0..31: thread -> (column, quad) = tid % 128, the two halves of
+  // the workgroup take 9 rows each (row term of the address wave-uniform); columns 32, 33 (144 quads): one more load per thread.
+  const int half = wave >> 1;
+  auto wrap_x = [&](int x) { x %= a.W; return x < 0 ? x + a.W : x; };
+  const int ystep = a.W * a.in_cs;
+  {
+    float4 pre[10];
+    const int cq = tid & 3, px = (tid & 127) >> 2;
+    const unsigned src_col = (unsigned)(wrap_x(x0 - 1 + px) * a.in_cs + 4 * cq) * 4u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int r = half * 9 + i, pz = r / PY, py = r - pz * PY;          // uniform
+      const int z = iz - 1 + pz, y = y0 - 1 + py;
+      pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H) {
+        const f32x4v v = pgrf_buffer_load_x4(rsrc, (int)src_col, (((vb * a.D + z) * a.H + y) * ystep) * 4, 0);
+        pre[i] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    }
+    const int row = tid >> 3, pxx = 32 + ((tid >> 2) & 1), pz = row / PY, py = row - pz * PY;
+    const int z = iz - 1 + pz, y = y0 - 1 + py;
+    const bool ok = tid < 144 && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H;
+    const unsigned src_x = ok ? (unsigned)((((vb * a.D + z) * a.H + y) * a.W + wrap_x(x0 - 1 + pxx)) * a.in_cs + 4 * cq) * 4u : 0x80000000u;
+    const f32x4v v = pgrf_buffer_load_x4(rsrc, (int)src_x, 0, 0);
+    pre[9] = make_float4(v.x, v.y, v.z, v.w);
+    char* dst_col = reinterpret_cast<char*>(brick) + ((half * 9 * PX + px) * VS + 4 * (cq ^ ((px >> 1) & 3))) * 4;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) *reinterpret_cast<float4*>(dst_col + i * (PX * VS * 4)) = pre[i];
+    if (tid < 144) *reinterpret_cast<float4*>(reinterpret_cast<char*>(brick) + ((row * PX + pxx) * VS + 4 * (cq ^ ((pxx >> 1) & 3))) * 4) = pre[9];
+  }
+  // wave w multiplies low-res row y0 + w: tiles x0 + j and x0 + 16 + j, four (py, px) parity sets each
+  const int iy = y0 + wave;
+  const int zc = iz == 0 ? 0 : (iz == a.D - 1 ? 2 : 1), yc = iy == 0 ? 0 : (iy >= a.H - 1 ? 2 : 1);
+  const int cls_off = (zc * 3 + yc) * (NSTREAM * 1024);              // bytes, wave-uniform
+  const float* bl[3];                                      // per nx: voxel (pz = 0, py = w, px = j + nx), this lane's (swizzled) channel quad
+#pragma unroll
+  for (int d = 0; d < 3; ++d) bl[d] = &brick[(wave * PX + j + d) * VS + 4 * (g ^ (((j + d) >> 1) & 3))];
+  const unsigned long long w_bits = (unsigned long long)a.wpk;
+  const i32x4v wrsrc = {(int)(unsigned)w_bits, (int)(unsigned)(w_bits >> 32), 9 * NSTREAM * 1024, 0x00020000};
+  f32x4v acc[NSET][2];
+  {
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + g * 4);
+#pragma unroll
+    for (int s = 0; s < NSET; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[s][t] = (f32x4v){b4.x, b4.y, b4.z, b4.w};
+  }
+  constexpr int AD = 6, RING = 10;                         // A loads in flight ahead of their MFMAs / ring size (>= AD + NSET)
+  float4 av[RING], bv[2][2];
+  auto issue_a = [&](int n) {                              // n = tap * 4 + parity set
+    const f32x4v r = pgrf_buffer_load_x4(wrsrc, lane * 16, cls_off + ((n & 3) * NTAP + (n >> 2)) * 1024, 0);          // packed [class][set][tap]
+    av[n % RING] = make_float4(r.x, r.y, r.z, r.w);
+  };
+  auto issue_b = [&](int slot, int tap) {
+    const int nz = tap / 9, ny = (tap / 3) % 3, nx = tap % 3;
+    const int off = (nz * PY + ny) * PX * VS;
+    bv[slot][0] = *reinterpret_cast<const float4*>(bl[nx] + off);
+    bv[slot][1] = *reinterpret_cast<const float4*>(bl[nx] + off + 16 * VS);
+  };
+  auto pick = [](const float4& q, int m) { return (m == 0) ? q.x : (m == 1) ? q.y : (m == 2) ? q.z : q.w; };
+#pragma unroll
+  for (int n = 0; n < AD; ++n) issue_a(n);
+  __syncthreads();
+  // seam bricks: which tile holds the seam column, the per-row deltas, the per-lane coefficients (zero off the seam)
+  const bool left = x0 == 0, right = x0 + 32 >= a.W;      // (the launcher guarantees W >= 33: never both)
+  const int xs = left ? 0 : a.W - 1 - x0;                  // seam column within the brick's outputs
+  float seam_f = 0.f;                                      // 1 in the seam lanes
+  const float* sv = seamv + wave * VS + 4 * g;             // row (pz = 0, py = w), this lane's channel quad (not swizzled: a broadcast read)
+  if (left || right) {
+    if (tid < NROW * 4) {
+      const int row = tid >> 2, q = tid & 3;
+      const int ca = left ? 0 : xs + 2, cb = xs + 1;       // delta = (col ca - col cb) / 2: left r0 - r1, right r2 - r1
+      const float4 va = *reinterpret_cast<const float4*>(&brick[(row * PX + ca) * VS + 4 * (q ^ ((ca >> 1) & 3))]);
+      const float4 vb4 = *reinterpret_cast<const float4*>(&brick[(row * PX + cb) * VS + 4 * (q ^ ((cb >> 1) & 3))]);
+      *reinterpret_cast<float4*>(&seamv[row * VS + 4 * q]) =
+          make_float4(0.5f * (va.x - vb4.x), 0.5f * (va.y - vb4.y), 0.5f * (va.z - vb4.z), 0.5f * (va.w - vb4.w));
+    }
+    seam_f = j == (xs & 15) ? 1.f : 0.f;
+    __syncthreads();
+  }
+  // TS = the tile with the seam lane (-1: none).  Coefficients of the delta per (x parity, nx): wave-uniform, times the lane flag.
+  auto run = [&](auto ts_tag) __attribute__((always_inline)) {
+    constexpr int TS = decltype(ts_tag)::value;
+    float4 fd = make_float4(0.f, 0.f, 0.f, 0.f);           // seam_f * delta of the current (nz, ny) row
+    auto load_d = [&](int tap) {
+      const float4 d = *reinterpret_cast<const float4*>(sv + ((tap / 9) * PY + (tap / 3) % 3) * VS);
+      fd = make_float4(seam_f * d.x, seam_f * d.y, seam_f * d.z, seam_f * d.w);
+    };
+    issue_b(0, 0);
+    if constexpr (TS >= 0) load_d(0);
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+#pragma unroll
+      for (int n = AD + 4 * tap; n < AD + 4 * tap + 4; ++n)
+        if (n < NSTREAM) issue_a(n);
+      if (tap + 1 < NTAP) issue_b((tap + 1) & 1, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      float4 bs[2];                                        // seam tile: corrected operand per x parity
+      if constexpr (TS >= 0) {
+        const float4 r = bv[tap & 1][TS];
+        const int nx = tap % 3;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const float kl = p == 0 ? (nx == 0 ? 1.f : nx == 1 ? -1.f : 3.f) : (nx == 0 ? -2.f : 0.f);      // left seam
+          const float kr = p == 0 ? (nx == 2 ? -2.f : 0.f) : (nx == 0 ? 3.f : nx == 1 ? -1.f : 1.f);      // right seam
+          const float k = left ? kl : kr;                  // uniform
+          bs[p] = make_float4(fmaf(k, fd.x, r.x), fmaf(k, fd.y, r.y), fmaf(k, fd.z, r.z), fmaf(k, fd.w, r.w));
+        }
+        if (nx == 2 && tap + 1 < NTAP) load_d(tap + 1);     // the next row's delta: in place, a whole tap ahead of its first use
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int s = 0; s < NSET; ++s)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float b = (t == TS) ? pick(bs[s & 1], m) : pick(bv[tap & 1][t], m);
+            acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pick(av[(4 * tap + s) % RING], m), b, acc[s][t], 0, 0, 0);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (!(left || right)) run(std::integral_constant<int, -1>{});
+  else if ((xs >> 4) == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+  // epilogue: rows 4g .. 4g+3 = z parity g / 2, channels 4 (g % 2) .. + 3 of high-res voxel (2 iz + pz, 2 iy + py, 2 ix + px)
+  if (iy < a.H) {
+    const int pz = g >> 1, c = (g & 1) * 4;
+#pragma unroll
+    for (int s = 0; s < NSET; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ix = x0 + 16 * t + j;
+        if (ix >= a.W) continue;
+        const unsigned ov = (unsigned)(((vb * a.Do + 2 * iz + pz) * a.Ho + 2 * iy + (s >> 1)) * a.Wo + 2 * ix + (s & 1));
+        float4 o = make_float4(acc[s][t][0], acc[s][t][1], acc[s][t][2], acc[s][t][3]);
+        o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
+        o.z = o.z > 0.f ? o.z : o.z * a.slope; o.w = o.w > 0.f ? o.w : o.w * a.slope;
+        if (a.residual) {
+          const float4 rr = *reinterpret_cast<const float4*>(a.residual + (ov * (unsigned)a.res_cs + (unsigned)(a.res_coff + c)));
+          o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(a.out + (ov * (unsigned)a.out_cs + (unsigned)(a.out_coff + c))) = o;
+      }
+  }
+}
+
 }  // namespace pgrf
 
 using namespace pgrf;
@@ -1908,6 +2090,72 @@ int pgrf_conv3d_upfused(const float* in, int in_cs, int in_coff, int Cin, float*
   else if (Cin == 16 && MT == 4) hipLaunchKernelGGL((conv3d_upfused_kernel<16, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, ua);
   else hipLaunchKernelGGL((conv3d_upfused_kernel<32, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, ua);
   PGRF_CHECK_LAUNCH("conv3d_upfused");
+  return PGRF_OK;
+}
+
+// ---- the same step on 16-row tiles with the low-res brick in LDS (conv3d_upbrick_kernel) ----
+// packed block: [class 9 = 3 zc + yc][parity set 4 = 2 py + px][tap 27][64 lanes][4] A operands | [16] bias by row
+static const size_t kUpBrickA = (size_t)9 * 4 * 27 * 256;
+static bool upbrick_ok(int Cout, int Cin) { return Cout == 8 && Cin == 16; }
+
+size_t pgrf_conv3d_upbrick_packed_floats(int Cout, int Cin) {
+  if (!upbrick_ok(Cout, Cin)) return 0;
+  return kUpBrickA + 16;
+}
+
+int pgrf_pack_conv3d_upbrick(const float* w_host, const float* bias_host, int Cout, int Cin, int D, int H, int W, float* packed_host) {
+  if (!w_host || !packed_host) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d_upbrick: null pointer");
+  if (!upbrick_ok(Cout, Cin)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv3d_upbrick: Cin %d (16), Cout %d (8)", Cin, Cout);
+  if (D < 2 || H < 2 || W < 33) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv3d_upbrick: low-res D, H >= 2 and W >= 33");
+  std::memset(packed_host, 0, sizeof(float) * (kUpBrickA + 16));
+  double Ez[3][2][3][3], Ey[3][2][3][3], Ex[3][2][3][3];
+  upfused_axis(D, false, Ez); upfused_axis(H, false, Ey); upfused_axis(W, true, Ex);
+  for (int cz = 0; cz < 3; ++cz)
+    for (int cy = 0; cy < 3; ++cy)
+      for (int set = 0; set < 4; ++set)
+        for (int nb = 0; nb < 27; ++nb) {
+          const int py = set >> 1, px = set & 1, bz = nb / 9, by = (nb / 3) % 3, bx = nb % 3;
+          float* blk = packed_host + ((((size_t)(cz * 3 + cy) * 4 + set) * 27 + nb) * 256);
+          for (int lane = 0; lane < 64; ++lane)
+            for (int m = 0; m < 4; ++m) {
+              const int row = lane & 15, pz = row >> 3, co = row & 7, ci = 4 * (lane >> 4) + m;
+              double k = 0.0;
+              for (int tp = 0; tp < 27; ++tp) {
+                const double f = Ez[cz][pz][bz][tp / 9] * Ey[cy][py][by][(tp / 3) % 3] * Ex[1][px][bx][tp % 3];      // x: interior class
+                if (f != 0.0) k += f * (double)w_host[((size_t)co * Cin + ci) * 27 + tp];
+              }
+              blk[lane * 4 + m] = (float)k;
+            }
+        }
+  float* bv = packed_host + kUpBrickA;
+  for (int r = 0; r < 16; ++r) bv[r] = bias_host ? bias_host[r & 7] : 0.f;
+  return PGRF_OK;
+}
+
+int pgrf_conv3d_upbrick(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                        const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                        int res_cs, int res_coff, void* stream) {
+  if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_upbrick: null pointer");
+  if (!upbrick_ok(Cout, Cin)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upbrick: Cin %d (16), Cout %d (8)", Cin, Cout);
+  // (W >= 33: a brick of 32 columns then never holds both seam columns)
+  if (B < 1 || D < 2 || H < 2 || W < 33) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upbrick: low-res D, H >= 2 and W >= 33");
+  if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upbrick: channel strides/offsets must be multiples of 4");
+  if ((double)B * D * H * W * in_cs * 4.0 >= 2147483648.0 || (double)B * D * H * W * 8.0 * (out_cs > res_cs ? out_cs : res_cs) >= 4294967296.0 ||
+      (long long)B * D > 65535 || (H + 3) / 4 > 65535)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upbrick: tensor too large (32-bit offsets)");
+  UpBrickArgs ua;
+  std::memset(&ua, 0, sizeof(ua));
+  ConvArgs& a = ua.c;
+  a.in = in; a.in_cs = in_cs; a.in_coff = in_coff; a.Cin = Cin; a.out = out; a.out_cs = out_cs; a.out_coff = out_coff; a.Cout = Cout;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.Do = 2 * D; a.Ho = 2 * H; a.Wo = 2 * W; a.stride = 1; a.slope = lrelu_slope;
+  a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wrap_w = 1;
+  a.wpk = packed;
+  a.bias = has_bias ? packed + kUpBrickA : nullptr;
+  ua.in_bytes = (unsigned)(((size_t)B * D * H * W * in_cs - (size_t)in_coff) * sizeof(float));
+  const dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 3) / 4), (unsigned)(B * D));
+  hipLaunchKernelGGL(conv3d_upbrick_kernel, grid, dim3(256), 0, (hipStream_t)stream, ua);
+  PGRF_CHECK_LAUNCH("conv3d_upbrick");
   return PGRF_OK;
 }
 

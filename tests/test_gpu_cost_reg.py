@@ -266,6 +266,51 @@ def test_unet2_winograd_equals_direct(monkeypatch):
     assert 0.0 < d < 1e-4 * max(1.0, float(outs[1].abs().max()))
 
 
+@pytest.mark.parametrize('B,D,H,W', [(1, 4, 6, 40), (2, 3, 5, 33), (1, 2, 2, 49), (1, 5, 9, 70), (1, 3, 4, 64), (1, 2, 3, 48)])
+def test_upsample_fused_brick_conv_vs_oracle(B, D, H, W, monkeypatch):
+    """pgrf_conv3d_upbrick (16 -> 8: the low-res brick in LDS, z / y position classes per brick / wave, interior x weights with
+    the corrected operand of the two seam columns) against the oracle's F.interpolate + F.conv3d with the LeakyReLU + residual
+    epilogue and channel-sliced buffers: ragged bricks in x and y, several bricks per axis, first / interior / last planes and
+    rows, the right seam in either tile of its brick (W % 32 = 1, 8, 16, 17, 0), axes of length 2.  And against the class-box
+    kernel it replaces (a different evaluation order: close, not equal)."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    cin, cout = 16, 8
+    g = torch.Generator().manual_seed(D * 3 + H * 5 + W + B)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5, 'c.bias': torch.randn(cout, generator=g) * 0.1}
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode='trilinear', align_corners=False)
+    conv = O._conv3(w, 'c', up)
+    res = torch.randn(conv.shape, generator=g)
+    ref = torch.nn.functional.leaky_relu(conv, 0.01) + res
+    pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
+    wide_in = torch.full((B, D, H, W, cin + 8), 3.0, device='cuda')
+    wide_in[..., 4:4 + cin] = R._to_ndhwc(x.cuda())
+    resv = R._Vol(res.cuda().permute(0, 2, 3, 4, 1).contiguous(), 0, cout)
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PANOGRF_CONV_UPBRICK', flag)
+        wide_out = R._Vol.empty(B, 2 * D, 2 * H, 2 * W, cout + 8, 'cuda')
+        wide_out.buf.fill_(7.0)
+        o = R._upconv(pc, R._Vol(wide_in, 4, cin), wide_out.slice(4, cout), lambda: R._Vol.empty(B, 2 * D, 2 * H, 2 * W, cin, 'cuda'), residual=resv)
+        outs[flag] = o.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
+        assert bool((o.buf[..., :4] == 7.0).all()) and bool((o.buf[..., 4 + cout:] == 7.0).all())
+        assert max_abs(outs[flag], ref) < 2e-5 * max(1.0, float(ref.abs().max())), flag
+    assert 0.0 < max_abs(outs['1'], outs['0']) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert ('upb', D, H, W) in pc._small and ('up', D, H, W) in pc._small          # both kernels really ran
+
+
+def test_upsample_fused_brick_conv_rejects_what_it_cannot_do():
+    from panogrf_amd._lib import lib
+    import ctypes
+    assert lib.pgrf_conv3d_upbrick_packed_floats(8, 16) == 9 * 4 * 27 * 256 + 16
+    assert lib.pgrf_conv3d_upbrick_packed_floats(16, 16) == 0 and lib.pgrf_conv3d_upbrick_packed_floats(8, 32) == 0
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.pgrf_pack_conv3d_upbrick(p, None, 8, 16, 4, 4, 32, p) != 0 and b'pgrf_pack_conv3d_upbrick' in lib.pgrf_last_error()
+    assert lib.pgrf_conv3d_upbrick(p, 16, 0, 16, p, 8, 0, 8, p, 1, 1, 4, 4, 32, 0.01, None, 0, 0, None) != 0 and b'W >= 33' in lib.pgrf_last_error()
+
+
 @pytest.mark.parametrize('cin,cout,B,D,H,W', [(16, 8, 1, 4, 6, 40), (32, 16, 2, 3, 5, 33), (16, 8, 1, 2, 2, 2), (16, 16, 1, 6, 4, 64),
                                               (32, 8, 1, 5, 3, 7)])
 def test_upsample_fused_conv_vs_oracle(cin, cout, B, D, H, W, monkeypatch):
@@ -286,6 +331,7 @@ def test_upsample_fused_conv_vs_oracle(cin, cout, B, D, H, W, monkeypatch):
     wide_in[..., 4:4 + cin] = R._to_ndhwc(x.cuda())
     resv = R._Vol(res.cuda().permute(0, 2, 3, 4, 1).contiguous(), 0, cout)
     outs = {}
+    monkeypatch.setenv('PANOGRF_CONV_UPBRICK', '0')               # this test is about the class-box kernel
     for flag in ('force', '0'):
         monkeypatch.setenv('PANOGRF_CONV_UPFUSE', flag)
         wide_out = R._Vol.empty(B, 2 * D, 2 * H, 2 * W, cout + 8, 'cuda')

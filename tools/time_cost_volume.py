@@ -46,5 +46,5 @@ for name, net, gf in [('CostRegNet', R.CostRegNet(dict(use_wrap_padding=True), 3
         for p in net.parameters():
             p.mul_(0.5)
         out = net.forward_ndhwc(cv)
-        t = timeit(lambda: net.forward_ndhwc(cv), n=3)
+        t = timeit(lambda: net.forward_ndhwc(cv), n=20)         # (n = 3 until round 3: that included ~15 % of start-up effects)
     print(f'{name} {h}x{w}: {t:.2f} ms -> {gf/t/1e9:.1f} TFLOP/s algorithmic, out finite={bool(torch.isfinite(out).all())}')
