@@ -1429,13 +1429,15 @@ static int grid_for(long long total) {
 // voxels for conv3d_upfused_kernel, whose waves quantise badly: 4112 items on 2048 slots).
 // Position classes: a brick is ONE low-res z plane (class of the plane = block-uniform) and a wave owns ONE low-res row (y class =
 // wave-uniform); the class only selects the weight block (scalar offset).  Along x every column is multiplied with the INTERIOR
-// weights.  The two seam columns (x = 0 and W - 1: clamped interpolation next to the circular wrap) get a corrected B operand
-// instead: with r0, r1, r2 the three x neighbours a seam lane reads and E the interior operator of the axis, the values
-//     left  seam, d = (r0 - r1) / 2:   x parity 0: (r0 + d, r1 - d, r2 + 3d)    parity 1: (r0 - 2d, r1, r2)
-//     right seam, e = (r2 - r1) / 2:   x parity 0: (r0, r1, r2 - 2e)            parity 1: (r0 + 3e, r1 - e, r2 + e)
+// weights.  The two seam columns (x = W - 1 and 0: clamped interpolation next to the circular wrap) get a corrected B operand
+// instead: with r0, r1, r2 the three x neighbours a seam lane reads, E the interior operator of the axis and
+// D = (t[W-1] - t[0]) / 2, the values
+//     x = 0:      x parity 0: (r0 + D, r1 - D, r2 + 3D)    parity 1: (r0 - 2D, r1, r2)
+//     x = W - 1:  x parity 0: (r0, r1, r2 + 2D)            parity 1: (r0 - 3D, r1 + D, r2 - D)
 // satisfy E^T b = E_seam^T r for every filter tap, i.e. the interior weights applied to them give exactly the seam voxel's
-// result.  d (or e) is formed once per brick row in LDS; the seam tile of a seam brick reads it per tap and adds c * d with a
-// per-lane coefficient that is zero off the seam (8 FMAs per tap in the bricks that hold a seam, nothing elsewhere).
+// result.  Bricks start at column -1 (= W - 1), so both seam columns are lanes 0 and 1 of the first tile of the FIRST brick of
+// a row of bricks: that brick forms D once per brick row in LDS, reads it per tap and adds c * D with a per-lane coefficient
+// that is zero off the seam (8 FMAs per tap in one brick out of W / 32, nothing elsewhere).
 struct UpBrickArgs {
   ConvArgs c;                 // in = low-res tensor (D, H, W = its dims), out / residual = high-res (2D, 2H, 2W)
   unsigned in_bytes;
@@ -1451,7 +1453,7 @@ __global__ void __launch_bounds__(256, 4) conv3d_upbrick_kernel(const UpBrickArg
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int vb = (int)blockIdx.z / a.D, iz = (int)blockIdx.z - vb * a.D;
-  const int x0 = (int)blockIdx.x * 32, y0 = (int)blockIdx.y * 4;
+  const int x0 = (int)blockIdx.x * 32 - 1, y0 = (int)blockIdx.y * 4;          // columns x0 .. x0 + 31 (mod W): brick 0 starts at the seam
   const float* inb = a.in + a.in_coff;
   const unsigned long long inb_bits = (unsigned long long)inb;
   const i32x4v rsrc = {(int)(unsigned)inb_bits, (int)(unsigned)(inb_bits >> 32), (int)ua.in_bytes, 0x00020000};
@@ -1519,33 +1521,31 @@ __global__ void __launch_bounds__(256, 4) conv3d_upbrick_kernel(const UpBrickArg
 #pragma unroll
   for (int n = 0; n < AD; ++n) issue_a(n);
   __syncthreads();
-  // seam bricks: which tile holds the seam column, the per-row deltas, the per-lane coefficients (zero off the seam)
-  const bool left = x0 == 0, right = x0 + 32 >= a.W;      // (the launcher guarantees W >= 33: never both)
-  const int xs = left ? 0 : a.W - 1 - x0;                  // seam column within the brick's outputs
-  float seam_f = 0.f;                                      // 1 in the seam lanes
+  // the seam brick (first of its row of bricks; lanes 0 = column W - 1 and 1 = column 0 of tile 0): per-row deltas D, per-lane coefficients
+  const bool seam = blockIdx.x == 0;
   const float* sv = seamv + wave * VS + 4 * g;             // row (pz = 0, py = w), this lane's channel quad (not swizzled: a broadcast read)
-  if (left || right) {
+  if (seam) {
     if (tid < NROW * 4) {
-      const int row = tid >> 2, q = tid & 3;
-      const int ca = left ? 0 : xs + 2, cb = xs + 1;       // delta = (col ca - col cb) / 2: left r0 - r1, right r2 - r1
-      const float4 va = *reinterpret_cast<const float4*>(&brick[(row * PX + ca) * VS + 4 * (q ^ ((ca >> 1) & 3))]);
-      const float4 vb4 = *reinterpret_cast<const float4*>(&brick[(row * PX + cb) * VS + 4 * (q ^ ((cb >> 1) & 3))]);
+      const int row = tid >> 2, q = tid & 3;               // brick columns 1, 2 = x = W - 1, 0
+      const float4 va = *reinterpret_cast<const float4*>(&brick[(row * PX + 1) * VS + 4 * (q ^ 0)]);
+      const float4 vb4 = *reinterpret_cast<const float4*>(&brick[(row * PX + 2) * VS + 4 * (q ^ 1)]);
       *reinterpret_cast<float4*>(&seamv[row * VS + 4 * q]) =
           make_float4(0.5f * (va.x - vb4.x), 0.5f * (va.y - vb4.y), 0.5f * (va.z - vb4.z), 0.5f * (va.w - vb4.w));
     }
-    seam_f = j == (xs & 15) ? 1.f : 0.f;
     __syncthreads();
   }
-  // TS = the tile with the seam lane (-1: none).  Coefficients of the delta per (x parity, nx): wave-uniform, times the lane flag.
-  auto run = [&](auto ts_tag) __attribute__((always_inline)) {
-    constexpr int TS = decltype(ts_tag)::value;
-    float4 fd = make_float4(0.f, 0.f, 0.f, 0.f);           // seam_f * delta of the current (nz, ny) row
-    auto load_d = [&](int tap) {
-      const float4 d = *reinterpret_cast<const float4*>(sv + ((tap / 9) * PY + (tap / 3) % 3) * VS);
-      fd = make_float4(seam_f * d.x, seam_f * d.y, seam_f * d.z, seam_f * d.w);
-    };
+  // SEAM: tile 0 takes corrected operands
+  auto run = [&](auto seam_tag) __attribute__((always_inline)) {
+    constexpr bool SEAM = decltype(seam_tag)::value;
+    float cf[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // coefficient of D per (x parity, nx), zero off the seam
+    float4 dd = make_float4(0.f, 0.f, 0.f, 0.f);           // D of the current (nz, ny) row
+    if constexpr (SEAM) {
+      if (j == 1) { cf[0][0] = 1.f; cf[0][1] = -1.f; cf[0][2] = 3.f; cf[1][0] = -2.f; }               // x = 0
+      if (j == 0) { cf[0][2] = 2.f; cf[1][0] = -3.f; cf[1][1] = 1.f; cf[1][2] = -1.f; }               // x = W - 1
+    }
+    auto load_d = [&](int tap) { dd = *reinterpret_cast<const float4*>(sv + ((tap / 9) * PY + (tap / 3) % 3) * VS); };
     issue_b(0, 0);
-    if constexpr (TS >= 0) load_d(0);
+    if constexpr (SEAM) load_d(0);
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap) {
 #pragma unroll
@@ -1553,18 +1553,14 @@ __global__ void __launch_bounds__(256, 4) conv3d_upbrick_kernel(const UpBrickArg
         if (n < NSTREAM) issue_a(n);
       if (tap + 1 < NTAP) issue_b((tap + 1) & 1, tap + 1);
       __builtin_amdgcn_sched_barrier(0);
-      float4 bs[2];                                        // seam tile: corrected operand per x parity
-      if constexpr (TS >= 0) {
-        const float4 r = bv[tap & 1][TS];
+      float4 bs[2];                                        // tile 0 of the seam brick: corrected operand per x parity
+      if constexpr (SEAM) {
+        const float4 r = bv[tap & 1][0];
         const int nx = tap % 3;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const float kl = p == 0 ? (nx == 0 ? 1.f : nx == 1 ? -1.f : 3.f) : (nx == 0 ? -2.f : 0.f);      // left seam
-          const float kr = p == 0 ? (nx == 2 ? -2.f : 0.f) : (nx == 0 ? 3.f : nx == 1 ? -1.f : 1.f);      // right seam
-          const float k = left ? kl : kr;                  // uniform
-          bs[p] = make_float4(fmaf(k, fd.x, r.x), fmaf(k, fd.y, r.y), fmaf(k, fd.z, r.z), fmaf(k, fd.w, r.w));
-        }
-        if (nx == 2 && tap + 1 < NTAP) load_d(tap + 1);     // the next row's delta: in place, a whole tap ahead of its first use
+        for (int p = 0; p < 2; ++p)
+          bs[p] = make_float4(fmaf(cf[p][nx], dd.x, r.x), fmaf(cf[p][nx], dd.y, r.y), fmaf(cf[p][nx], dd.z, r.z), fmaf(cf[p][nx], dd.w, r.w));
+        if (nx == 2 && tap + 1 < NTAP) load_d(tap + 1);     // the next row's D: in place, a whole tap ahead of its first use
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -1572,15 +1568,14 @@ __global__ void __launch_bounds__(256, 4) conv3d_upbrick_kernel(const UpBrickArg
         for (int s = 0; s < NSET; ++s)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const float b = (t == TS) ? pick(bs[s & 1], m) : pick(bv[tap & 1][t], m);
+            const float b = (SEAM && t == 0) ? pick(bs[s & 1], m) : pick(bv[tap & 1][t], m);
             acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pick(av[(4 * tap + s) % RING], m), b, acc[s][t], 0, 0, 0);
           }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (!(left || right)) run(std::integral_constant<int, -1>{});
-  else if ((xs >> 4) == 0) run(std::integral_constant<int, 0>{});
-  else run(std::integral_constant<int, 1>{});
+  if (seam) run(std::true_type{});
+  else run(std::false_type{});
   // epilogue: rows 4g .. 4g+3 = z parity g / 2, channels 4 (g % 2) .. + 3 of high-res voxel (2 iz + pz, 2 iy + py, 2 ix + px)
   if (iy < a.H) {
     const int pz = g >> 1, c = (g & 1) * 4;
@@ -1588,8 +1583,9 @@ __global__ void __launch_bounds__(256, 4) conv3d_upbrick_kernel(const UpBrickArg
     for (int s = 0; s < NSET; ++s)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int ix = x0 + 16 * t + j;
-        if (ix >= a.W) continue;
+        int ix = x0 + 16 * t + j;                          // -1 = column W - 1 (first brick); the last brick ends at column W - 2
+        if (ix > a.W - 2) continue;
+        ix = ix < 0 ? ix + a.W : ix;
         const unsigned ov = (unsigned)(((vb * a.Do + 2 * iz + pz) * a.Ho + 2 * iy + (s >> 1)) * a.Wo + 2 * ix + (s & 1));
         float4 o = make_float4(acc[s][t][0], acc[s][t][1], acc[s][t][2], acc[s][t][3]);
         o.x = o.x > 0.f ? o.x : o.x * a.slope; o.y = o.y > 0.f ? o.y : o.y * a.slope;
@@ -2137,7 +2133,7 @@ int pgrf_conv3d_upbrick(const float* in, int in_cs, int in_coff, int Cin, float*
                         int res_cs, int res_coff, void* stream) {
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_upbrick: null pointer");
   if (!upbrick_ok(Cout, Cin)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upbrick: Cin %d (16), Cout %d (8)", Cin, Cout);
-  // (W >= 33: a brick of 32 columns then never holds both seam columns)
+  // (W >= 33: the first brick, columns W - 1, 0 .. 30, then holds each column once)
   if (B < 1 || D < 2 || H < 2 || W < 33) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upbrick: low-res D, H >= 2 and W >= 33");
   if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_upbrick: channel strides/offsets must be multiples of 4");
