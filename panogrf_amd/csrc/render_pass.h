@@ -242,6 +242,60 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
     return;
   }
   constexpr int KS4 = (KS + 3) / 4;
+#ifdef PGRF_A_PREFETCH
+#ifndef PGRF_A_FENCE
+#define PGRF_A_FENCE 1
+#endif
+  // experiment: A operands PGRF_A_PREFETCH groups of four k-steps ahead of their MFMAs, order pinned by scheduling fences
+  // (bit 8 of PGRF_A_FENCE: sched_group_barrier pattern "one load, then the group's MFMAs" instead of full fences)
+  {
+    constexpr int Q = MT * KS4, PD = (PGRF_A_PREFETCH) < Q ? (PGRF_A_PREFETCH) : Q;
+    auto load_a = [&](int q) {
+      const int m = q / KS4, s4 = q % KS4;
+      return (Limg && limg_full)          ? reinterpret_cast<const float4*>(Limg)[(m * KS4 + s4) * 64 + lane]
+             : (Limg && limg_a > 0 && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
+                                           : reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
+    };
+    float4 ring[PD + 1];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) ring[q] = load_a(q);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int m = q / KS4, s4 = q % KS4;
+      if (q + PD < Q) ring[(q + PD) % (PD + 1)] = load_a(q + PD);
+#if PGRF_A_FENCE == 1
+      __builtin_amdgcn_sched_barrier(0);
+#elif PGRF_A_FENCE == 2
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one vector-memory read ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);  // ... then the group's MFMAs
+#endif
+      const float4 a = ring[q % (PD + 1)];
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      f32x16 bv;
+      if (INIT_BIAS && s4 == 0) {
+        const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
+        const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (s4 * 4 + j < KS) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (INIT_BIAS && s4 == 0 && j == 0)
+              acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[t][0], bv, 0, 0, 0);
+            else
+              acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[t][s4 * 4 + j], acc[t][m], 0, 0, 0);
+          }
+        }
+      }
+#if PGRF_A_FENCE == 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 bv;
