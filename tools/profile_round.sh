@@ -62,5 +62,7 @@ python3 $R/tools/train_demo.py 30 1024 2>&1 | grep -E "step|rays x" > $OUT/train
 # 9. memory-side counters of the 4-view kernel and the CostRegNet layer trace
 bash $R/tools/pmc_mem.sh v4 --views 4 2>&1 | grep "per-launch" > $OUT/views4_mem_pmc.txt
 bash $R/tools/trace_costreg.sh $TAG 128 256 2>&1 | grep -E " us$|sum " > $OUT/costregnet_layer_trace_128x256.txt
+{ echo "# SQ counters of CostRegNet's conv kernels at 128x256x64, averages per (kernel, grid) over the launches of tools/time_cost_volume.py (tools/pmc_conv.sh: rocprofv3 --pmc, separate passes)";
+  bash $R/tools/pmc_conv.sh $TAG costregnet 128 256 2>&1 | grep "mfma_busy"; } > $OUT/costreg_conv_pmc.txt
 rm -rf $OUT/pmc[0-9] $OUT/bench_trace $OUT/cv_trace
 ls $OUT

@@ -113,6 +113,7 @@ if rows:
     out.append('')
 for name, title in [('costvolume_timings.txt', 'Cost-volume side (`tools/time_cost_volume.py`)'),
                     ('costregnet_layer_trace_128x256.txt', 'CostRegNet per-layer kernel durations at 128x256x64'),
+                    ('costreg_conv_pmc.txt', "SQ counters of CostRegNet's conv kernels (`tools/pmc_conv.sh`)"),
                     ('frame_timing.txt', 'Whole frames, shipped configuration (`tools/time_frame.py`)'),
                     ('whole_frame_rank_shares.txt', 'Per-rank shares of one frame under the 8-GPU split (`tools/time_frame_shares.py`, one GPU)'),
                     ('train_demo.txt', 'Training steps through the HIP forward / backward (`tools/train_demo.py`)'),
