@@ -550,6 +550,8 @@ struct SmallArgs {
   int ns;        // depth shifts packed on the rows
   int nsteps;    // ceil((ns + 2) * 9 * Cin / 32)
   unsigned in_bytes;          // conv3d_brick16_kernel: extent of the input behind in + in_coff (buffer descriptor)
+  int nbx;                    //   bricks along x (blockIdx.x = output-channel group * nbx + brick)
+  int grp_floats;             //   packed floats per group of 16 output channels
 };
 
 template <int CIN, int NS, int NT>
@@ -857,7 +859,8 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
   // order, so with W = 256 (8 bricks along x) an XCD owns one 32-column band of the volume and the y / z halos stay in its L2.
   const int nbz = (a.D + 1) >> 1;
   const int vb = (int)blockIdx.z / nbz, bz = (int)blockIdx.z - vb * nbz;
-  const int x0 = (int)blockIdx.x * 32, y0 = (int)blockIdx.y * 4, z0 = bz * 2;
+  const int cg = (int)blockIdx.x / sa.nbx;                 // group of 16 output channels (NS = 1 layers with Cout = 32, 64, ...)
+  const int x0 = ((int)blockIdx.x - cg * sa.nbx) * 32, y0 = (int)blockIdx.y * 4, z0 = bz * 2;
   const float* inb = a.in + a.in_coff;
   // fill plan (NPRE = 13 loads and ds_writes per thread and chunk, ~no address arithmetic): the brick is 24 rows (pz, py) of 34
   // voxels x 4 channel quads.  Columns 0..31: thread -> (column, quad) = tid % 128, the two halves of the workgroup take 12 rows
@@ -906,7 +909,7 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
   f32x4v acc[NACC];                                       // NS = 2: [x half]; NS = 1: [output plane][x half]
   {
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + g * 4);
+    if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + cg * 16 + g * 4);
 #pragma unroll
     for (int t = 0; t < NACC; ++t) acc[t] = (f32x4v){b4.x, b4.y, b4.z, b4.w};
   }
@@ -915,7 +918,7 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
   const float* bl[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) bl[d] = &brick[(wave * PX + j + d) * VS + 4 * (g ^ (((j + d) >> 1) & 3))];
-  const unsigned long long w_bits = (unsigned long long)a.wpk;
+  const unsigned long long w_bits = (unsigned long long)(a.wpk + (size_t)cg * sa.grp_floats);
   const i32x4v wrsrc = {(int)(unsigned)w_bits, (int)(unsigned)(w_bits >> 32), NGRP * 1024, 0x00020000};
   park();
   __syncthreads();
@@ -996,7 +999,7 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
       const int x = x0 + 16 * (t & 1) + j;
-      const int z = z0 + (NS == 2 ? (g >> 1) : (t >> 1)), c = NS == 2 ? (g & 1) * 4 : 4 * g;
+      const int z = z0 + (NS == 2 ? (g >> 1) : (t >> 1)), c = NS == 2 ? (g & 1) * 4 : cg * 16 + 4 * g;
       if (x >= a.W || z >= a.D) continue;
       const unsigned ov = (unsigned)(((vb * a.D + z) * a.H + y) * a.W + x);
       float4 o = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
@@ -1854,39 +1857,45 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
 // ---- narrow layers on the 16-row tile (conv3d_small16_kernel) ------------------------------------------------------
 // packed block: [groups][64 lanes][4] A operands | [16] bias by row
 static bool small16_ok(int Cout, int Cin, int ns) {
-  return (Cin == 8 || Cin == 16 || Cin == 32) && ((ns == 2 && Cout == 8) || (ns == 1 && Cout == 16));
+  if (ns == 2) return Cout == 8 && (Cin == 8 || Cin == 16 || Cin == 32);
+  if (ns != 1) return false;
+  if (Cout == 16 && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64)) return true;
+  return Cout >= 16 && Cout % 16 == 0 && (Cin == 16 || Cin == 32 || Cin == 64);          // several row groups: LDS-brick kernel only
 }
 static int small16_groups(int Cin, int ns) { return (((ns + 2) * 9 * Cin + 15) / 16 + 1) & ~1; }
+static int small16_cgroups(int Cout, int ns) { return ns == 1 ? Cout / 16 : 1; }
+#define PGRF_SMALL16_SHAPES "Cin 8 | 16 | 32 (| 64), Cout 8 with nshift 2 or a multiple of 16 with nshift 1"
 
 size_t pgrf_conv3d_small16_packed_floats(int Cout, int Cin, int nshift) {
   if (!small16_ok(Cout, Cin, nshift)) return 0;
-  return (size_t)small16_groups(Cin, nshift) * 256 + 16;
+  return (size_t)small16_cgroups(Cout, nshift) * small16_groups(Cin, nshift) * 256 + (size_t)(Cout > 16 ? Cout : 16);
 }
 
 int pgrf_pack_conv3d_small16(const float* w_host, const float* bias_host, int Cout, int Cin, int nshift, float* packed_host) {
   if (!w_host || !packed_host) return set_error(PGRF_ERR_ARG, "pgrf_pack_conv3d_small16: null pointer");
   if (!small16_ok(Cout, Cin, nshift))
-    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv3d_small16: Cin %d (8 | 16 | 32), Cout %d with nshift %d (8 x 2 | 16 x 1)", Cin, Cout, nshift);
-  const int groups = small16_groups(Cin, nshift), rps = 16 / nshift;
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_pack_conv3d_small16: Cin %d, Cout %d, nshift %d (" PGRF_SMALL16_SHAPES ")", Cin, Cout, nshift);
+  const int groups = small16_groups(Cin, nshift), rps = 16 / nshift, ncg = small16_cgroups(Cout, nshift);
   std::memset(packed_host, 0, sizeof(float) * pgrf_conv3d_small16_packed_floats(Cout, Cin, nshift));
-  for (int G = 0; G < groups; ++G)
-    for (int lane = 0; lane < 64; ++lane)
-      for (int m = 0; m < 4; ++m) {
-        const int row = lane & 15, g = lane >> 4;
-        // reduction order: Cin >= 16 -> group G = chunk * ntap + tap carries channels 16 chunk + 4 g + m; Cin = 8 -> k = tap * 8 + c
-        const int ntap = (nshift + 2) * 9;
-        const int k = G * 16 + 4 * g + m;
-        const int tap = Cin >= 16 ? G % ntap : k / Cin;
-        const int ci = Cin >= 16 ? 16 * (G / ntap) + 4 * g + m : k % Cin;
-        if (Cin >= 16 ? G >= ntap * (Cin / 16) : tap >= ntap) continue;          // padding of the last pair of groups
-        const int delta = row / rps, co = row % rps;
-        const int kz = tap / 9 - 1 - delta;                 // which of the 3 depth taps of output (delta, co) this plane is
-        if (kz < -1 || kz > 1) continue;
-        const int t27 = (kz + 1) * 9 + tap % 9;
-        packed_host[((size_t)G * 64 + lane) * 4 + m] = w_host[((size_t)co * Cin + ci) * 27 + t27];
-      }
-  float* bv = packed_host + (size_t)groups * 256;
-  for (int r = 0; r < 16; ++r) bv[r] = bias_host ? bias_host[r % rps] : 0.f;
+  for (int cg = 0; cg < ncg; ++cg)
+    for (int G = 0; G < groups; ++G)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int m = 0; m < 4; ++m) {
+          const int row = lane & 15, g = lane >> 4;
+          // reduction order: Cin >= 16 -> group G = chunk * ntap + tap carries channels 16 chunk + 4 g + m; Cin = 8 -> k = tap * 8 + c
+          const int ntap = (nshift + 2) * 9;
+          const int k = G * 16 + 4 * g + m;
+          const int tap = Cin >= 16 ? G % ntap : k / Cin;
+          const int ci = Cin >= 16 ? 16 * (G / ntap) + 4 * g + m : k % Cin;
+          if (Cin >= 16 ? G >= ntap * (Cin / 16) : tap >= ntap) continue;          // padding of the last pair of groups
+          const int delta = row / rps, co = cg * 16 + row % rps;
+          const int kz = tap / 9 - 1 - delta;                 // which of the 3 depth taps of output (delta, co) this plane is
+          if (kz < -1 || kz > 1) continue;
+          const int t27 = (kz + 1) * 9 + tap % 9;
+          packed_host[(((size_t)cg * groups + G) * 64 + lane) * 4 + m] = w_host[((size_t)co * Cin + ci) * 27 + t27];
+        }
+  float* bv = packed_host + (size_t)ncg * groups * 256;
+  for (int r = 0; r < (Cout > 16 ? Cout : 16); ++r) bv[r] = bias_host ? bias_host[nshift == 2 ? r % rps : r] : 0.f;
   return PGRF_OK;
 }
 
@@ -1896,7 +1905,7 @@ int pgrf_conv3d_small16(const float* in, int in_cs, int in_coff, int Cin, float*
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_small16: null pointer");
   if (stride != 1 && stride != 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: stride %d", stride);
   if (!small16_ok(Cout, Cin, nshift))
-    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: Cin %d (8 | 16 | 32), Cout %d with nshift %d (8 x 2 | 16 x 1)", Cin, Cout, nshift);
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: Cin %d, Cout %d, nshift %d (" PGRF_SMALL16_SHAPES ")", Cin, Cout, nshift);
   if (B < 1 || D < 1 || H < 1 || W < 2) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_small16: bad dims");
   if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (res_cs & 3) || (res_coff & 3))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: channel strides/offsets must be multiples of 4");
@@ -1913,21 +1922,27 @@ int pgrf_conv3d_small16(const float* in, int in_cs, int in_coff, int Cin, float*
   if ((double)B * D * H * W * in_cs >= 2147483648.0 || (double)H * W * in_cs >= 8388608.0 || (double)B * a.Do * a.Ho * a.Wo * (mcs > 1 ? mcs : 1) >= 4294967296.0)
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: tensor too large (32-bit element offsets, 24-bit plane stride)");
   sa.ns = nshift; sa.nsteps = small16_groups(Cin, nshift);
+  const int ncg = small16_cgroups(Cout, nshift);
+  sa.grp_floats = sa.nsteps * 256;
   a.wpk = packed;
-  a.bias = has_bias ? packed + (size_t)sa.nsteps * 256 : nullptr;
-  const bool no_brick = getenv("PGRF_CONV16_NO_BRICK") != nullptr;                          // A/B switch: B operand from registers
+  a.bias = has_bias ? packed + (size_t)ncg * sa.grp_floats : nullptr;
+  const bool no_brick = getenv("PGRF_CONV16_NO_BRICK") != nullptr && ncg == 1 && Cin <= 32;  // A/B switch: B operand from registers
+  if (!(Cin >= 16 && stride == 1) && (ncg > 1 || Cin > 32))
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: Cout %d / Cin %d need stride 1 (LDS-brick kernel)", Cout, Cin);
   if (Cin >= 16 && stride == 1 && !no_brick) {
     // B operand staged through LDS: bricks of 2 x 4 x 32 output voxels
     sa.in_bytes = (unsigned)(((size_t)B * D * H * W * in_cs - (size_t)in_coff) * sizeof(float));          // < 2^31 elements checked above: fits
     if (sa.in_bytes >= 0x80000000u) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: input beyond 2 GB");
     if ((long long)B * ((D + 1) / 2) > 65535 || (H + 3) / 4 > 65535) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: grid too large");
-    const dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 3) / 4), (unsigned)(B * ((D + 1) / 2)));
+    sa.nbx = (W + 31) / 32;
+    const dim3 grid((unsigned)(sa.nbx * ncg), (unsigned)((H + 3) / 4), (unsigned)(B * ((D + 1) / 2)));
     if (nshift == 2) {
       if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
       else hipLaunchKernelGGL((conv3d_brick16_kernel<32, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
     } else {
       if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
-      else hipLaunchKernelGGL((conv3d_brick16_kernel<32, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+      else if (Cin == 32) hipLaunchKernelGGL((conv3d_brick16_kernel<32, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+      else hipLaunchKernelGGL((conv3d_brick16_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
     }
     PGRF_CHECK_LAUNCH("conv3d_brick16");
     return PGRF_OK;

@@ -35,10 +35,11 @@ def test_unet2_vs_reference():
 
 
 @pytest.mark.parametrize('cin,cout,stride', [(32, 64, 1), (64, 64, 1), (8, 16, 2), (128, 1, 1), (1, 1, 1), (16, 8, 1), (8, 1, 1)])
-def test_single_conv_vs_oracle(cin, cout, stride):
+def test_single_conv_vs_oracle(cin, cout, stride, monkeypatch):
     """One wrap-padded conv against the oracle's F.conv3d restatement, incl. ragged tile counts."""
     from oracle import cost_volume_oracle as O
     from panogrf_amd import cost_reg as R
+    monkeypatch.setenv('PANOGRF_CONV_SMALL16_WIDE', '0')          # the general kernel (the 16-row kernels have their own tests)
     g = torch.Generator().manual_seed(cin * 131 + cout)
     B, D, H, W = 1, 6, 10, 12
     x = torch.randn(B, cin, D, H, W, generator=g)
@@ -90,7 +91,8 @@ def test_narrow_layer_kernel_vs_oracle(cin, cout, stride, D, ns, monkeypatch):
 @pytest.mark.parametrize('cin,cout,stride,D,ns,nt', [(32, 8, 1, 8, 2, 0), (16, 8, 1, 12, 2, 0), (32, 8, 1, 8, 2, 8), (16, 8, 1, 12, 2, 4),
                                                      (8, 8, 1, 4, 0, 0), (16, 16, 1, 6, 1, 0), (32, 16, 1, 5, 1, 0), (32, 16, 1, 5, 1, 8),
                                                      (16, 16, 1, 6, 1, 2), (8, 16, 2, 6, 1, 0), (8, 16, 2, 7, 1, 4), (16, 16, 2, 7, 1, 2),
-                                                     (32, 8, 1, 5, 0, 0), (16, 32, 1, 4, 0, 0)])
+                                                     (32, 8, 1, 5, 0, 0), (16, 32, 1, 4, 1, 0), (64, 64, 1, 3, 1, 0), (32, 32, 1, 6, 1, 0),
+                                                     (64, 32, 2, 4, 0, 0), (64, 16, 1, 2, 1, 0)])
 def test_narrow_layer_16_row_kernel_vs_oracle(cin, cout, stride, D, ns, nt, monkeypatch):
     """pgrf_conv3d_small16 (v_mfma_f32_16x16x4_f32 tiles: 8 channels x 2 depth shifts, or 16 channels) against F.conv3d of the
     oracle, with a residual, a channel-sliced output, ragged bricks / tiles (H = 5, W = 11: the brick is wider than the panorama),
@@ -148,7 +150,8 @@ def test_narrow_layer_16_row_kernel_rejects_what_it_cannot_do():
     import ctypes
     assert lib.pgrf_conv3d_small16_packed_floats(8, 32, 2) == 72 * 256 + 16
     assert lib.pgrf_conv3d_small16_packed_floats(16, 8, 1) == 14 * 256 + 16          # 13.5 groups padded to a pair
-    assert lib.pgrf_conv3d_small16_packed_floats(8, 32, 4) == 0 and lib.pgrf_conv3d_small16_packed_floats(32, 32, 1) == 0
+    assert lib.pgrf_conv3d_small16_packed_floats(8, 32, 4) == 0 and lib.pgrf_conv3d_small16_packed_floats(24, 32, 1) == 0
+    assert lib.pgrf_conv3d_small16_packed_floats(32, 64, 1) == 2 * 108 * 256 + 32          # two groups of 16 rows
     buf = (ctypes.c_float * 16)()
     assert lib.pgrf_pack_conv3d_small16(ctypes.cast(buf, ctypes.c_void_p), None, 16, 16, 2, ctypes.cast(buf, ctypes.c_void_p)) != 0
     assert b'pgrf_pack_conv3d_small16' in lib.pgrf_last_error()
@@ -174,6 +177,7 @@ def test_interior_wave_pipeline_vs_oracle(cin, cout, nt, split, monkeypatch):
     from panogrf_amd import cost_reg as R
     monkeypatch.setenv('PGRF_CONV_NT', str(nt))
     monkeypatch.setenv('PGRF_CONV_SPLIT', str(split))
+    monkeypatch.setenv('PANOGRF_CONV_SMALL16_WIDE', '0')          # the general kernel
     g = torch.Generator().manual_seed(cin * 7 + cout * 3 + nt)
     B, D, H, W = 1, 5, 6, 128
     x = torch.randn(B, cin, D, H, W, generator=g)
