@@ -143,16 +143,17 @@ def _small16_shift(pc, x, stride):
     8 output channels x 2 shifts from 16 / 32 input channels (LDS-brick kernel, 75 % useful products against the 32-row
     kernel's 50 %: conv0 of CostRegNet 573 -> 341 us) or 16 channels unshifted (100 % against 67 %; stride 1 from 16 / 32
     channels on the LDS-brick kernel, everything else from registers).  PANOGRF_CONV_SMALL16=0 disables."""
-    if os.environ.get('PANOGRF_CONV_SMALL16', '1') == '0' or pc.cin not in (8, 16, 32, 64):
+    if os.environ.get('PANOGRF_CONV_SMALL16', '1') == '0' or (pc.cin != 8 and pc.cin % 16):
         return 0
     if pc.cout == 8:
-        return 2 if pc.cin >= 16 and stride == 1 and x.D % 2 == 0 else 0
-    if pc.cout == 16:
+        return 2 if pc.cin in (16, 32) and stride == 1 and x.D % 2 == 0 else 0
+    if pc.cout == 16 and pc.cin in (8, 16, 32):
         return 1
     # wider layers in groups of 16 output channels (LDS-brick kernel, stride 1): the 1/4- and 1/8-resolution layers of
     # CostRegNet, where the general kernel's waves mostly wait for their own loads.  PANOGRF_CONV_SMALL16_WIDE = max voxels.
     wide = int(os.environ.get('PANOGRF_CONV_SMALL16_WIDE', '65536'))
-    if pc.cout % 16 == 0 and pc.cout <= 64 and pc.cin in (16, 32, 64) and stride == 1 and x.B * x.D * x.H * x.W <= wide:
+    if (pc.cout % 16 == 0 and pc.cout <= int(os.environ.get('PANOGRF_CONV_SMALL16_COUT', '64')) and pc.cin % 16 == 0 and pc.cin <= 1024 and stride == 1
+            and x.B * x.D * x.H * x.W <= wide):
         wino = os.environ.get('PANOGRF_CONV_WINOGRAD', '1')          # layers the Winograd kernel takes stay there
         if wino == 'force' or (wino != '0' and lib.pgrf_conv3d_wino_preferred(pc.cin, pc.cout, x.B, x.D, x.H, x.W)):
             return 0

@@ -551,6 +551,7 @@ struct SmallArgs {
   int nsteps;    // ceil((ns + 2) * 9 * Cin / 32)
   unsigned in_bytes;          // conv3d_brick16_kernel: extent of the input behind in + in_coff (buffer descriptor)
   int nbx;                    //   bricks along x (blockIdx.x = output-channel group * nbx + brick)
+  int nch;                    //   16-channel chunks of the input (instances with CIN = 0)
   int grp_floats;             //   packed floats per group of 16 output channels
 };
 
@@ -848,8 +849,9 @@ struct Brick16 {
 template <int CIN, int NS>
 __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs sa) {
   const ConvArgs& a = sa.c;
-  constexpr int NCH = CIN / 16, NSTEP = 36, NTAP = (NS + 2) * 9, NSTREAM = NS == 2 ? 36 : 54, NACC = NS == 2 ? 2 : 4;
-  constexpr int NGRP = NS == 2 ? NTAP * NCH : ((NTAP * NCH + 1) & ~1);          // groups in the packed block (padded to a pair)
+  constexpr int NSTEP = 36, NTAP = (NS + 2) * 9, NSTREAM = NS == 2 ? 36 : 54, NACC = NS == 2 ? 2 : 4;
+  const int NCH = CIN ? CIN / 16 : sa.nch;                // CIN = 0: any multiple of 16, chunk count at run time
+  const int NGRP = NS == 2 ? NTAP * NCH : ((NTAP * NCH + 1) & ~1);              // groups in the packed block (padded to a pair)
   constexpr int PX = 34, PY = 6, PZ = 4, VS = 16;          // brick extent in voxels, voxel pitch in floats
   constexpr int NV = PX * PY * PZ, NQ = NV * 4, NPRE = (NQ + 255) / 256;
   __shared__ __attribute__((aligned(16))) float brick[NV * VS];
@@ -1859,12 +1861,12 @@ int pgrf_conv3d_small(const float* in, int in_cs, int in_coff, int Cin, float* o
 static bool small16_ok(int Cout, int Cin, int ns) {
   if (ns == 2) return Cout == 8 && (Cin == 8 || Cin == 16 || Cin == 32);
   if (ns != 1) return false;
-  if (Cout == 16 && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64)) return true;
-  return Cout >= 16 && Cout % 16 == 0 && (Cin == 16 || Cin == 32 || Cin == 64);          // several row groups: LDS-brick kernel only
+  if (Cout == 16 && (Cin == 8 || Cin == 16 || Cin == 32)) return true;
+  return Cout >= 16 && Cout % 16 == 0 && Cin >= 16 && Cin % 16 == 0 && Cin <= 1024;       // LDS-brick kernel only (stride 1)
 }
 static int small16_groups(int Cin, int ns) { return (((ns + 2) * 9 * Cin + 15) / 16 + 1) & ~1; }
 static int small16_cgroups(int Cout, int ns) { return ns == 1 ? Cout / 16 : 1; }
-#define PGRF_SMALL16_SHAPES "Cin 8 | 16 | 32 (| 64), Cout 8 with nshift 2 or a multiple of 16 with nshift 1"
+#define PGRF_SMALL16_SHAPES "Cout 8 with nshift 2 from Cin 8 | 16 | 32, or Cout % 16 == 0 with nshift 1 from Cin 8 | a multiple of 16"
 
 size_t pgrf_conv3d_small16_packed_floats(int Cout, int Cin, int nshift) {
   if (!small16_ok(Cout, Cin, nshift)) return 0;
@@ -1934,7 +1936,7 @@ int pgrf_conv3d_small16(const float* in, int in_cs, int in_coff, int Cin, float*
     sa.in_bytes = (unsigned)(((size_t)B * D * H * W * in_cs - (size_t)in_coff) * sizeof(float));          // < 2^31 elements checked above: fits
     if (sa.in_bytes >= 0x80000000u) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: input beyond 2 GB");
     if ((long long)B * ((D + 1) / 2) > 65535 || (H + 3) / 4 > 65535) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: grid too large");
-    sa.nbx = (W + 31) / 32;
+    sa.nbx = (W + 31) / 32; sa.nch = Cin / 16;
     const dim3 grid((unsigned)(sa.nbx * ncg), (unsigned)((H + 3) / 4), (unsigned)(B * ((D + 1) / 2)));
     if (nshift == 2) {
       if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
@@ -1942,7 +1944,7 @@ int pgrf_conv3d_small16(const float* in, int in_cs, int in_coff, int Cin, float*
     } else {
       if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
       else if (Cin == 32) hipLaunchKernelGGL((conv3d_brick16_kernel<32, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
-      else hipLaunchKernelGGL((conv3d_brick16_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+      else hipLaunchKernelGGL((conv3d_brick16_kernel<0, 1>), grid, dim3(256), 0, (hipStream_t)stream, sa);
     }
     PGRF_CHECK_LAUNCH("conv3d_brick16");
     return PGRF_OK;
