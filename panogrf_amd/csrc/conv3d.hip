@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "conv3d_common.h"
@@ -1311,6 +1312,132 @@ __global__ void __launch_bounds__(256) conv3d_cout1_c8_kernel(const ConvArgs a, 
   }
 }
 
+// The same head with the input brick staged in LDS.  The kernel above is bound by the L1: 27 x 32 bytes per output (halved by the
+// y reuse) at the 64 B/clk/CU of the vector-memory path is the 57 us it takes at 64x128x256.  Here a workgroup owns 2 x 16 x 32
+// outputs; the 4 x 18 x 34 input voxels go through the L1 once (quad-planar in LDS: consecutive lanes = consecutive 16-byte
+// slots, conflict-free), a thread owns 2 x 2 outputs (z, y) of one column and walks the 4 x 4 input rows it needs: the weights
+// it needs come from scalar loads (FMA with a scalar operand), and every input row of 3 voxels is read ONCE and feeds all of the
+// thread's outputs whose window covers it: 24 ds_read_b128 per output instead of 54 loads through the L1.
+struct C8Sub {                                               // sub-step t of the head kernel below: the t-th valid (pz, r, zo, yo), pz-major
+  int pz, r, zo, yo;
+  static constexpr C8Sub of(int t) {
+    int n = 0;
+    for (int pz = 0; pz < 4; ++pz)
+      for (int r = 0; r < 4; ++r)
+        for (int zo = 0; zo < 2; ++zo)
+          for (int yo = 0; yo < 2; ++yo) {
+            if (pz - zo < 0 || pz - zo > 2 || r - yo < 0 || r - yo > 2) continue;
+            if (n == t) return C8Sub{pz, r, zo, yo};
+            ++n;
+          }
+    return C8Sub{0, 0, 0, 0};
+  }
+};
+template <int... I, class F>
+__device__ __forceinline__ void c8_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void c8_static_for(F&& f) { c8_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+__device__ f32x4c pgrf_buffer_load_x4c(__attribute__((ext_vector_type(4))) int rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__global__ void __launch_bounds__(256, 2) conv3d_cout1_c8_brick_kernel(const ConvArgs a, const float* __restrict__ wlin, int has_bias, unsigned in_bytes) {
+  constexpr int BX = 32, BY = 16, PX = BX + 2, PY = BY + 2, PZ = 4, NVOX = PX * PY * PZ, NROW = PY * PZ;
+  __shared__ float4 bq[2][NVOX];                           // [channel quad][voxel]: 78 336 B, two workgroups per CU
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbz = (a.D + 1) >> 1;
+  const int vb = (int)blockIdx.z / nbz, bz = (int)blockIdx.z - vb * nbz;
+  const int x0 = (int)blockIdx.x * BX, y0 = (int)blockIdx.y * BY, z0 = bz * 2;
+  {
+    // fill: 72 rows (pz, py) of 34 voxels x 2 quads; thread slot u = tid % 128 < 68 -> (column u / 2, quad u % 2), the two halves of the
+    // workgroup take 36 rows each (row term wave-uniform, rows in the zero padding skipped)
+    typedef int i32x4c __attribute__((ext_vector_type(4)));
+    const unsigned long long bits = (unsigned long long)(a.in + a.in_coff);
+    const i32x4c rsrc = {(int)(unsigned)bits, (int)(unsigned)(bits >> 32), (int)in_bytes, 0x00020000};
+    const int half = wave >> 1, u = tid & 127, px = u >> 1, q = u & 1;
+    int x = (x0 - 1 + px) % a.W;
+    x = x < 0 ? x + a.W : x;
+    const unsigned voff = u < 2 * PX ? (unsigned)(x * a.in_cs + 4 * q) * 4u : 0x80000000u;
+    const int ystep = a.W * a.in_cs;
+    // (all 36 loads of a thread in flight at once: the compute phase needs a quarter of the 256 registers two workgroups per CU allow)
+    float4 v[NROW / 2];
+#pragma unroll
+    for (int i = 0; i < NROW / 2; ++i) {
+      const int r = half * (NROW / 2) + i, pz = r / PY, py = r - pz * PY;          // uniform
+      const int z = z0 - 1 + pz, y = y0 - 1 + py;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H) {
+        const f32x4c t = pgrf_buffer_load_x4c(rsrc, (int)voff, (((vb * a.D + z) * a.H + y) * ystep) * 4, 0);
+        v[i] = make_float4(t.x, t.y, t.z, t.w);
+      }
+    }
+    if (u < 2 * PX) {
+#pragma unroll
+      for (int i = 0; i < NROW / 2; ++i) bq[q][(half * (NROW / 2) + i) * PX + px] = v[i];
+    }
+  }
+  __syncthreads();
+  const int xi = lane & 31, yp = wave * 2 + (lane >> 5);   // column, pair of output rows 2 yp, 2 yp + 1
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};              // [output plane][output row]
+  // walk the 4 x 4 input (plane, row) pairs of the thread's column: each is read once (6 ds_read_b128) and feeds every (output plane,
+  // output row) whose window covers it: 36 sub-steps (pz, r, zo, yo) of 24 FMAs against the 24 weights of kernel (plane, row) =
+  // (pz - zo, r - yo), which come from scalar loads issued ONE sub-step ahead.
+  constexpr int NSUB = 36;
+  typedef float f32x8s __attribute__((ext_vector_type(8)));
+  f32x8s wn[3];                                            // weights of the next sub-step: [dx][8 channels]
+  auto load_w = [&](auto t_tag) __attribute__((always_inline)) {
+    constexpr C8Sub u = C8Sub::of(decltype(t_tag)::value);
+    // uniform address: scalar loads.  Made opaque per sub-step and chained on the accumulators, so that the loads of sub-step
+    // t + 1 are issued behind the FMAs of sub-step t - 1 and not all at the kernel entry (216 weights do not fit the scalar
+    // registers: the compiler spilled them lane by lane), then declared wave-uniform again behind the asm
+    unsigned long long wbits = (unsigned long long)(wlin + ((u.pz - u.zo) * 3 + (u.r - u.yo)) * 24);
+    unsigned wlo = (unsigned)wbits, whi = (unsigned)(wbits >> 32);
+    asm volatile("" : "+s"(wlo), "+s"(whi), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+    wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
+    const f32x8s __attribute__((address_space(4)))* wp = (const f32x8s __attribute__((address_space(4)))*)(((unsigned long long)whi << 32) | wlo);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) wn[dx] = wp[dx];
+  };
+  float4 in0[3], in1[3];
+  load_w(std::integral_constant<int, 0>{});
+  c8_static_for<NSUB>([&](auto t_tag) __attribute__((always_inline)) {
+    constexpr int t = decltype(t_tag)::value;
+    constexpr C8Sub u = C8Sub::of(t), up = C8Sub::of(t > 0 ? t - 1 : 0);
+    const f32x8s w0 = wn[0], w1 = wn[1], w2 = wn[2];
+    if constexpr (t + 1 < NSUB) load_w(std::integral_constant<int, t + 1>{});
+    if constexpr (t == 0 || up.pz != u.pz || up.r != u.r) {          // a new input row: row 2 yp - 1 + r of input plane z0 - 1 + pz
+      const float4* p0 = &bq[0][(u.pz * PY + 2 * yp + u.r) * PX + xi];
+      const float4* p1 = &bq[1][(u.pz * PY + 2 * yp + u.r) * PX + xi];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) { in0[dx] = p0[dx]; in1[dx] = p1[dx]; }
+    }
+    float sacc = acc[u.zo][u.yo];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const f32x8s w = dx == 0 ? w0 : dx == 1 ? w1 : w2;
+      sacc = fmaf(in0[dx].x, w[0], sacc); sacc = fmaf(in0[dx].y, w[1], sacc); sacc = fmaf(in0[dx].z, w[2], sacc); sacc = fmaf(in0[dx].w, w[3], sacc);
+      sacc = fmaf(in1[dx].x, w[4], sacc); sacc = fmaf(in1[dx].y, w[5], sacc); sacc = fmaf(in1[dx].z, w[6], sacc); sacc = fmaf(in1[dx].w, w[7], sacc);
+    }
+    acc[u.zo][u.yo] = sacc;
+  });
+  const float bias = has_bias ? wlin[216] : 0.f;
+  const int x = x0 + xi;
+  if (x < a.W) {
+#pragma unroll
+    for (int zo = 0; zo < 2; ++zo)
+#pragma unroll
+      for (int yo = 0; yo < 2; ++yo) {
+        const int z = z0 + zo, y = y0 + 2 * yp + yo;
+        if (z >= a.D || y >= a.H) continue;
+        const long long ov = (((long long)vb * a.D + z) * a.H + y) * a.W + x;
+        float v = acc[zo][yo] + bias;
+        const float rr = a.residual ? a.residual[ov * a.res_cs + a.res_coff] : 0.f;
+        if (a.res_first) v += rr;
+        v = conv_act(a, v);
+        if (!a.res_first) v += rr;
+        a.out[ov * a.out_cs + a.out_coff] = v;
+      }
+  }
+}
+
 // Second half of the Cout == 1 convolution: out[p] = act(bias + sum_tap y[tap][p + tap]) where y[tap][q] =
 // <w[:, tap], x[q, :]> was produced by the pointwise MFMA pass in tap-major order (so a wave reads 64 consecutive
 // voxels of one row per tap; the channel-last form touched one 128-byte line per lane and tap: 975 -> ~100 us).
@@ -1680,6 +1807,14 @@ static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, fl
   if (Cout == 1) {
     const int lpv = ((Cin & 3) == 0 && Cin >= 32) ? 8 : 1;
     const float* wlin = packed + a_floats + a.cot_total * 32;
+    if (Cin == 8 && stride == 1 && wrap_w && !getenv("PGRF_CONV_NO_C8") && !getenv("PGRF_CONV_NO_C8_BRICK") &&
+        (double)B * D * H * W * in_cs * 4.0 < 2147483648.0 && (long long)B * ((D + 1) / 2) <= 65535 && (H + 15) / 16 <= 65535) {
+      const unsigned in_bytes = (unsigned)(((size_t)B * D * H * W * in_cs - (size_t)in_coff) * sizeof(float));
+      const dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 15) / 16), (unsigned)(B * ((D + 1) / 2)));
+      hipLaunchKernelGGL(conv3d_cout1_c8_brick_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, wlin, has_bias ? 1 : 0, in_bytes);
+      PGRF_CHECK_LAUNCH("conv3d_cout1_c8_brick");
+      return PGRF_OK;
+    }
     if (Cin == 8 && stride == 1 && !getenv("PGRF_CONV_NO_C8")) {
       const long long threads = (long long)B * a.Do * ((a.Ho + kC8YB - 1) / kC8YB) * a.Wo;
       hipLaunchKernelGGL(conv3d_cout1_c8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, wlin,
