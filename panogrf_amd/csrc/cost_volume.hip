@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "pgrf_internal.h"
 
@@ -122,6 +123,7 @@ struct CvArgs {
   float div;              // each view's cost is divided by this before accumulation (mv: S-2)
   int cost_type;          // 0 abs_diff, 1 dot, 2 none
   int dataset;            // PGRF_DATASET_*: spherical convention (spherical_cost_volume.py:153-190,281-296)
+  int stream_stores;      // write the volume with non-temporal stores
 };
 
 struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
@@ -353,7 +355,15 @@ __global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const C
 #else
       if (opix < hw)
 #endif
-        *reinterpret_cast<float4*>(op + (size_t)opix * C + cg * 4) = acc[g];
+      {
+        if (a.stream_stores) {                             // opt-in (PGRF_CV_STREAM_STORES=1), see launch_cost_volume
+          typedef float f32x4nt __attribute__((ext_vector_type(4)));
+          const f32x4nt vv = {acc[g].x, acc[g].y, acc[g].z, acc[g].w};
+          __builtin_nontemporal_store(vv, reinterpret_cast<f32x4nt*>(op + (size_t)opix * C + cg * 4));
+        } else {
+          *reinterpret_cast<float4*>(op + (size_t)opix * C + cg * 4) = acc[g];
+        }
+      }
     }
   };
 
@@ -466,6 +476,10 @@ int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const fl
   a.feats = feats; a.depth = depth_volume; a.rots = rots; a.trans = trans; a.out = out;
   a.B = B; a.S = S; a.h = h; a.w = w; a.C = C; a.D = D; a.ref_idx = ref_idx; a.n_src = n_src; a.div = src_div;
   a.cost_type = cost_type; a.dataset = dataset;
+  // Non-temporal stores: the kernel alone 75-76 -> 62 us at 128x256x64 (4.6 TB/s), but the volume then is not in the last-level
+  // cache when the regulariser's first convolution reads it right behind: cost-volume stage of bench.py 1.76-1.78 ms either way
+  // (profiles/r03_dead_ends.txt).  Opt-in for callers that consume the volume later.
+  a.stream_stores = getenv("PGRF_CV_STREAM_STORES") != nullptr && atoi(getenv("PGRF_CV_STREAM_STORES")) != 0;
   for (int i = 0; i < kMaxSrc; ++i) {
     a.src_idx[i] = i < n_src ? src_idx_host[i] : 0;
     if (i < n_src && (src_idx_host[i] < 0 || src_idx_host[i] >= S)) return set_error(PGRF_ERR_ARG, "pgrf_cost_volume_erp: src_idx out of range");
