@@ -1850,8 +1850,15 @@ static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, fl
   bool split = (nt == 1) && waves_plain < 1536 && (long long)27 * a.chunks >= 16;
   if (const char* e = getenv("PGRF_CONV_SPLIT")) split = (nt == 1) && atoi(e) != 0;                       // tuning knob
   if (split) {
-    dim3 sgrid((unsigned)tiles, (unsigned)(a.cot_total / mt));
-    if (mt == 2) hipLaunchKernelGGL((conv3d_wrap_kernel<2, 1, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
+    // tuning knobs: one cout tile per workgroup (twice the workgroups, half the chain per wave) / the two-wave LEAN instantiation
+    int smt = mt;
+    if (const char* e = getenv("PGRF_CONV_SPLIT_MT")) { if (atoi(e) == 1) smt = 1; }
+    bool slean = false;
+    if (const char* e = getenv("PGRF_CONV_SPLIT_LEAN")) slean = atoi(e) != 0 && (Cin & 31) == 0 && a.wtaps == 27;
+    dim3 sgrid((unsigned)tiles, (unsigned)(a.cot_total / smt));
+    if (smt == 2 && slean) hipLaunchKernelGGL((conv3d_wrap_kernel<2, 1, true, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (smt == 2) hipLaunchKernelGGL((conv3d_wrap_kernel<2, 1, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (slean) hipLaunchKernelGGL((conv3d_wrap_kernel<1, 1, true, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv3d_wrap_kernel<1, 1, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
     PGRF_CHECK_LAUNCH("conv3d_wrap(split)");
     return PGRF_OK;
