@@ -258,7 +258,9 @@ int pgrf_depth_hypotheses(const float* ref_mu, int B, int hw, const float* guide
  *           S=2, ref_idx=1, src_idx={0}, src_div=1
  *   multi-view (models/spherical_cost_volume_mv.py:219-347 calculate_cost_volume_erp_multiview):
  *           ref_idx=curr_idx, src_idx = {v in 0..S-2, v != curr_idx}, src_div = S-2
- * Both call get_cv_per_depth (:135-230) D times; helpers/my_torch_helpers.py:34-38,62-96. */
+ * Both call get_cv_per_depth (:135-230) D times; helpers/my_torch_helpers.py:34-38,62-96.
+ * Environment PGRF_CV_STREAM_STORES=1: the volume is written with non-temporal stores (the kernel alone 75 -> 62 us at 128x256x64;
+ * a regulariser that reads the volume right behind then finds it in HBM instead of the last-level cache, so it is off by default). */
 int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const float* rots, const float* trans, int B,
                          int S, int h, int w, int C, int D, int ref_idx, const int* src_idx_host, int n_src,
                          float src_div, int cost_type, int dataset /* PGRF_DATASET_* = args["dataset_name"] */,
