@@ -21,6 +21,35 @@ def test_cost_reg_net_vs_reference():
     assert max_abs(out.cpu(), fx['out']) < 5e-5 * max(1.0, float(fx['out'].abs().max()))
 
 
+@pytest.mark.parametrize('D,H,W', [(24, 40, 72), (8, 24, 296)])
+def test_cost_reg_net_ragged_volume_vs_oracle(D, H, W):
+    """CostRegNet on volumes whose sizes are not multiples of the 16-row kernels' bricks (2 x 4 x 32 voxels; the up-sampling-fused
+    brick kernel needs a low-res W >= 33: W = 72 takes it with a ragged last brick, W = 296 with five bricks per row) against the oracle's F.conv3d restatement of
+    models/cost_reg.py:99-175: ragged bricks in x and y on every level, the 1/4-resolution layers on groups of 16 output channels,
+    the Cout = 1 head from its LDS brick."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd.cost_reg import CostRegNet
+    torch.manual_seed(11)
+    net = CostRegNet(dict(use_wrap_padding=True), 32).eval()
+    gw = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for name, p in net.state_dict().items():
+            if p.dim() > 1:
+                p.mul_(0.5)
+            elif name.endswith('running_var'):
+                p.copy_(0.5 + torch.rand(p.shape, generator=gw))
+            elif name.endswith('running_mean') or name.endswith('bias'):
+                p.copy_(0.1 * torch.randn(p.shape, generator=gw))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    x = torch.randn(1, 32, D, H, W, generator=torch.Generator().manual_seed(13))
+    with torch.no_grad():
+        got = net(x.cuda()).cpu()
+        ref = O.cost_reg_net(sd, x)
+    assert got.shape == ref.shape
+    assert max_abs(got, ref) < 5e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_unet2_vs_reference():
     from panogrf_amd.cost_reg import UNet2Reg
     fx = CF.load()['unet']
