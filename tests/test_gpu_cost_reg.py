@@ -166,7 +166,9 @@ def test_narrow_layer_16_row_kernel_c_abi_shapes(cin, cout, ns, D, H, W):
     w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5, 'c.bias': torch.randn(cout, generator=g) * 0.1}
     ref = torch.nn.functional.leaky_relu(O._conv3(w, 'c', x, 1), 0.01)
     pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
-    xin = R._Vol(R._to_ndhwc(x.cuda()), 0, cin)
+    wide_in = torch.full((1, D, H, W, cin + 8), float('nan'), device='cuda')          # a channel slice of a wider buffer
+    wide_in[..., 4:4 + cin] = R._to_ndhwc(x.cuda())
+    xin = R._Vol(wide_in, 4, cin)
     out = R._Vol.empty(1, D, H, W, cout, 'cuda')
     lib.check(lib.pgrf_conv3d_small16(R._ptr(xin.buf), xin.cs, xin.coff, cin, R._ptr(out.buf), out.cs, out.coff, cout, R._ptr(pc.small16(ns)),
                                       1, ns, 1, D, H, W, 1, 0.01, None, 0, 0, R._stream()))
