@@ -1337,8 +1337,6 @@ template <int... I, class F>
 __device__ __forceinline__ void c8_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void c8_static_for(F&& f) { c8_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-typedef float f32x4c __attribute__((ext_vector_type(4)));
-__device__ f32x4c pgrf_buffer_load_x4c(__attribute__((ext_vector_type(4))) int rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __global__ void __launch_bounds__(256, 2) conv3d_cout1_c8_brick_kernel(const ConvArgs a, const float* __restrict__ wlin, int has_bias, unsigned in_bytes) {
   constexpr int BX = 32, BY = 16, PX = BX + 2, PY = BY + 2, PZ = 4, NVOX = PX * PY * PZ, NROW = PY * PZ;
   __shared__ float4 bq[2][NVOX];                           // [channel quad][voxel]: 78 336 B, two workgroups per CU
@@ -1349,9 +1347,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_cout1_c8_brick_kernel(const Con
   {
     // fill: 72 rows (pz, py) of 34 voxels x 2 quads; thread slot u = tid % 128 < 68 -> (column u / 2, quad u % 2), the two halves of the
     // workgroup take 36 rows each (row term wave-uniform, rows in the zero padding skipped)
-    typedef int i32x4c __attribute__((ext_vector_type(4)));
     const unsigned long long bits = (unsigned long long)(a.in + a.in_coff);
-    const i32x4c rsrc = {(int)(unsigned)bits, (int)(unsigned)(bits >> 32), (int)in_bytes, 0x00020000};
+    const i32x4v rsrc = {(int)(unsigned)bits, (int)(unsigned)(bits >> 32), (int)in_bytes, 0x00020000};
     const int half = wave >> 1, u = tid & 127, px = u >> 1, q = u & 1;
     int x = (x0 - 1 + px) % a.W;
     x = x < 0 ? x + a.W : x;
@@ -1365,7 +1362,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_cout1_c8_brick_kernel(const Con
       const int z = z0 - 1 + pz, y = y0 - 1 + py;
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H) {
-        const f32x4c t = pgrf_buffer_load_x4c(rsrc, (int)voff, (((vb * a.D + z) * a.H + y) * ystep) * 4, 0);
+        const f32x4v t = pgrf_buffer_load_x4(rsrc, (int)voff, (((vb * a.D + z) * a.H + y) * ystep) * 4, 0);
         v[i] = make_float4(t.x, t.y, t.z, t.w);
       }
     }
