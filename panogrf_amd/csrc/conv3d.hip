@@ -831,30 +831,37 @@ __global__ void __launch_bounds__(256) conv3d_small16_kernel(const SmallArgs sa)
 //   NS = 1 (Cout = 16): rows = 16 channels; the wave owns both output planes of its row (4 tiles).  Walking the 36 PLANE taps
 //   (pz, dy, dx) instead of the 27 kernel taps per output plane, one B operand serves output plane 0 (kernel tap dz = pz - 1) and
 //   output plane 1 (dz = pz - 2): the depth-shift reuse without a single structural zero (100 % useful products).
+//   NS = 1, YB = 2 (small volumes): bricks of 2 x 2 x 32, so that a launch has twice the workgroups, four of them fit a CU (35 KB of
+//   LDS) and a wave's MFMA chain halves: wave = (row, output plane), the 27 kernel taps of its plane, one A operand per tap.
 struct Brick16 {
-  // A-operand stream of one chunk: which kernel tap the n-th A load fetches, and where step s (= plane tap) finds its operands
-  static constexpr int a_count(int ns, int s) { return ns == 2 ? 1 : (s / 9 <= 2) + (s / 9 >= 1); }
+  // A-operand stream of one chunk: which kernel tap the n-th A load fetches, and where step s finds its operands.  `ns` = 1 selects
+  // the plane walk (two output planes per wave); everything else is one operand per step.
+  static constexpr int a_count(int ns, int s) { return ns != 1 ? 1 : (s / 9 <= 2) + (s / 9 >= 1); }
   static constexpr int a_pos(int ns, int s) {
-    if (ns == 2) return s;
+    if (ns != 1) return s;
     const int pz = s / 9, r = s % 9;
     return pz == 0 ? r : pz == 1 ? 9 + 2 * r : pz == 2 ? 27 + 2 * r : 45 + r;
   }
   static constexpr int a_tap(int ns, int n) {
-    if (ns == 2) return n;
+    if (ns != 1) return n;
     if (n < 9) return n;
     if (n < 27) return (n - 9) % 2 == 0 ? 9 + (n - 9) / 2 : (n - 9) / 2;
     if (n < 45) return (n - 27) % 2 == 0 ? 18 + (n - 27) / 2 : 9 + (n - 27) / 2;
     return 18 + (n - 45);
   }
 };
-template <int CIN, int NS>
-__global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs sa) {
+template <int CIN, int NS, int YB = 4>
+__global__ void __launch_bounds__(256, YB == 2 ? 4 : 3) conv3d_brick16_kernel(const SmallArgs sa) {
   const ConvArgs& a = sa.c;
-  constexpr int NSTEP = 36, NTAP = (NS + 2) * 9, NSTREAM = NS == 2 ? 36 : 54, NACC = NS == 2 ? 2 : 4;
+  static_assert(YB == 4 || (YB == 2 && NS == 1), "bricks of two rows: the unshifted (16-channel) layers only");
+  constexpr bool kPlaneWave = YB == 2;                     // wave = (row, output plane) instead of (row, both planes)
+  constexpr int WALK = kPlaneWave ? 0 : NS;                // Brick16 stream selector: 1 = plane walk
+  constexpr int NTAP = (NS + 2) * 9, NSTEP = kPlaneWave ? 27 : 36, NSTREAM = NS == 2 ? 36 : (kPlaneWave ? 27 : 54);
+  constexpr int NACC = (NS == 2 || kPlaneWave) ? 2 : 4;
   const int NCH = CIN ? CIN / 16 : sa.nch;                // CIN = 0: any multiple of 16, chunk count at run time
   const int NGRP = NS == 2 ? NTAP * NCH : ((NTAP * NCH + 1) & ~1);              // groups in the packed block (padded to a pair)
-  constexpr int PX = 34, PY = 6, PZ = 4, VS = 16;          // brick extent in voxels, voxel pitch in floats
-  constexpr int NV = PX * PY * PZ, NQ = NV * 4, NPRE = (NQ + 255) / 256;
+  constexpr int PX = 34, PY = YB + 2, PZ = 4, VS = 16;     // brick extent in voxels, voxel pitch in floats
+  constexpr int NV = PX * PY * PZ, NROW = PY * PZ, HROW = NROW / 2, NPRE = HROW + 1;
   __shared__ __attribute__((aligned(16))) float brick[NV * VS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -863,13 +870,13 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
   const int nbz = (a.D + 1) >> 1;
   const int vb = (int)blockIdx.z / nbz, bz = (int)blockIdx.z - vb * nbz;
   const int cg = (int)blockIdx.x / sa.nbx;                 // group of 16 output channels (NS = 1 layers with Cout = 32, 64, ...)
-  const int x0 = ((int)blockIdx.x - cg * sa.nbx) * 32, y0 = (int)blockIdx.y * 4, z0 = bz * 2;
+  const int x0 = ((int)blockIdx.x - cg * sa.nbx) * 32, y0 = (int)blockIdx.y * YB, z0 = bz * 2;
   const float* inb = a.in + a.in_coff;
-  // fill plan (NPRE = 13 loads and ds_writes per thread and chunk, ~no address arithmetic): the brick is 24 rows (pz, py) of 34
-  // voxels x 4 channel quads.  Columns 0..31: thread -> (column, quad) = tid % 128, the two halves of the workgroup take 12 rows
-  // each; the row term of the address is wave-uniform (soffset of the buffer load, a compile-time ds offset) and rows in the zero
-  // padding are skipped by a uniform branch.  Columns 32, 33 (192 quads): one more load per thread, whose lanes in the padding
-  // carry an offset past the end of the buffer descriptor and read zeros.
+  // fill plan (NPRE = 13 (9) loads and ds_writes per thread and chunk, ~no address arithmetic): the brick is 24 (16) rows (pz, py) of
+  // 34 voxels x 4 channel quads.  Columns 0..31: thread -> (column, quad) = tid % 128, the two halves of the workgroup take half of the
+  // rows (two planes) each; the row term of the address is wave-uniform (soffset of the buffer load, a compile-time ds offset) and
+  // rows in the zero padding are skipped by a uniform branch.  Columns 32, 33 (8 quads per row): one more load per thread, whose
+  // lanes in the padding carry an offset past the end of the buffer descriptor and read zeros.
   const unsigned long long inb_bits = (unsigned long long)inb;
   const i32x4v rsrc = {(int)(unsigned)inb_bits, (int)(unsigned)(inb_bits >> 32), (int)sa.in_bytes, 0x00020000};          // raw buffer, 32-bit data
   const int half = __builtin_amdgcn_readfirstlane(wave >> 1);
@@ -880,16 +887,16 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
   {
     const int cq = tid & 3, px = (tid & 127) >> 2;
     src_col = (unsigned)(wrap_x(x0 - 1 + px) * a.in_cs + 4 * cq) * 4u;
-    dst_col = (unsigned)(((half * 12 * PX + px) * VS + 4 * (cq ^ ((px >> 1) & 3))) * 4);
+    dst_col = (unsigned)(((half * HROW * PX + px) * VS + 4 * (cq ^ ((px >> 1) & 3))) * 4);
     const int row = tid >> 3, pxx = 32 + ((tid >> 2) & 1), pz = row / PY, py = row - pz * PY;
     const int z = z0 - 1 + pz, y = y0 - 1 + py;
-    const bool ok = tid < 192 && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H;
+    const bool ok = tid < NROW * 8 && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H;
     src_x = ok ? (unsigned)((((vb * a.D + z) * a.H + y) * a.W + wrap_x(x0 - 1 + pxx)) * a.in_cs + 4 * cq) * 4u : 0x80000000u;
     dst_x = (unsigned)(((row * PX + pxx) * VS + 4 * (cq ^ ((pxx >> 1) & 3))) * 4);
   }
   float4 pre[NPRE];
   auto fetch_one = [&](int chunk, int i) {
-    if (i < 12) {
+    if (i < HROW) {
       const int z = z0 - 1 + 2 * half + i / PY, y = y0 - 1 + i % PY;              // uniform
       pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H) {
@@ -903,10 +910,10 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
   };
   auto park = [&]() {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) *reinterpret_cast<float4*>(reinterpret_cast<char*>(brick) + dst_col + i * (PX * VS * 4)) = pre[i];
-    if (tid < 192) *reinterpret_cast<float4*>(reinterpret_cast<char*>(brick) + dst_x) = pre[12];
+    for (int i = 0; i < HROW; ++i) *reinterpret_cast<float4*>(reinterpret_cast<char*>(brick) + dst_col + i * (PX * VS * 4)) = pre[i];
+    if (tid < NROW * 8) *reinterpret_cast<float4*>(reinterpret_cast<char*>(brick) + dst_x) = pre[HROW];
   };
-  static_assert(NPRE == 13, "12 row loads + 1 for the two last columns");
+  static_assert(NROW * 8 <= 256, "one load per thread covers the two last columns");
 #pragma unroll
   for (int i = 0; i < NPRE; ++i) fetch_one(0, i);
   f32x4v acc[NACC];                                       // NS = 2: [x half]; NS = 1: [output plane][x half]
@@ -916,11 +923,13 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
 #pragma unroll
     for (int t = 0; t < NACC; ++t) acc[t] = (f32x4v){b4.x, b4.y, b4.z, b4.w};
   }
-  // wave w multiplies row y0 + w: tiles x0 + j and x0 + 16 + j.  Per dx one LDS base at the (dz, dy) = (-1, -1) corner, so that every
-  // tap is that base + a non-negative immediate: voxel (pz = 0, py = w, px = j + dx + 1), this lane's (swizzled) channel quad
+  // wave w multiplies row y0 + w (YB = 2: row y0 + w % 2 of output plane w / 2): tiles x0 + j and x0 + 16 + j.  Per dx one LDS base at
+  // the (dz, dy) = (-1, -1) corner, so that every tap is that base + a non-negative immediate: voxel (pz = 0 (or the wave's plane),
+  // py = its row, px = j + dx + 1), this lane's (swizzled) channel quad
+  const int wrow = kPlaneWave ? (wave & 1) : wave, wzo = kPlaneWave ? (wave >> 1) : 0;
   const float* bl[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) bl[d] = &brick[(wave * PX + j + d) * VS + 4 * (g ^ (((j + d) >> 1) & 3))];
+  for (int d = 0; d < 3; ++d) bl[d] = &brick[((wzo * PY + wrow) * PX + j + d) * VS + 4 * (g ^ (((j + d) >> 1) & 3))];
   const unsigned long long w_bits = (unsigned long long)(a.wpk + (size_t)cg * sa.grp_floats);
   const i32x4v wrsrc = {(int)(unsigned)w_bits, (int)(unsigned)(w_bits >> 32), NGRP * 1024, 0x00020000};
   park();
@@ -934,7 +943,7 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
     constexpr int AD = 6, RING = 8;
     float4 av[RING], bv[2][2];
     auto issue_a = [&](int n) {                            // n = position in the A stream
-      const f32x4v r = pgrf_buffer_load_x4(wrsrc, lane * 16, (chunk * NTAP + Brick16::a_tap(NS, n)) * 1024, 0);
+      const f32x4v r = pgrf_buffer_load_x4(wrsrc, lane * 16, (chunk * NTAP + Brick16::a_tap(WALK, n)) * 1024, 0);
       av[n % RING] = make_float4(r.x, r.y, r.z, r.w);
     };
     auto issue_a_upto = [&](int from, int to) {
@@ -943,7 +952,7 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
         if (n < NSTREAM) issue_a(n);
     };
     auto a_limit = [](int s) {                             // A loads issued once step s has issued: everything up to AD - 1 beyond its own
-      return s < 0 ? AD - 1 : (s >= NSTEP ? NSTREAM : Brick16::a_pos(NS, s) + Brick16::a_count(NS, s) + AD - 1);
+      return s < 0 ? AD - 1 : (s >= NSTEP ? NSTREAM : Brick16::a_pos(WALK, s) + Brick16::a_count(WALK, s) + AD - 1);
     };
     auto issue_b = [&](int slot, int s) {
       const int pz = s / 9, dy = (s / 3) % 3, dx = s % 3;
@@ -953,8 +962,8 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
     };
     auto pick = [](const float4& q, int m) { return (m == 0) ? q.x : (m == 1) ? q.y : (m == 2) ? q.z : q.w; };
     auto compute = [&](int slot, int s) {
-      const int n0 = Brick16::a_pos(NS, s);
-      if (NS == 2) {
+      const int n0 = Brick16::a_pos(WALK, s);
+      if (WALK != 1) {
         const float4 a4 = av[n0 % RING];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -989,7 +998,7 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
       compute(st & 1, st);
       __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(NPRE <= NSTEP / 2, "one fill load per pair of steps");
+    static_assert(NPRE <= (NSTEP + 1) / 2, "one fill load per pair of steps");
     if (more) {
       __syncthreads();
       park();
@@ -997,12 +1006,12 @@ __global__ void __launch_bounds__(256, 3) conv3d_brick16_kernel(const SmallArgs 
     }
   }
   // epilogue: rows 4g .. 4g+3 = (NS = 2) shift g / 2, channels 4 (g % 2) .. + 3 | (NS = 1) channels 4g .. 4g + 3 of the tile's plane
-  const int y = y0 + wave;
+  const int y = y0 + wrow;
   if (y < a.H) {
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
       const int x = x0 + 16 * (t & 1) + j;
-      const int z = z0 + (NS == 2 ? (g >> 1) : (t >> 1)), c = NS == 2 ? (g & 1) * 4 : cg * 16 + 4 * g;
+      const int z = z0 + (NS == 2 ? (g >> 1) : (kPlaneWave ? wzo : (t >> 1))), c = NS == 2 ? (g & 1) * 4 : cg * 16 + 4 * g;
       if (x >= a.W || z >= a.D) continue;
       const unsigned ov = (unsigned)(((vb * a.D + z) * a.H + y) * a.W + x);
       float4 o = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
@@ -2084,8 +2093,17 @@ int pgrf_conv3d_small16(const float* in, int in_cs, int in_coff, int Cin, float*
     if (sa.in_bytes >= 0x80000000u) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: input beyond 2 GB");
     if ((long long)B * ((D + 1) / 2) > 65535 || (H + 3) / 4 > 65535) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: grid too large");
     sa.nbx = (W + 31) / 32; sa.nch = Cin / 16;
-    const dim3 grid((unsigned)(sa.nbx * ncg), (unsigned)((H + 3) / 4), (unsigned)(B * ((D + 1) / 2)));
-    if (nshift == 2) {
+    dim3 grid((unsigned)(sa.nbx * ncg), (unsigned)((H + 3) / 4), (unsigned)(B * ((D + 1) / 2)));
+    // small volumes (at most two rounds of 768 resident four-row bricks): two-row bricks, four workgroups per CU, half the chain per wave
+    bool yb2 = nshift == 1 && (long long)grid.x * grid.y * grid.z <= 1536;
+    if (const char* e = getenv("PGRF_CONV16_YB")) yb2 = nshift == 1 && atoi(e) == 2;          // tuning knob
+    if (yb2) {
+      if ((H + 1) / 2 > 65535) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_small16: grid too large");
+      grid.y = (unsigned)((H + 1) / 2);
+      if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+      else if (Cin == 32) hipLaunchKernelGGL((conv3d_brick16_kernel<32, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+      else hipLaunchKernelGGL((conv3d_brick16_kernel<0, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
+    } else if (nshift == 2) {
       if (Cin == 16) hipLaunchKernelGGL((conv3d_brick16_kernel<16, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
       else hipLaunchKernelGGL((conv3d_brick16_kernel<32, 2>), grid, dim3(256), 0, (hipStream_t)stream, sa);
     } else {

@@ -145,13 +145,17 @@ def test_narrow_layer_16_row_kernel_vs_oracle(cin, cout, stride, D, ns, nt, monk
     xin = R._Vol(R._to_ndhwc(x.cuda()), 0, cin)
     assert R._small16_shift(pc, xin, stride) == ns
     Do, Ho, Wo = ref.shape[2:]
-    wide = R._Vol.empty(B, Do, Ho, Wo, cout + 8, 'cuda')
-    wide.buf.fill_(7.0)
     resv = R._Vol(res.cuda().permute(0, 2, 3, 4, 1).contiguous(), 0, cout)
-    out = R._conv(pc, xin, wide.slice(4, cout), stride=stride, residual=resv)
-    got = out.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
-    assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
-    assert bool((out.buf[..., :4] == 7.0).all()) and bool((out.buf[..., 4 + cout:] == 7.0).all())
+    # the unshifted layers on the LDS-brick kernel: both brick shapes (four rows; two rows = what small volumes take by themselves)
+    for yb in (('2', '4') if ns == 1 and nt == 0 and stride == 1 and cin >= 16 else ('',)):
+        if yb:
+            monkeypatch.setenv('PGRF_CONV16_YB', yb)
+        wide = R._Vol.empty(B, Do, Ho, Wo, cout + 8, 'cuda')
+        wide.buf.fill_(7.0)
+        out = R._conv(pc, xin, wide.slice(4, cout), stride=stride, residual=resv)
+        got = out.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu()
+        assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max())), yb
+        assert bool((out.buf[..., :4] == 7.0).all()) and bool((out.buf[..., 4 + cout:] == 7.0).all())
 
 
 @pytest.mark.parametrize('cin,cout,ns,D,H,W', [(32, 8, 2, 6, 9, 70), (16, 16, 1, 5, 6, 40), (32, 16, 1, 4, 8, 64), (8, 8, 2, 4, 5, 19)])
