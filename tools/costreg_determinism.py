@@ -1,6 +1,6 @@
 """CostRegNet forward repeated: every output must equal the first bit for bit (no races in the LDS-brick kernels)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from panogrf_amd import cost_reg as R
 for (h, w) in ((128, 256), (40, 72)):
     cv = torch.randn(1, 64 if h == 128 else 24, h, w, 32, device='cuda')

@@ -1,6 +1,6 @@
 """Is a CostRegNet forward host-bound?  wall time of enqueueing n forwards vs GPU time of the same n."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from panogrf_amd import cost_reg as R
 h, w = 128, 256
 cv = torch.randn(1, 64, h, w, 32, device='cuda')
