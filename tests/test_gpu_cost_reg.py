@@ -192,6 +192,33 @@ def test_narrow_layer_16_row_kernel_rejects_what_it_cannot_do():
     assert b'pgrf_pack_conv3d_small16' in lib.pgrf_last_error()
 
 
+@pytest.mark.parametrize('B,D,H,W,res', [(2, 5, 19, 45, True), (1, 2, 16, 32, False), (1, 7, 3, 70, True)])
+def test_single_channel_head_from_lds_brick_vs_oracle(B, D, H, W, res, monkeypatch):
+    """The Cout = 1 head from eight channels (conv3d_cout1_c8_brick_kernel: 4 x 18 x 34 input brick in LDS, scalar-loaded weights)
+    against the oracle's F.conv3d: ragged bricks in every axis, odd depths, a batch, the residual epilogue, a channel-sliced input;
+    and BIT-IDENTICAL to the kernel it replaces (PGRF_CONV_NO_C8_BRICK): both run the same fmaf chain per output, in (dz, dy, dx, channel) order."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    g = torch.Generator().manual_seed(B * 1000 + D * 100 + H + W)
+    x = torch.randn(B, 8, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(1, 8, 3, 3, 3, generator=g) * (2.0 / 216) ** 0.5, 'c.bias': torch.randn(1, generator=g) * 0.1}
+    conv = O._conv3(w, 'c', x, 1)
+    r = torch.randn(conv.shape, generator=g) if res else None
+    ref = torch.nn.functional.leaky_relu(conv, 0.01) + (r if res else 0.0)
+    pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
+    wide_in = torch.full((B, D, H, W, 16), float('nan'), device='cuda')
+    wide_in[..., 4:12] = R._to_ndhwc(x.cuda())
+    resv = R._Vol(r.cuda().permute(0, 2, 3, 4, 1).contiguous(), 0, 1) if res else None
+    outs = []
+    for flag in (None, '1'):
+        if flag:
+            monkeypatch.setenv('PGRF_CONV_NO_C8_BRICK', flag)
+        out = R._conv(pc, R._Vol(wide_in, 4, 8), R._Vol.empty(B, D, H, W, 1, 'cuda'), slope=0.01, residual=resv)
+        outs.append(out.buf.permute(0, 4, 1, 2, 3).cpu())
+        assert max_abs(outs[-1], ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_narrow_layer_kernel_rejects_what_it_cannot_do():
     from panogrf_amd._lib import lib
     assert lib.pgrf_conv3d_small_packed_floats(8, 16, 4) == ((6 * 9 * 16 + 31) // 32) * 1024 + 32
