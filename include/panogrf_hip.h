@@ -343,6 +343,14 @@ int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, 
 int pgrf_conv3d_cout1_gather(const float* y, const float* packed, int Cin, int has_bias, float* out, int out_cs, int out_coff,
                              int B, int D, int H, int W, float lrelu_slope, const float* residual, int res_cs, int res_coff,
                              void* stream);
+/* The gather for a Cout = 1 convolution over torch.cat((up(x), skip)) (UNet2's last decoder step, models/common_blocks.py:225-241):
+ * y_lo = pgrf_conv3d_cout1_project of x at LOW resolution with the weights of the up-sampled channels, y_hi = the projection of the
+ * skip half at full resolution; the trilinear x2 interpolation of the 27 low-resolution planes happens inside the gather (the
+ * projection commutes with it), so up(x) is never written.  B, D, H, W = the full (even) resolution; packed_hi / Cin_hi / has_bias:
+ * the pgrf_pack_conv3d(Cout = 1) block of the skip half (it carries the bias). */
+int pgrf_conv3d_cout1_gather_up(const float* y_hi, const float* y_lo, const float* packed_hi, int Cin_hi, int has_bias, float* out, int out_cs,
+                                int out_coff, int B, int D, int H, int W, float lrelu_slope, const float* residual, int res_cs, int res_coff,
+                                void* stream);
 /* nn.AvgPool3d(2) (common_blocks.py:380) and F.interpolate(scale_factor=2, mode="trilinear",
  * align_corners=False) (common_blocks.py:221-236, cost_reg.py:85-88). */
 int pgrf_avgpool3d_2(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff, int B, int D, int H,

@@ -110,6 +110,8 @@ SYMBOLS = {
     "pgrf_pack_conv3d_small": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_small": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P]),
+    "pgrf_conv3d_cout1_gather_up": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                              _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_cout1_project": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_cout1_gather": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_float, _P, C.c_int, C.c_int, _P]),

@@ -322,6 +322,13 @@ class UNet2Reg(_RegBase):
             for i, blk in enumerate(getattr(self, grp)):
                 pk[f'{grp}.{i}.1'] = _PackedConv(blk.conv1.weight, blk.conv1.bias, device)
                 pk[f'{grp}.{i}.2'] = _PackedConv(blk.conv2.weight, blk.conv2.bias, device)
+        # the last decoder step is a Cout = 1 convolution over cat((up(x), skip)): its two channel halves as convolutions of their own
+        # (forward_ndhwc projects the up-sampled half at LOW resolution, pgrf_conv3d_cout1_gather_up)
+        w0 = self.decoders[0].conv1.weight
+        if self.n >= 2 and w0.shape[0] == 1 and w0.shape[1] % 2 == 0 and w0.shape[1] // 2 >= 64:
+            c = w0.shape[1] // 2
+            pk['decoders.0.1.up'] = _PackedConv(w0[:, :c], None, device)
+            pk['decoders.0.1.skip'] = _PackedConv(w0[:, c:], self.decoders[0].conv1.bias, device)
         return pk
 
     def forward_ndhwc(self, vol):
@@ -350,8 +357,23 @@ class UNet2Reg(_RegBase):
         x = _conv(d[1], _conv(d[0], x, E(n - 1, d[0].cout)), E(n - 1, d[1].cout))
         for i in range(n - 2, -1, -1):
             cat = cats[i]
-            _up(x, cat.slice(0, x.C))                         # torch.cat((upsampled, skip), dim=1)
             d = pk[f'decoders.{i}.1'], pk[f'decoders.{i}.2']
+            if i == 0 and 'decoders.0.1.up' in pk and x.C * 2 == cat.cs and os.environ.get('PANOGRF_UNET_HEAD_FUSE', '1') != '0':
+                # Cout = 1 over cat((up(x), skip)): project x at LOW resolution and the skip half at full resolution onto the 27 tap
+                # vectors, interpolate inside the gather -- up(x) is never written (UNet2 at 128x256x64: see profiles/)
+                pu, ps = pk['decoders.0.1.up'], pk['decoders.0.1.skip']
+                skip = cat.slice(x.C, x.C)
+                y_lo = torch.empty(x.B, x.D, x.H, x.W, 32, dtype=torch.float32, device=dev)
+                y_hi = torch.empty(skip.B, skip.D, skip.H, skip.W, 32, dtype=torch.float32, device=dev)
+                lib.check(lib.pgrf_conv3d_cout1_project(_ptr(x.buf), x.cs, x.coff, pu.cin, _ptr(pu.dev), _ptr(y_lo), x.B, x.D, x.H, x.W, _stream()))
+                lib.check(lib.pgrf_conv3d_cout1_project(_ptr(skip.buf), skip.cs, skip.coff, ps.cin, _ptr(ps.dev), _ptr(y_hi), skip.B, skip.D,
+                                                        skip.H, skip.W, _stream()))
+                t = E(0, 1)
+                lib.check(lib.pgrf_conv3d_cout1_gather_up(_ptr(y_hi), _ptr(y_lo), _ptr(ps.dev), ps.cin, int(ps.has_bias), _ptr(t.buf), t.cs,
+                                                          t.coff, skip.B, skip.D, skip.H, skip.W, 0.01, None, 0, 0, _stream()))
+                x = _conv(d[1], t, E(0, d[1].cout))
+                continue
+            _up(x, cat.slice(0, x.C))                         # torch.cat((upsampled, skip), dim=1)
             x = _conv(d[1], _conv(d[0], _Vol(cat.buf, 0, cat.cs), E(i, d[0].cout)), E(i, d[1].cout))
         return x.buf
 

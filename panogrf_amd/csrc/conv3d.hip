@@ -1471,6 +1471,64 @@ __global__ void __launch_bounds__(256) cout1_gather_kernel(const float* __restri
   }
 }
 
+// F.interpolate(scale_factor=2, mode='trilinear', align_corners=False) on channel-last data
+__device__ __forceinline__ void up_idx(int o, int n, int& i0, int& i1, float& l0, float& l1) {
+  float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+// The same gather for a convolution over torch.cat((up(x), skip)) -- the last decoder step of UNet2 (models/common_blocks.py:225-241):
+// the projection onto the 27 tap vectors is linear and channel-wise, so it commutes with the trilinear up-sampling,
+//     <w_tap, up(x)[q]> = up(<w_tap, x>)[q].
+// x is projected at LOW resolution (y_lo, 1/8 of the voxels), the skip half at full resolution (y_hi), and this kernel interpolates
+// the 27 low-resolution planes at q = p + tap on the fly (same per-axis weights as upsample3d_kernel).  The up-sampled tensor is never
+// written (64 channels at full resolution: 537 MB at 64x128x256) and the full-resolution projection reads half the channels.
+__global__ void __launch_bounds__(256) cout1_gather_up_kernel(const float* __restrict__ y_hi, const float* __restrict__ y_lo,
+                                                              const float* __restrict__ bias0, float* __restrict__ out, int out_cs, int out_coff,
+                                                              int B, int D, int H, int W, float slope, const float* __restrict__ residual,
+                                                              int res_cs, int res_coff) {
+  const long long nvox = (long long)B * D * H * W;
+  const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+  const long long nlow = (long long)B * Dl * Hl * Wl;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+    long long t = v;
+    const int x = (int)(t % W); t /= W;
+    const int yy = (int)(t % H); t /= H;
+    const int z = (int)(t % D); const int b = (int)(t / D);
+    // per axis: the three high-res neighbours, their low-res support and weights
+    int zi[3], yi[3], xi[3], z0[3], z1[3], y0[3], y1[3], x0[3], x1[3];
+    float lz0[3], lz1[3], ly0[3], ly1[3], lx0[3], lx1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      zi[k] = z + k - 1; yi[k] = yy + k - 1;
+      int xw = x + k - 1;
+      xi[k] = xw < 0 ? xw + W : (xw >= W ? xw - W : xw);
+      up_idx(min(max(zi[k], 0), D - 1), Dl, z0[k], z1[k], lz0[k], lz1[k]);
+      up_idx(min(max(yi[k], 0), H - 1), Hl, y0[k], y1[k], ly0[k], ly1[k]);
+      up_idx(xi[k], Wl, x0[k], x1[k], lx0[k], lx1[k]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int a = tap / 9, bb = (tap / 3) % 3, c = tap % 3;
+      if (zi[a] < 0 || zi[a] >= D || yi[bb] < 0 || yi[bb] >= H) continue;
+      const float* lo = y_lo + (long long)tap * nlow + (long long)b * Dl * Hl * Wl;
+      const long long r00 = ((long long)z0[a] * Hl + y0[bb]) * Wl, r01 = ((long long)z0[a] * Hl + y1[bb]) * Wl;
+      const long long r10 = ((long long)z1[a] * Hl + y0[bb]) * Wl, r11 = ((long long)z1[a] * Hl + y1[bb]) * Wl;
+      const float up = lz0[a] * (ly0[bb] * (lx0[c] * lo[r00 + x0[c]] + lx1[c] * lo[r00 + x1[c]]) + ly1[bb] * (lx0[c] * lo[r01 + x0[c]] + lx1[c] * lo[r01 + x1[c]])) +
+                       lz1[a] * (ly0[bb] * (lx0[c] * lo[r10 + x0[c]] + lx1[c] * lo[r10 + x1[c]]) + ly1[bb] * (lx0[c] * lo[r11 + x0[c]] + lx1[c] * lo[r11 + x1[c]]));
+      s += up + y_hi[(long long)tap * nvox + (((long long)b * D + zi[a]) * H + yi[bb]) * W + xi[c]];
+    }
+    if (bias0) s += bias0[0];
+    s = s > 0.f ? s : s * slope;
+    if (residual) s += residual[v * res_cs + res_coff];
+    out[v * out_cs + out_coff] = s;
+  }
+}
+
 // AvgPool3d(2) on channel-last data; thread per (output voxel, 4-channel group)
 __global__ void avgpool3d_kernel(const float* __restrict__ in, int in_cs, int in_coff, float* __restrict__ out, int out_cs,
                                  int out_coff, int B, int D, int H, int W, int C, int stream_loads) {
@@ -1496,15 +1554,6 @@ __global__ void avgpool3d_kernel(const float* __restrict__ in, int in_cs, int in
   }
 }
 
-// F.interpolate(scale_factor=2, mode='trilinear', align_corners=False) on channel-last data
-__device__ __forceinline__ void up_idx(int o, int n, int& i0, int& i1, float& l0, float& l1) {
-  float src = 0.5f * ((float)o + 0.5f) - 0.5f;
-  if (src < 0.f) src = 0.f;
-  i0 = (int)src;
-  i1 = i0 + (i0 < n - 1 ? 1 : 0);
-  l1 = src - (float)i0;
-  l0 = 1.f - l1;
-}
 // One thread = one INPUT voxel and channel quad = the 2x2x2 output block around it: the 27 neighbours are loaded once
 // (3.4 loads per output instead of 8; the one-thread-per-output version ran at 2.4 TB/s of output because of its load
 // count).  Every output is the same expression as torch's trilinear kernel (align_corners=False): output 2i+a reads
@@ -2372,6 +2421,20 @@ int pgrf_conv3d_cout1_gather(const float* y, const float* packed, int Cin, int h
   hipLaunchKernelGGL(cout1_gather_kernel, dim3(grid_for(nvox)), dim3(256), 0, (hipStream_t)stream, y, bias0, out, out_cs, out_coff, B, D,
                      H, W, lrelu_slope, residual, res_cs, res_coff);
   PGRF_CHECK_LAUNCH("conv3d_cout1_gather");
+  return PGRF_OK;
+}
+
+int pgrf_conv3d_cout1_gather_up(const float* y_hi, const float* y_lo, const float* packed_hi, int Cin_hi, int has_bias, float* out, int out_cs,
+                                int out_coff, int B, int D, int H, int W, float lrelu_slope, const float* residual, int res_cs, int res_coff,
+                                void* stream) {
+  if (!y_hi || !y_lo || !packed_hi || !out) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_cout1_gather_up: null pointer");
+  if ((D & 1) || (H & 1) || (W & 1) || D < 2 || H < 2 || W < 2) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_cout1_gather_up: dims must be even");
+  const int chunks = (Cin_hi + 31) / 32;
+  const float* bias0 = has_bias ? packed_hi + (size_t)27 * chunks * 1024 + 32 + (size_t)27 * Cin_hi : nullptr;
+  const long long nvox = (long long)B * D * H * W;
+  hipLaunchKernelGGL(cout1_gather_up_kernel, dim3(grid_for(nvox)), dim3(256), 0, (hipStream_t)stream, y_hi, y_lo, bias0, out, out_cs, out_coff, B, D,
+                     H, W, lrelu_slope, residual, res_cs, res_coff);
+  PGRF_CHECK_LAUNCH("conv3d_cout1_gather_up");
   return PGRF_OK;
 }
 

@@ -313,6 +313,56 @@ def test_winograd_conv_rejects_what_it_cannot_do():
     assert pref(64, 64, 1, 64, 128, 256) == 1 and pref(512, 128, 1, 16, 16, 32) == 0 and pref(48, 64, 1, 64, 128, 256) == 0
 
 
+@pytest.mark.parametrize('B,D,H,W,C', [(1, 4, 6, 8, 64), (2, 2, 2, 66, 64), (1, 6, 4, 34, 96)])
+def test_single_channel_conv_over_upsampled_concat_vs_oracle(B, D, H, W, C):
+    """UNet2's last decoder step, conv(cat((up(x), skip))) with one output channel (models/common_blocks.py:225-241), as two
+    projections onto the 27 tap vectors -- x at LOW resolution, the skip half at full resolution -- and
+    pgrf_conv3d_cout1_gather_up, which interpolates the low-resolution planes inside the gather: against the oracle's
+    F.interpolate + torch.cat + F.conv3d (volume faces, the W seam, axes of length 1 at low resolution)."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    from panogrf_amd._lib import lib
+    g = torch.Generator().manual_seed(B + D * 7 + H * 3 + W + C)
+    x = torch.randn(B, C, D // 2, H // 2, W // 2, generator=g)
+    skip = torch.randn(B, C, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(1, 2 * C, 3, 3, 3, generator=g) * (2.0 / (54 * C)) ** 0.5, 'c.bias': torch.randn(1, generator=g) * 0.1}
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode='trilinear', align_corners=False)
+    ref = torch.nn.functional.leaky_relu(O._conv3(w, 'c', torch.cat((up, skip), 1)), 0.01)
+    pu = R._PackedConv(w['c.weight'][:, :C], None, 'cuda')
+    ps = R._PackedConv(w['c.weight'][:, C:], w['c.bias'], 'cuda')
+    xl = R._Vol(R._to_ndhwc(x.cuda()), 0, C)
+    sk = R._Vol(R._to_ndhwc(skip.cuda()), 0, C)
+    y_lo = torch.empty(B, D // 2, H // 2, W // 2, 32, device='cuda')
+    y_hi = torch.empty(B, D, H, W, 32, device='cuda')
+    lib.check(lib.pgrf_conv3d_cout1_project(R._ptr(xl.buf), xl.cs, xl.coff, C, R._ptr(pu.dev), R._ptr(y_lo), B, D // 2, H // 2, W // 2, R._stream()))
+    lib.check(lib.pgrf_conv3d_cout1_project(R._ptr(sk.buf), sk.cs, sk.coff, C, R._ptr(ps.dev), R._ptr(y_hi), B, D, H, W, R._stream()))
+    out = torch.empty(B, D, H, W, 1, device='cuda')
+    lib.check(lib.pgrf_conv3d_cout1_gather_up(R._ptr(y_hi), R._ptr(y_lo), R._ptr(ps.dev), C, 1, R._ptr(out), 1, 0, B, D, H, W, 0.01, None, 0, 0,
+                                              R._stream()))
+    got = out.permute(0, 4, 1, 2, 3).cpu()
+    assert max_abs(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert lib.pgrf_conv3d_cout1_gather_up(R._ptr(y_hi), R._ptr(y_lo), R._ptr(ps.dev), C, 1, R._ptr(out), 1, 0, B, D + 1, H, W, 0.01, None, 0, 0, None) != 0
+
+
+def test_unet2_fused_head_equals_unfused(monkeypatch):
+    """UNet2 with its last decoder step through pgrf_conv3d_cout1_gather_up (default) against the up-sample + concat + convolution
+    form of the same step: a different order of the same sums."""
+    from panogrf_amd.cost_reg import UNet2Reg
+    torch.manual_seed(5)
+    net = UNet2Reg().eval().cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+    x = torch.randn(2, 32, 8, 16, 64, generator=torch.Generator().manual_seed(6)).cuda()
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PANOGRF_UNET_HEAD_FUSE', flag)
+        with torch.no_grad():
+            outs.append(net(x).clone())
+    d = max_abs(outs[0], outs[1])
+    assert 0.0 < d < 2e-5 * max(1.0, float(outs[1].abs().max()))
+
+
 def test_unet2_winograd_equals_direct(monkeypatch):
     """The whole UNet2 regulariser with its wide layers on the Winograd kernel vs all layers on the direct kernel (a volume
     wide enough that the first two resolution levels qualify)."""
