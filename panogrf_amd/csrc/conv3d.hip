@@ -1250,6 +1250,43 @@ __global__ void __launch_bounds__(256) conv3d_cout1_kernel(const ConvArgs a, con
   }
 }
 
+// Cout == 1 from ONE input channel (the second convolution of UNet2's last block, models/common_blocks.py:366-455 with one channel):
+// the general kernel above spends ~40 instructions of 64-bit index arithmetic and branches per tap (78 us at 64x128x256 for 8 MB in,
+// 8 MB out).  One thread per output, 32-bit indices, the 27 weights in scalar registers, row bases per (dz, dy): 11 us.
+__global__ void __launch_bounds__(256) conv3d_cout1_c1_kernel(const ConvArgs a, const float* __restrict__ wlin, int has_bias) {
+  const unsigned nvox = (unsigned)(a.B * a.D * a.H * a.W);
+  const unsigned v = blockIdx.x * 256u + threadIdx.x;
+  if (v >= nvox) return;
+  const int x = (int)(v % (unsigned)a.W);
+  unsigned t = v / (unsigned)a.W;
+  const int y = (int)(t % (unsigned)a.H); t /= (unsigned)a.H;
+  const int z = (int)(t % (unsigned)a.D), b = (int)(t / (unsigned)a.D);
+  const int xl = x == 0 ? a.W - 1 : x - 1, xr = x == a.W - 1 ? 0 : x + 1;
+  const float* base = a.in + a.in_coff;
+  float s = 0.f;
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz) {
+    const int zi = z + dz - 1;
+    if (zi < 0 || zi >= a.D) continue;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yi = y + dy - 1;
+      if (yi < 0 || yi >= a.H) continue;
+      const unsigned row = (unsigned)(((b * a.D + zi) * a.H + yi) * a.W);
+      const float* w = wlin + (dz * 3 + dy) * 3;
+      s = fmaf(base[(row + (unsigned)xl) * (unsigned)a.in_cs], w[0], s);
+      s = fmaf(base[(row + (unsigned)x) * (unsigned)a.in_cs], w[1], s);
+      s = fmaf(base[(row + (unsigned)xr) * (unsigned)a.in_cs], w[2], s);
+    }
+  }
+  if (has_bias) s += wlin[27];
+  const float rr = a.residual ? a.residual[(size_t)v * a.res_cs + a.res_coff] : 0.f;
+  if (a.res_first) s += rr;
+  s = conv_act(a, s);
+  if (!a.res_first) s += rr;
+  a.out[(size_t)v * a.out_cs + a.out_coff] = s;
+}
+
 // Cout == 1 from EIGHT input channels (CostRegNet's prob head, models/cost_reg.py:165-172, at full resolution): the general
 // kernel above issues 54 16-byte loads per output voxel (27 taps x 2) and ran at 143 us for 64x128x256 -- 67 MB in, 8 MB out.
 // Here a thread owns YB = 4 consecutive outputs along y of one (b, z, x): an input row (dz, y0 - 1 + r, dx) is loaded once
@@ -1883,6 +1920,11 @@ static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, fl
       hipLaunchKernelGGL(conv3d_cout1_c8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, wlin,
                          has_bias ? 1 : 0);
       PGRF_CHECK_LAUNCH("conv3d_cout1_c8");
+      return PGRF_OK;
+    }
+    if (Cin == 1 && stride == 1 && wrap_w && (double)nvox * (in_cs > 1 ? in_cs : 1) < 4294967296.0 && !getenv("PGRF_CONV_NO_C1")) {
+      hipLaunchKernelGGL(conv3d_cout1_c1_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, wlin, has_bias ? 1 : 0);
+      PGRF_CHECK_LAUNCH("conv3d_cout1_c1");
       return PGRF_OK;
     }
     const long long threads = nvox * lpv;
