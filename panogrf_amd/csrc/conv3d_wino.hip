@@ -386,12 +386,21 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
         constexpr int kCy = fy == 3 ? 1 : 0, kCx = fx == 3 ? 1 : 0;
         constexpr bool kCornerNeg = (fy == 3) != (fx == 3);
         const float4 aq = A[g];
+        // the x transform of two k-steps per instruction (v_pk_add_f32 through vector types: UNet2 6.80 -> 6.65 ms; the same as inline
+        // asm was faster still and WRONG -- the hazards between the packed add and the MFMAs around it are the compiler's to handle)
+        f32x2_t bpk[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x2_t p0 = h2 == 0 ? (f32x2_t){tv[buf][0].x, tv[buf][0].y} : (f32x2_t){tv[buf][0].z, tv[buf][0].w};
+          const f32x2_t p1 = h2 == 0 ? (f32x2_t){tv[buf][1].x, tv[buf][1].y} : (f32x2_t){tv[buf][1].z, tv[buf][1].w};
+          if constexpr (fx == 1) bpk[h2] = p0 + p1;       // (vector types: the compiler selects v_pk_add_f32 and knows its hazards)
+          else if constexpr (kCorner && kCornerNeg) bpk[h2] = p1 - p0;
+          else bpk[h2] = p0 - p1;
+        }
 #pragma unroll
         for (int kl = 0; kl < 4; ++kl) {
-          const float t0 = kl == 0 ? tv[buf][0].x : kl == 1 ? tv[buf][0].y : kl == 2 ? tv[buf][0].z : tv[buf][0].w;
-          const float t1 = kl == 0 ? tv[buf][1].x : kl == 1 ? tv[buf][1].y : kl == 2 ? tv[buf][1].z : tv[buf][1].w;
           // (corner frequencies: the sign of their single output-transform term is folded into the operand)
-          const float bv = (fx == 1) ? t0 + t1 : (kCorner && kCornerNeg) ? t1 - t0 : t0 - t1;
+          const float bv = kl == 0 ? bpk[0].x : kl == 1 ? bpk[0].y : kl == 2 ? bpk[1].x : bpk[1].y;
           const float av = kl == 0 ? aq.x : kl == 1 ? aq.y : kl == 2 ? aq.z : aq.w;
 #ifdef PGRF_WINO_ABL_NOADD
           M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, (n == 0 && kl == 0) ? zero16 : M, 0, 0, 0);
