@@ -388,7 +388,9 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
         constexpr bool kCornerNeg = (fy == 3) != (fx == 3);
         const float4 aq = A[g];
         // the x transform of two k-steps per instruction (v_pk_add_f32 through vector types: UNet2 6.80 -> 6.65 ms; the same as inline
-        // asm was faster still and WRONG -- the hazards between the packed add and the MFMAs around it are the compiler's to handle)
+        // asm was faster still (6.54) and WRONG: a VALU result needs two wait states before an MFMA reads it as SrcB, which the hazard
+        // recogniser does not insert around inline asm; with `s_nop 1` in the asm 6.62, correct on every test -- not worth carrying a
+        // hand-maintained hazard for 1 %)
         f32x2_t bpk[2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
