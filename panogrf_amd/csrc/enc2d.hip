@@ -116,7 +116,21 @@ __global__ void __launch_bounds__(256) instnorm_stats_kernel(const float* __rest
   if (pl < plan && p0 < p1) {
     const float* xp = x + (size_t)n * HW * cs + coff + q * 4;
     const float4 sh = *reinterpret_cast<const float4*>(xp + (size_t)p0 * cs);
-    for (int p = p0 + pl; p < p1; p += plan) {
+    // eight loads in flight per thread (one at a time the loop is a chain of memory latencies: 19 us for 8 MB at 64x128x128)
+    constexpr int UN = 8;
+    int p = p0 + pl;
+    for (; p + (UN - 1) * plan < p1; p += UN * plan) {
+      float4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (size_t)(p + u * plan) * cs);
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        v[u].x -= sh.x; v[u].y -= sh.y; v[u].z -= sh.z; v[u].w -= sh.w;
+        s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
+        ss[0] = fmaf(v[u].x, v[u].x, ss[0]); ss[1] = fmaf(v[u].y, v[u].y, ss[1]); ss[2] = fmaf(v[u].z, v[u].z, ss[2]); ss[3] = fmaf(v[u].w, v[u].w, ss[3]);
+      }
+    }
+    for (; p < p1; p += plan) {
       float4 v = *reinterpret_cast<const float4*>(xp + (size_t)p * cs);
       v.x -= sh.x; v.y -= sh.y; v.z -= sh.z; v.w -= sh.w;
       s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
