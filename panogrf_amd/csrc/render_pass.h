@@ -14,6 +14,7 @@
 #pragma once
 #include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "pgrf_internal.h"
 #include "pgrf_layout.h"
@@ -145,6 +146,9 @@ template <int V> constexpr bool kRecomputeNf = kTwoWave<V> && V > 3;
 #ifndef PGRF_KT
 #define PGRF_KT 2
 #endif
+#ifndef PGRF_V
+#define PGRF_V 2
+#endif
 // Experiment (-DPGRF_LDS_STATE, off by default): 4 views at two waves (f32) with the per-view state of one view PAIR in LDS
 // while the other pair is worked on (see "kLdsState" in render_pass_kernel) -- that needs the LDS the first weight chunks
 // would take, so those kernels then carry the slim image.  Measured in round 3 (profiles/r03_dead_ends.txt): spilled
@@ -155,7 +159,9 @@ template <int V> constexpr bool kLdsState = (V == 4) && kTwoWave<V> && (kPrec ==
 #else
 template <int V> constexpr bool kLdsState = false;
 #endif
-template <int V> constexpr bool kSlimImg = ((PGRF_KT == 2) && (V == 2 || V == 3)) || kLdsState<V>;
+// (in the 4-view translation units the V = 2 stage functions belong to the wave-pair kernel, whose LDS is taken by the exchange
+// buffers: slim image for every sample count there)
+template <int V> constexpr bool kSlimImg = ((PGRF_KT == 2) && (V == 2 || V == 3)) || kLdsState<V> || (PGRF_V == 4 && V == 2);
 template <int V> constexpr int kImgMode = (kPrec == 1) ? 1 : (kTwoWave<V> ? (kSlimImg<V> ? 3 : 0) : 2);
 // no image in the split-f16 mode (see above).  (Tried for > 2 views at two waves: image dropped in favour of parking the
 // first view group's prob_embed features through stage B — the register allocator answered with MORE spills, 170 -> 289.)
@@ -543,14 +549,16 @@ struct PointGeom {
 // ---------------------------------------------------------------------------------------------
 // Stage A for NT views starting at V0: projection, gathers, dist decoder, prob_embed, neuray_fc,
 // ray_dir_fc.  Fills vs[V0..V0+NT).
-template <int V, int V0, int NT, bool DBG, bool GEN>
+// V = views held by THIS wave (the per-instance policies are keyed on it), VT = views of the frame, vb = global index of the
+// wave's first view: the wave-pair kernel for 4 views (render_pass_pair_kernel) runs these stages with V = 2, VT = 4, vb = 0 | 2.
+template <int V, int V0, int NT, bool DBG, bool GEN, int VT = V>
 __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, const PointGeom& g, ViewState (&vs)[V], int lane,
                                             size_t pt /* ray*DN+sample */, size_t npts, bool store_ok,
                                             float* const* sdbg
 #ifdef PGRF_STAGE_TIMING
                                             , unsigned long long& t_prev
 #endif
-                                            ) {
+                                            , int vb = 0) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
 
@@ -637,7 +645,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
   if constexpr (kDedupe) {
     // both lane halves hold the same point: half 0 projects it into view V0, half 1 into view V0+1, and one
     // v_permlane32_swap per value hands each result to the other half (instead of both halves computing both views)
-    const ViewProj mine = project_view(V0 + half);
+    const ViewProj mine = project_view(vb + V0 + half);
     auto both = [&](float x, float& x0, float& x1) {
       const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
       x0 = __uint_as_float(r[0]); x1 = __uint_as_float(r[1]);
@@ -656,7 +664,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     both(mine.brf.wsw, vp[0].brf.wsw, vp[1].brf.wsw); both(mine.brf.wse, vp[0].brf.wse, vp[1].brf.wse);
   } else {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) vp[t] = project_view(V0 + t);
+    for (int t = 0; t < NT; ++t) vp[t] = project_view(vb + V0 + t);
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -666,18 +674,18 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #pragma unroll
     for (int c = 0; c < 4; ++c) vs[v].dd[c] = vp[t].dd[c];
     brf[t] = vp[t].brf;
-    prj[t] = p.prj + (size_t)v * p.hr * p.wr * kPrjCh;
+    prj[t] = p.prj + (size_t)(vb + v) * p.hr * p.wr * kPrjCh;
     pxy[t][0] = xn; pxy[t][1] = yn;
     if constexpr (!kLazyTaps) {
       bfeat_e[t] = bilin_setup(xn, yn, p.hf, p.wf, p.hf == p.H && p.wf == p.W);
       bimg_e[t] = bilin_setup(xn, yn, p.H, p.W, true);
     }
     if (DBG && store_ok) {
-      const size_t o = (size_t)v * npts + pt;
+      const size_t o = (size_t)(vb + v) * npts + pt;
       if (sdbg[0] && half == 0) { sdbg[0][o * 2] = px; sdbg[0][o * 2 + 1] = py; }
       if (sdbg[1] && half == 0) sdbg[1][o] = r;
       if (sdbg[2] && half == 0) for (int c = 0; c < 4; ++c) sdbg[2][o * 4 + c] = vs[v].dd[c];
-      if (sdbg[5]) dump_tile32(sdbg[5] + o * 32, gather32(p.ray_feats + (size_t)v * p.hr * p.wr * 32, brf[t], half), half);
+      if (sdbg[5]) dump_tile32(sdbg[5] + o * 32, gather32(p.ray_feats + (size_t)(vb + v) * p.hr * p.wr * 32, brf[t], half), half);
     }
   }
 
@@ -753,21 +761,21 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
   };
   if constexpr (kDedupe) {
     float visib, hitp;
-    prob_of(V0 + half, half ? dv[1] : dv[0], hm, visib, hitp);
+    prob_of(vb + V0 + half, half ? dv[1] : dv[0], hm, visib, hitp);
     // half 0 holds (hit, vis) of view V0, half 1 of view V0+1; one swap puts hit into the lower and vis into the upper
     // half of each view's register, which is exactly the operand layout prob_embed.0 wants
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint((hitp - 0.5f) * 2.f), __float_as_uint((visib - 0.5f) * 2.f), false, false);
     hvs[0] = __uint_as_float(r[0]);
     hvs[1] = __uint_as_float(r[1]);
     if (DBG && store_ok) {
-      const size_t o = (size_t)(V0 + half) * npts + pt;
+      const size_t o = (size_t)(vb + V0 + half) * npts + pt;
       if (sdbg[3]) sdbg[3][o] = visib;
       if (sdbg[4]) sdbg[4][o] = hitp;
     }
   } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int v = V0 + t;
+      const int v = vb + V0 + t;
       float visib, hitp;
       prob_of(v, dv[t], head[t], visib, hitp);
       hvs[t] = half ? (visib - 0.5f) * 2.f : (hitp - 0.5f) * 2.f;
@@ -807,7 +815,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
       mfma_layer<16, 1, NT, true>(W + layer_a_off(L_PE2), W + layer_b_off(L_PE2), lane, b2, a2, W + layer_h_off(L_PE2), PGRF_LIMG(L_PE2));
       if (store_ok)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) dump_tile32(sdbg[8] + (pt * V + (V0 + t)) * 32, a2[t][0], half);
+        for (int t = 0; t < NT; ++t) dump_tile32(sdbg[8] + (pt * VT + (vb + V0 + t)) * 32, a2[t][0], half);
     }
   }
   PGRF_TICK(19);  // A: prob_embed
@@ -818,7 +826,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int s = 0; s < 16; ++s) b16[t][s] = vs[V0 + t].nf[s];
-    const float wgt = 1.f / ((float)V + 1e-8f);
+    const float wgt = 1.f / ((float)VT + 1e-8f);
     if constexpr (kSmallV<V>) {
       float o8[NT][8];
       mfma_small<16, 2, NT>(W + OFF_S_NF1_A, W + OFF_S_NF1_B, lane, b16, o8);
@@ -887,8 +895,8 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
         bfeat[t] = bfeat_e[t];
         bimg[t] = bimg_e[t];
       }
-      const f32x16 imf = gather32<32, kBatchGather>(p.img_feats + (size_t)v * p.hf * p.wf * 32, bfeat[t], half);
-      const float* ib = p.imgs + (size_t)v * p.H * p.W * 4;
+      const f32x16 imf = gather32<32, kBatchGather>(p.img_feats + (size_t)(vb + v) * p.hf * p.wf * 32, bfeat[t], half);
+      const float* ib = p.imgs + (size_t)(vb + v) * p.H * p.W * 4;
       const float4 c00 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o00 * 4);
       const float4 c01 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o01 * 4);
       const float4 c10 = *reinterpret_cast<const float4*>(ib + (size_t)bimg[t].o10 * 4);
@@ -901,7 +909,7 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #pragma unroll
       for (int c = 0; c < 3; ++c) vs[v].fb[c] = vs[v].rgb[c] + elu1(rgbdir[t][c]);
       if (DBG && store_ok) {
-        const size_t o = (size_t)v * npts + pt;
+        const size_t o = (size_t)(vb + v) * npts + pt;
         if (sdbg[7]) dump_tile32(sdbg[7] + o * 32, imf, half);
         if (sdbg[6] && half == 0) for (int c = 0; c < 3; ++c) sdbg[6][o * 3 + c] = vs[v].rgb[c];
       }
@@ -911,12 +919,12 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 
 // ---------------------------------------------------------------------------------------------
 // Stage C for NT views: base_fc (per-view part, onto the shared partial G), vis_fc, vis_fc2.
-template <int V, int V0, int NT, bool DBG>
+template <int V, int V0, int NT, bool DBG, int VT = V>
 __device__ __forceinline__ void stage_mid(const PassArgs& p, const float* LI, const f32x16 (&G)[2], ViewState (&vs)[V], int lane,
-                                          size_t pt, bool store_ok, float* const* sdbg) {
+                                          size_t pt, bool store_ok, float* const* sdbg, int vb = 0) {
   const int half = lane >> 5;
   const float* __restrict__ W = p.blob;
-  const float wgt = 1.f / ((float)V + 1e-8f);
+  const float wgt = 1.f / ((float)VT + 1e-8f);
   if constexpr (kRecomputeNf<V>) {
     const float a16 = kHasImg<V> ? (LI + img_layer_off(L_PE1, kImgMode<V>))[lane * 4]
                                  : reinterpret_cast<const float4*>(W + layer_a_off(L_PE1))[4 * 64 + lane].x;
@@ -924,7 +932,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const float* LI, co
     for (int t = 0; t < NT; ++t) {
       const int v = V0 + t;
       const Bilin b = bilin_setup(vs[v].xn, vs[v].yn, p.hr, p.wr, p.hr == p.H && p.wr == p.W);
-      const f32x16 pe = gather32<kPrjCh>(p.prj + (size_t)v * p.hr * p.wr * kPrjCh + 3 * 32, b, half);
+      const f32x16 pe = gather32<kPrjCh>(p.prj + (size_t)(vb + v) * p.hr * p.wr * kPrjCh + 3 * 32, b, half);
       const f32x16 a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a16, vs[v].hv, pe, 0, 0, 0);
 #pragma unroll
       for (int s = 0; s < 16; ++s) vs[v].nf[s] = fmaxf(a1[s], 0.f);
@@ -961,7 +969,7 @@ __device__ __forceinline__ void stage_mid(const PassArgs& p, const float* LI, co
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       elu16(x[t][0]);
-      if (DBG && store_ok && sdbg[9]) dump_tile32(sdbg[9] + (pt * V + (V0 + t)) * 32, x[t][0], half);
+      if (DBG && store_ok && sdbg[9]) dump_tile32(sdbg[9] + (pt * VT + (vb + V0 + t)) * 32, x[t][0], half);
     }
   }
   // vis_fc(x * weight): 32 -> 32 elu -> 33 elu; x += x_res; vis = sigmoid(.)   (ibrnet.py:347-350)
@@ -1069,6 +1077,237 @@ template <int V> constexpr int kNT0 = (V <= 3 || !kTwoWave<V>) ? V : 2;
 #endif
 constexpr int kKStride = 17;   // K rows in LDS: odd stride -> conflict-free column reads (A operand)
 constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast float4 reads
+
+// ---------------------------------------------------------------------------------------------
+// Per-point tail of stage D: geometry_fc.0 pre-activations `g1` -> geometry_fc.2 -> positional encoding -> q|k|v -> 4-head
+// attention over the samples of the ray (K, V of the workgroup's points in LDS) -> fc + LayerNorm -> out_geometry_fc -> density.
+// pt_local = the point's row in lds_k / lds_v, key_base = first row of its ray.  Contains one workgroup barrier.
+template <int KT, int V, bool DBG, int VT = V>
+__device__ __forceinline__ float point_tail(const PassArgs& p, const float* LI, const f32x16 (&g1)[1][2], int lane, int si, size_t pt,
+                                            int pt_local, int key_base, float* lds_k, float* lds_v, bool store_ok, float* const* sdbg
+#ifdef PGRF_STAGE_TIMING
+                                            , unsigned long long& t_prev
+#endif
+                                            ) {
+  const int half = lane >> 5;
+  const int pl = lane & 31;
+  const float* __restrict__ W = p.blob;
+  float b32[1][32];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) { b32[0][s] = elu1(g1[0][0][s]); b32[0][16 + s] = elu1(g1[0][1][s]); }
+  f32x16 g2[1][1];
+  mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2, W + layer_h_off(L_G2), PGRF_LIMG(L_G2));
+  float gp[1][8];     // geometry feature + positional encoding (ibrnet.py:356-358)
+  {
+    const float4* pp = reinterpret_cast<const float4*>(W + OFF_POS + si * 16 + half * 8);
+    const float4 p0 = pp[0], p1 = pp[1];
+    const float pe[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float ge = elu1(g2[0][0][r]);
+      g2[0][0][r] = ge;
+      gp[0][r] = ge + pe[r];
+    }
+    if (DBG && store_ok && sdbg[10]) dump_tile16(sdbg[10] + pt * 16, g2[0][0], half);
+  }
+  // q|k and v projections (ibrnet.py:80-82); rows permuted so register 2*head+s carries dims (2s,2s+1)
+  f32x16 qkv[1][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { qkv[0][0][r] = 0.f; qkv[0][1][r] = 0.f; }   // no bias on w_qs/w_ks/w_vs
+  mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv, W + layer_h_off(L_QKV), PGRF_LIMG(L_QKV));
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
+    lds_v[pt_local * kVStride + 2 * r + half] = qkv[0][1][r];
+  }
+  PGRF_TICK(4);   // stage D up to the q/k/v projections
+  PGRF_SYNC();
+  PGRF_TICK(5);   // barrier wait
+  float oatt[16];
+#pragma unroll
+  for (int hd = 0; hd < 4; ++hd) {
+    f32x16 S[KT];
+#pragma unroll
+    for (int k2 = 0; k2 < KT; ++k2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[k2][r] = 0.f;
+      // One source view: the reference masks the attention with (num_valid_obs > 1), which is false everywhere, and
+      // masked_fill(mask == 0, -1e9) makes every logit equal (ibrnet.py:20,358-360): uniform weights, the output is
+      // the mean of V over the ray's samples.  Equal logits = the zero-initialised S, so the products are skipped.
+      if constexpr (VT > 1)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float a = lds_k[(key_base + k2 * 32 + pl) * kKStride + hd * 4 + 2 * s + half];
+        // q / temperature (sqrt(d_k) = 2), times log2(e) so that the softmax below is a bare v_exp_f32
+        const float q = qkv[0][0][2 * hd + s] * (0.5f * 1.4426950408889634f);
+        S[k2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, q, S[k2], 0, 0, 0);
+      }
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k2 = 0; k2 < KT; ++k2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[k2][r]);
+    mx = xmax(mx);
+    float l = 0.f, o0, o1, o2, o3;
+#ifndef PGRF_PV_MFMA
+#if PGRF_PV_PACKED
+    {
+      // the four value dimensions of a head as two v_pk_fma_f32 (5.1 cycles per pair against 2 x 4.4 for v_fmac: tools/ubench/valu_rates)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
+#pragma unroll
+      for (int k2 = 0; k2 < KT; ++k2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
+          const float4 vv = *reinterpret_cast<const float4*>(&lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4]);
+          l += pe;
+          const f32x2 pp = {pe, pe};
+          o01 = __builtin_elementwise_fma(pp, (f32x2){vv.x, vv.y}, o01);
+          o23 = __builtin_elementwise_fma(pp, (f32x2){vv.z, vv.w}, o23);
+        }
+      o0 = o01[0]; o1 = o01[1]; o2 = o23[0]; o3 = o23[1];
+    }
+#else
+    o0 = o1 = o2 = o3 = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < KT; ++k2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
+        const float4 vv = *reinterpret_cast<const float4*>(&lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4]);
+        l += pe;
+        o0 = fmaf(pe, vv.x, o0); o1 = fmaf(pe, vv.y, o1); o2 = fmaf(pe, vv.z, o2); o3 = fmaf(pe, vv.w, o3);
+      }
+#endif
+#else
+    // experiment (measured slower: 38.2 -> 39.0 ms): softmax-weighted values on v_mfma_f32_4x4x1_16b_f32: block = 4
+    // consecutive lanes = 4 queries with the SAME key (k2, r, half); B = the lane's own weight for that key, A = value
+    // dimension (lane & 3) of that key, so D leaves the 4 output dimensions of the lane's own query in registers 0..3.
+    {
+      f32x4 ov[KT];
+#pragma unroll
+      for (int k2 = 0; k2 < KT; ++k2) ov[k2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int k2 = 0; k2 < KT; ++k2) {
+          const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
+          const float vd = lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4 + (lane & 3)];
+          l += pe;
+          ov[k2] = __builtin_amdgcn_mfma_f32_4x4x1f32(vd, pe, ov[k2], 0, 0, 0);
+        }
+#pragma unroll
+      for (int k2 = 1; k2 < KT; ++k2) ov[0] += ov[k2];
+      o0 = ov[0][0]; o1 = ov[0][1]; o2 = ov[0][2]; o3 = ov[0][3];
+    }
+#endif
+    l = xsum(l);
+    o0 = xsum(o0); o1 = xsum(o1); o2 = xsum(o2); o3 = xsum(o3);
+    const float rl = rcp1(l);
+    oatt[hd * 4 + 0] = o0 * rl; oatt[hd * 4 + 1] = o1 * rl; oatt[hd * 4 + 2] = o2 * rl; oatt[hd * 4 + 3] = o3 * rl;
+  }
+  PGRF_TICK(6);   // attention
+  // fc + residual + LayerNorm(eps 1e-6)  (ibrnet.py:95-102)
+  float bo[1][8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bo[0][s] = half ? oatt[4 * (s >> 1) + 2 * (s & 1) + 1] : oatt[4 * (s >> 1) + 2 * (s & 1)];
+  f32x16 fo[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) fo[0][0][r] = (r < 8) ? gp[0][r < 8 ? r : 0] : 0.f;     // residual as the initial accumulator
+  mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo, W + layer_h_off(L_FC), PGRF_LIMG(L_FC));
+  float ln[1][8];
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sum += fo[0][0][r];
+    sum = xsum(sum);
+    const float mean = sum * 0.0625f;
+    float sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const float d = fo[0][0][r] - mean; sq += d * d; }
+    sq = xsum(sq);
+    const float rstd = __builtin_amdgcn_rsqf(sq * 0.0625f + 1e-6f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      ln[0][r] = (fo[0][0][r] - mean) * rstd * W[OFF_LN_G + half * 8 + r] + W[OFF_LN_B + half * 8 + r];
+    if (DBG && store_ok && sdbg[11]) {
+      f32x16 tmp;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) tmp[r] = ln[0][r];
+      dump_tile16(sdbg[11] + pt * 16, tmp, half);
+    }
+  }
+  // out_geometry_fc 16 -> 16 elu -> 1 relu  (ibrnet.py:361)
+  f32x16 og[1][1];
+  mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og, W + layer_h_off(L_OG1), PGRF_LIMG(L_OG1));
+#pragma unroll
+  for (int r = 0; r < 8; ++r) og[0][0][r] = elu1(og[0][0][r]);
+  return fmaxf(head_dot<8>(PGRF_LHEAD(OFF_OGH_W), half, og[0][0]) + W[OFF_OGH_B], 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage F: alpha compositing along the ray.  slot = the 32-sample tile's index inside the workgroup (tiles of one ray are
+// consecutive slots, kt = the tile's position on its ray).  Contains two workgroup barriers.
+template <int KT, int V>
+__device__ __forceinline__ void composite(const PassArgs& p, float sigma, const float (&col)[3], float tdepth, int lane, int slot, int kt,
+                                          int ray, size_t pt, bool store_ok, float* lds_alpha, float (*lds_red)[4]
+#ifdef PGRF_STAGE_TIMING
+                                          , unsigned long long& t_prev
+#endif
+                                          ) {
+  const int half = lane >> 5;
+  const int pl = lane & 31;
+  // ---- stage F: alpha compositing along the ray (renderer.py:216-218,291-304; render_ops.py:145-153)
+  const float alpha = 1.f - __expf(-fmaxf(sigma, 0.f));
+  // transmittance T(i) = prod_{j<i} (1 - alpha_j + 1e-10): inclusive product scan over the wave's 32 samples (both lane
+  // halves carry the same value), then the totals of the ray's earlier waves through LDS
+  float incl = 1.f - alpha + 1e-10f;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const float up = __shfl_up(incl, off, 32);
+    if (pl >= off) incl *= up;
+  }
+  float T = __shfl_up(incl, 1, 32);
+  if (pl == 0) T = 1.f;
+  if (KT > 1) {
+    if (lane == 31) lds_alpha[slot] = incl;
+    PGRF_SYNC();
+  }
+  PGRF_TICK(10);  // composite: barrier
+#pragma unroll
+  for (int k2 = 0; k2 < KT - 1; ++k2)
+    if (k2 < kt) T *= lds_alpha[slot - kt + k2];
+  const float hit = alpha * T;
+  // NaN report (the reference's ipdb breakpoints): a NaN in density, colour or weight of any sample sets the flag
+  if (p.nan_flag && store_ok && (hit != hit || sigma != sigma || col[0] != col[0] || col[1] != col[1] || col[2] != col[2]))
+    *p.nan_flag = 1;
+  PGRF_TICK(11);  // composite: transmittance scan
+  if (store_ok && half == 0) {
+    if (p.out_hit) p.out_hit[pt] = hit;
+    if (p.out_density) p.out_density[pt] = sigma;
+    if (p.out_colors) { p.out_colors[pt * 3] = col[0]; p.out_colors[pt * 3 + 1] = col[1]; p.out_colors[pt * 3 + 2] = col[2]; }
+  }
+  PGRF_TICK(12);  // composite: per-point stores
+  float acc4[4] = {hit * col[0], hit * col[1], hit * col[2], hit * tdepth};
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc4[c] += __shfl_xor(acc4[c], off, 64);
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds_red[slot][c] = acc4[c];
+  PGRF_SYNC();
+  if (kt == 0 && lane < 4 && store_ok) {
+    float s = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < KT; ++k2) s += lds_red[slot + k2][lane];
+    if (lane < 3) { if (p.out_pixel) p.out_pixel[(size_t)ray * 3 + lane] = s; }
+    else if (p.out_depth) p.out_depth[ray] = s;
+  }
+  PGRF_TICK(9);   // composite
+}
 
 // GEN = false: the m3d ERP convention only (the shipped configuration; the other conventions and the pinhole branch
 // compiled in cost 1.2 % through 5 more spilled registers); GEN = true: run-time switch over PgrfFrame.dataset /
@@ -1323,160 +1562,11 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
     b33[0][32] = wmean;
     f32x16 g1[1][2];
     mfma_layer<33, 2, 1, true>(W + layer_a_off(L_G1), W + layer_b_off(L_G1), lane, b33, g1, W + layer_h_off(L_G1), PGRF_LIMG(L_G1));
-    float b32[1][32];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) { b32[0][s] = elu1(g1[0][0][s]); b32[0][16 + s] = elu1(g1[0][1][s]); }
-    f32x16 g2[1][1];
-    mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2, W + layer_h_off(L_G2), PGRF_LIMG(L_G2));
-    float gp[1][8];     // geometry feature + positional encoding (ibrnet.py:356-358)
-    {
-      const float4* pp = reinterpret_cast<const float4*>(W + OFF_POS + si * 16 + half * 8);
-      const float4 p0 = pp[0], p1 = pp[1];
-      const float pe[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float ge = elu1(g2[0][0][r]);
-        g2[0][0][r] = ge;
-        gp[0][r] = ge + pe[r];
-      }
-      if (DBG && store_ok && sdbg[10]) dump_tile16(sdbg[10] + pt * 16, g2[0][0], half);
-    }
-    // q|k and v projections (ibrnet.py:80-82); rows permuted so register 2*head+s carries dims (2s,2s+1)
-    f32x16 qkv[1][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { qkv[0][0][r] = 0.f; qkv[0][1][r] = 0.f; }   // no bias on w_qs/w_ks/w_vs
-    mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv, W + layer_h_off(L_QKV), PGRF_LIMG(L_QKV));
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
-      lds_v[pt_local * kVStride + 2 * r + half] = qkv[0][1][r];
-    }
-    PGRF_TICK(4);   // stage D up to the q/k/v projections
-    PGRF_SYNC();
-    PGRF_TICK(5);   // barrier wait
-    float oatt[16];
-    const int key_base = ray_local * DN;
-#pragma unroll
-    for (int hd = 0; hd < 4; ++hd) {
-      f32x16 S[KT];
-#pragma unroll
-      for (int k2 = 0; k2 < KT; ++k2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[k2][r] = 0.f;
-        // One source view: the reference masks the attention with (num_valid_obs > 1), which is false everywhere, and
-        // masked_fill(mask == 0, -1e9) makes every logit equal (ibrnet.py:20,358-360): uniform weights, the output is
-        // the mean of V over the ray's samples.  Equal logits = the zero-initialised S, so the products are skipped.
-        if constexpr (V > 1)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const float a = lds_k[(key_base + k2 * 32 + pl) * kKStride + hd * 4 + 2 * s + half];
-          // q / temperature (sqrt(d_k) = 2), times log2(e) so that the softmax below is a bare v_exp_f32
-          const float q = qkv[0][0][2 * hd + s] * (0.5f * 1.4426950408889634f);
-          S[k2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, q, S[k2], 0, 0, 0);
-        }
-      }
-      float mx = -3.0e38f;
-#pragma unroll
-      for (int k2 = 0; k2 < KT; ++k2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[k2][r]);
-      mx = xmax(mx);
-      float l = 0.f, o0, o1, o2, o3;
-#ifndef PGRF_PV_MFMA
-#if PGRF_PV_PACKED
-      {
-        // the four value dimensions of a head as two v_pk_fma_f32 (5.1 cycles per pair against 2 x 4.4 for v_fmac: tools/ubench/valu_rates)
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
-#pragma unroll
-        for (int k2 = 0; k2 < KT; ++k2)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
-            const float4 vv = *reinterpret_cast<const float4*>(&lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4]);
-            l += pe;
-            const f32x2 pp = {pe, pe};
-            o01 = __builtin_elementwise_fma(pp, (f32x2){vv.x, vv.y}, o01);
-            o23 = __builtin_elementwise_fma(pp, (f32x2){vv.z, vv.w}, o23);
-          }
-        o0 = o01[0]; o1 = o01[1]; o2 = o23[0]; o3 = o23[1];
-      }
-#else
-      o0 = o1 = o2 = o3 = 0.f;
-#pragma unroll
-      for (int k2 = 0; k2 < KT; ++k2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
-          const float4 vv = *reinterpret_cast<const float4*>(&lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4]);
-          l += pe;
-          o0 = fmaf(pe, vv.x, o0); o1 = fmaf(pe, vv.y, o1); o2 = fmaf(pe, vv.z, o2); o3 = fmaf(pe, vv.w, o3);
-        }
+    sigma = point_tail<KT, V, DBG>(p, LI, g1, lane, si, pt, pt_local, ray_local * DN, lds_k, lds_v, store_ok, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                  , t_prev
 #endif
-#else
-      // experiment (measured slower: 38.2 -> 39.0 ms): softmax-weighted values on v_mfma_f32_4x4x1_16b_f32: block = 4
-      // consecutive lanes = 4 queries with the SAME key (k2, r, half); B = the lane's own weight for that key, A = value
-      // dimension (lane & 3) of that key, so D leaves the 4 output dimensions of the lane's own query in registers 0..3.
-      {
-        f32x4 ov[KT];
-#pragma unroll
-        for (int k2 = 0; k2 < KT; ++k2) ov[k2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-          for (int k2 = 0; k2 < KT; ++k2) {
-            const float pe = __builtin_amdgcn_exp2f(S[k2][r] - mx);
-            const float vd = lds_v[(key_base + k2 * 32 + rho(r, half)) * kVStride + hd * 4 + (lane & 3)];
-            l += pe;
-            ov[k2] = __builtin_amdgcn_mfma_f32_4x4x1f32(vd, pe, ov[k2], 0, 0, 0);
-          }
-#pragma unroll
-        for (int k2 = 1; k2 < KT; ++k2) ov[0] += ov[k2];
-        o0 = ov[0][0]; o1 = ov[0][1]; o2 = ov[0][2]; o3 = ov[0][3];
-      }
-#endif
-      l = xsum(l);
-      o0 = xsum(o0); o1 = xsum(o1); o2 = xsum(o2); o3 = xsum(o3);
-      const float rl = rcp1(l);
-      oatt[hd * 4 + 0] = o0 * rl; oatt[hd * 4 + 1] = o1 * rl; oatt[hd * 4 + 2] = o2 * rl; oatt[hd * 4 + 3] = o3 * rl;
-    }
-    PGRF_TICK(6);   // attention
-    // fc + residual + LayerNorm(eps 1e-6)  (ibrnet.py:95-102)
-    float bo[1][8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) bo[0][s] = half ? oatt[4 * (s >> 1) + 2 * (s & 1) + 1] : oatt[4 * (s >> 1) + 2 * (s & 1)];
-    f32x16 fo[1][1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) fo[0][0][r] = (r < 8) ? gp[0][r < 8 ? r : 0] : 0.f;     // residual as the initial accumulator
-    mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo, W + layer_h_off(L_FC), PGRF_LIMG(L_FC));
-    float ln[1][8];
-    {
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) sum += fo[0][0][r];
-      sum = xsum(sum);
-      const float mean = sum * 0.0625f;
-      float sq = 0.f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) { const float d = fo[0][0][r] - mean; sq += d * d; }
-      sq = xsum(sq);
-      const float rstd = __builtin_amdgcn_rsqf(sq * 0.0625f + 1e-6f);
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        ln[0][r] = (fo[0][0][r] - mean) * rstd * W[OFF_LN_G + half * 8 + r] + W[OFF_LN_B + half * 8 + r];
-      if (DBG && store_ok && sdbg[11]) {
-        f32x16 tmp;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) tmp[r] = ln[0][r];
-        dump_tile16(sdbg[11] + pt * 16, tmp, half);
-      }
-    }
-    // out_geometry_fc 16 -> 16 elu -> 1 relu  (ibrnet.py:361)
-    f32x16 og[1][1];
-    mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og, W + layer_h_off(L_OG1), PGRF_LIMG(L_OG1));
-#pragma unroll
-    for (int r = 0; r < 8; ++r) og[0][0][r] = elu1(og[0][0][r]);
-    sigma = fmaxf(head_dot<8>(PGRF_LHEAD(OFF_OGH_W), half, og[0][0]) + W[OFF_OGH_B], 0.f);
+    );
   }
   PGRF_TICK(7);   // fc + LayerNorm + density head
 
@@ -1521,62 +1611,389 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
   PGRF_TICK(8);   // stage E
 
   if constexpr (V > 2) __builtin_amdgcn_sched_barrier(0);   // V>2: keep the stages apart (cross-stage interleaving made the compiler spill 342 VGPRs)
-  // ---- stage F: alpha compositing along the ray (renderer.py:216-218,291-304; render_ops.py:145-153)
-  const float alpha = 1.f - __expf(-fmaxf(sigma, 0.f));
-  // transmittance T(i) = prod_{j<i} (1 - alpha_j + 1e-10): inclusive product scan over the wave's 32 samples (both lane
-  // halves carry the same value), then the totals of the ray's earlier waves through LDS
-  float incl = 1.f - alpha + 1e-10f;
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    const float up = __shfl_up(incl, off, 32);
-    if (pl >= off) incl *= up;
-  }
-  float T = __shfl_up(incl, 1, 32);
-  if (pl == 0) T = 1.f;
-  if (KT > 1) {
-    if (lane == 31) lds_alpha[wave] = incl;
-    PGRF_SYNC();
-  }
-  PGRF_TICK(10);  // composite: barrier
-#pragma unroll
-  for (int k2 = 0; k2 < KT - 1; ++k2)
-    if (k2 < kt) T *= lds_alpha[ray_local * KT + k2];
-  const float hit = alpha * T;
-  // NaN report (the reference's ipdb breakpoints): a NaN in density, colour or weight of any sample sets the flag
-  if (p.nan_flag && store_ok && (hit != hit || sigma != sigma || col[0] != col[0] || col[1] != col[1] || col[2] != col[2]))
-    *p.nan_flag = 1;
-  PGRF_TICK(11);  // composite: transmittance scan
-  if (store_ok && half == 0) {
-    if (p.out_hit) p.out_hit[pt] = hit;
-    if (p.out_density) p.out_density[pt] = sigma;
-    if (p.out_colors) { p.out_colors[pt * 3] = col[0]; p.out_colors[pt * 3 + 1] = col[1]; p.out_colors[pt * 3 + 2] = col[2]; }
-  }
-  PGRF_TICK(12);  // composite: per-point stores
-  float acc4[4] = {hit * col[0], hit * col[1], hit * col[2], hit * tdepth};
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc4[c] += __shfl_xor(acc4[c], off, 64);
-  if (lane == 0)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) lds_red[wave][c] = acc4[c];
-  PGRF_SYNC();
-  if (kt == 0 && lane < 4 && store_ok) {
-    float s = 0.f;
-#pragma unroll
-    for (int k2 = 0; k2 < KT; ++k2) s += lds_red[wave + k2][lane];
-    if (lane < 3) { if (p.out_pixel) p.out_pixel[(size_t)ray * 3 + lane] = s; }
-    else if (p.out_depth) p.out_depth[ray] = s;
-  }
-  PGRF_TICK(9);   // composite
+  composite<KT, V>(p, sigma, col, tdepth, lane, wave, kt, ray, pt, store_ok, lds_alpha, lds_red
+#ifdef PGRF_STAGE_TIMING
+                   , t_prev
+#endif
+  );
 }
+
+// =============================================================================================
+// 4 source views on WAVE PAIRS (round 4).  render_pass_kernel gives a wave all V views of its 32 samples; at V = 4 that is two
+// view pairs one after the other with the first pair's state live across the second pair's front end: 157 spilled registers and
+// 9-12 points of the roofline behind the 2-view kernel, unmoved by two rounds of in-wave rescheduling (profiles/r03_dead_ends.txt).
+// Here a 32-sample tile belongs to TWO waves: role 0 holds views 0, 1 and role 1 views 2, 3 -- each with the register picture of
+// the 2-view kernel (V = 2 policies of the stage functions, VT = 4, vb = first view) -- and what couples the views goes through LDS:
+//   stage B  the view statistics of feature j need x_v[j] of all four views: role 0 takes j in [0, 8), role 1 j in [8, 16) and the
+//            colour channels; each wave sends the other the half of its two tiles that the other owns (+ its w0), computes ITS
+//            statistics in the reference's view order, multiplies them with ITS k-steps of the shared base_fc.0 block (a K split:
+//            32 | 38 of the 70 k-steps) and the two partial [64 x 32] products are exchanged and added;
+//   stage D  the same for the pooled geometry feature (vis weights of the four views, weighted mean / variance of x) and
+//            geometry_fc.0 (16 | 17 of 33 k-steps);
+//   stage E  role 1 hands over its two blending logits and colours.
+// The per-point tail (geometry_fc.2 ... density, ~7 % of the multiply-adds at four views) and the composite run in both waves;
+// role 0 stores.  Workgroup = 4 waves = 2 tiles = 64 points; K / V of the ray attention share the LDS rows of the x exchange.
+constexpr int kPairXRows = 22;
+constexpr int kPairGRows = 32;
+
+// k-steps of a K-split layer: the wave's i-th A chunk (four k-steps) is chunk `CH(i)` of the layer's block
+template <int NCH, int MT, int KS, class CH>
+__device__ __forceinline__ void mfma_chunks(const float* __restrict__ A, int lane, const float (&b)[NCH * 4], f32x16 (&acc)[MT], CH chunk_of) {
+  constexpr int KS4 = (KS + 3) / 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = chunk_of(i);
+      const float4 a = reinterpret_cast<const float4*>(A)[(m * KS4 + c) * 64 + lane];
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c * 4 + j < KS) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[i * 4 + j], acc[m], 0, 0, 0);
+    }
+  }
+}
+// accumulator tiles start from the bias (role 0) or from zero (role 1): the partial products are added afterwards
+template <int ROLE, int MT>
+__device__ __forceinline__ void pair_acc_init(const float* __restrict__ B, int lane, f32x16 (&acc)[MT]) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if constexpr (ROLE == 0) {
+      const float4* bp = reinterpret_cast<const float4*>(B + m * 32 + (lane >> 5) * 16);
+      const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+      acc[m] = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    }
+  }
+}
+// values of the four views in the reference's order from (own pair, partner's pair)
+template <int ROLE>
+__device__ __forceinline__ void pair_order(float o0, float o1, float r0, float r1, float (&x)[4]) {
+  if constexpr (ROLE == 0) { x[0] = o0; x[1] = o1; x[2] = r0; x[3] = r1; }
+  else { x[0] = r0; x[1] = r1; x[2] = o0; x[3] = o1; }
+}
+
+// stage B, sending half: the features the PARTNER computes statistics of
+template <int ROLE>
+__device__ __forceinline__ void pair_send_feats(const ViewState (&vs)[2], float (*xb)[256], int tid, int half, bool with_colour) {
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xb[v * 8 + i][tid] = vs[v].fa[ROLE == 0 ? 8 + i : i];
+    if (ROLE == 0 && with_colour) {
+      xb[16 + v][tid] = half ? vs[v].fb[1] : vs[v].fb[0];
+      xb[18 + v][tid] = vs[v].fb[2];
+    }
+  }
+}
+
+// stage B, receiving half: statistics of this wave's features over the four views and its k-steps of base_fc.0's shared block
+template <int ROLE>
+__device__ __forceinline__ void pair_shared_base(const PassArgs& p, const ViewState (&vs)[2], float (*xb)[256], int lane, int tid,
+                                                 f32x16 (&G)[2]) {
+  const int half = lane >> 5, pt = tid ^ 64;      // pt = the partner's column
+  const float* __restrict__ W = p.blob;
+  const float wgt = 1.f / (4.f + 1e-8f);
+  float w0a[4], w1a[4] = {wgt, wgt, wgt, wgt};
+  pair_order<ROLE>(vs[0].w0, vs[1].w0, xb[20][pt], xb[21][pt], w0a);
+  auto stats = [&](const float (&xv)[4], const float (&wa)[4], float& m, float& var) {
+    m = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) m += xv[v] * wa[v];
+    var = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const float d = xv[v] - m; var += wa[v] * (d * d); }
+  };
+  constexpr int NCH = ROLE == 0 ? 8 : 10;
+  float bop[NCH * 4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float xv[4];
+    pair_order<ROLE>(vs[0].fa[ROLE * 8 + i], vs[1].fa[ROLE * 8 + i], xb[i][pt], xb[8 + i][pt], xv);
+    stats(xv, w0a, bop[i], bop[8 + i]);
+    stats(xv, w1a, bop[16 + i], bop[24 + i]);
+  }
+  if constexpr (ROLE == 1) {
+    float xv[4], wsel[4];
+    pair_order<ROLE>(half ? vs[0].fb[1] : vs[0].fb[0], half ? vs[1].fb[1] : vs[1].fb[0], xb[16][pt], xb[17][pt], xv);
+    stats(xv, w0a, bop[32], bop[33]);
+    stats(xv, w1a, bop[34], bop[35]);
+    pair_order<ROLE>(vs[0].fb[2], vs[1].fb[2], xb[18][pt], xb[19][pt], xv);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) wsel[v] = half ? wgt : w0a[v];
+    stats(xv, wsel, bop[36], bop[37]);
+    bop[38] = bop[39] = 0.f;
+  }
+  pair_acc_init<ROLE, 2>(W + layer_b_off(L_BG), lane, G);
+  // this wave's k-steps of the block (k-step order of L_BG: mean0 | var0 | mean1 | var1 of the 16 feature registers, then colours)
+  mfma_chunks<NCH, 2, 70>(W + layer_a_off(L_BG), lane, bop, G, [](int i) { return i < 8 ? 4 * (i >> 1) + (i & 1) + 2 * ROLE : 8 + i; });
+}
+
+// stage D, receiving half: vis weights, pooled statistics of this wave's features of x, its k-steps of geometry_fc.0
+template <int ROLE>
+__device__ __forceinline__ void pair_geometry(const PassArgs& p, const ViewState (&vs)[2], float (*xb)[256], int lane, int tid,
+                                              f32x16 (&g1)[2]) {
+  const int pt = tid ^ 64;
+  const float* __restrict__ W = p.blob;
+  float v2a[4];
+  pair_order<ROLE>(vs[0].v2, vs[1].v2, xb[20][pt], xb[21][pt], v2a);
+  float vsum = 0.f;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) vsum += v2a[v];
+  const float rvs = rcp1(vsum + 1e-8f);
+  float w2[4], wmean = 0.f;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { w2[v] = v2a[v] * rvs; wmean += w2[v]; }
+  wmean = wmean / 4.f;
+  constexpr int NCH = ROLE == 0 ? 4 : 5;
+  float bop[NCH * 4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float xr[4];
+    pair_order<ROLE>(vs[0].fa[ROLE * 8 + i], vs[1].fa[ROLE * 8 + i], xb[i][pt], xb[8 + i][pt], xr);
+    float m = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) m += xr[v] * w2[v];
+    float var = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { const float d = xr[v] - m; var += w2[v] * (d * d); }
+    bop[i] = m;
+    bop[8 + i] = var;
+  }
+  if constexpr (ROLE == 1) { bop[16] = wmean; bop[17] = bop[18] = bop[19] = 0.f; }
+  pair_acc_init<ROLE, 2>(W + layer_b_off(L_G1), lane, g1);
+  mfma_chunks<NCH, 2, 33>(W + layer_a_off(L_G1), lane, bop, g1, [](int i) { return i < 4 ? 4 * (i >> 1) + (i & 1) + 2 * ROLE : 8; });
+}
+
+template <int KT, bool DBG, bool GEN>
+__global__ void __launch_bounds__(256, 2) render_pass_pair_kernel(const PassArgs p) {
+  static_assert(KT == 1 || KT == 2, "one workgroup = two 32-sample tiles");
+  constexpr int V = 2, VT = 4;         // V keys the per-instance policies of the stage functions (those of the 2-view kernels)
+  constexpr int DN = 32 * KT;
+  constexpr int RPW = 2 / KT;          // rays per workgroup
+  __shared__ __attribute__((aligned(16))) float lds_x[kPairXRows][256];    // x exchange; later K | V of the workgroup's 64 points
+  __shared__ __attribute__((aligned(16))) float lds_g[kPairGRows][256];    // partial-product exchange; later logits / colours
+  __shared__ float lds_park[V * 7][128];
+  __shared__ float lds_alpha[2];
+  __shared__ float lds_red[2][4];
+  __shared__ __attribute__((aligned(16))) float lds_img[img_floats(kImgMode<V>)];
+  static_assert(64 * (kKStride + kVStride) <= kPairXRows * 256, "K / V alias the x-exchange rows");
+  float* lds_k = &lds_x[0][0];
+  float* lds_v = lds_k + 64 * kKStride + ((64 * kKStride) & 3 ? 4 - ((64 * kKStride) & 3) : 0);
+  const float* LI = lds_img;
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.blob + img_blob_off(kImgMode<V>));
+    for (int i = threadIdx.x; i < img_floats(kImgMode<V>) / 4; i += 256) reinterpret_cast<float4*>(lds_img)[i] = src[i];
+  }
+  __shared__ float* lds_dbg[DBG ? 12 : 1];
+  float* const* sdbg = lds_dbg;
+  if (DBG) {
+    if (threadIdx.x < 12) lds_dbg[threadIdx.x] = reinterpret_cast<float* const*>(&p.dbg)[threadIdx.x];
+    __syncthreads();
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef PGRF_STAGE_TIMING
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave & 1, tile = wave >> 1;
+  const int vb = role * 2;
+  const int half = lane >> 5;
+  const int pl = lane & 31;
+  const int ray_local = tile / KT;
+  const int kt = tile % KT;
+  int wg = blockIdx.x;
+  if (!p.order_w) {     // XCD bands (see render_pass_kernel): kept from the one-wave-per-tile 4-view kernel
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int ray_raw = wg * RPW + ray_local;
+  if (p.order_w) {
+    const int per_tile = p.order_tw * p.order_th, tiles_x = p.order_w / p.order_tw;
+    const int t = ray_raw / per_tile, in = ray_raw - t * per_tile;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int iy = in / p.order_tw, ix = in - iy * p.order_tw;
+    ray_raw = (ty * p.order_th + iy) * p.order_w + tx * p.order_tw + ix;
+  }
+  const bool ray_ok = ray_raw < p.rn;
+  const int ray = ray_ok ? ray_raw : p.rn - 1;
+  const int si = kt * 32 + pl;
+  const int pt_local = tile * 32 + pl;
+  const size_t pt = (size_t)ray * DN + si;
+  const size_t npts = (size_t)p.rn * DN;
+
+  // ---- ray generation (as in render_pass_kernel)
+  PointGeom g;
+  float tdepth;
+  {
+    float wx, wy, wz;
+    if (p.raytab) {
+      const float4 rt = reinterpret_cast<const float4*>(p.raytab)[ray];
+      wx = rt.x; wy = rt.y; wz = rt.z;
+    } else {
+      ray_direction<GEN>(p, ray, wx, wy, wz);
+    }
+    const float* drow = p.depth + (size_t)ray * DN;
+    tdepth = drow[si];
+    g.p[0] = p.c2w[3] + wx * tdepth;
+    g.p[1] = p.c2w[7] + wy * tdepth;
+    g.p[2] = p.c2w[11] + wz * tdepth;
+    const float wn = sqrtf(wx * wx + wy * wy + wz * wz);
+    { const float rw = rcp1(wn); g.qdir[0] = -wx * rw; g.qdir[1] = -wy * rw; g.qdir[2] = -wz * rw; }
+    const float qn = -1.f / p.que_near, qf = -1.f / p.que_far;
+    const float d_c = (-1.f / tdepth - qn) / (qf - qn);
+    const float d_p = (-1.f / drow[max(si - 1, 0)] - qn) / (qf - qn);
+    const float d_n = (-1.f / drow[min(si + 1, DN - 1)] - qn) / (qf - qn);
+    const float dist_c = (si == DN - 1) ? 1e6f : d_n - d_c;
+    const float dist_p = (si == 0) ? dist_c : d_c - d_p;
+    g.near_hw = dist_p / 2.f;
+    g.far_hw = dist_c / 2.f;
+  }
+  ViewState vs[V];
+  const bool store_ok = ray_ok;              // debug dumps of the wave's own views
+  const bool store_pt = ray_ok && role == 0; // per-point results: one wave of the pair
+  __syncthreads();
+  PGRF_TICK(0);
+
+  // ---- stage A: this wave's two views
+  stage_front<V, 0, 2, DBG, GEN, VT>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                     , t_prev
+#endif
+                                     , vb);
+  PGRF_TICK(1);
+  const int park_col = wave * 32 + pl;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lds_park[v * 7 + c][park_col] = vs[v].dd[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lds_park[v * 7 + 4 + c][park_col] = vs[v].rgb[c];
+  }
+  // ---- stage B: view statistics + the shared block of base_fc.0, split between the waves of the pair
+  f32x16 G[1][2];
+  if (role == 0) pair_send_feats<0>(vs, lds_x, tid, half, true); else pair_send_feats<1>(vs, lds_x, tid, half, true);
+  lds_x[20][tid] = vs[0].w0;
+  lds_x[21][tid] = vs[1].w0;
+  __syncthreads();
+  if (role == 0) pair_shared_base<0>(p, vs, lds_x, lane, tid, G[0]); else pair_shared_base<1>(p, vs, lds_x, lane, tid, G[0]);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds_g[m * 16 + r][tid] = G[0][m][r];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[0][m][r] += lds_g[m * 16 + r][tid ^ 64];
+  PGRF_TICK(2);
+
+  // ---- stage C: per-view base_fc / vis_fc / vis_fc2 of this wave's views
+  stage_mid<V, 0, 2, DBG, VT>(p, LI, G[0], vs, lane, pt, store_ok, sdbg, vb);
+  PGRF_TICK(3);
+
+  // ---- stage D: pooled geometry feature and geometry_fc.0, split as stage B; then the per-point tail in both waves
+  float sigma;
+  {
+    f32x16 g1[1][2];
+    if (role == 0) pair_send_feats<0>(vs, lds_x, tid, half, false); else pair_send_feats<1>(vs, lds_x, tid, half, false);
+    lds_x[20][tid] = vs[0].v2;
+    lds_x[21][tid] = vs[1].v2;
+    __syncthreads();
+    if (role == 0) pair_geometry<0>(p, vs, lds_x, lane, tid, g1[0]); else pair_geometry<1>(p, vs, lds_x, lane, tid, g1[0]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds_g[m * 16 + r][tid] = g1[0][m][r];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g1[0][m][r] += lds_g[m * 16 + r][tid ^ 64];
+    // (the partner has read its x rows before the barrier above: K / V may overwrite them now)
+    sigma = point_tail<KT, V, DBG, VT>(p, LI, g1, lane, si, pt, pt_local, ray_local * DN, lds_k, lds_v, store_pt, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                       , t_prev
+#endif
+    );
+  }
+  PGRF_TICK(7);
+
+  // ---- stage E: blending logits of this wave's views; softmax over the four
+  float col[3];
+  {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vs[v].dd[c] = *(volatile float*)&lds_park[v * 7 + c][park_col];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vs[v].rgb[c] = *(volatile float*)&lds_park[v * 7 + 4 + c][park_col];
+    }
+    float lg[V];
+    stage_rgb<V, 0, 2>(p, LI, vs, lane, lg);
+    // (lds_g was last read before the barrier inside point_tail)
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      lds_g[v][tid] = lg[v];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) lds_g[2 + v * 3 + c][tid] = vs[v].rgb[c];
+    }
+    __syncthreads();
+    float logit[4], rgb[4][3];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int vo = role ? 2 + v : v, vp = role ? v : 2 + v;      // own / partner's view in the reference's order
+      logit[vo] = lg[v];
+      logit[vp] = lds_g[v][tid ^ 64];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { rgb[vo][c] = vs[v].rgb[c]; rgb[vp][c] = lds_g[2 + v * 3 + c][tid ^ 64]; }
+    }
+    float mx = logit[0];
+#pragma unroll
+    for (int v = 1; v < 4; ++v) mx = fmaxf(mx, logit[v]);
+    float e[4], es = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { e[v] = __expf(logit[v] - mx); es += e[v]; }
+    col[0] = col[1] = col[2] = 0.f;
+    const float res_ = rcp1(es);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float bw = e[v] * res_;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[c] += rgb[v][c] * bw;
+    }
+  }
+  PGRF_TICK(8);
+  composite<KT, V>(p, sigma, col, tdepth, lane, tile, kt, ray, pt, store_pt, lds_alpha, lds_red
+#ifdef PGRF_STAGE_TIMING
+                   , t_prev
+#endif
+  );
+}
+
 
 template <int KT, int V, bool DBG>
 int launch_instance(const PassArgs& a, void* stream) {
-  constexpr int RPW = 4 / KT;
-  const int blocks = (a.rn + RPW - 1) / RPW;
   // debug instances exist in the general form only (they serve every convention at test sizes)
   const bool general = DBG || a.dataset != PGRF_DATASET_M3D || a.perspective;
+  if constexpr (V == 4 && KT <= 2 && kPrec == 0) {
+    // 4 views, f32: the wave-pair kernel (PGRF_V4_KERNEL=wave selects the one-wave-per-tile kernel: A/B and tests)
+    const char* knob = getenv("PGRF_V4_KERNEL");
+    if (!(knob && knob[0] == 'w')) {
+      constexpr int RPWP = 2 / KT;
+      const int nb = (a.rn + RPWP - 1) / RPWP;
+      if (general) hipLaunchKernelGGL((render_pass_pair_kernel<KT, DBG, true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((render_pass_pair_kernel<KT, DBG, DBG>), dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return set_error(PGRF_ERR_LAUNCH, "render_pass (wave-pair) launch failed: %s", hipGetErrorString(e));
+      return PGRF_OK;
+    }
+  }
+  constexpr int RPW = 4 / KT;
+  const int blocks = (a.rn + RPW - 1) / RPW;
   if (general) hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((render_pass_kernel<KT, V, DBG, DBG>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
