@@ -11,7 +11,7 @@
     defined(PGRF_NO_LDS_IMG) || defined(PGRF_NO_PARK) || defined(PGRF_NO_RECOMPUTE_NF) || defined(PGRF_NO_SMALL) ||           \
     defined(PGRF_NO_STAGE_FENCE) || defined(PGRF_NO_XCD_REMAP) || defined(PGRF_NT_ALL) || defined(PGRF_NT_PAIRS) ||           \
     defined(PGRF_ONE_WG_PER_CU) || defined(PGRF_PV_MFMA) || defined(PGRF_PV_PACKED) || defined(PGRF_TWO_WAVE_MAX_V) ||        \
-    defined(PGRF_FENCE_MASK) || defined(PGRF_GROUP_FENCE) || defined(PGRF_LDS_STATE) || defined(PGRF_SMALL_V4) || defined(PGRF_BATCH_GATHER) || defined(PGRF_A_PREFETCH) ||                                                              \
+    defined(PGRF_FENCE_MASK) || defined(PGRF_GROUP_FENCE) || defined(PGRF_LDS_STATE) || defined(PGRF_SMALL_V4) || defined(PGRF_BATCH_GATHER) || defined(PGRF_A_PREFETCH) || defined(PGRF_PAIR_NO_HEAD_SPLIT) ||                                                              \
     defined(PGRF_CONV_ABL_A) || defined(PGRF_CONV_ABL_B) || defined(PGRF_CONV_ABL_NOISSUE) ||                                 \
     defined(PGRF_CONV_ABL_NOREFILL_A) || defined(PGRF_CONV_ABL_NOREFILL_B) || defined(PGRF_CONV_NO_FAST) ||                   \
     defined(PGRF_CONV_NO_FUSE) || defined(PGRF_CONV_SPREAD_REFILL) || defined(PGRF_UPF_ABL) || defined(PGRF_CONV_WAVES) ||                             \

@@ -1082,13 +1082,15 @@ constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast flo
 // Per-point tail of stage D: geometry_fc.0 pre-activations `g1` -> geometry_fc.2 -> positional encoding -> q|k|v -> 4-head
 // attention over the samples of the ray (K, V of the workgroup's points in LDS) -> fc + LayerNorm -> out_geometry_fc -> density.
 // pt_local = the point's row in lds_k / lds_v, key_base = first row of its ray.  Contains one workgroup barrier.
-template <int KT, int V, bool DBG, int VT = V>
+// HSEL >= 0 (wave-pair kernel): this wave evaluates heads 2 HSEL, 2 HSEL + 1 only and fetches the other two from its partner
+// (column tid ^ 64 of the exchange rows `xo`; one more barrier); HSEL = 0 writes K, HSEL = 1 writes V.
+template <int KT, int V, bool DBG, int VT = V, int HSEL = -1>
 __device__ __forceinline__ float point_tail(const PassArgs& p, const float* LI, const f32x16 (&g1)[1][2], int lane, int si, size_t pt,
                                             int pt_local, int key_base, float* lds_k, float* lds_v, bool store_ok, float* const* sdbg
 #ifdef PGRF_STAGE_TIMING
                                             , unsigned long long& t_prev
 #endif
-                                            ) {
+                                            , float (*xo)[256] = nullptr, int tid = 0) {
   const int half = lane >> 5;
   const int pl = lane & 31;
   const float* __restrict__ W = p.blob;
@@ -1117,15 +1119,15 @@ __device__ __forceinline__ float point_tail(const PassArgs& p, const float* LI, 
   mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv, W + layer_h_off(L_QKV), PGRF_LIMG(L_QKV));
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
-    lds_v[pt_local * kVStride + 2 * r + half] = qkv[0][1][r];
+    if (HSEL != 1) lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
+    if (HSEL != 0) lds_v[pt_local * kVStride + 2 * r + half] = qkv[0][1][r];
   }
   PGRF_TICK(4);   // stage D up to the q/k/v projections
   PGRF_SYNC();
   PGRF_TICK(5);   // barrier wait
   float oatt[16];
 #pragma unroll
-  for (int hd = 0; hd < 4; ++hd) {
+  for (int hd = (HSEL < 0 ? 0 : 2 * HSEL); hd < (HSEL < 0 ? 4 : 2 * HSEL + 2); ++hd) {
     f32x16 S[KT];
 #pragma unroll
     for (int k2 = 0; k2 < KT; ++k2) {
@@ -1207,6 +1209,13 @@ __device__ __forceinline__ float point_tail(const PassArgs& p, const float* LI, 
     o0 = xsum(o0); o1 = xsum(o1); o2 = xsum(o2); o3 = xsum(o3);
     const float rl = rcp1(l);
     oatt[hd * 4 + 0] = o0 * rl; oatt[hd * 4 + 1] = o1 * rl; oatt[hd * 4 + 2] = o2 * rl; oatt[hd * 4 + 3] = o3 * rl;
+  }
+  if constexpr (HSEL >= 0) {      // (every lane holds its point's outputs: the partner's column carries the same point)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xo[i][tid] = oatt[HSEL * 8 + i];
+    PGRF_SYNC();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oatt[(1 - HSEL) * 8 + i] = xo[i][tid ^ 64];
   }
   PGRF_TICK(6);   // attention
   // fc + residual + LayerNorm(eps 1e-6)  (ibrnet.py:95-102)
@@ -1914,11 +1923,25 @@ __global__ void __launch_bounds__(256, 2) render_pass_pair_kernel(const PassArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) g1[0][m][r] += lds_g[m * 16 + r][tid ^ 64];
     // (the partner has read its x rows before the barrier above: K / V may overwrite them now)
+#ifdef PGRF_PAIR_NO_HEAD_SPLIT
     sigma = point_tail<KT, V, DBG, VT>(p, LI, g1, lane, si, pt, pt_local, ray_local * DN, lds_k, lds_v, store_pt, sdbg
 #ifdef PGRF_STAGE_TIMING
                                        , t_prev
 #endif
     );
+#else
+    // attention heads 0, 1 in role 0 and 2, 3 in role 1; outputs exchanged through rows 8..15 of lds_g (rows 0..7 carry stage E)
+    if (role == 0) sigma = point_tail<KT, V, DBG, VT, 0>(p, LI, g1, lane, si, pt, pt_local, ray_local * DN, lds_k, lds_v, store_pt, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                       , t_prev
+#endif
+                                       , lds_g + 8, tid);
+    else sigma = point_tail<KT, V, DBG, VT, 1>(p, LI, g1, lane, si, pt, pt_local, ray_local * DN, lds_k, lds_v, store_pt, sdbg
+#ifdef PGRF_STAGE_TIMING
+                                       , t_prev
+#endif
+                                       , lds_g + 8, tid);
+#endif
   }
   PGRF_TICK(7);
 
