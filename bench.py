@@ -246,6 +246,132 @@ def eager_strip_baseline(case, dev, rows=64, budget_s=20.0):
     return res, outs
 
 
+def train_bench(args, dev, rank, world, distributed):
+    """one TRAINING step of the per-ray networks as the reference's trainer runs it through
+    network/renderer.py:567-633 -- coarse pass, importance sampling from the detached weights, fine pass, a photometric loss on
+    both images, backward to every per-ray weight and to the two feature maps, Adam.  The 2-D encoders that produce the maps are
+    torch modules outside this path (their outputs are leaf tensors here).  Forward = the fused HIP kernel, backward =
+    pgrf_render_pass_backward (rematerialising).  Ranks are data-parallel: each its own rays, gradients all-reduced (RCCL)."""
+    from panogrf_amd import engine as E
+    H, W, V, dn, rays = args.height, args.width, args.views, args.samples, args.train_rays
+    case = synthetic_case(H, W, V, dn, seed=0, fine=True)
+    f = {k: v.to(dev) for k, v in case['frame'].items()}
+    params = {k: torch.nn.Parameter(v.to(dev).clone()) for k, v in case['weights'].items()}
+    img_feats = f['img_feats'].clone().requires_grad_(True)
+    ray_feats = f['ray_feats'].clone().requires_grad_(True)
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4)
+    use_vis = case['cfg']['dist_decoder_cfg']['use_vis']
+    target_img = f['imgs'][0].permute(1, 2, 0).reshape(-1, 3)
+    g = torch.Generator().manual_seed(100 + rank)
+    n_batches = args.warmup + args.steps
+    idxs = [torch.randperm(H * W, generator=g)[:rays].to(dev) for _ in range(n_batches)]
+    us = [torch.rand(rays, dn, generator=g).to(dev) for _ in range(n_batches)]
+    que_dr = [0.5, 15.0]
+    common = (f['imgs'], img_feats, ray_feats, f['w2c'], f['ref_depth_range'], case['frame']['que_c2w'], case['frame']['que_depth_range'], params)
+    flat_grads = None
+
+    def step(i):
+        idx = idxs[i]
+        coords = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+        tgt = target_img[idx]
+        depth = E.sample_coarse_depth(case['cfg']['min_depth'], case['cfg']['max_depth'], rays, dn, device=dev)
+        oc = E.render_pass_autograd(*common, 'dist_decoder', 'agg_net', use_vis, coords, depth)
+        fd = E.sample_fine_depth(depth, oc['hit_prob_nr'].detach(), que_dr, dn, u=us[i])
+        of = E.render_pass_autograd(*common, 'fine_dist_decoder', 'fine_agg_net', use_vis, coords, fd)
+        loss = ((of['pixel_colors_nr'] - tgt) ** 2).mean() + ((oc['pixel_colors_nr'] - tgt) ** 2).mean()
+        opt.zero_grad(set_to_none=True)
+        img_feats.grad = ray_feats.grad = None
+        loss.backward()
+        if distributed:
+            gl = [p.grad for p in params.values() if p.grad is not None]
+            flat = torch.cat([t.reshape(-1) for t in gl])
+            torch.distributed.all_reduce(flat)
+            flat /= world
+            off = 0
+            for t in gl:
+                t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
+        opt.step()
+        return loss
+
+    def sync_all():
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.steps):
+        losses.append(step(args.warmup + i))
+    e1.record()
+    sync_all()
+    dt = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1) / args.steps
+    if distributed:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    # algorithmic FLOPs of a training step: forward + 2x for the backward (dX and dW products) = 3x the forward of both passes
+    flops_step = 3 * flop_per_ray(V, dn, 2) * rays
+    achieved = flops_step / (gpu_ms * 1e-3) / 1e12
+    res = {'metric': f'trained rays/sec ({dn} + {dn} samples, {V} views, forward + backward + Adam of the per-ray networks)',
+           'value': rays * world * args.steps / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+           'data': 'synthetic',
+           'config': {'workload': f'training step: {rays} random rays per rank of a {H}x{W} ERP query, {V} source views, {dn} coarse + {dn} fine '
+                                  f'samples; gradients to all per-ray weights and to img_feats / ray_feats; Adam; encoders outside',
+                      'rays_per_step_per_rank': rays, 'parallelism': f'data-parallel x{world}, gradient all-reduce'},
+           'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                        'traffic': None, 'kernel': 'whole step on the stream (2 fused forward passes, 2 staged forwards + backwards, sampler, loss, Adam)',
+                        'kernel_ms': gpu_ms, 'flop_per_ray': 3 * flop_per_ray(V, dn, 2), 'rays_per_launch': rays,
+                        'note': 'algorithmic = 3 x forward FLOPs (the rematerialising backward executes 4 x)'},
+           'loss_first_last': [float(losses[0].detach()), float(losses[-1].detach())]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the eager-autograd port on the same GPU: the oracle's torch ops (the reference's graph) under torch.autograd, same rays
+        from oracle import render_oracle as O
+        pw = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        fr = {k: v for k, v in f.items()}
+        fr['img_feats'] = f['img_feats'].clone().requires_grad_(True)
+        fr['ray_feats'] = f['ray_feats'].clone().requires_grad_(True)
+        eopt = torch.optim.Adam(list(pw.values()), lr=1e-4)
+        qdr = case['frame']['que_depth_range'].to(dev)
+
+        def estep(i):
+            idx = idxs[i]
+            coords = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+            tgt = target_img[idx]
+            depth = O.sample_coarse_depth(case['cfg']['min_depth'], case['cfg']['max_depth'], rays, dn).to(dev)
+            oc = O.render_pass(pw, 'dist_decoder', 'agg_net', fr, coords, depth, {'use_vis': use_vis})
+            fd = O.sample_fine_depth(depth, oc['hit_prob_nr'].detach(), qdr, dn, u=us[i])
+            fd = torch.sort(fd, -1)[0]
+            of = O.render_pass(pw, 'fine_dist_decoder', 'fine_agg_net', fr, coords, fd, {'use_vis': use_vis})
+            loss = ((of['pixel_colors_nr'] - tgt) ** 2).mean() + ((oc['pixel_colors_nr'] - tgt) ** 2).mean()
+            eopt.zero_grad(set_to_none=True)
+            loss.backward()
+            eopt.step()
+            return loss
+        try:
+            for i in range(2):
+                estep(i)
+            torch.cuda.synchronize()
+            n_e = max(1, min(args.steps, 5))
+            t0 = time.perf_counter()
+            for i in range(n_e):
+                el = estep(args.warmup + i)
+            torch.cuda.synchronize()
+            et = (time.perf_counter() - t0) / n_e
+            res['torch_eager_gpu_baseline'] = {'value': rays / et, 'unit': 'rays/s', 'ms_per_step': et * 1e3,
+                                               'kind': 'port: the oracle (reference graph) under torch.autograd + Adam on this GPU, same rays',
+                                               'speedup_hip_over_eager': (rays * world * args.steps / dt) / (rays / et)}
+        except Exception as ex:      # the baseline must never take the measurement down
+            res['torch_eager_gpu_baseline'] = {'error': repr(ex)[:300]}
+    return res
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` typed without a launcher: start the N ranks as a CHILD torchrun (this process has not
     touched the GPU yet and never execs), relay their output and rank 0's JSON line, exit with the child's code."""
@@ -280,6 +406,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the whole-module frame timing reported beside the headline (--no-cpu-baseline skips it too)')
     ap.add_argument('--eager-baseline', action='store_true', help='also time the eager PyTorch-ROCm port on this GPU over the WHOLE frame (minutes); a bounded strip is timed by default')
+    ap.add_argument('--train', action='store_true', help='time a coarse + fine TRAINING step of the per-ray networks (forward, backward, Adam) on --train-rays rays per rank')
+    ap.add_argument('--train-rays', type=int, default=2048)
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the process group and run every collective even with ONE rank (exercises the RCCL branch on a 1-GPU box)')
     args = ap.parse_args()
@@ -317,6 +445,13 @@ def main():
     from panogrf_amd import dist as D
 
     H, W, V, dn = args.height, args.width, args.views, args.samples
+    if args.train:
+        res = train_bench(args, dev, rank, world, distributed)
+        if rank == 0:
+            print(json.dumps(res))
+        if distributed:
+            torch.distributed.destroy_process_group()
+        return
     case = synthetic_case(H, W, V, dn, seed=0, fine=args.fine)
     case['cfg']['hip_precision'] = args.precision
     fr_in = {k: v.to(dev) for k, v in case['frame'].items()}
@@ -339,7 +474,7 @@ def main():
                   trans=torch.tensor([[[0.5, 0.0, 0.0], [-0.5, 0.0, 0.0]]]).repeat(V, 1, 1).to(dev),
                   k=CVm.depth_sampling(5, 3), args=dict(dataset_name='m3d', contain_dnet=True),
                   net=(CR.UNet2Reg() if args.reg == 'unet2' else CR.CostRegNet(dict(use_wrap_padding=True), 32)).to(dev).eval(),
-                  CV=CVm, ms=[])
+                  CV=CVm, ms=[], sub=[])
         with torch.no_grad():
             for prm in cv['net'].parameters():
                 prm.mul_(0.5)
@@ -356,10 +491,16 @@ def main():
             c0.record()
             regs = []
             for v in D.view_shard(rank, world, V):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # sub-stage boundaries (roofline sub-blocks)
                 dv = cv['CV'].build_depth_volume(cv['ref_mu'][v:v + 1], cv['k'], 0.5, 0.1, 10.0, 64)
+                ev[0].record()
                 vol = cv['CV'].calculate_cost_volume_erp(cv['args'], cv['feats'][v:v + 1], None, cv['trans'][v:v + 1],
                                                          cv['rots'][v:v + 1], depth_volume=dv)
+                ev[1].record()
                 regs.append(cv['net'].forward_ndhwc(vol).reshape(-1))
+                ev[2].record()
+                if timed and rank == 0:
+                    cv['sub'].append(ev)
             local = torch.stack(regs, 0) if regs else torch.zeros(0, cv['reg_numel'], device=dev)
             cv['reg_all'] = D.allgather_views(local, V)
             c1.record()
@@ -448,8 +589,28 @@ def main():
     if rank == 0 and cv is not None:
         cms = sum(a.elapsed_time(b) for a, b in cv['ms']) / max(len(cv['ms']), 1)
         gf = (438.5e9 if args.reg == 'unet2' else 16.2e9) * (cv['h'] * cv['w']) / (64 * 128) * V
+        # sub-stage rooflines, per launch = per reference view: the build is HBM-bound -- algorithmic bytes =
+        # D h w (C + 1) 4 (volume written, hypotheses read) + S h w C 4 (features read); the regulariser is f32-MFMA-bound.  UNet2's
+        # wide layers run Winograd F(2x2x2, 3x3x3), which executes 1 / 3.375 of the direct convolution's multiplies: its roof
+        # fraction is priced on the EXECUTED products (direct FLOPs / 3.375 against the f32 MFMA peak), not on the direct count.
+        n_sub = max(len(cv['sub']), 1)
+        build_ms = sum(e[0].elapsed_time(e[1]) for e in cv['sub']) / n_sub
+        reg_ms = sum(e[1].elapsed_time(e[2]) for e in cv['sub']) / n_sub
+        cv_bytes = 64 * cv['h'] * cv['w'] * (32 + 1) * 4 + 2 * cv['h'] * cv['w'] * 32 * 4
+        gf_view = gf / V
+        wino = 3.375 if args.reg == 'unet2' else 1.0
+        rl_build = {'bound': 'hbm', 'achieved': cv_bytes / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0, 'peak': 8000.0, 'unit': 'GB/s',
+                    'kernel': 'cost_volume_kernel', 'kernel_ms': build_ms, 'algorithmic_bytes_per_launch': cv_bytes, 'traffic': None}
+        rl_build['frac'] = rl_build['achieved'] / rl_build['peak']
+        rl_reg = {'bound': 'mfma', 'achieved': gf_view / wino / (reg_ms * 1e-3) / 1e12 if reg_ms > 0 else 0.0, 'peak': PEAK_F32_MFMA_TFLOPS,
+                  'unit': 'TFLOP/s', 'kernel': args.reg + ' forward (all its launches)', 'kernel_ms': reg_ms,
+                  'direct_conv_flop_per_launch': gf_view, 'executed_flop_divisor': wino,
+                  'note': ('achieved = direct-convolution FLOPs / 3.375 (Winograd F(2^3, 3^3) executes 8 / 27 of the multiplies) / time'
+                           if wino > 1 else 'achieved = direct-convolution FLOPs / time')}
+        rl_reg['frac'] = rl_reg['achieved'] / rl_reg['peak']
         res['cost_volume_stage'] = {'ms_per_step': cms, 'views': V, 'res': [cv['h'], cv['w']], 'D': 64, 'C': 32,
-                                    'regulariser': args.reg, 'reg_algorithmic_tflops': gf / (cms * 1e-3) / 1e12,
+                                    'regulariser': args.reg, 'reg_direct_conv_tflops': gf_view / (reg_ms * 1e-3) / 1e12 if reg_ms > 0 else 0.0,
+                                    'roofline': rl_reg, 'roofline_build': rl_build,
                                     'view_shards': min(world, V),
                                     'note': 'hypotheses + spherical cost volume + 3-D regulariser per source view, views sharded over ranks + all-gather; included in ms_per_step/value'}
         res['config']['workload'] += f' + D=64 cost volume {cv["h"]}x{cv["w"]} + {args.reg} per view (BASELINE configs[2])'

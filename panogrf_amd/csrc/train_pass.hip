@@ -15,6 +15,7 @@
 #include "pgrf_experiments.h"
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "pgrf_internal.h"
@@ -63,44 +64,50 @@ __global__ void rowscale_kernel(float* __restrict__ y, int ldy, int yc, const fl
   }
 }
 // gx[r, gxc + c] += gy[r, gyc + c] * scale_r ;  gs[r] (=) sum_c gy[r, gyc + c] * x[r, xc + c]
-__global__ void rowscale_bwd_kernel(const float* __restrict__ gy, int ldgy, int gyc, const float* __restrict__ x, int ldx, int xc,
-                                    const float* __restrict__ s, int sstride, float cst, long rows, int cols, float* __restrict__ gx, int ldgx,
-                                    int gxc, float* __restrict__ gs) {
-  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) rowscale_bwd_kernel(const float* __restrict__ gy, int ldgy, int gyc, const float* __restrict__ x, int ldx,
+                                                           int xc, const float* __restrict__ s, int sstride, float cst, long rows, int cols,
+                                                           float* __restrict__ gx, int ldgx, int gxc, float* __restrict__ gs) {
+  // 32 lanes per row (coalesced column runs; one thread per row walked its columns at a stride of ld floats: 515 us per call)
+  const long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int c0 = threadIdx.x & 31;
   if (r >= rows) return;
   const float sc = s ? s[r * sstride] : cst;
   float acc = 0.f;
-  for (int c = 0; c < cols; ++c) {
+  for (int c = c0; c < cols; c += 32) {
     const float g = gy[r * ldgy + gyc + c];
     gx[r * ldgx + gxc + c] += g * sc;
     acc += g * x[r * ldx + xc + c];
   }
-  if (gs) gs[r] = acc;
+  if (gs) {
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 32);
+    if (c0 == 0) gs[r] = acc;
+  }
 }
 // rgb_feat = [rgb | img_feats] + dir_feat  (ibrnet.py:325-327) -> xin[:, 140:175]
 __global__ void rgbfeat_kernel(const float* __restrict__ rgb, const float* __restrict__ imf, const float* __restrict__ dfeat, long PV,
                                float* __restrict__ xin) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= PV * 35) return;
-  const long pv = i / 35; const int c = (int)(i % 35);
-  xin[pv * 207 + 140 + c] = (c < 3 ? rgb[pv * 3 + c] : imf[pv * 32 + c - 3]) + dfeat[pv * 35 + c];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 35; i += (long)gridDim.x * blockDim.x) {
+    const long pv = i / 35; const int c = (int)(i % 35);
+    xin[pv * 207 + 140 + c] = (c < 3 ? rgb[pv * 3 + c] : imf[pv * 32 + c - 3]) + dfeat[pv * 35 + c];
+  }
 }
 // x2 = x + x_res, v1 = sigmoid(xv[32])  (ibrnet.py:347-350); x2 -> xr[:, 0:32]
 __global__ void visfc_post_kernel(const float* __restrict__ x, const float* __restrict__ xv, long PV, float* __restrict__ xr, float* __restrict__ v1) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= PV * 33) return;
-  const long pv = i / 33; const int c = (int)(i % 33);
-  if (c < 32) xr[pv * 37 + c] = x[pv * 32 + c] + xv[pv * 33 + c];
-  else v1[pv] = 1.f / (1.f + expf(-xv[pv * 33 + 32]));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 33; i += (long)gridDim.x * blockDim.x) {
+    const long pv = i / 33; const int c = (int)(i % 33);
+    if (c < 32) xr[pv * 37 + c] = x[pv * 32 + c] + xv[pv * 33 + c];
+    else v1[pv] = 1.f / (1.f + expf(-xv[pv * 33 + 32]));
+  }
 }
 // backward of the line above: gx = gxr[:, :32]; gxv[:, :32] = gxr[:, :32]; gxv[:, 32] = gv1 * v1 (1 - v1)
 __global__ void visfc_post_bwd_kernel(const float* __restrict__ gxr, const float* __restrict__ gv1, const float* __restrict__ v1, long PV,
                                       float* __restrict__ gx, float* __restrict__ gxv) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= PV * 33) return;
-  const long pv = i / 33; const int c = (int)(i % 33);
-  if (c < 32) { const float g = gxr[pv * 37 + c]; gx[pv * 32 + c] = g; gxv[pv * 33 + c] = g; }
-  else gxv[pv * 33 + 32] = gv1[pv] * v1[pv] * (1.f - v1[pv]);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 33; i += (long)gridDim.x * blockDim.x) {
+    const long pv = i / 33; const int c = (int)(i % 33);
+    if (c < 32) { const float g = gxr[pv * 37 + c]; gx[pv * 32 + c] = g; gxv[pv * 33 + c] = g; }
+    else gxv[pv * 33 + 32] = gv1[pv] * v1[pv] * (1.f - v1[pv]);
+  }
 }
 // wgt2 = v2 / (sum_v v2 + 1e-8);  gin[:, 64] = mean_v wgt2   (ibrnet.py:352-355); v2 lives in xr[:, 32]
 __global__ void wgt2_kernel(const float* __restrict__ xr, long P, int V, float* __restrict__ wgt2, float* __restrict__ gin) {
@@ -126,10 +133,10 @@ __global__ void wgt2_bwd_kernel(const float* __restrict__ xr, const float* __res
 }
 // gp = g2 + positional encoding of the sample index (ibrnet.py:356-358); pos [dn,16]
 __global__ void posenc_kernel(const float* __restrict__ g2, const float* __restrict__ pos, long P, int dn, float* __restrict__ gp) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P * 16) return;
-  const long p = i / 16; const int c = (int)(i % 16);
-  gp[i] = g2[i] + pos[(p % dn) * 16 + c];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P * 16; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / 16; const int c = (int)(i % 16);
+    gp[i] = g2[i] + pos[(p % dn) * 16 + c];
+  }
 }
 __global__ void fill_kernel(float* __restrict__ x, float v, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
@@ -196,10 +203,11 @@ struct Ctx {
 };
 
 static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float* Y, int ldy, long rows, int IN, int OUT, int act) {
-  dim3 grid((OUT + 63) / 64, (unsigned)((rows + 63) / 64), 1);
-  hipLaunchKernelGGL((gemm_kernel<false, true, false>), grid, dim3(256), 0, c.st, X, ldx, c.raw[rw], IN, Y, ldy, (int)rows, OUT, IN, 0, IN);
-  if (rb >= 0 || act != ACT_NONE)
-    hipLaunchKernelGGL(bias_act_kernel, dim3(nblk(rows * OUT)), dim3(256), 0, c.st, Y, ldy, rb >= 0 ? c.raw[rb] : nullptr, rows, OUT, act);
+  // Y = act(X W^T + b) in one launch (bias and activation in the epilogue): 128 rows per workgroup, all OUT <= 64 columns per wave
+  const dim3 grid((unsigned)((rows + 127) / 128), 1, 1);
+  const float* bias = rb >= 0 ? c.raw[rb] : nullptr;
+  if (OUT <= 32) hipLaunchKernelGGL((lin_mfma_kernel<false, 1>), grid, dim3(256), 0, c.st, X, ldx, c.raw[rw], IN, bias, Y, ldy, rows, OUT, IN, act, 0);
+  else hipLaunchKernelGGL((lin_mfma_kernel<false, 2>), grid, dim3(256), 0, c.st, X, ldx, c.raw[rw], IN, bias, Y, ldy, rows, OUT, IN, act, 0);
   PGRF_TCHECK("train linear forward");
   return PGRF_OK;
 }
@@ -209,20 +217,35 @@ static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ld
                    int acc_dx, long rows, int IN, int OUT, int act) {
   float* gb = (rb >= 0) ? c.graw[rb] : nullptr;
   if (act != ACT_NONE || gb)
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(rows * OUT) > 2048 ? 2048 : nblk(rows * OUT)), dim3(256), 0, c.st, dY, lddy, Y, ldy, rows, OUT,
+  {
+    int cp = 1;
+    while (cp < OUT) cp <<= 1;
+    if (cp > 64) return set_error(PGRF_ERR_UNSUPPORTED, "train linear backward: %d outputs (at most 64)", OUT);
+    const long nb = (rows * cp + 256 * 8 - 1) / (256 * 8);            // ~8 rows per thread
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb))), dim3(256), 0, c.st, dY, lddy, Y, ldy, rows, OUT, cp,
                        act, gb);
+  }
   if (c.graw[rw]) {
-    // the reduction runs over the ROWS (sample points x views): split it so that the launch has ~2048 workgroups even when
-    // the weight matrix is one 64x64 tile (atomics into at most 207 x 64 outputs: no contention to speak of)
-    const long tiles = (long)((IN + 63) / 64) * ((OUT + 63) / 64);
-    long kc = (rows * tiles / 2048 + 15) / 16 * 16;
-    const int kchunk = (int)(kc < 128 ? 128 : kc);
-    dim3 grid((IN + 63) / 64, (OUT + 63) / 64, (unsigned)((rows + kchunk - 1) / kchunk));
-    hipLaunchKernelGGL((gemm_kernel<true, false, true>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], IN, OUT, IN, (int)rows, 1, kchunk);
+    // gW += delta^T X: the reduction runs over the ROWS (sample points x views), split over gridDim.z so that the launch has
+    // ~1024 workgroups; partial tiles are summed inside a workgroup, then one atomic per element and workgroup
+    const int nt = IN > 64 ? 4 : (IN > 32 ? 2 : 1);
+    const int gx = (IN + 32 * nt - 1) / (32 * nt), gy = (OUT + 31) / 32, groups = gx * gy;
+    const int gpw = groups >= 4 ? 4 : (groups == 2 ? 2 : 1);                  // groups per workgroup
+    const int nwg = (groups + gpw - 1) / gpw;
+    static const int target_wgs = [] { const char* e = getenv("PGRF_TRAIN_DW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();   // tuning knob (192: 21.0, 384: 17.5, 768: 16.7, 1536+: 17.8 ms per 2 048-ray step)
+    long chunk = (rows * nwg / target_wgs + 63) / 64 * 64;                    // ~target_wgs workgroups per launch
+    if (chunk < 128) chunk = 128;
+    const dim3 grid(nwg, 1, (unsigned)((rows + chunk - 1) / chunk));
+    if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], OUT, IN, rows, (int)chunk, gx, groups);
+    else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], OUT, IN, rows, (int)chunk, gx, groups);
+    else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], OUT, IN, rows, (int)chunk, gx, groups);
   }
   if (dX) {
-    dim3 grid((IN + 63) / 64, (unsigned)((rows + 63) / 64), 1);
-    hipLaunchKernelGGL((gemm_kernel<false, false, false>), grid, dim3(256), 0, c.st, dY, lddy, c.raw[rw], IN, dX, lddx, (int)rows, IN, OUT, acc_dx, OUT);
+    // dX (=|+=) delta W: the same kernel with the weight read transposed (W is [OUT, IN]: "M" = IN, "K" = OUT)
+    const int mt = IN > 32 ? 2 : 1;
+    const dim3 grid((unsigned)((rows + 127) / 128), (unsigned)((IN + 32 * mt - 1) / (32 * mt)), 1);
+    if (mt == 2) hipLaunchKernelGGL((lin_mfma_kernel<true, 2>), grid, dim3(256), 0, c.st, dY, lddy, c.raw[rw], IN, (const float*)nullptr, dX, lddx, rows, IN, OUT, (int)ACT_NONE, acc_dx);
+    else hipLaunchKernelGGL((lin_mfma_kernel<true, 1>), grid, dim3(256), 0, c.st, dY, lddy, c.raw[rw], IN, (const float*)nullptr, dX, lddx, rows, IN, OUT, (int)ACT_NONE, acc_dx);
   }
   PGRF_TCHECK("train linear backward");
   return PGRF_OK;
@@ -259,7 +282,9 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   }
   const int V = frame->rfn;
   const long P = (long)rn * dn, PV = P * V;
-  if ((double)PV * 207.0 >= 2147483648.0) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass_backward: batch too large (rn * dn * rfn * 207 >= 2^31)");
+  // (one-element-per-thread kernels are launched with up to 65535 * 16 workgroups: the bound keeps every such launch complete)
+  if (PV > 8000000L || P > 4000000L)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass_backward: batch too large (rn * dn = %ld > 4 000 000 or rn * dn * rfn = %ld > 8 000 000): split the rays", P, PV);
   Ws w;
   const size_t need = plan(w, P, V, dn, nullptr);
   if (!workspace || workspace_bytes < need)
@@ -379,26 +404,26 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   L(lin_bwd(c, w.g1, 64, w.g2, 16, w.ggp, 16, R_GEO_2_W, R_GEO_2_B, w.gg1, 64, 0, P, 64, 16, ACT_ELU));           // d(gp)/d(g2) = 1
   L(lin_bwd(c, w.gin, 65, w.g1, 64, w.gg1, 64, R_GEO_0_W, R_GEO_0_B, w.ggin, 65, 0, P, 65, 64, ACT_ELU));
   (void)hipMemsetAsync(w.gwgt2, 0, PV * 4, st);
-  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32, w.ggin, 65, 0, 32, w.gxr,
+  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32, w.ggin, 65, 0, 32, w.gxr,
                      37, 0, w.gwgt2);
   hipLaunchKernelGGL(wgt2_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, w.gwgt2, w.ggin, P, V, w.gxr);
   PGRF_TCHECK("train pooled geometry backward");
   L(lin_bwd(c, w.f1, 32, w.xr + 32, 37, w.gxr + 32, 37, R_V2_2_W, R_V2_2_B, w.gf1, 32, 0, PV, 32, 1, ACT_SIGMOID));
   L(lin_bwd(c, w.xv1, 32, w.f1, 32, w.gf1, 32, R_V2_0_W, R_V2_0_B, w.gxv1, 32, 0, PV, 32, 32, ACT_ELU));
-  hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gxv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32, w.gxr, 37, 0, w.gv1);
+  hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32, w.gxr, 37, 0, w.gv1);
   hipLaunchKernelGGL(visfc_post_bwd_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.gxr, w.gv1, w.v1, PV, w.gx, w.gxv);
   L(lin_bwd(c, w.v1h, 32, w.xv, 33, w.gxv, 33, R_VF_2_W, R_VF_2_B, w.gv1h, 32, 0, PV, 32, 33, ACT_ELU));
   L(lin_bwd(c, w.xw, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, w.gxw, 32, 0, PV, 32, 32, ACT_ELU));
-  hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gxw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32, w.gx, 32, 0,
+  hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32, w.gx, 32, 0,
                      (float*)nullptr);
   PGRF_TCHECK("train visibility backward");
   L(lin_bwd(c, w.b1, 64, w.x, 32, w.gx, 32, R_BASE_2_W, R_BASE_2_B, w.gb1, 64, 0, PV, 64, 32, ACT_ELU));
   L(lin_bwd(c, w.xin, 207, w.b1, 64, w.gb1, 64, R_BASE_0_W, R_BASE_0_B, w.gxin, 207, 0, PV, 207, 64, ACT_ELU));
   hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 140)), dim3(256), 0, st, w.gglob, 140, 0, w.gxin, 207, 0, P, V, 140, 0);
   (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
-  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35, w.gglob, 140, 0, 35,
+  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35, w.gglob, 140, 0, 35,
                      w.gxin, 207, 140, w.gw0);
-  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105, w.gglob, 140, 70, 105,
+  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105, w.gglob, 140, 70, 105,
                      w.gxin, 207, 140, (float*)nullptr);
   PGRF_TCHECK("train view statistics backward");
   // weight0 = sigmoid(neuray_fc) * wgt: the gradient enters the sigmoid output scaled by wgt

@@ -52,6 +52,7 @@ def pack_pass_weights(state_dict, dd_prefix, agg_prefix, use_vis, max_dn=128):
     names = raw_names()
     keep = []          # keep the contiguous host copies alive during the call
     arr = (C.c_void_p * len(names))()
+    present = []
     for i, n in enumerate(names):
         if n.startswith('dist_decoder.'):
             key = dd_prefix + n[len('dist_decoder'):]
@@ -62,9 +63,21 @@ def pack_pass_weights(state_dict, dd_prefix, agg_prefix, use_vis, max_dn=128):
                 arr[i] = None
                 continue
             raise PgrfError(f"state_dict lacks '{key}'")
-        t = state_dict[key].detach().to('cpu', torch.float32).contiguous()
-        keep.append(t)
-        arr[i] = t.data_ptr()
+        present.append((i, state_dict[key].detach()))
+    if present and all(t.is_cuda for _, t in present):
+        # GPU-resident parameters (training): ONE device->host copy of the concatenated tensors instead of one (and one
+        # host sync) per tensor -- 62-68 of them per pass
+        flat = torch.cat([t.to(torch.float32).reshape(-1) for _, t in present]).cpu()
+        keep.append(flat)
+        off = 0
+        for i, t in present:
+            arr[i] = flat.data_ptr() + 4 * off
+            off += t.numel()
+    else:
+        for i, t in present:
+            t = t.to('cpu', torch.float32).contiguous()
+            keep.append(t)
+            arr[i] = t.data_ptr()
     blob = torch.empty(lib.pgrf_blob_floats(), dtype=torch.float32)
     lib.check(lib.pgrf_pack_weights(arr, len(names), int(bool(use_vis)), int(max_dn), C.c_void_p(blob.data_ptr())))
     return blob
@@ -361,24 +374,57 @@ class RenderPassFunction(torch.autograd.Function):
     outputs) and the pass's weights in pgrf_raw_name order; everything else (source images, poses, sample depths) is a
     constant, as in the reference's training graph (the importance sampler's inputs are detached, renderer.py:437)."""
 
+    # The channel-last Frame (shared by the coarse and the fine pass of a step) and the packed weight blob are reused while
+    # they are built from the same tensors (same storage address, shape and version counter; the cache holds the tensors, so
+    # their addresses cannot be recycled under it): an optimiser step or a new encoder output rebuilds them, a second pass over
+    # the same tensors does not (was: ~70 device->host copies and two map re-layouts per pass).
+    _frames, _blobs = [], []
+
+    @staticmethod
+    def _lookup(cache, ts, extra):
+        for ent_ts, ent_ver, ent_extra, val in cache:
+            if ent_extra == extra and len(ent_ts) == len(ts) and all((a is b) or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype) for a, b in zip(ent_ts, ts)) and \
+                    ent_ver == [None if t is None else t._version for t in ts]:
+                return val
+        return None
+
+    @staticmethod
+    def _store(cache, ts, extra, val, keep):
+        del cache[:max(0, len(cache) - keep + 1)]
+        cache.append((list(ts), [None if t is None else t._version for t in ts], extra, val))
+
     @staticmethod
     def forward(ctx, meta, coords, depth, img_feats, ray_feats, *raw):
         imgs, w2c, ref_dr, que_c2w, que_dr, use_vis, precision, frame_kw = meta
-        frame = Frame(imgs, img_feats.detach(), ray_feats.detach(), w2c, ref_dr, que_c2w, que_dr, device=imgs.device, **frame_kw)
-        names = raw_names()
-        host = {n: (t.detach() if t is not None else None) for n, t in zip(names, raw)}
-        blob = pack_pass_weights({k: v for k, v in host.items() if v is not None}, 'dist_decoder', 'agg_net', use_vis).to(frame.device)
+        F_ = RenderPassFunction
+        kw_t = [v for _, v in sorted(frame_kw.items()) if torch.is_tensor(v)]
+        f_ts = [imgs, img_feats, ray_feats, w2c, ref_dr, que_c2w if torch.is_tensor(que_c2w) else None, que_dr] + kw_t
+        f_extra = repr(sorted((k, v) for k, v in frame_kw.items() if not torch.is_tensor(v))) + repr(None if torch.is_tensor(que_c2w) else que_c2w)
+        frame = F_._lookup(F_._frames, f_ts, f_extra)
+        if frame is None:
+            frame = Frame(imgs, img_feats.detach(), ray_feats.detach(), w2c, ref_dr, que_c2w, que_dr, device=imgs.device, **frame_kw)
+            F_._store(F_._frames, f_ts, f_extra, frame, keep=1)
+        blob = F_._lookup(F_._blobs, list(raw), bool(use_vis))
+        if blob is None:
+            names = raw_names()
+            blob = pack_pass_weights({n: t.detach() for n, t in zip(names, raw) if t is not None}, 'dist_decoder', 'agg_net', use_vis).to(frame.device)
+            F_._store(F_._blobs, list(raw), bool(use_vis), blob, keep=4)
         out = render_pass(frame, blob, use_vis, coords, depth, precision=precision)
         ctx.frame, ctx.use_vis = frame, use_vis
         ctx.coords, ctx.depth = coords.detach(), depth.detach()
-        ctx.raw = [None if t is None else t.detach().to(frame.device, torch.float32).contiguous() for t in raw]
+        # the weights go through save_for_backward: an in-place update between forward and backward (an optimiser step) is then
+        # caught by autograd's version check instead of silently rematerialising the forward with the NEW weights
+        ctx.present = [t is not None for t in raw]
+        ctx.save_for_backward(*[t for t in raw if t is not None])
         ctx.need_maps = img_feats.requires_grad or ray_feats.requires_grad
         return out['pixel_colors_nr'], out['render_depth'], out['hit_prob_nr'], out['colors_nr'], out['density_nr']
 
     @staticmethod
     def backward(ctx, g_pixel, g_depth, g_hit, g_colors, g_density):
         grads = {'pixel_colors_nr': g_pixel, 'render_depth': g_depth, 'hit_prob_nr': g_hit, 'colors_nr': g_colors, 'density_nr': g_density}
-        g_raw, g_if, g_rf, _ = render_pass_backward(ctx.frame, ctx.raw, ctx.use_vis, ctx.coords, ctx.depth, grads, want_maps=ctx.need_maps)
+        saved = iter(ctx.saved_tensors)
+        raw = [(next(saved).detach().to(ctx.frame.device, torch.float32).contiguous() if p else None) for p in ctx.present]
+        g_raw, g_if, g_rf, _ = render_pass_backward(ctx.frame, raw, ctx.use_vis, ctx.coords, ctx.depth, grads, want_maps=ctx.need_maps)
         return (None, None, None, g_if, g_rf) + tuple(g_raw)
 
 

@@ -69,8 +69,8 @@ if b:
         out.append(f'HBM-side traffic per launch (`profiles/{TAG}_render_pass_pmc.txt`, separate `--pmc` passes; FETCH_SIZE doubled per the gfx950 note of '
                    f'MI355X_MICROARCH.md): 2 x {c["FETCH_SIZE"] * 1024 / 1e9:.2f} + {c["WRITE_SIZE"] * 1024 / 1e9:.2f} = **{traffic / 1e9:.2f} GB** '
                    f'({traffic / (r["kernel_ms"] * 1e-3) / 1e12:.2f} TB/s); L2 hit rate TCC_HIT / (HIT + MISS) = {hit * 100:.1f} %; '
-                   f'MFMA-pipe busy SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE) = '
-                   f'{c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * max(c.get("GRBM_GUI_ACTIVE", 1), 1)) * 100:.0f} %.')
+                   f'MFMA-pipe busy SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8: the counter sums the 8 XCDs) = '
+                   f'{c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * max(c.get("GRBM_GUI_ACTIVE", 1), 1) / 8.0) * 100:.0f} %.')
     e = b.get('torch_eager_gpu_baseline')
     if e:
         out.append(f'Eager PyTorch-ROCm port of the reference path on the same GPU (driver-run, bounded strip: {e.get("sample", "")}): '
@@ -102,7 +102,11 @@ for name, label in [('bench_config3.json', 'config 3: + D=64 cost volume 128x256
         continue
     extra = ''
     if 'cost_volume_stage' in d:
-        extra = f'; cost-volume stage {d["cost_volume_stage"]["ms_per_step"]:.2f} ms'
+        cs = d['cost_volume_stage']
+        extra = f'; cost-volume stage {cs["ms_per_step"]:.2f} ms'
+        if 'roofline' in cs:
+            extra += (f' (per view: build {cs["roofline_build"]["kernel_ms"] * 1e3:.0f} us = {cs["roofline_build"]["frac"] * 100:.0f} % of 8 TB/s, '
+                      f'{cs["regulariser"]} {cs["roofline"]["kernel_ms"]:.2f} ms = {cs["roofline"]["frac"] * 100:.0f} % of its MFMA roof)')
     if 'psnr' in d:
         extra += f'; PSNR vs oracle {d["psnr"]["float_vs_oracle_db"]:.1f} dB, |dPSNR vs GT| {d["psnr"]["abs_delta_vs_gt_db"]:.1e} dB'
     rows.append(f'| {label} | {d["ms_per_step"]:.2f} | {d["value"] / 1e6:.2f} | {d["roofline"]["frac"] * 100:.1f} %{extra} | `{TAG}_{name}` |')
