@@ -154,6 +154,15 @@ def end_to_end_frames(H, W, V, dn, fine, dev, frames=5):
             'ms_per_frame_source_maps_reused': kept, 'rays_per_s_source_maps_reused': H * W / kept * 1e3}
 
 
+def cpu_baseline_config0(budget_s=6.0):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case: 256x512 ERP, 2 source views, 32 coarse + 32 fine samples --
+    through the CPU oracle on a bounded random sample of the frame's rays."""
+    case0 = synthetic_case(256, 512, 2, 32, seed=0, fine=True)
+    base, _, _ = cpu_baseline(case0, budget_s=budget_s)
+    base['workload'] = '256x512 ERP, 2 source views, 32 + 32 samples (BASELINE configs[0])'
+    return base
+
+
 def cpu_baseline(case, budget_s=15.0):
     """The CPU oracle (a port of the reference algorithm) timed on a bounded sample of the workload."""
     from oracle import render_oracle as O
@@ -640,6 +649,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, ccoords, cout = cpu_baseline(case)
         res['cpu_baseline'] = base
+        if (H, W, V, dn) == (512, 1024, 2, 64) and not args.fine:
+            res['cpu_baseline_config0'] = cpu_baseline_config0()
         # PSNR of the HIP image against the oracle on the sampled rays
         idx = (ccoords[:, 1].long() * W + ccoords[:, 0].long()).to(dev)
         key = 'pixel_colors_nr_fine' if args.fine else 'pixel_colors_nr'

@@ -204,6 +204,16 @@ int pgrf_merge_c2f(const float* depth_c, const float* colors_c, const float* den
                    const float* depth_f, const float* colors_f, const float* density_f, int dn_f, int rn,
                    const PgrfPassOut* out, void* stream);
 
+/* Backward of pgrf_merge_c2f (the trainer differentiates network/renderer.py:484-518 like everything else; round 4): the sort is a
+ * permutation, so the merged composite's gradient is gathered back to the coarse and the fine pass's per-sample colours and
+ * densities (the depths are constants: the importance sampler's inputs are detached, renderer.py:437).  grad: upstream gradients
+ * of the MERGED outputs (hit_prob / density [rn,dn_c+dn_f], colors [rn,dn_c+dn_f,3], pixel_colors [rn,3], render_depth [rn]; any
+ * entry may be NULL); g_*: written (not accumulated), [rn,dn_c(,3)] / [rn,dn_f(,3)]. */
+int pgrf_merge_c2f_backward(const float* depth_c, const float* colors_c, const float* density_c, int dn_c,
+                            const float* depth_f, const float* colors_f, const float* density_f, int dn_f, int rn,
+                            const PgrfPassGrad* grad, float* g_colors_c, float* g_density_c, float* g_colors_f,
+                            float* g_density_f, void* stream);
+
 /* ------------------------------------------------------------------ whole per-batch path --- */
 typedef struct PgrfRenderCfg {
   float min_depth, max_depth;  /* cfg min_depth / max_depth */

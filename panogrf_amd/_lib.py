@@ -72,6 +72,7 @@ SYMBOLS = {
     "pgrf_render_pass": (C.c_int, [C.POINTER(PgrfFrame), _P, C.c_int, _P, _P, C.c_int, C.c_int,
                                    C.POINTER(PgrfPassOut), C.POINTER(PgrfPassDebug), _P, C.c_size_t, _P]),
     "pgrf_merge_c2f": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.POINTER(PgrfPassOut), _P]),
+    "pgrf_merge_c2f_backward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.POINTER(PgrfPassGrad), _P, _P, _P, _P, _P]),
     "pgrf_conv3d_upbrick_packed_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "pgrf_pack_conv3d_upbrick": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_upbrick": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -496,6 +496,133 @@ int launch_render_uncert(const float* depth, const float* hit, const float* rdep
   return PGRF_OK;
 }
 
+// Backward of the merge (round 4; SURVEY.md 8 f-3 with render_c2f_all): the sort is a permutation of the concatenated samples
+// (the depths are constants of the training graph: the importance sampler's inputs are detached, renderer.py:437), so the gradient
+// of the merged composite -- w_i = a_i T_i, T_i = prod_{j<i} (1 - a_j + 1e-10), a = 1 - exp(-relu(sigma)) -- is computed on the
+// sorted samples and GATHERED back through the same ranks: coarse slot k -> g_colors_c / g_density_c, fine slot k -> g_colors_f /
+// g_density_f.  grad: upstream of pixel_colors [rn,3], render_depth [rn], hit_prob / density [rn,total], colors [rn,total,3]
+// (any may be null).  One wave per ray; ranks exactly as in merge_c2f_kernel.
+__global__ void __launch_bounds__(256) merge_c2f_bwd_kernel(const float* __restrict__ zc, const float* __restrict__ colc,
+                                                            const float* __restrict__ denc, int dnc, const float* __restrict__ zf,
+                                                            const float* __restrict__ colf, const float* __restrict__ denf, int dnf,
+                                                            int rn, PgrfPassGrad g, float* __restrict__ gcolc, float* __restrict__ gdenc,
+                                                            float* __restrict__ gcolf, float* __restrict__ gdenf) {
+  __shared__ float s_z[4][2 * kMaxS];
+  __shared__ float s_sz[4][2 * kMaxS];
+  __shared__ float s_a[4][2 * kMaxS];
+  __shared__ float s_c[4][2 * kMaxS][3];
+  __shared__ float s_den[4][2 * kMaxS];
+  __shared__ int s_src[4][2 * kMaxS];
+  __shared__ float s_T[4][2 * kMaxS];
+  __shared__ float s_q[4][2 * kMaxS];       // g_w_i * w_i
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  const bool ok = ray < rn;
+  const int rayc = ok ? ray : rn - 1;
+  const int total = dnc + dnf;
+  for (int i = lane; i < total; i += 64)
+    s_z[wv][i] = (i < dnc) ? zc[(size_t)rayc * dnc + i] : zf[(size_t)rayc * dnf + (i - dnc)];
+  __syncthreads();
+  auto lt = [](float o, float v) { return (o < v) || (v != v && o == o); };
+  bool mine_sorted = true;
+  for (int j = lane; j + 1 < total; j += 64)
+    if (j + 1 != dnc && lt(s_z[wv][j + 1], s_z[wv][j])) mine_sorted = false;
+  const bool presorted = __all(mine_sorted);
+  for (int j = lane; j < total; j += 64) {
+    const float v = s_z[wv][j];
+    int rank = 0;
+    if (presorted) {
+      const bool coarse = j < dnc;
+      const float* other = &s_z[wv][coarse ? dnc : 0];
+      int lo = 0, hi = coarse ? dnf : dnc;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float o = other[mid];
+        if (coarse ? lt(o, v) : !lt(v, o)) lo = mid + 1; else hi = mid;
+      }
+      rank = (coarse ? j : j - dnc) + lo;
+    } else {
+      for (int k = 0; k < total; ++k) rank += sorts_before(s_z[wv][k], k, v, j) ? 1 : 0;
+    }
+    const float den = (j < dnc) ? denc[(size_t)rayc * dnc + j] : denf[(size_t)rayc * dnf + (j - dnc)];
+    const float* cp = (j < dnc) ? colc + ((size_t)rayc * dnc + j) * 3 : colf + ((size_t)rayc * dnf + (j - dnc)) * 3;
+    s_sz[wv][rank] = v;
+    s_den[wv][rank] = den;
+    s_a[wv][rank] = 1.f - __expf(-fmaxf(den, 0.f));
+    s_c[wv][rank][0] = cp[0]; s_c[wv][rank][1] = cp[1]; s_c[wv][rank][2] = cp[2];
+    s_src[wv][rank] = j;
+  }
+  __syncthreads();
+  const float gp0 = g.pixel_colors ? g.pixel_colors[(size_t)rayc * 3] : 0.f, gp1 = g.pixel_colors ? g.pixel_colors[(size_t)rayc * 3 + 1] : 0.f,
+              gp2 = g.pixel_colors ? g.pixel_colors[(size_t)rayc * 3 + 2] : 0.f, gd = g.render_depth ? g.render_depth[rayc] : 0.f;
+  // forward transmittance (inclusive product scan per block of 64 sorted samples, as in the forward kernel)
+  float carry = 1.f;
+  for (int i = lane; i < total + lane; i += 64) {
+    const bool in = i < total;
+    const float f = in ? (1.f - s_a[wv][i] + 1e-10f) : 1.f;
+    float incl = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl *= up;
+    }
+    float T = __shfl_up(incl, 1, 64);
+    if (lane == 0) T = 1.f;
+    T *= carry;
+    carry *= __shfl(incl, 63, 64);
+    if (!in) continue;
+    const float w = s_a[wv][i] * T;
+    const size_t pt = (size_t)rayc * total + i;
+    const float gw = (g.hit_prob ? g.hit_prob[pt] : 0.f) + gp0 * s_c[wv][i][0] + gp1 * s_c[wv][i][1] + gp2 * s_c[wv][i][2] + gd * s_sz[wv][i];
+    s_T[wv][i] = T;
+    s_q[wv][i] = gw * w;
+    // colours: direct upstream + through the pixel colour
+    const int j = s_src[wv][i];
+    float* gc = (j < dnc) ? gcolc + ((size_t)rayc * dnc + j) * 3 : gcolf + ((size_t)rayc * dnf + (j - dnc)) * 3;
+    if (ok) {
+      gc[0] = (g.colors ? g.colors[pt * 3] : 0.f) + w * gp0;
+      gc[1] = (g.colors ? g.colors[pt * 3 + 1] : 0.f) + w * gp1;
+      gc[2] = (g.colors ? g.colors[pt * 3 + 2] : 0.f) + w * gp2;
+    }
+  }
+  __syncthreads();
+  // S_k = sum_{i>k} g_w_i w_i: reverse scan over the blocks of 64, last block first
+  const int nblk = (total + 63) >> 6;
+  float tail = 0.f;
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int i = b * 64 + lane;
+    const bool in = i < total;
+    const float q = in ? s_q[wv][i] : 0.f;
+    float incl = q;                                        // inclusive suffix sum within the block
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float dn_ = __shfl_down(incl, off, 64);
+      if (lane + off < 64) incl += dn_;
+    }
+    const float S = incl - q + tail;                       // strictly after i
+    tail += __shfl(incl, 0, 64);
+    if (!in || !ok) continue;
+    const float a = s_a[wv][i], T = s_T[wv][i];
+    const size_t pt = (size_t)rayc * total + i;
+    const float gw = (g.hit_prob ? g.hit_prob[pt] : 0.f) + gp0 * s_c[wv][i][0] + gp1 * s_c[wv][i][1] + gp2 * s_c[wv][i][2] + gd * s_sz[wv][i];
+    const float ga = gw * T - S / (1.f - a + 1e-10f);
+    const float den = s_den[wv][i];
+    const float gs = (den > 0.f ? ga * (1.f - a) : 0.f) + (g.density ? g.density[pt] : 0.f);   // d alpha / d sigma = exp(-sigma) = 1 - alpha
+    const int j = s_src[wv][i];
+    if (j < dnc) gdenc[(size_t)rayc * dnc + j] = gs; else gdenf[(size_t)rayc * dnf + (j - dnc)] = gs;
+  }
+}
+
+int launch_merge_c2f_bwd(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
+                         const float* denf, int dnf, int rn, const PgrfPassGrad& g, float* gcolc, float* gdenc, float* gcolf,
+                         float* gdenf, void* stream) {
+  const int blocks = (rn + 3) / 4;
+  hipLaunchKernelGGL(merge_c2f_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, zc, colc, denc, dnc, zf, colf, denf, dnf, rn, g,
+                     gcolc, gdenc, gcolf, gdenf);
+  PGRF_CHECK_LAUNCH("merge_c2f backward");
+  return PGRF_OK;
+}
+
 int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
                      const float* denf, int dnf, int rn, const PgrfPassOut& o, void* stream) {
   const int blocks = (rn + 3) / 4;

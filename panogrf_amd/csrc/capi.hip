@@ -30,6 +30,9 @@ int launch_fine_depth(const float* depth, const float* hit, float qnear, float q
 int launch_merge_c2f(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
                      const float* denf, int dnf, int rn, const PgrfPassOut& o, void* stream);
 
+int launch_merge_c2f_bwd(const float* zc, const float* colc, const float* denc, int dnc, const float* zf, const float* colf,
+                         const float* denf, int dnf, int rn, const PgrfPassGrad& g, float* gcolc, float* gdenc, float* gcolf,
+                         float* gdenf, void* stream);
 int launch_render_uncert(const float* depth, const float* hit, const float* rdepth, int rn, int dn, float* out, void* stream);
 
 static const char* kRawNames[R_COUNT] = {
@@ -219,6 +222,20 @@ int pgrf_merge_c2f(const float* depth_c, const float* colors_c, const float* den
   if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_merge_c2f: rn < 0");
   if (rn == 0) return PGRF_OK;
   return launch_merge_c2f(depth_c, colors_c, density_c, dn_c, depth_f, colors_f, density_f, dn_f, rn, *out, stream);
+}
+
+int pgrf_merge_c2f_backward(const float* depth_c, const float* colors_c, const float* density_c, int dn_c, const float* depth_f,
+                            const float* colors_f, const float* density_f, int dn_f, int rn, const PgrfPassGrad* grad,
+                            float* g_colors_c, float* g_density_c, float* g_colors_f, float* g_density_f, void* stream) {
+  if (!depth_c || !colors_c || !density_c || !depth_f || !colors_f || !density_f || !grad || !g_colors_c || !g_density_c || !g_colors_f ||
+      !g_density_f)
+    return set_error(PGRF_ERR_ARG, "pgrf_merge_c2f_backward: null pointer");
+  if (dn_c < 1 || dn_f < 1 || dn_c > PGRF_MAX_DN || dn_f > PGRF_MAX_DN)
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_merge_c2f_backward: dn_c=%d dn_f=%d outside [1,%d]", dn_c, dn_f, PGRF_MAX_DN);
+  if (rn < 0) return set_error(PGRF_ERR_ARG, "pgrf_merge_c2f_backward: rn < 0");
+  if (rn == 0) return PGRF_OK;
+  return launch_merge_c2f_bwd(depth_c, colors_c, density_c, dn_c, depth_f, colors_f, density_f, dn_f, rn, *grad, g_colors_c, g_density_c,
+                              g_colors_f, g_density_f, stream);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }

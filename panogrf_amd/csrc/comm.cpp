@@ -4,6 +4,7 @@
 //   unique id (rank 0) -> broadcast out of band by the caller -> pgrf_comm_init on every rank -> pgrf_allgather_image per frame
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
@@ -22,6 +23,7 @@ struct Rccl {
 
 Rccl g_rccl;
 std::mutex g_mu;
+char g_why[256] = "unknown";       // why load_rccl() failed (dlerror() may be NULL: never handed to a %s directly)
 
 bool load_rccl() {
   std::lock_guard<std::mutex> lock(g_mu);
@@ -33,7 +35,11 @@ bool load_rccl() {
   if (!so)
     for (const char* n : names)
       if ((so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-  if (!so) return false;
+  if (!so) {
+    const char* e = dlerror();
+    std::snprintf(g_why, sizeof(g_why), "librccl.so not found (%s)", e ? e : "unknown");
+    return false;
+  }
   Rccl r;
   r.so = so;
   r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(so, "ncclGetUniqueId"));
@@ -41,7 +47,22 @@ bool load_rccl() {
   r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(so, "ncclAllGather"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(so, "ncclCommDestroy"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(so, "ncclGetErrorString"));
-  if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) return false;
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) {
+    std::snprintf(g_why, sizeof(g_why), "the RCCL library in this process lacks %s",
+                  !r.GetUniqueId ? "ncclGetUniqueId" : !r.CommInitRank ? "ncclCommInitRank" : !r.AllGather ? "ncclAllGather" : "ncclCommDestroy");
+    dlclose(so);
+    return false;
+  }
+  // the id is passed BY VALUE (128 bytes): refuse a library whose ABI this was not written against
+  static_assert(sizeof(PgrfUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (auto ver = reinterpret_cast<int (*)(int*)>(dlsym(so, "ncclGetVersion"))) {
+    int v = 0;
+    if (ver(&v) == 0 && v > 0 && v < 20000) {          // NCCL_VERSION_CODE = major * 10000 + ...: RCCL 2.x and later
+      std::snprintf(g_why, sizeof(g_why), "RCCL version code %d is older than 2.0", v);
+      dlclose(so);
+      return false;
+    }
+  }
   g_rccl = r;
   return true;
 }
@@ -56,7 +77,7 @@ extern "C" {
 
 int pgrf_comm_unique_id(PgrfUniqueId* id) {
   if (!id) return set_error(PGRF_ERR_ARG, "pgrf_comm_unique_id: null pointer");
-  if (!load_rccl()) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_comm_unique_id: librccl.so not found (%s)", dlerror());
+  if (!load_rccl()) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_comm_unique_id: %s", g_why);
   const int rc = g_rccl.GetUniqueId(id);
   if (rc) return set_error(PGRF_ERR_LAUNCH, "ncclGetUniqueId failed: %s", rccl_err(rc));
   return PGRF_OK;
@@ -65,7 +86,7 @@ int pgrf_comm_unique_id(PgrfUniqueId* id) {
 int pgrf_comm_init(const PgrfUniqueId* id, int rank, int nranks, void** comm) {
   if (!id || !comm) return set_error(PGRF_ERR_ARG, "pgrf_comm_init: null pointer");
   if (nranks < 1 || rank < 0 || rank >= nranks) return set_error(PGRF_ERR_ARG, "pgrf_comm_init: rank %d of %d", rank, nranks);
-  if (!load_rccl()) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_comm_init: librccl.so not found (%s)", dlerror());
+  if (!load_rccl()) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_comm_init: %s", g_why);
   void* c = nullptr;
   const int rc = g_rccl.CommInitRank(&c, nranks, *id, rank);
   if (rc) return set_error(PGRF_ERR_LAUNCH, "ncclCommInitRank failed: %s", rccl_err(rc));

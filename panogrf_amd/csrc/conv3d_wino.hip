@@ -59,7 +59,8 @@ template <bool TWO> struct WinoGeom {
   static constexpr int kFStride = TY * 8 * 2 * XW * 4; // floats per (fz, fy) slab of T: [tyy][quad 8][parity][XW][4 channels]
   static constexpr int kTFloats = 16 * kFStride;
   static constexpr int kStageFloats = 16 * TY * 16 * 4;   // halo staging: 16 TY items x 16 (dz,dy) float4
-  static constexpr int kLdsBytes = (kTFloats + kStageFloats) * 4;
+  static constexpr int kBiasFloats = 1024;               // the layer's bias in accumulator order (Cout <= 1024), copied once per workgroup
+  static constexpr int kLdsBytes = (kTFloats + kStageFloats + kBiasFloats) * 4;
 };
 
 // (the same on packed adds, through vector types: UNet2 6.60 -> 6.68 ms -- the loaders' transform is not on the MFMA waves' path)
@@ -155,8 +156,12 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
   // Channel quads are innermost so that a loader writes its float4 with ONE ds_write_b128 and an MFMA wave reads the
   // four k-steps of a group (lane half h, group g -> quad 4h + g) with ONE ds_read_b128 per patch column.
   auto tq = [](int fzfy, int tyy, int q, int p) { return ((((fzfy * TY + tyy) * 8 + q) * 2 + (p & 1)) * XW + (p >> 1)) * 4; };
-  float* red = lds;                                      // z-reduction buffer (reuses T): [m][fz][oy*2+ox][r][lane]
-  auto ridx = [&](int fz, int oyox, int m, int r) { return ((((m * 4 + fz) * 4 + oyox) * 16 + r) << 6) + lane; };
+  // z-reduction buffer (reuses T): [m][fz][oy*2+ox][lane][16], a lane's four register quads at slots q ^ ((lane >> 2) & 3): every
+  // 16-lane group of a ds_write_b128 / ds_read_b128 then covers 16 different bank quads (round 4; was [..][r][lane] with one
+  // 4-byte access per register: 64 writes + 96 reads per lane and row, 12 % of a one-block row)
+  float* red = lds;
+  const int rsw = (lane >> 2) & 3;
+  auto rquad = [&](int fz, int oyox, int m, int q) { return reinterpret_cast<float4*>(red + ((((m * 4 + fz) * 4 + oyox) << 10) + lane * 16 + 4 * (q ^ rsw))); };
   // Epilogue of one row, the 8 MFMA waves: wave w finishes cout tile w >> 2, outputs (oz, oy) = ((w >> 1) & 1, w & 1), both ox:
   // the z output transform over the four fz partials, LeakyReLU, stores.
   auto epilogue = [&](const Row& cur) {
@@ -166,17 +171,13 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
     const int cot = cur.cot0 + m;
 #pragma unroll
     for (int ox = 0; ox < 2; ++ox) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        auto rd = [&](int fz) { return red[ridx(fz, oy * 2 + ox, m, r)]; };
-        acc[r] = oz == 0 ? (rd(0) + rd(1)) + rd(2) : (rd(1) - rd(2)) - rd(3);
-      }
       const long long ov = ovrow + ox;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = cot * 32 + q * 8 + half * 4;
-        float4 v = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+        const float4 p1 = *rquad(1, oy * 2 + ox, m, q), p2 = *rquad(2, oy * 2 + ox, m, q);
+        const float4 p03 = *rquad(oz == 0 ? 0 : 3, oy * 2 + ox, m, q);
+        float4 v = oz == 0 ? f4add(f4add(p03, p1), p2) : f4sub(f4sub(p1, p2), p03);
         // LeakyReLU only (slope 1 = none): the ELU / residual epilogues of conv3d.hip are not needed by the layers
         // this kernel serves
         v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
@@ -188,6 +189,12 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
 
   int rowi = blockIdx.x;
   if (rowi >= nrows) return;
+  // the bias block in LDS: the first MFMA of a row is a corner frequency that accumulates straight onto it, so a global load
+  // at row start is an exposed memory latency per row (6 % of a one-block row)
+  float* lbias = lds + G::kTFloats + G::kStageFloats;
+  if (a.bias)
+    for (int i = tid; i < a.cot_total * 32; i += 1024) lbias[i] = a.bias[i];
+  __syncthreads();
   // Barrier protocol per 32-channel block (all 8 waves):  B1 = "T may be overwritten" (the MFMA waves are done with the
   // previous block / everybody is done with the reduction buffer), B2 = "T is complete".  Per row two more around the
   // z reduction: E1 = "T is dead", E2 = "partials are in LDS".
@@ -330,7 +337,7 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
     {
       f32x16 binit = zero16;
       if (a.bias && fzw == 1) {
-        const float4* bp = reinterpret_cast<const float4*>(a.bias + (cur.cot0 + mw) * 32 + half * 16);
+        const float4* bp = reinterpret_cast<const float4*>(lbias + (cur.cot0 + mw) * 32 + half * 16);
         const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
         binit = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
       }
@@ -447,7 +454,8 @@ __global__ void __launch_bounds__(1024) conv3d_wino_kernel(const ConvArgs a, int
 #pragma unroll
       for (int ox = 0; ox < 2; ++ox)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[ridx(fzw, oy * 2 + ox, mw, r)] = R[oy][ox][r];
+        for (int q = 0; q < 4; ++q)
+          *rquad(fzw, oy * 2 + ox, mw, q) = make_float4(R[oy][ox][4 * q], R[oy][ox][4 * q + 1], R[oy][ox][4 * q + 2], R[oy][ox][4 * q + 3]);
     WT_TICK(5)                                             // partials to LDS
     lds_barrier();                                         // E2: partials are in LDS
     WT_TICK(6)

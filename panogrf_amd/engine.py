@@ -428,6 +428,44 @@ class RenderPassFunction(torch.autograd.Function):
         return (None, None, None, g_if, g_rf) + tuple(g_raw)
 
 
+class MergeC2fFunction(torch.autograd.Function):
+    """`render_c2f_all` under torch.autograd (network/renderer.py:484-518): forward = pgrf_merge_c2f (stable sort of the concatenated
+    coarse and fine samples + one composite over the union), backward = pgrf_merge_c2f_backward (the sort is a permutation: a
+    gather).  Differentiable inputs: the two passes' per-sample colours and densities; depths are constants."""
+
+    @staticmethod
+    def forward(ctx, depth_c, colors_c, density_c, depth_f, colors_f, density_f):
+        dev = depth_c.device
+        args = [_f32c(t, dev) for t in (depth_c, colors_c, density_c, depth_f, colors_f, density_f)]
+        rn, dn_c = args[0].shape
+        dn_f = args[3].shape[1]
+        t, o = _alloc_out(rn, dn_c + dn_f, dev)
+        lib.check(lib.pgrf_merge_c2f(_ptr(args[0]), _ptr(args[1]), _ptr(args[2]), dn_c, _ptr(args[3]), _ptr(args[4]), _ptr(args[5]), dn_f, rn,
+                                     C.byref(o), _stream()))
+        ctx.save_for_backward(*args)
+        return t['pixel_colors_nr'], t['render_depth'], t['hit_prob_nr'], t['colors_nr'], t['density_nr']
+
+    @staticmethod
+    def backward(ctx, g_pixel, g_depth, g_hit, g_colors, g_density):
+        from ._lib import PgrfPassGrad
+        zc, cc, dc, zf, cf, df = ctx.saved_tensors
+        dev = zc.device
+        rn, dn_c = zc.shape
+        dn_f = zf.shape[1]
+        gs = [None if g is None else _f32c(g, dev) for g in (g_pixel, g_depth, g_hit, g_colors, g_density)]
+        pg = PgrfPassGrad(*[(None if g is None else g.data_ptr()) for g in gs])
+        gcc, gdc, gcf, gdf = torch.empty_like(cc), torch.empty_like(dc), torch.empty_like(cf), torch.empty_like(df)
+        lib.check(lib.pgrf_merge_c2f_backward(_ptr(zc), _ptr(cc), _ptr(dc), dn_c, _ptr(zf), _ptr(cf), _ptr(df), dn_f, rn, C.byref(pg),
+                                              _ptr(gcc), _ptr(gdc), _ptr(gcf), _ptr(gdf), _stream()))
+        return None, gcc, gdc, None, gcf, gdf
+
+
+def merge_c2f_autograd(depth_c, colors_c, density_c, depth_f, colors_f, density_f):
+    """-> dict with the merged composite's outputs (the keys the reference overwrites in the fine pass's dict, renderer.py:499-506)"""
+    px, rd, hit, col, den = MergeC2fFunction.apply(depth_c, colors_c, density_c, depth_f, colors_f, density_f)
+    return {'pixel_colors_nr': px, 'render_depth': rd, 'hit_prob_nr': hit, 'colors_nr': col, 'density_nr': den}
+
+
 def render_pass_autograd(imgs, img_feats, ray_feats, w2c, ref_depth_range, que_c2w, que_depth_range, named_params, dd_prefix,
                          agg_prefix, use_vis, coords, depth, precision='f32', **frame_kw):
     """named_params: name -> Parameter (the module's own, so the gradients land on them).  -> dict like render_pass()."""

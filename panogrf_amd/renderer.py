@@ -223,8 +223,8 @@ class NeuralRayBaseRenderer(nn.Module):
         enabled the per-ray passes run as torch.autograd Functions whose backward is pgrf_render_pass_backward
         (panogrf_amd.engine.RenderPassFunction) and the 2-D encoders stay on torch.  What has no backward is refused."""
         if is_train and torch.is_grad_enabled():
-            if self.cfg.get('render_c2f_all'):
-                raise NotImplementedError("cfg['render_c2f_all'] has no backward pass (pgrf_merge_c2f is forward only)")
+            if self.cfg.get('render_c2f_all') and self.cfg.get('render_uncert'):
+                raise NotImplementedError("cfg['render_c2f_all'] together with cfg['render_uncert'] has no backward pass")
             if self.cfg.get('hip_precision', 'f32') != 'f32':
                 raise NotImplementedError("training runs in exact fp32 (cfg['hip_precision']='f32')")
 
@@ -276,8 +276,12 @@ class NeuralRayBaseRenderer(nn.Module):
         kw = dict(dataset_name=c.get('dataset_name', 'm3d'))
         que_c2w = None
         if is_perspec:
+            if que['poses'].shape[0] != 1:
+                raise PgrfError('one query view per call (qn = 1)')
             kw.update(que_pose=que['poses'], que_K=que['Ks'])
         else:
+            if que['c2w'].shape[0] != 1:
+                raise PgrfError('que_imgs_info c2w.shape[0]=1')
             que_c2w = que['c2w']
         use_disp = bool(c.get('use_disp', True))
         depth = E.sample_coarse_depth(c['min_depth'], c['max_depth'], rn, dn, use_disp=use_disp, device=dev)
@@ -295,6 +299,8 @@ class NeuralRayBaseRenderer(nn.Module):
                 pre, vis_f = ('fine_dist_decoder', 'fine_agg_net'), self.fine_dist_decoder.cfg['use_vis']
             fine = E.render_pass_autograd(*common, pre[0], pre[1], vis_f, coords, fd, **kw)
             fine['depth'] = fd
+            if c.get('render_c2f_all'):      # one composite over the sorted union of both passes' samples (renderer.py:484-518)
+                fine.update(E.merge_c2f_autograd(depth, out['colors_nr'], out['density_nr'], fd, fine['colors_nr'], fine['density_nr']))
             for k, v in fine.items():
                 out[k + '_fine'] = v
         if c.get('render_uncert'):        # renderer.py:305-312, in torch so that it stays differentiable
@@ -358,7 +364,11 @@ class NeuralRayBaseRenderer(nn.Module):
         (4 MB per 512x1024 view) are all-gathered; the small visibility encoder stays replicated.  -> (mine, offset) or None.
         cfg['hip_shard_encoders']=False keeps every rank on all views."""
         import torch.distributed as tdist
+        # (never in training mode, like the MVS stage's view shards: a data-parallel job whose ranks each hold their own batch and
+        #  run a training-mode forward under no_grad must not mix each other's feature maps, nor hang in an all-gather only some
+        #  ranks reach)
         if not (self.cfg.get('hip_shard_encoders', True) and imgs.is_cuda and not torch.is_grad_enabled() and
+                not self.__dict__.get('_pgrf_is_train', False) and
                 tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1 and imgs.shape[0] > 1):
             return None
         from . import dist as D
@@ -437,13 +447,16 @@ class NeuralRayBaseRenderer(nn.Module):
 
     def _reuse_enabled(self, imgs, is_train):
         """Source-map reuse (new; the reference recomputes per frame): a trajectory renders many query poses against the
-        SAME source views (render.py:248-278 rebuilds identical ref/src infos for every frame), and everything in front of
+        SAME source views, and everything in front of
         the per-ray kernel -- MVS stage, 2-D encoders: 8.5 of 84 ms at the shipped configuration -- depends on the source
         views and the weights only.  With cfg['hip_reuse_source_maps'] (default on; eval, GPU, no autograd) those results
         are kept and returned again while the inputs are unchanged (`_unchanged`) and the weights' version counters are.
         True (default) recognises the SAME tensor objects at the same version counters only -- no device work, no host
-        sync; 'equal' additionally accepts new tensors of equal contents (a caller that rebuilds identical infos per
-        frame, at one torch.equal = one sync per tensor and frame); False recomputes always.  Off under
+        sync: the caller keeps its ref / src infos across the frames of a trajectory (render.py of THIS repository does; the
+        frame timings published with "source-map reuse" use this mode).  The reference's render.py:248-278 rebuilds the infos
+        from disk for every frame: such a caller gets new tensor objects each frame, which this mode treats as new data (the
+        stage is recomputed, as in the reference) -- 'equal' additionally accepts new tensors of equal contents, at one
+        torch.equal = one sync per tensor and frame; False recomputes always.  Off under
         torch.inference_mode(): inference tensors have no version counter to watch."""
         return (bool(self.cfg.get('hip_reuse_source_maps', True)) and imgs.is_cuda and not is_train
                 and not torch.is_grad_enabled() and not torch.is_inference_mode_enabled())
@@ -516,6 +529,7 @@ class NeuralRayBaseRenderer(nn.Module):
         """Whole query view (network/renderer.py:635-686).  Mutates ref_imgs_info['img_feats'/'ray_feats'] and
         que_imgs_info['coords'] like the reference does."""
         self._check_train(is_train)
+        self.__dict__['_pgrf_is_train'] = bool(is_train)
         ref_img_feats, ray_feats = self._encode_reusing(ref_imgs_info['imgs'], ref_imgs_info['ray_feats'], is_train)
         ref_imgs_info['img_feats'] = ref_img_feats
         ref_imgs_info['ray_feats'] = ray_feats
@@ -591,6 +605,7 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         if not hasattr(self, 'init_net'):
             raise PgrfError('NeuralRayGenRenderer needs an init_net module (see class docstring); '
                             'or put ray_feats into ref_imgs_info and call render()')
+        self.__dict__['_pgrf_is_train'] = bool(is_train)
         ret = self._init_net_reusing(ref_imgs_info, src_imgs_info, is_train)
         ref_imgs_info['ray_feats'] = ret['ray_feats']
         if 'mvs_depth' in ret:

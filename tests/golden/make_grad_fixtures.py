@@ -125,10 +125,19 @@ def c2f_fixture(src, out_name, rn=40):
     ray_feats = frame['ray_feats'].clone().requires_grad_(True)
     que = {'c2w': frame['que_c2w'][None], 'w2c': frame['que_w2c'][None], 'coords': coords[None], 'depth_range': frame['que_depth_range'][None]}
     ref = {'imgs': frame['imgs'], 'w2c': frame['w2c'], 'depth_range': frame['ref_depth_range'], 'ray_feats': ray_feats, 'img_feats': img_feats}
+    cap = {}
+    rbd = r.render_by_depth
+
+    def spy(que_depth, *a, **k):               # the sample depths of the two passes (the fine ones come out of the importance sampler)
+        cap['fine' if (a[3] if len(a) > 3 else k.get('is_fine')) else 'coarse'] = que_depth.detach().clone()
+        return rbd(que_depth, *a, **k)
+    r.render_by_depth = spy
     out = r.render_impl(que, ref, False)       # eval-mode sampler (no random draws), gradients enabled
+    r.render_by_depth = rbd
     loss = sum((out[k][0] * up[k]).sum() for k in up)
     loss.backward()
-    arrs = {'source': np.frombuffer(src.encode(), dtype=np.uint8), 'coords': coords.numpy(), 'loss': np.float64(loss.item())}
+    arrs = {'source': np.frombuffer(src.encode(), dtype=np.uint8), 'coords': coords.numpy(), 'loss': np.float64(loss.item()),
+            'depth.coarse': cap['coarse'][0].numpy(), 'depth.fine': cap['fine'][0].numpy()}
     for k in up:
         arrs['up.' + k] = up[k].numpy()
         arrs['out.' + k] = out[k][0].detach().numpy()

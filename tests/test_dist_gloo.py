@@ -139,3 +139,13 @@ def test_encoder_views_go_to_the_ranks_the_mvs_stage_leaves_idle():
 
 def test_allgather_views_world4_with_owner_offset():
     _run_views(4, 2, offset=2)       # views owned by ranks 2 and 3; ranks 0 and 1 contribute empty shards
+
+
+def test_allgather_tiles_and_views_world8():
+    """world size 8 (the driver's scaling run): equal and ragged row tiles; 2 and 4 reference views over 8 ranks (6 / 4 idle ranks
+    pass empty shards through the view all-gather), with and without the encoder's owner offset."""
+    _run(8, 16, 6)
+    _run(8, 13, 5)
+    _run_views(8, 2)
+    _run_views(8, 4)
+    _run_views(8, 2, offset=2)

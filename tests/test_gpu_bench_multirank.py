@@ -101,6 +101,37 @@ def test_plain_bench_gpus_2_launches_its_own_ranks():
     assert d['config']['gathered_image_max_abs_diff_vs_unsharded'] == 0.0
 
 
+@pytest.mark.parametrize('extra', [[], ['--fine'], ['--with-cost-volume', '--cv-res', '16', '32', '--reg', 'costregnet'], ['--views', '4']],
+                         ids=['single-pass', 'coarse+fine', 'cost-volume', 'four-views'])
+def test_plain_bench_gpus_8_on_one_gpu(extra):
+    """The driver's 8-GPU invocation, as typed -- `python bench.py --gpus 8 ...` -- on the one GPU of the test box (gloo: eight
+    self-launched ranks share it): 8 row tiles of 8 rows each, frame all-gathered and bit-identical to unsharded rendering; with
+    the cost-volume stage 2 (or 4) ranks hold a reference view each and 6 (4) ranks pass an empty shard through the view
+    all-gather (round 4; the earlier tests stopped at 4 ranks)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['PGRF_BENCH_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--height', '64',
+           '--width', '128', '--samples', '32', '--no-cpu-baseline'] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 8 and d['config']['ray_tiles'] == 8 and d['scaling'] == 'strong'
+    assert d['roofline']['rays_per_launch'] == 64 * 128 // 8
+    assert d['config']['gathered_image_max_abs_diff_vs_unsharded'] == 0.0
+    if '--with-cost-volume' in extra:
+        assert d['cost_volume_stage']['view_shards'] == 2 and d['cost_volume_stage']['ms_per_step'] > 0
+
+
+def test_renderer_module_shards_rays_and_views_eight_ranks():
+    """`renderer(data)` under an 8-rank process group (gloo, one GPU): 8 ray shards, the MVS stage on 2 ranks, the image encoder on
+    2 others, 4 ranks idle through both -- the same result as the unsharded call on every rank."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(ROOT, 'tests', 'mp_render_shard.py')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert r.stdout.count('sharded == unsharded') == 8
+
+
 def test_cabi_rccl_image_allgather_one_rank():
     """The C-ABI collective entry points (include/panogrf_hip.h: pgrf_comm_unique_id / pgrf_comm_init / pgrf_allgather_image /
     pgrf_comm_destroy) for hosts without torch.distributed: a one-rank communicator on this GPU, the image

@@ -6,7 +6,8 @@ whole result and CPU-oracle parity on strips / planes / slabs small enough for t
   configs[4]  1024x2048 ERP, 4 source views (multi-view cost volume), 64 samples
   configs[3]  512x1024 ERP, 2 views, 64 coarse + 64 fine samples
   configs[2]  D=64 cost volume at 128x256 + regulariser (UNet2 / CostRegNet)
-(configs[1] = tests/test_gpu_render.py::test_full_size_properties_and_oracle_strip, configs[0] = the CPU oracle tests.)
+  configs[0]  256x512 ERP, 2 views, 32 + 32 samples, random-init nets through render.py's plumbing (round 4)
+(configs[1] = tests/test_gpu_render.py::test_full_size_properties_and_oracle_strip.)
 """
 import os
 
@@ -204,3 +205,67 @@ def test_config3_regulariser_128x256x64_winograd_vs_direct_and_oracle_slab(reg, 
     mine_c = mine.cpu().reshape(ref.shape)                               # one channel: [B,D,H,W,1] and [B,1,D,H,W] coincide
     err = max_abs(mine_c, ref)
     assert err < 5e-5 * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))
+
+
+def test_config0_256x512_random_init_through_render_py_plumbing_vs_oracle_strip():
+    """BASELINE configs[0] AS WRITTEN: one 256x512 ERP panorama, 2 source views, 32 + 32 samples, RANDOM-INIT nets (PyTorch's
+    default initialisation, no density boost, no checkpoint), through the plumbing of the reference's render.py:97-305 --
+    cfg merge, `name2network[cfg['network']](cfg)`, `build_imgs_info` / `build_render_imgs_info`, `renderer(data)` with 'eval' --
+    on the HIP path; whole-frame properties, chunking invariance, and a >= 2 048-ray strip (poles, seam, corners) against the CPU
+    oracle on the module's own encoder outputs and parameters."""
+    import numpy as np
+    from oracle import render_oracle as O
+    from render import DEFAULT_CFG
+    from bench import synthetic_case
+    from panogrf_amd.imgs_info import build_imgs_info, build_render_imgs_info, imgs_info_to_torch
+    from panogrf_amd.renderer import name2network
+    H, W, V, dn = 256, 512, 2, 32
+    cfg = {**DEFAULT_CFG, 'height': H, 'width': W, 'depth_sample_num': dn, 'fine_depth_sample_num': dn, 'sample_num': dn}
+    torch.manual_seed(0)
+    net = name2network[cfg['network']](cfg).cuda().eval()            # random init: nothing is loaded
+    case = synthetic_case(H, W, V, dn)
+    imgs, w2c = case['frame']['imgs'].numpy(), case['frame']['w2c'].numpy()
+    rng = [[cfg['min_depth'], cfg['max_depth']]] * V
+    ref = imgs_info_to_torch(build_imgs_info(imgs, w2c, rng), 'cuda')
+    ray_feats_in = torch.randn(V, 32, H // 8, W // 8, generator=torch.Generator().manual_seed(99))
+    ref['ray_feats'] = ray_feats_in.cuda()
+    pose = np.concatenate([np.eye(3), np.array([[0.1], [0.0], [0.02]])], 1)
+    que = imgs_info_to_torch(build_render_imgs_info(pose, (H, W), [cfg['min_depth'], cfg['max_depth']]), 'cuda')
+    with torch.no_grad():
+        ref_run = dict(ref)
+        out = net({'que_imgs_info': dict(que), 'ref_imgs_info': ref_run, 'eval': True})
+        net.cfg['ray_batch_num'] = net.cfg['hip_ray_batch_num'] = 1536    # chunking invariance (renderer.py:656-683): not a divisor of H*W
+        out2 = net({'que_imgs_info': dict(que), 'ref_imgs_info': dict(ref), 'eval': True})
+    want_keys = {'pixel_colors_nr', 'pixel_colors_nr_fine', 'render_depth', 'render_depth_fine', 'colors_nr', 'colors_nr_fine',
+                 'density_nr', 'density_nr_fine'}
+    assert want_keys <= set(out), sorted(want_keys - set(out))
+    assert not any(k.startswith('hit_prob') for k in out)             # eval drops them (renderer.py:675)
+    pf = out['pixel_colors_nr_fine'][0]
+    assert pf.shape == (H * W, 3) and bool(torch.isfinite(pf).all())
+    assert float(pf.min()) >= -1e-5 and float(pf.max()) <= 1.0 + 1e-4
+    rd = out['render_depth_fine'][0]
+    assert bool(torch.isfinite(rd).all()) and float(rd.min()) >= 0.0 and float(rd.max()) <= cfg['max_depth'] * (1 + 1e-4)
+    for k in ('pixel_colors_nr', 'pixel_colors_nr_fine', 'render_depth_fine'):
+        assert torch.equal(out[k], out2[k]), k
+    # CPU oracle on a strip: the module's parameters and the encoder outputs render() left in ref_imgs_info
+    strip = _strip(H, W, 2048, 5)
+    assert strip.numel() >= 2048
+    coords = _coords(H, W)[strip]
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    c2w = que['c2w'][0].cpu()
+    # (renderer(data) shallow-copies its dicts, renderer.py:778-781; render() leaves the encoder outputs in the dict it is given)
+    ref_run = dict(ref)
+    que_few = dict(que, coords=que['coords'][:, :64])
+    with torch.no_grad():
+        net.render(que_few, ref_run, False)
+    fr = dict(imgs=case['frame']['imgs'], img_feats=ref_run['img_feats'].float().cpu().contiguous(), ray_feats=ref_run['ray_feats'].float().cpu().contiguous(),
+              w2c=case['frame']['w2c'], ref_depth_range=torch.tensor(rng), que_c2w=c2w, que_depth_range=torch.tensor(rng[0]))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ocfg = dict(min_depth=cfg['min_depth'], max_depth=cfg['max_depth'], use_disp=True, depth_sample_num=dn, fine_depth_sample_num=dn,
+                use_hierarchical_sampling=True, dist_decoder_cfg={'use_vis': False}, fine_dist_decoder_cfg={'use_vis': False}, height=H, width=W)
+    want = O.render_rays(sd, fr, coords, ocfg)
+    sc = strip.cuda()
+    assert max_abs(out['pixel_colors_nr'][0][sc].cpu(), want['pixel_colors_nr']) < 2e-5
+    assert max_abs(out['density_nr'][0][sc].cpu(), want['density_nr']) < 2e-5 * max(1.0, float(want['density_nr'].abs().max()))
+    assert FX.psnr(pf[sc].cpu(), want['pixel_colors_nr_fine']) > 70.0
+    assert max_abs(out['render_depth'][0][sc].cpu(), want['render_depth']) < 2e-4 * cfg['max_depth']
