@@ -305,6 +305,19 @@ int pgrf_conv3d_wino_preferred(int Cin, int Cout, int B, int D, int H, int W);
 int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                      const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
                      int res_cs, int res_coff, void* stream);
+
+/* The same algorithm, second kernel generation (round 4; csrc/conv3d_wino16.hip): rows of 16 tiles, v_mfma_f32_16x16x4_f32, TWO
+ * independent 8-wave workgroups per CU (78 KB of LDS each) instead of one 16-wave workgroup -- one's barriers, epilogue and operand
+ * formation run under the other's MFMAs.  Own packing (k permutation of the 16-row MFMA, bias in natural order).  Needs
+ * Cin % 32 == 0, Cout % 64 == 0 (<= 1024), even D and H, W % 32 == 0.  Environment switch of the Python host: PANOGRF_WINO=32
+ * selects the first generation where both apply. */
+size_t pgrf_conv3d_wino16_packed_floats(int Cout, int Cin);
+int pgrf_pack_conv3d_wino16(const float* w_host, const float* bias_host, int Cout, int Cin, float* packed_host);
+int pgrf_conv3d_wino16_supported(int Cin, int Cout, int D, int H, int W);
+int pgrf_conv3d_wino16_preferred(int Cin, int Cout, int B, int D, int H, int W);
+int pgrf_conv3d_wino16(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                       const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope,
+                       const float* residual, int res_cs, int res_coff, void* stream);
 /* Narrow layers of CostRegNet (models/cost_reg.py:99-175: 8/16/32-channel convs): the same wrap-padded 3x3x3 conv,
  * but the reduction is cut into 32-deep steps over (tap, channel) (two or four taps per step when Cin is 16 or 8) and
  * `nshift` consecutive output depths share one 32-row tile (nshift * Cout <= 32; nshift > 1 needs stride 1 and

@@ -29,7 +29,7 @@ class _PackedConv:
         lib.check(lib.pgrf_pack_conv3d(_ptr(w), _ptr(b), cout, cin, _ptr(host)))
         self.dev = host.to(device)
         self.cout, self.cin, self.has_bias = cout, cin, b is not None
-        self._w, self._b, self._device, self._small, self._wino = w, b, device, {}, None
+        self._w, self._b, self._device, self._small, self._wino, self._wino16 = w, b, device, {}, None, None
 
     def wino(self):
         """Packed block of the Winograd kernel (pgrf_conv3d_wino): filters transformed on the host, built on first use."""
@@ -39,6 +39,15 @@ class _PackedConv:
             lib.check(lib.pgrf_pack_conv3d_wino(_ptr(self._w), _ptr(self._b), self.cout, self.cin, _ptr(host)))
             self._wino = host.to(self._device)
         return self._wino
+
+    def wino16(self):
+        """Packed block of the second-generation Winograd kernel (pgrf_conv3d_wino16), built on first use."""
+        if self._wino16 is None:
+            n = lib.pgrf_conv3d_wino16_packed_floats(self.cout, self.cin)
+            host = torch.empty(n, dtype=torch.float32)
+            lib.check(lib.pgrf_pack_conv3d_wino16(_ptr(self._w), _ptr(self._b), self.cout, self.cin, _ptr(host)))
+            self._wino16 = host.to(self._device)
+        return self._wino16
 
     def small(self, nshift):
         """Packed block of the narrow-layer kernel (pgrf_conv3d_small), built on first use per depth-shift count."""
@@ -155,7 +164,8 @@ def _small16_shift(pc, x, stride):
     if (pc.cout % 16 == 0 and pc.cout <= int(os.environ.get('PANOGRF_CONV_SMALL16_COUT', '64')) and pc.cin % 16 == 0 and pc.cin <= 1024 and stride == 1
             and x.B * x.D * x.H * x.W <= wide):
         wino = os.environ.get('PANOGRF_CONV_WINOGRAD', '1')          # layers the Winograd kernel takes stay there
-        if wino == 'force' or (wino != '0' and lib.pgrf_conv3d_wino_preferred(pc.cin, pc.cout, x.B, x.D, x.H, x.W)):
+        if wino == 'force' or (wino != '0' and (lib.pgrf_conv3d_wino_preferred(pc.cin, pc.cout, x.B, x.D, x.H, x.W) or
+                                                 lib.pgrf_conv3d_wino16_preferred(pc.cin, pc.cout, x.B, x.D, x.H, x.W))):
             return 0
         return 1
     return 0
@@ -187,6 +197,14 @@ def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
                                         _ptr(residual.buf) if residual is not None else None,
                                         residual.cs if residual is not None else 0,
                                         residual.coff if residual is not None else 0, _stream()))
+        return out
+    force = os.environ.get('PANOGRF_CONV_WINOGRAD') == 'force'
+    if (stride == 1 and residual is None and os.environ.get('PANOGRF_CONV_WINOGRAD', '1') != '0' and os.environ.get('PANOGRF_WINO', '16') != '32' and
+            (lib.pgrf_conv3d_wino16_preferred(pc.cin, pc.cout, x.B, x.D, x.H, x.W) or
+             (force and lib.pgrf_conv3d_wino16_supported(pc.cin, pc.cout, x.D, x.H, x.W)))):
+        # wide stride-1 layers: Winograd F(2x2x2, 3x3x3), 3.4x fewer MFMAs; two independent workgroups per CU (csrc/conv3d_wino16.hip)
+        lib.check(lib.pgrf_conv3d_wino16(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                         _ptr(pc.wino16()), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope), None, 0, 0, _stream()))
         return out
     if (stride == 1 and residual is None and os.environ.get('PANOGRF_CONV_WINOGRAD', '1') != '0' and
             (lib.pgrf_conv3d_wino_preferred(pc.cin, pc.cout, x.B, x.D, x.H, x.W) or

@@ -42,6 +42,12 @@ else:
     for (cin, cout, D, H, W) in [(32, 64, 64, 128, 256), (64, 64, 64, 128, 256), (64, 128, 32, 64, 128), (128, 128, 32, 64, 128),
                                  (256, 64, 32, 64, 128), (64, 64, 32, 64, 128), (128, 256, 16, 32, 64), (256, 256, 16, 32, 64)]:
         gf = 27 * cin * cout * 2 * D * H * W / 1e9
+        os.environ['PANOGRF_WINO'] = '16'
         _, tw = run(cin, cout, 1, D, H, W, True, reps=5)
+        os.environ['PANOGRF_WINO'] = '32'
+        _, t32 = run(cin, cout, 1, D, H, W, True, reps=5)
+        os.environ['PANOGRF_WINO'] = '16'
         _, td = run(cin, cout, 1, D, H, W, False, reps=5)
-        print(f'cin={cin:3d} cout={cout:3d} {D}x{H}x{W}: winograd {tw*1e3:8.1f} us ({gf/tw:6.1f} TF/s alg)   direct {td*1e3:8.1f} us ({gf/td:6.1f} TF/s)   x{td/tw:.2f}')
+        # roof of the Winograd-domain products: direct FLOPs / 3.375 at the f32 MFMA peak (157.3 TFLOP/s)
+        print(f'cin={cin:3d} cout={cout:3d} {D}x{H}x{W}: winograd {tw*1e3:8.1f} us ({gf/tw:6.1f} TF/s alg, {gf / 3.375 / tw / 157.3 * 100:4.1f} % of the Winograd-MFMA roof)   '
+              f'first generation (32-tile rows) {t32*1e3:8.1f} us   direct {td*1e3:8.1f} us ({gf/td:6.1f} TF/s)   x{td/tw:.2f}')
