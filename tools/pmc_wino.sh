@@ -12,7 +12,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         if 'wino' not in row['Kernel_Name']: continue
-        k = 'wino grid=' + row['Grid_Size']
+        k = ('wino16' if 'wino16' in row['Kernel_Name'] else 'wino32') + ' grid=' + row['Grid_Size']
         agg[k][row['Counter_Name']] += float(row['Counter_Value']); cnt[k][row['Counter_Name']] += 1
 for k, v in sorted(agg.items()):
     g = lambda c: v.get(c, 0.0) / max(cnt[k][c], 1)

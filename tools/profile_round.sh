@@ -64,5 +64,20 @@ bash $R/tools/pmc_mem.sh v4 --views 4 2>&1 | grep "per-launch" > $OUT/views4_mem
 bash $R/tools/trace_costreg.sh $TAG 128 256 2>&1 | grep -E " us$|sum " > $OUT/costregnet_layer_trace_128x256.txt
 { echo "# SQ counters of CostRegNet's conv kernels at 128x256x64, averages per (kernel, grid) over the launches of tools/time_cost_volume.py (tools/pmc_conv.sh: rocprofv3 --pmc, separate passes)";
   bash $R/tools/pmc_conv.sh $TAG costregnet 128 256 2>&1 | grep "mfma_busy"; } > $OUT/costreg_conv_pmc.txt
-rm -rf $OUT/pmc[0-9] $OUT/bench_trace $OUT/cv_trace
+# 10. round 4: training step (bench line + kernel stats), SQ counters of the 4-view wave-pair kernel, the Winograd kernels (both
+#     generations, per kernel name), UNet2's conv kernels and the cost-volume kernel
+python3 $R/bench.py --train --steps 10 --warmup 3 > $OUT/bench_train.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_trace -- python3 $R/bench.py --train --steps 5 --warmup 2 --no-cpu-baseline > $OUT/train_trace.log 2>&1
+cp $(find $OUT/train_trace -name "*kernel_stats.csv" | head -1) $OUT/train_kernel_stats.csv
+{ echo "# SQ counters of the 4-view render pass (render_pass_pair_kernel), per-launch averages: bash tools/pmc_cmd.sh v4 render_pass bench.py --views 4 ...";
+  bash $R/tools/pmc_cmd.sh ${TAG}v4 render_pass $R/bench.py --views 4 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep "per-launch"; } > $OUT/views4_pair_pmc.txt
+{ echo "# rocprofv3 --kernel-trace --pmc (three passes) on: python3 tools/check_wino.py time (both kernel generations on the 8 UNet2 layer shapes); tools/pmc_wino.sh";
+  echo "# mfma_busy% = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8); SQ_INSTS_VALU counts the MFMAs themselves (subtract 1 per MFMA)";
+  bash $R/tools/pmc_wino.sh 2>&1 | grep -vE "amdgpu.ids|^W20"; } > $OUT/winograd_pmc.txt
+{ echo "# SQ counters of UNet2's conv kernels at 128x256x64 (tools/pmc_conv.sh: rocprofv3 --pmc, separate passes), averages per (kernel, grid)";
+  bash $R/tools/pmc_conv.sh ${TAG}u unet2 128 256 2>&1 | grep "mfma_busy"; } > $OUT/unet2_conv_pmc.txt
+{ echo "# memory-side and SQ counters of cost_volume_kernel at 128x256x64, per-launch averages (tools/pmc_cmd.sh ... tools/time_cost_volume.py 128 256 costregnet)";
+  bash $R/tools/pmc_cmd.sh ${TAG}cv cost_volume $R/tools/time_cost_volume.py 128 256 costregnet 2>&1 | grep "per-launch"; } > $OUT/cost_volume_pmc.txt
+PANOGRF_WINO=32 python3 $R/tools/time_cost_volume.py 128 256 2>&1 | grep -E "UNet2" | sed 's/^/first-generation Winograd kernel (PANOGRF_WINO=32): /' >> $OUT/cv_128x256.log
+rm -rf $OUT/pmc[0-9] $OUT/bench_trace $OUT/cv_trace $OUT/train_trace
 ls $OUT
