@@ -185,7 +185,10 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
         *reinterpret_cast<float4*>(b1 + t_block(f, 0, 0) * kBlk) = raw[8 + f];
       }
     };
-    auto halo_store = [&]() {
+    // halo columns: thread (item, fz, fy) combines the 2 x 2 raw values its transformed entry is made of.  The values come from
+    // the staging area, which only this wave's own lanes write (an item's 16 threads sit in one wave): the arithmetic runs BEFORE
+    // barrier B1, only the store into T between the barriers (the section the MFMA waves wait for).
+    auto halo_value = [&]() {
       const int fz = hzy >> 2, fy = hzy & 3;
       // Bt row f = +d[ia] + sb * d[ib]:   0: d0 - d2 | 1: d1 + d2 | 2: d2 - d1 | 3: d1 - d3
       const int za = (fz == 0) ? 0 : (fz == 2 ? 2 : 1), zb = (fz == 2) ? 1 : (fz == 3 ? 3 : 2);
@@ -194,9 +197,8 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
       const float* sp = stage + hitem * 64;
       const float4 daa = *reinterpret_cast<const float4*>(sp + (za * 4 + ya) * 4), dab = *reinterpret_cast<const float4*>(sp + (za * 4 + yb) * 4);
       const float4 dba = *reinterpret_cast<const float4*>(sp + (zb * 4 + ya) * 4), dbb = *reinterpret_cast<const float4*>(sp + (zb * 4 + yb) * 4);
-      *reinterpret_cast<float4*>(T + tq(hzy, hcq, 2 * TX + hp)) =
-          make_float4((daa.x + syb * dab.x) + szb * (dba.x + syb * dbb.x), (daa.y + syb * dab.y) + szb * (dba.y + syb * dbb.y),
-                      (daa.z + syb * dab.z) + szb * (dba.z + syb * dbb.z), (daa.w + syb * dab.w) + szb * (dba.w + syb * dbb.w));
+      return make_float4((daa.x + syb * dab.x) + szb * (dba.x + syb * dbb.x), (daa.y + syb * dab.y) + szb * (dba.y + syb * dbb.y),
+                         (daa.z + syb * dab.z) + szb * (dba.z + syb * dbb.z), (daa.w + syb * dab.w) + szb * (dba.w + syb * dbb.w));
     };
     Row cur = setup(rowi);
 #ifndef PGRF_WINO_ABL_NOB       // timing experiment (wrong results): the loader waves only keep the barrier protocol
@@ -209,11 +211,15 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
 #ifndef PGRF_WINO_ABL_NOB
         *reinterpret_cast<float4*>(stage + (hitem * 16 + hzy) * 4) = ((cur.zyok >> hzy) & 1u) ? hraw : make_float4(0.f, 0.f, 0.f, 0.f);
         transform(cur.zyok);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging writes of this wave's lanes (same wave: no barrier needed)
+        __builtin_amdgcn_wave_barrier();
+        float4 hval = halo_value();
+        asm volatile("" : "+v"(hval.x), "+v"(hval.y), "+v"(hval.z), "+v"(hval.w));   // (pinned in front of the barrier)
 #endif
         lds_barrier();                                     // B1
 #ifndef PGRF_WINO_ABL_NOB
         store();
-        halo_store();
+        *reinterpret_cast<float4*>(T + tq(hzy, hcq, 2 * TX + hp)) = hval;
 #endif
         lds_barrier();                                     // B2
 #ifndef PGRF_WINO_ABL_NOB

@@ -57,3 +57,26 @@ with torch.no_grad():
     with torch.cuda.graph(g2, stream=s):
         o = he(imgs, ray_feats)
     print(f'encoders on HIP, hipGraph replay: {timeit(g2.replay):.2f} ms')
+
+# roofline of the stage (round 4): algorithmic FLOPs of both encoders from torch's FlopCounterMode on the same modules (CPU), and the
+# compulsory bytes (input images + every layer's output written once + read once), against the time of the HIP graph replay
+try:
+    from torch.utils.flop_counter import FlopCounterMode
+    enc_c, vis_c = EN.ResUNetLight().eval(), EN.DefaultVisEncoder().eval()
+    enc_c.load_state_dict(enc.state_dict()); vis_c.load_state_dict(vis.state_dict())
+    sizes = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: sizes.append(o.numel() * 4) if torch.is_tensor(o) else None)
+             for m in list(enc_c.modules()) + list(vis_c.modules()) if isinstance(m, (torch.nn.Conv2d, torch.nn.InstanceNorm2d))]
+    with torch.no_grad(), FlopCounterMode(display=False) as fc:
+        f_c = enc_c(imgs.cpu())
+        vis_c(ray_feats.cpu(), f_c)
+    flops = fc.get_total_flops()
+    for h in hooks:
+        h.remove()
+    bytes_ = imgs.numel() * 4 + 2 * sum(sizes)
+    t_ms = timeit(g2.replay)
+    print(f'encoders roofline: {flops / 1e9:.1f} GFLOP, ~{bytes_ / 1e6:.0f} MB of layer outputs written + read once; HIP graph {t_ms:.2f} ms = '
+          f'{flops / t_ms / 1e9:.1f} TFLOP/s = {flops / t_ms / 1e9 / 157.3 * 100:.1f} % of the f32 MFMA peak, {bytes_ / t_ms / 1e9 * 1e3 / 1e3:.2f} TB/s = '
+          f'{bytes_ / t_ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s: bound by neither -- ~110 dependent launches of 5-30 us (ms per launch {t_ms / 111:.4f})')
+except Exception as ex:       # the roofline line must never take the timing down
+    print('encoders roofline: n/a', repr(ex)[:200])

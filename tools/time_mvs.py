@@ -63,3 +63,11 @@ with torch.no_grad():
         for b in dn.decoders2: t = b(t)
         return t
     print(f'  decoders2: {timeit(dec):.2f} ms')
+    # roofline of the stage (round 4): the 3-D regulariser is its only MFMA-bound part -- UNet2: 438.5 GFLOP per 64x128x64 volume (direct
+    # convolution count, scales with the volume), executed as Winograd products (/ 3.375) -- the 2-D nets around it are launch / latency bound
+    t_reg = timeit(lambda: dn.unet3d.forward_ndhwc(vol))
+    t_all = timeit(lambda: holder._run_init_net(ref, src, False))
+    gf = 438.5 * (dh // 4) * (dw // 4) / (64 * 128) * 2
+    print(f'MVS stage roofline: regulariser {t_reg:.2f} of {t_all:.2f} ms = {gf / 3.375 / t_reg / 157.3 * 100:.1f} % of the f32 MFMA roof of its executed '
+          f'products ({gf:.0f} GFLOP direct / 3.375); the remaining {t_all - t_reg:.2f} ms are ~150 launches of 2-D layers (feature net, decoders, heads) at '
+          f'{(t_all - t_reg) / 150 * 1e3:.0f} us per launch on average: bound by launch latency and dependent small kernels, not by HBM or MFMA')
