@@ -122,6 +122,21 @@ def test_plain_bench_gpus_8_on_one_gpu(extra):
         assert d['cost_volume_stage']['view_shards'] == 2 and d['cost_volume_stage']['ms_per_step'] > 0
 
 
+def test_bench_train_two_ranks_data_parallel():
+    """`bench.py --train --gpus 2` (gloo, one GPU): each rank its own rays, per-ray weight gradients all-reduced, weak scaling; the
+    loss falls over the steps and the line carries the training roofline block."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['PGRF_BENCH_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--train', '--gpus', '2', '--steps', '6', '--warmup', '1', '--height', '64',
+           '--width', '128', '--samples', '32', '--train-rays', '256', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['roofline']['bound'] == 'mfma' and d['roofline']['flop_per_ray'] == 3 * 2 * 32 * 2 * (2 * 28464 + 6480 + 32 * 32)
+    assert d['loss_first_last'][1] < d['loss_first_last'][0]
+
+
 def test_renderer_module_shards_rays_and_views_eight_ranks():
     """`renderer(data)` under an 8-rank process group (gloo, one GPU): 8 ray shards, the MVS stage on 2 ranks, the image encoder on
     2 others, 4 ranks idle through both -- the same result as the unsharded call on every rank."""
