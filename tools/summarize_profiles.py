@@ -90,6 +90,16 @@ if b:
                    f'encoders recomputed per frame, {ee["ms_per_frame_source_maps_reused"]:.1f} ms on a trajectory against fixed source views.')
     out.append('')
 
+bt = load_json('bench_train.json')
+if bt:
+    r = bt['roofline']
+    eg = bt.get('torch_eager_gpu_baseline') or {}
+    out.append(f'**Training step (`profiles/{TAG}_bench_train.json`, `python bench.py --train`):** {bt["config"]["rays_per_step_per_rank"]} rays x (64 + 64) samples, '
+               f'forward + backward + Adam of the per-ray networks: {bt["ms_per_step"]:.2f} ms per step = {bt["value"] / 1e3:.1f} k rays/s = {r["achieved"]:.1f} TFLOP/s '
+               f'algorithmic (3 x the forward) = **{r["frac"] * 100:.1f} %** of the f32 MFMA peak'
+               + (f'; eager-autograd port of the reference graph on the same GPU {eg["ms_per_step"]:.0f} ms per step -> {eg["speedup_hip_over_eager"]:.1f} x.' if 'ms_per_step' in eg else '.'))
+    out.append('')
+
 rows = []
 for name, label in [('bench_config3.json', 'config 3: + D=64 cost volume 128x256 + UNet2 per source view (`--with-cost-volume`)'),
                     ('bench_config3_costregnet.json', 'config 3 with CostRegNet (`--reg costregnet`)'),
@@ -118,6 +128,8 @@ if rows:
 for name, title in [('costvolume_timings.txt', 'Cost-volume side (`tools/time_cost_volume.py`)'),
                     ('costregnet_layer_trace_128x256.txt', 'CostRegNet per-layer kernel durations at 128x256x64'),
                     ('costreg_conv_pmc.txt', "SQ counters of CostRegNet's conv kernels (`tools/pmc_conv.sh`)"),
+                    ('winograd_vs_direct_layers.txt', 'Winograd kernels per UNet2 layer shape (`tools/check_wino.py time`: second generation | first generation | direct kernel)'),
+                    ('unet2_layer_trace_128x256.txt', 'Per-launch durations of one UNet2 forward at 128x256x64 (`tools/layer_trace.sh`)'),
                     ('frame_timing.txt', 'Whole frames, shipped configuration (`tools/time_frame.py`)'),
                     ('whole_frame_rank_shares.txt', 'Per-rank shares of one frame under the 8-GPU split (`tools/time_frame_shares.py`, one GPU)'),
                     ('train_demo.txt', 'Training steps through the HIP forward / backward (`tools/train_demo.py`)'),
@@ -126,7 +138,7 @@ for name, title in [('costvolume_timings.txt', 'Cost-volume side (`tools/time_co
     if t:
         out.append(f'{title} -- `profiles/{TAG}_{name}`:')
         out.append('```')
-        out += [ln for ln in t.splitlines() if not ln.startswith('W2026') and 'rocprofv3' not in ln][:24]
+        out += [ln[:260] for ln in t.splitlines() if not ln.startswith('W2026') and 'rocprofv3' not in ln][:26]
         out.append('```')
 block = '\n'.join(out).rstrip() + '\n'
 
