@@ -249,7 +249,10 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
   };
   // A operands: a ring of three (output tile, frequency) slots x two k groups, refilled in place two tiles ahead of their use
   // (step s = 4 fyfx + tile uses slot s % 3)
-  float4 A[3][2];
+#ifndef PGRF_W16_RING
+#define PGRF_W16_RING 3
+#endif
+  float4 A[PGRF_W16_RING][2];
   const unsigned long long w_bits = (unsigned long long)a.wpk;
   const i32x4w wrsrc = {(int)(unsigned)w_bits, (int)(unsigned)(w_bits >> 32), (int)0x7fffffff, 0x00020000};      // raw buffer, 32-bit data
   auto a_load = [&](unsigned off) {
@@ -270,7 +273,7 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
     return (st < 64 ? abase + (unsigned)(st >> 2) * astride : anext) + (unsigned)(st & 3) * 2048u;
   };
 #pragma unroll
-  for (int st = 0; st < 3; ++st)
+  for (int st = 0; st < PGRF_W16_RING; ++st)
 #pragma unroll
     for (int g = 0; g < 2; ++g) A[st][g] = a_load(a_off(cur.cg, 0, 0) + st * 2048 + g * 1024);
   while (true) {
@@ -373,7 +376,7 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
       static_for<64>([&](auto s_tag) __attribute__((always_inline)) {
         constexpr int st = decltype(s_tag)::value, fyfx = st >> 2, t = st & 3, fy = fyfx >> 2, fx = fyfx & 3;
         constexpr bool corner = (fy == 0 || fy == 3) && (fx == 0 || fx == 3);
-        constexpr int slot = st % 3;
+        constexpr int slot = st % PGRF_W16_RING;
         const float4 a0 = A[slot][0], a1 = A[slot][1];
         f32x4v m;
         if constexpr (corner) m = R[fy == 3 ? 1 : 0][fx == 3 ? 1 : 0][t]; else m = (f32x4v){0.f, 0.f, 0.f, 0.f};
@@ -398,7 +401,8 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
         // freed by steps 61, 62, 63 (1, 2, 0) take the NEXT block's steps 1, 2, 0, which is where that block looks for them (its
         // step 0 is requested last; the two barriers in front of the next MFMA phase cover its latency)
         {
-          constexpr int nst = st <= 60 ? st + 3 : 64 + (st - 60) % 3;
+          // (a ring of four divides 64: plain st + 4)
+          constexpr int nst = (PGRF_W16_RING == 4) ? st + 4 : (st <= 60 ? st + 3 : 64 + (st - 60) % 3);
           const unsigned nb = a_step(abase, astride, anext, nst);
           A[slot][0] = a_load(nb);
           A[slot][1] = a_load(nb + 1024);
