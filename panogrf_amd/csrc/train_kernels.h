@@ -136,9 +136,14 @@ __global__ void __launch_bounds__(256) lin_mfma_kernel(const float* __restrict__
 // A tile GROUP = one 32-row m tile x NT n tiles.  The four waves of a workgroup take WPG = 4 / min(4, groups) waves per group: with
 // >= 4 groups (base_fc.0: 2 x 2 groups of 4 n tiles) every wave owns its own group over the SAME rows, so that each row of delta and
 // X crosses the L2 once (the waves' re-reads hit the L1); small layers (one group) split the rows four ways instead.
+constexpr size_t kRepStride = (size_t)68 * 13312;     // R_COUNT * kGradSlot floats between replicas (train_pass.hip checks)
 template <int NT>
 __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ X, int ldx,
-                                                      float* __restrict__ gW, int M, int K, long rows, int chunk, int gx, int groups) {
+                                                      float* __restrict__ gW0, float* __restrict__ gWrep, int M, int K, long rows, int chunk,
+                                                      int gx, int groups) {
+  // replica of the gradient this workgroup adds into (train_pass.hip kGradReplicas): 0 = the caller's buffer
+  const int rep = blockIdx.z & 7;
+  float* __restrict__ gW = rep == 0 ? gW0 : gWrep + (size_t)(rep - 1) * kRepStride;
   __shared__ float red[3][NT][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, half = lane >> 5;
   const int wpg = groups >= 4 ? 1 : (groups == 2 ? 2 : 4);           // waves per group
@@ -229,12 +234,27 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(float* __restrict__ dY, in
   __shared__ float s_b[256];
   const int c = threadIdx.x & (cp - 1), slot = threadIdx.x / cp, nslot = 256 / cp;
   float sum = 0.f;
-  if (c < cols)
-    for (long r = (long)blockIdx.x * nslot + slot; r < rows; r += (long)gridDim.x * nslot) {
+  if (c < cols) {
+    // four rows per trip with their loads issued together (one dependent load pair per trip ran at half the HBM rate)
+    const long step = (long)gridDim.x * nslot;
+    long r = (long)blockIdx.x * nslot + slot;
+    for (; r + 3 * step < rows; r += 4 * step) {
+      float dv[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { dv[u] = dY[(r + u * step) * lddy + c]; yv[u] = Y[(r + u * step) * ldy + c]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = dv[u] * act_grad(yv[u], act);
+        dY[(r + u * step) * lddy + c] = d;
+        sum += d;
+      }
+    }
+    for (; r < rows; r += step) {
       const float d = dY[r * lddy + c] * act_grad(Y[r * ldy + c], act);
       dY[r * lddy + c] = d;
       sum += d;
     }
+  }
   if (!gbias) return;
   s_b[threadIdx.x] = sum;
   __syncthreads();

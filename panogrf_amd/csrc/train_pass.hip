@@ -26,6 +26,8 @@
 namespace pgrf {
 namespace train {
 
+struct GradPtrs { float* p[R_COUNT]; int n[R_COUNT]; };
+
 #define PGRF_TCHECK(what)                                                                              \
   do {                                                                                                \
     const hipError_t e__ = hipGetLastError();                                                         \
@@ -152,10 +154,30 @@ __global__ void posenc_table_kernel(float* __restrict__ pos, int dn) {     // ib
 static inline unsigned nblk(long n, int per = 256) { const long b = (n + per - 1) / per; return (unsigned)(b < 1 ? 1 : (b > 65535L * 16 ? 65535L * 16 : b)); }
 
 // ---- workspace ------------------------------------------------------------------------------------------------------
+// Weight-gradient replicas: the dW kernel's workgroups add their partial tiles with float atomics, and with ~768 workgroups per launch
+// every one of a layer's <= 13 248 addresses takes ~768 same-address atomics, which the L2 serialises (the launch's tail: 47 us for a 32 x 32
+// layer whose row walk is ~15 us).  Workgroup z adds into replica z % kGradReplicas (replica 0 = the caller's buffer, the others in the
+// workspace, one kGradSlot-float slot per raw tensor); reduce_replicas_kernel folds them at the end of the pass.
+constexpr int kGradReplicas = 8;
+constexpr int kGradSlot = 13312;          // >= 64 x 207 (base_fc.0.weight, the largest tensor), multiple of 256
+static_assert((size_t)R_COUNT * kGradSlot == kRepStride && kGradReplicas == 8 && kGradSlot >= 64 * 207, "replica layout shared with dw_mfma_kernel");
+__global__ void reduce_replicas_kernel(const float* __restrict__ rep, GradPtrs gp) {
+  const int t = blockIdx.y;
+  float* dst = gp.p[t];
+  const int n = gp.n[t];
+  if (!dst) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < kGradReplicas - 1; ++r) s += rep[((size_t)r * R_COUNT + t) * kGradSlot + i];
+    dst[i] += s;
+  }
+}
+
 struct Ws {
   // constants
   int *tap_rf_o, *tap_if_o;
-  float *tap_rf_w, *tap_if_w, *rgb, *dd, *depth_v, *hw, *w1, *pos;
+  float *tap_rf_w, *tap_if_w, *rgb, *dd, *depth_v, *hw, *w1, *pos, *grep;
   // forward activations
   float *pe_in, *imf;
   float *dh1[4], *dh2[4], *dout[4];
@@ -177,6 +199,7 @@ static size_t plan(Ws& w, long P, int V, int dn, char* base) {
   w.tap_rf_o = (int*)take(PV * 4); w.tap_if_o = (int*)take(PV * 4);
   w.tap_rf_w = take(PV * 4); w.tap_if_w = take(PV * 4);
   w.rgb = take(PV * 3); w.dd = take(PV * 4); w.depth_v = take(PV); w.hw = take(P * 2); w.w1 = take(PV); w.pos = take((long)dn * 16);
+  w.grep = take((long)(kGradReplicas - 1) * kGradSlot * R_COUNT);
   w.pe_in = take(PV * 34); w.imf = take(PV * 32);
   for (int m = 0; m < 4; ++m) { w.dh1[m] = take(PV * 32); w.dh2[m] = take(PV * 32); w.dout[m] = take(PV * 2); }
   w.vis = take(PV); w.hit = take(PV); w.pe_h = take(PV * 32); w.d1 = take(PV * 16); w.dfeat = take(PV * 35); w.n1 = take(PV * 8);
@@ -200,6 +223,8 @@ struct Ctx {
   hipStream_t st;
   const float* const* raw;     // device pointers, reference layouts
   float* const* graw;          // device pointers (accumulated), entries may be null = not wanted
+  float* grep;                 // kGradReplicas - 1 further replicas of every weight gradient (workspace, zeroed per pass)
+  int* gsize;                  // floats per raw tensor, recorded by lin_bwd for the final fold (host array)
 };
 
 static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float* Y, int ldy, long rows, int IN, int OUT, int act) {
@@ -222,7 +247,7 @@ static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ld
     while (cp < OUT) cp <<= 1;
     if (cp > 64) return set_error(PGRF_ERR_UNSUPPORTED, "train linear backward: %d outputs (at most 64)", OUT);
     const long nb = (rows * cp + 256 * 8 - 1) / (256 * 8);            // ~8 rows per thread
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb))), dim3(256), 0, c.st, dY, lddy, Y, ldy, rows, OUT, cp,
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb)))   /* (<= 1 024 same-address atomics per bias element) */, dim3(256), 0, c.st, dY, lddy, Y, ldy, rows, OUT, cp,
                        act, gb);
   }
   if (c.graw[rw]) {
@@ -236,9 +261,11 @@ static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ld
     long chunk = (rows * nwg / target_wgs + 63) / 64 * 64;                    // ~target_wgs workgroups per launch
     if (chunk < 128) chunk = 128;
     const dim3 grid(nwg, 1, (unsigned)((rows + chunk - 1) / chunk));
-    if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], OUT, IN, rows, (int)chunk, gx, groups);
-    else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], OUT, IN, rows, (int)chunk, gx, groups);
-    else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], OUT, IN, rows, (int)chunk, gx, groups);
+    float* rep = c.grep + (size_t)rw * kGradSlot;          // this tensor's slot of replica 1 (replica r at + (r - 1) * R_COUNT * kGradSlot)
+    c.gsize[rw] = OUT * IN;
+    if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups);
+    else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups);
+    else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups);
   }
   if (dX) {
     // dX (=|+=) delta W: the same kernel with the weight read transposed (W is [OUT, IN]: "M" = IN, "K" = OUT)
@@ -290,7 +317,9 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   if (!workspace || workspace_bytes < need)
     return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
   plan(w, P, V, dn, (char*)workspace);
-  Ctx c{(hipStream_t)stream, raw_dev, g_raw_dev};
+  int gsize[R_COUNT] = {};
+  Ctx c{(hipStream_t)stream, raw_dev, g_raw_dev, w.grep, gsize};
+  (void)hipMemsetAsync(w.grep, 0, (size_t)(kGradReplicas - 1) * kGradSlot * R_COUNT * 4, c.st);
   hipStream_t st = c.st;
   const int NM = use_vis ? 4 : 3;
   static const int kDD[4][6] = {{R_DD_MEAN_0_W, R_DD_MEAN_0_B, R_DD_MEAN_2_W, R_DD_MEAN_2_B, R_DD_MEAN_4_W, R_DD_MEAN_4_B},
@@ -449,6 +478,12 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   if (g_ray_feats)
     hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, g_ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.gpe_in, 34, 0);
   PGRF_TCHECK("train gather backward");
+  {   // fold the weight-gradient replicas into the caller's buffers
+    GradPtrs gp;
+    for (int i = 0; i < R_COUNT; ++i) { gp.p[i] = gsize[i] > 0 ? g_raw_dev[i] : nullptr; gp.n[i] = gsize[i]; }
+    hipLaunchKernelGGL(reduce_replicas_kernel, dim3(13, R_COUNT), dim3(256), 0, st, w.grep, gp);
+    PGRF_TCHECK("train replica fold");
+  }
 #undef L
   return PGRF_OK;
 }

@@ -348,9 +348,15 @@ def render_pass_backward(frame, raw, use_vis, coords, depth, grads, want_maps=Tr
     n = len(raw)
     raw_arr, g_arr = (C.c_void_p * n)(), (C.c_void_p * n)()
     g_raw = []
+    # one zeroed buffer for all weight gradients (62-68 torch.zeros_like launches per pass otherwise), 64-float aligned views
+    offs, total = [], 0
+    for t in raw:
+        offs.append(total)
+        total += 0 if t is None else (t.numel() + 63) // 64 * 64
+    flat = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
     for i, t in enumerate(raw):
         raw_arr[i] = None if t is None else t.data_ptr()
-        gt = None if t is None else torch.zeros_like(t)
+        gt = None if t is None else flat[offs[i]:offs[i] + t.numel()].view(t.shape)
         g_raw.append(gt)
         g_arr[i] = None if gt is None else gt.data_ptr()
     fs = frame.c_struct()
