@@ -56,7 +56,8 @@ with torch.no_grad():
     g2 = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g2, stream=s):
         o = he(imgs, ray_feats)
-    print(f'encoders on HIP, hipGraph replay: {timeit(g2.replay):.2f} ms')
+    t_hip_graph = timeit(g2.replay)
+    print(f'encoders on HIP, hipGraph replay: {t_hip_graph:.2f} ms')
 
 # roofline of the stage (round 4): algorithmic FLOPs of both encoders from torch's FlopCounterMode on the same modules (CPU), and the
 # compulsory bytes (input images + every layer's output written once + read once), against the time of the HIP graph replay
@@ -74,7 +75,7 @@ try:
     for h in hooks:
         h.remove()
     bytes_ = imgs.numel() * 4 + 2 * sum(sizes)
-    t_ms = timeit(g2.replay)
+    t_ms = t_hip_graph          # (measured above, with the GPU warm: after the CPU flop count the clocks have dropped)
     print(f'encoders roofline: {flops / 1e9:.1f} GFLOP, ~{bytes_ / 1e6:.0f} MB of layer outputs written + read once; HIP graph {t_ms:.2f} ms = '
           f'{flops / t_ms / 1e9:.1f} TFLOP/s = {flops / t_ms / 1e9 / 157.3 * 100:.1f} % of the f32 MFMA peak, {bytes_ / t_ms / 1e9 * 1e3 / 1e3:.2f} TB/s = '
           f'{bytes_ / t_ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s: bound by neither -- ~110 dependent launches of 5-30 us (ms per launch {t_ms / 111:.4f})')
