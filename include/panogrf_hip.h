@@ -83,6 +83,14 @@ const char* pgrf_raw_name(int i);
  * Replaces: nothing computed — it is the load_state_dict-time transform
  * (network/dist_decoder.py:53-97, network/aggregate_net.py:16-39, network/ibrnet.py:239-313). */
 int pgrf_pack_weights(const float* const* raw_host, int n_raw, int use_vis, int max_dn, float* blob_host);
+/* The same blob, bit for bit, built ON THE DEVICE from device-resident tensors: raw_dev is a HOST array of n_raw DEVICE pointers (same
+ * order and shapes), blob_dev a device buffer of pgrf_blob_floats() floats; enqueued on `stream`, no host synchronisation (the first
+ * call per (device, use_vis, max_dn) builds and uploads a source map).  For training, where the weights change every optimizer step
+ * (the reference re-reads its nn.Parameters on every call: network/renderer.py:223-304 runs on the live modules). */
+int pgrf_pack_weights_device(const float* const* raw_dev, int n_raw, int use_vis, int max_dn, float* blob_dev, void* stream);
+/* Diagnostic (host only, no GPU): evaluates the device packer's source map on the host against pgrf_pack_weights on pseudo-random
+ * weights; PGRF_OK when every blob word is reproduced bit for bit. */
+int pgrf_pack_map_selftest(int use_vis, int max_dn);
 
 /* ------------------------------------------------------------------ sampling --------------- */
 /* Deterministic (eval) stratified depths, depth[rn,dn].  network/render_ops.py:292-339 sample_depth. */

@@ -64,6 +64,8 @@ SYMBOLS = {
     "pgrf_raw_count": (C.c_int, []),
     "pgrf_raw_name": (C.c_char_p, [C.c_int]),
     "pgrf_pack_weights": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P]),
+    "pgrf_pack_weights_device": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, _P, _P]),
+    "pgrf_pack_map_selftest": (C.c_int, [C.c_int, C.c_int]),
     "pgrf_sample_coarse_depth": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P]),
     "pgrf_sample_fine_depth": (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "pgrf_sample_coarse_depth_train": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P]),

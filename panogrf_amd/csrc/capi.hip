@@ -168,6 +168,7 @@ const char* pgrf_raw_name(int i) { return (i >= 0 && i < R_COUNT) ? kRawNames[i]
 int pgrf_pack_weights(const float* const* raw_host, int n_raw, int use_vis, int max_dn, float* blob_host) {
   return pack_weights_host(raw_host, n_raw, use_vis, max_dn, blob_host);
 }
+int pgrf_pack_map_selftest(int use_vis, int max_dn) { return pack_map_selftest(use_vis, max_dn); }
 
 int pgrf_sample_coarse_depth_train(float min_depth, float max_depth, int use_disp, int rn, int dn, const float* jitter,
                                    float* depth, void* stream) {

@@ -1,6 +1,7 @@
 // Host-side packing of one pass's per-ray network weights (reference state_dict layout) into
 // the MFMA-operand-ordered blob described in pgrf_layout.h.  Pure host code (no HIP calls).
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <functional>
 #include <vector>
@@ -75,49 +76,52 @@ int ident_out(int, int r) { return r; }                          // rows 0..31 -
 
 }  // namespace
 
-int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_dn, float* blob) {
-  if (!raw || !blob) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: null argument");
-  if (n_raw != R_COUNT) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: expected %d raw tensors, got %d", R_COUNT, n_raw);
-  if (max_dn < 1 || max_dn > kMaxDn) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: max_dn %d out of range [1,%d]", max_dn, kMaxDn);
-  for (int i = 0; i < R_COUNT; ++i) {
-    const bool is_vis = (i >= R_DD_VIS_0_W && i <= R_DD_VIS_4_B);
-    if (!raw[i] && !(is_vis && !use_vis)) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: raw tensor %d is null", i);
+// ---- prob_embed.2 folded into its two consumers.  Its output ("neuray feature", aggregate_net.py:61) carries no
+// activation and only enters neuray_fc.0 and columns 175..206 of base_fc.0 (ibrnet.py:338,344), both Linear:
+//   W_c (W_pe2 r + b_pe2) + b_c = (W_c W_pe2) r + (W_c b_pe2 + b_c),   r = relu(prob_embed.0(.))
+// so the per-point 32x32 layer disappears (16 of the 441 MFMAs per view and wave); products accumulated in double (every product
+// of two floats is exact in double and the sum runs in index order: pack_device.hip reproduces it bit for bit).
+static void fold_host(const float* const* raw, std::vector<float>& base_fused, std::vector<float>& base_bias, std::vector<float>& nf_fused,
+                      std::vector<float>& nf_bias) {
+  base_fused.assign(raw[R_BASE_0_W], raw[R_BASE_0_W] + 64 * 207);
+  base_bias.assign(raw[R_BASE_0_B], raw[R_BASE_0_B] + 64);
+  nf_fused.assign(8 * 32, 0.f);
+  nf_bias.assign(8, 0.f);
+  const float* Wp = raw[R_PE_2_W];   // [32 out][32 in]
+  const float* bp = raw[R_PE_2_B];
+  for (int o = 0; o < 64; ++o) {
+    const float* Wc = raw[R_BASE_0_W] + (size_t)o * 207 + 175;
+    for (int j = 0; j < 32; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 32; ++k) acc += (double)Wc[k] * (double)Wp[k * 32 + j];
+      base_fused[(size_t)o * 207 + 175 + j] = (float)acc;
+    }
+    double accb = raw[R_BASE_0_B][o];
+    for (int k = 0; k < 32; ++k) accb += (double)Wc[k] * (double)bp[k];
+    base_bias[o] = (float)accb;
   }
+  for (int o = 0; o < 8; ++o) {
+    const float* Wc = raw[R_NF_0_W] + (size_t)o * 32;
+    for (int j = 0; j < 32; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 32; ++k) acc += (double)Wc[k] * (double)Wp[k * 32 + j];
+      nf_fused[o * 32 + j] = (float)acc;
+    }
+    double accb = raw[R_NF_0_B][o];
+    for (int k = 0; k < 32; ++k) accb += (double)Wc[k] * (double)bp[k];
+    nf_bias[o] = (float)accb;
+  }
+}
+
+// the blob as a function of the EXTENDED table (raw tensors + the four folded ones, pgrf_layout.h X_*): copies, zero padding, the
+// positional table and the split-f16 conversion only -- no arithmetic between weights, which is what lets build_pack_maps() below
+// recover the source of every blob word by probing this function
+static void pack_permute(const float* const* raw, int use_vis, int max_dn, float* blob) {
   std::memset(blob, 0, sizeof(float) * kBlobFloats);
-
-  // ---- prob_embed.2 folded into its two consumers.  Its output ("neuray feature", aggregate_net.py:61) carries no
-  // activation and only enters neuray_fc.0 and columns 175..206 of base_fc.0 (ibrnet.py:338,344), both Linear:
-  //   W_c (W_pe2 r + b_pe2) + b_c = (W_c W_pe2) r + (W_c b_pe2 + b_c),   r = relu(prob_embed.0(.))
-  // so the per-point 32x32 layer disappears (16 of the 441 MFMAs per view and wave); products accumulated in double.
-  std::vector<float> base_fused(raw[R_BASE_0_W], raw[R_BASE_0_W] + 64 * 207), base_bias(raw[R_BASE_0_B], raw[R_BASE_0_B] + 64);
-  std::vector<float> nf_fused(8 * 32), nf_bias(8);
-  {
-    const float* Wp = raw[R_PE_2_W];   // [32 out][32 in]
-    const float* bp = raw[R_PE_2_B];
-    for (int o = 0; o < 64; ++o) {
-      const float* Wc = raw[R_BASE_0_W] + (size_t)o * 207 + 175;
-      for (int j = 0; j < 32; ++j) {
-        double acc = 0.0;
-        for (int k = 0; k < 32; ++k) acc += (double)Wc[k] * (double)Wp[k * 32 + j];
-        base_fused[(size_t)o * 207 + 175 + j] = (float)acc;
-      }
-      double accb = raw[R_BASE_0_B][o];
-      for (int k = 0; k < 32; ++k) accb += (double)Wc[k] * (double)bp[k];
-      base_bias[o] = (float)accb;
-    }
-    for (int o = 0; o < 8; ++o) {
-      const float* Wc = raw[R_NF_0_W] + (size_t)o * 32;
-      for (int j = 0; j < 32; ++j) {
-        double acc = 0.0;
-        for (int k = 0; k < 32; ++k) acc += (double)Wc[k] * (double)Wp[k * 32 + j];
-        nf_fused[o * 32 + j] = (float)acc;
-      }
-      double accb = raw[R_NF_0_B][o];
-      for (int k = 0; k < 32; ++k) accb += (double)Wc[k] * (double)bp[k];
-      nf_bias[o] = (float)accb;
-    }
-  }
-
+  const float* base_fused = raw[X_BASE_FUSED];
+  const float* base_bias = raw[X_BASE_BIAS];
+  const float* nf_fused = raw[X_NF_FUSED];
+  const float* nf_bias = raw[X_NF_BIAS];
   // ---- dist decoder -----------------------------------------------------------------
   const int dec0[4] = {R_DD_MEAN_0_W, R_DD_VAR_0_W, R_DD_AW_0_W, R_DD_VIS_0_W};
   {  // fused layer 0: tile m = MLP m
@@ -154,7 +158,7 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
              [](int s, int h) { return s < 16 ? rho(s, h) : 32 + h; }, ident_out);
   pack_layer(blob, L_PE2, raw[R_PE_2_W], 32, raw[R_PE_2_B], ident_in, ident_out);
   // ---- neuray_fc --------------------------------------------------------------------
-  pack_layer(blob, L_NF1, nf_fused.data(), 32, nf_bias.data(), ident_in, [](int, int r) { return r < 8 ? r : -1; });   // on relu(prob_embed.0)
+  pack_layer(blob, L_NF1, nf_fused, 32, nf_bias, ident_in, [](int, int r) { return r < 8 ? r : -1; });   // on relu(prob_embed.0)
   pack_head(blob + OFF_NFH_W, raw[R_NF_2_W], 4, [](int r, int h) { return rho(r, h); });
   blob[OFF_NFH_B] = raw[R_NF_2_B][0];
   // ---- ray_dir_fc -------------------------------------------------------------------
@@ -169,7 +173,7 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
   // 3 colour columns of each, packed two per step with no empty slot (6 steps, 70 in all instead of 4 x 19 = 76):
   //   64: (mean0.r | mean0.g)  65: (var0.r | var0.g)  66: (mean1.r | mean1.g)  67: (var1.r | var1.g)
   //   68: (mean0.b | mean1.b)  69: (var0.b  | var1.b)         (lane half 0 | lane half 1)
-  pack_layer(blob, L_BG, base_fused.data(), 207, base_bias.data(),
+  pack_layer(blob, L_BG, base_fused, 207, base_bias,
              [](int s, int h) {
                if (s < 64) return 35 * (s / 16) + 3 + rho(s % 16, h);
                const int t = s - 64;
@@ -178,7 +182,7 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
              },
              [](int m, int r) { return 32 * m + r; });
   // per-view block: image features (16 steps), colour (r | g), (b | -), prob_embed features (16 steps): 34 steps
-  pack_layer(blob, L_BV, base_fused.data(), 207, nullptr,
+  pack_layer(blob, L_BV, base_fused, 207, nullptr,
              [](int s, int h) {
                if (s < 16) return 140 + 3 + rho(s, h);
                if (s == 16) return 140 + h;
@@ -264,7 +268,7 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
     }
   }
   // ---- small layers for the 4x4x1 MFMA path (pgrf_layout.h: OFF_S_*)
-  pack_small(blob + OFF_S_NF1_A, blob + OFF_S_NF1_B, nf_fused.data(), 32, nf_bias.data(), 16, 2, 8, 0, ident_in);
+  pack_small(blob + OFF_S_NF1_A, blob + OFF_S_NF1_B, nf_fused, 32, nf_bias, 16, 2, 8, 0, ident_in);
   for (int o = 0; o < 8; ++o) blob[OFF_S_NF1_H + o] = raw[R_NF_2_W][o];
   pack_small(blob + OFF_S_RDC_A, blob + OFF_S_RDC_B, raw[R_RD_2_W], 16, raw[R_RD_2_B], 8, 1, 3, 0, ident_in);
   pack_small(blob + OFF_S_RGB2_A, blob + OFF_S_RGB2_B, raw[R_RGB_2_W], 16, raw[R_RGB_2_B], 8, 2, 8, 0, ident_in);
@@ -302,6 +306,123 @@ int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_d
       if (img_has_bias(id))
         std::memcpy(dst + img_a_floats(id, mode), blob + layer_b_off(id), sizeof(float) * b_size(kMT[id]));
     }
+  }
+}
+
+int pack_weights_host(const float* const* raw, int n_raw, int use_vis, int max_dn, float* blob) {
+  if (!raw || !blob) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: null argument");
+  if (n_raw != R_COUNT) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: expected %d raw tensors, got %d", R_COUNT, n_raw);
+  if (max_dn < 1 || max_dn > kMaxDn) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: max_dn %d out of range [1,%d]", max_dn, kMaxDn);
+  for (int i = 0; i < R_COUNT; ++i) {
+    const bool is_vis = (i >= R_DD_VIS_0_W && i <= R_DD_VIS_4_B);
+    if (!raw[i] && !(is_vis && !use_vis)) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights: raw tensor %d is null", i);
+  }
+  std::vector<float> base_fused, base_bias, nf_fused, nf_bias;
+  fold_host(raw, base_fused, base_bias, nf_fused, nf_bias);
+  const float* ext[X_COUNT];
+  for (int i = 0; i < R_COUNT; ++i) ext[i] = raw[i];
+  ext[X_BASE_FUSED] = base_fused.data(); ext[X_BASE_BIAS] = base_bias.data(); ext[X_NF_FUSED] = nf_fused.data(); ext[X_NF_BIAS] = nf_bias.data();
+  pack_permute(ext, use_vis, max_dn, blob);
+  return PGRF_OK;
+}
+
+// ---- source map of the blob, for the device-side packer (pack_device.hip) ------------------------------------------------
+// pack_permute() is probed with coded inputs instead of restating its layout rules a second time:
+//   zeros                                  -> the constant words (positional table)
+//   element (t, e) = its id t * 2^14 + e + 1 -> the f32 words (ids < 2^24 are exact floats)
+//   every element = 1 + 2^-12              -> which 16-bit halves are a first piece (0x3C00), a second piece (0x0C00) or padding
+//   id low / high 11 bits as x and as 4096 + x / 2048   -> the source of first pieces (f16(x) = x) and of second pieces
+//                                                          (f16(4096 + x/2048) = 4096, remainder x / 2048 exact in f16)
+int build_pack_maps(int use_vis, int max_dn, std::vector<uint32_t>& d0, std::vector<uint32_t>& d1, std::vector<float>& c0) {
+  if (max_dn < 1 || max_dn > kMaxDn) return set_error(PGRF_ERR_ARG, "pgrf_pack_weights_device: max_dn %d out of range [1,%d]", max_dn, kMaxDn);
+  std::vector<std::vector<float>> buf(X_COUNT);
+  const float* ext[X_COUNT];
+  for (int t = 0; t < X_COUNT; ++t) { buf[t].assign(kExtFloats[t], 0.f); ext[t] = buf[t].data(); }
+  auto run = [&](const std::function<float(uint32_t)>& f, std::vector<float>& out) {
+    for (int t = 0; t < X_COUNT; ++t)
+      for (int e = 0; e < kExtFloats[t]; ++e) buf[t][e] = f(((uint32_t)t << 14) | (uint32_t)e);
+    out.assign(kBlobFloats, 0.f);
+    pack_permute(ext, use_vis, max_dn, out.data());
+  };
+  std::vector<float> ids, piece, lo1, hi1, lo2, hi2;
+  run([](uint32_t) { return 0.f; }, c0);
+  run([](uint32_t id) { return (float)(id + 1); }, ids);
+  run([](uint32_t) { return 1.f + 1.f / 4096.f; }, piece);
+  run([](uint32_t id) { return (float)(id & 2047u); }, lo1);
+  run([](uint32_t id) { return (float)(id >> 11); }, hi1);
+  run([](uint32_t id) { return 4096.f + (float)(id & 2047u) / 2048.f; }, lo2);
+  run([](uint32_t id) { return 4096.f + (float)(id >> 11) / 2048.f; }, hi2);
+  d0.assign(kBlobFloats, 0u);
+  d1.assign(kBlobFloats, 0u);
+  auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  auto half_val = [](uint32_t h) { _Float16 x; uint16_t u = (uint16_t)h; std::memcpy(&x, &u, 2); return (float)x; };
+  const uint32_t probe_bits = bits(1.f + 1.f / 4096.f);
+  auto check_id = [&](uint32_t id) { const uint32_t t = id >> 14, e = id & 16383u; return t < (uint32_t)X_COUNT && (int)e < kExtFloats[t]; };
+  for (int i = 0; i < kBlobFloats; ++i) {
+    if (c0[i] != 0.f) continue;                                    // constant word
+    const uint32_t pb = bits(piece[i]);
+    if (pb == 0u) continue;                                        // padding (constant 0)
+    if (pb == probe_bits) {                                        // f32 copy
+      const uint32_t id = (uint32_t)ids[i] - 1u;
+      if (ids[i] < 1.f || !check_id(id)) return set_error(PGRF_ERR_UNSUPPORTED, "pack map: f32 word %d has no source", i);
+      d0[i] = 1u | (id << 3);
+      continue;
+    }
+    uint32_t d[2] = {0u, 0u};
+    for (int h = 0; h < 2; ++h) {                                  // a pair of split-f16 halves
+      const uint32_t ph = (pb >> (16 * h)) & 0xffffu;
+      if (ph == 0u) { d[h] = 4u; continue; }
+      if (ph != 0x3C00u && ph != 0x0C00u) return set_error(PGRF_ERR_UNSUPPORTED, "pack map: word %d is neither f32 nor split-f16", i);
+      const bool second = ph == 0x0C00u;
+      const float lo = half_val((bits(second ? lo2[i] : lo1[i]) >> (16 * h)) & 0xffffu) * (second ? 2048.f : 1.f);
+      const float hi = half_val((bits(second ? hi2[i] : hi1[i]) >> (16 * h)) & 0xffffu) * (second ? 2048.f : 1.f);
+      const uint32_t id = ((uint32_t)hi << 11) | (uint32_t)lo;
+      if (!check_id(id)) return set_error(PGRF_ERR_UNSUPPORTED, "pack map: half %d of word %d has no source", h, i);
+      d[h] = 1u | (second ? 2u : 0u) | 4u | (id << 3);
+    }
+    d0[i] = d[0] | 4u;
+    d1[i] = d[1];
+  }
+  return PGRF_OK;
+}
+
+// host evaluation of the source map against the packer itself on pseudo-random weights (what pack_device.hip's kernel does, word
+// by word): 0 when every word of the blob is reproduced bit for bit
+int pack_map_selftest(int use_vis, int max_dn) {
+  std::vector<uint32_t> d0, d1;
+  std::vector<float> c0;
+  if (int rc = build_pack_maps(use_vis, max_dn, d0, d1, c0)) return rc;
+  std::vector<std::vector<float>> buf(R_COUNT);
+  const float* raw[R_COUNT];
+  uint32_t seed = 12345u;
+  for (int t = 0; t < R_COUNT; ++t) {
+    buf[t].resize(kExtFloats[t]);
+    for (auto& v : buf[t]) { seed = seed * 1664525u + 1013904223u; v = ((float)(seed >> 8) / 8388608.f - 1.f) * 0.37f; }
+    const bool is_vis = (t >= R_DD_VIS_0_W && t <= R_DD_VIS_4_B);
+    raw[t] = (is_vis && !use_vis) ? nullptr : buf[t].data();
+  }
+  std::vector<float> want(kBlobFloats);
+  if (int rc = pack_weights_host(raw, R_COUNT, use_vis, max_dn, want.data())) return rc;
+  std::vector<float> base_fused, base_bias, nf_fused, nf_bias;
+  fold_host(raw, base_fused, base_bias, nf_fused, nf_bias);
+  const float* ext[X_COUNT];
+  for (int i = 0; i < R_COUNT; ++i) ext[i] = raw[i];
+  ext[X_BASE_FUSED] = base_fused.data(); ext[X_BASE_BIAS] = base_bias.data(); ext[X_NF_FUSED] = nf_fused.data(); ext[X_NF_BIAS] = nf_bias.data();
+  auto src = [&](uint32_t d) { const float* p = ext[d >> 17]; return p ? p[(d >> 3) & 16383u] : 0.f; };
+  auto half = [&](uint32_t d) -> uint32_t {
+    if (!(d & 1u)) return 0u;
+    const float x = src(d);
+    const _Float16 h1 = (_Float16)x;
+    const _Float16 h = (d & 2u) ? (_Float16)(x - (float)h1) : h1;
+    uint16_t u; std::memcpy(&u, &h, 2);
+    return u;
+  };
+  for (int i = 0; i < kBlobFloats; ++i) {
+    uint32_t got, exp;
+    std::memcpy(&exp, &want[i], 4);
+    if (!(d0[i] & 4u)) { const float v = (d0[i] & 1u) ? src(d0[i]) : c0[i]; std::memcpy(&got, &v, 4); }
+    else got = half(d0[i]) | (half(d1[i]) << 16);
+    if (got != exp) return set_error(PGRF_ERR_UNSUPPORTED, "pack map selftest: word %d is %08x, the packer wrote %08x", i, got, exp);
   }
   return PGRF_OK;
 }

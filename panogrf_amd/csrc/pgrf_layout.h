@@ -205,5 +205,23 @@ enum RawId {
   R_NF_0_W, R_NF_0_B, R_NF_2_W, R_NF_2_B,
   R_COUNT
 };
+// the packer's extended table: the raw tensors, then prob_embed.2 folded into base_fc.0 (weight [64, 207], bias [64]) and into
+// neuray_fc.0 (weight [8, 32], bias [8]) (pack_weights.cpp fold_host)
+enum ExtId { X_BASE_FUSED = R_COUNT, X_BASE_BIAS, X_NF_FUSED, X_NF_BIAS, X_COUNT };
+// floats per entry (nn.Linear [out, in] + [out])
+constexpr int kExtFloats[X_COUNT] = {
+  1024, 32, 1024, 32, 64, 2,   1024, 32, 1024, 32, 64, 2,   1024, 32, 1024, 32, 32, 1,   1024, 32, 1024, 32, 32, 1,     // dist decoder: mean, var, aw, vis
+  32 * 34, 32, 1024, 32,       // prob_embed
+  16 * 4, 16, 35 * 16, 35,     // ray_dir_fc
+  64 * 207, 64, 32 * 64, 32,   // base_fc
+  1024, 32, 33 * 32, 33,       // vis_fc
+  1024, 32, 32, 1,             // vis_fc2
+  64 * 65, 64, 16 * 64, 16,    // geometry_fc
+  256, 256, 256, 256, 16, 16,  // ray attention q, k, v, fc, LayerNorm
+  256, 16, 16, 1,              // out_geometry_fc
+  16 * 37, 16, 8 * 16, 8, 8, 1,   // rgb_fc
+  8 * 32, 8, 8, 1,             // neuray_fc
+  64 * 207, 64, 8 * 32, 8      // folded
+};
 
 }  // namespace pgrf

@@ -140,10 +140,13 @@ constexpr size_t kRepStride = (size_t)68 * 13312;     // R_COUNT * kGradSlot flo
 template <int NT>
 __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ X, int ldx,
                                                       float* __restrict__ gW0, float* __restrict__ gWrep, int M, int K, long rows, int chunk,
-                                                      int gx, int groups) {
+                                                      int gx, int groups, float* __restrict__ gb0, float* __restrict__ gbrep) {
   // replica of the gradient this workgroup adds into (train_pass.hip kGradReplicas): 0 = the caller's buffer
   const int rep = blockIdx.z & 7;
   float* __restrict__ gW = rep == 0 ? gW0 : gWrep + (size_t)(rep - 1) * kRepStride;
+  // bias gradient = column sums of delta: the lanes hold delta[row][m0 + i] anyway (the groups with n0 == 0 add them up)
+  float* __restrict__ gb = gb0 ? (rep == 0 ? gb0 : gbrep + (size_t)(rep - 1) * kRepStride) : nullptr;
+  float colsum = 0.f;
   __shared__ float red[3][NT][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, half = lane >> 5;
   const int wpg = groups >= 4 ? 1 : (groups == 2 ? 2 : 4);           // waves per group
@@ -187,6 +190,7 @@ __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ 
       const bool ok = r0 + u * step < r_end;
       const int du = ok ? u * step : 0;
       a[u] = dpr[du * ldd] * (ok ? amask : 0.f);
+      colsum += a[u];
 #pragma unroll
       for (int t = 0; t < NT; ++t) b[u][t] = xpr[du * ldx + xoff[t]] * (ok ? bmask[t] : 0.f);
     }
@@ -194,6 +198,11 @@ __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ 
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+  }
+  __shared__ float cs_red[4][32];
+  if (gb) {      // both lane halves walked different rows of column i; then the sub-waves of the group
+    colsum += __shfl_xor(colsum, 32, 64);
+    if (half == 0) cs_red[wave][i] = colsum;
   }
   if (wpg > 1) {
     if (sub > 0) {
@@ -203,6 +212,12 @@ __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ 
         for (int r = 0; r < 16; ++r) red[wave - 1][t][r][lane] = acc[t][r];
     }
     __syncthreads();
+  }
+  if (gb && wpg == 1) __syncthreads();       // (cs_red of this wave is its own: only the memory ordering is needed; wpg > 1 synchronised above)
+  if (gb && sub == 0 && grp_ok && n0 == 0 && half == 0 && m0 + i < M) {
+    float t = cs_red[wave][i];
+    for (int k = 1; k < wpg; ++k) t += cs_red[wave + k][i];
+    if (t != 0.f) unsafeAtomicAdd(gb + m0 + i, t);
   }
   if (sub == 0 && grp_ok) {
 #pragma unroll
@@ -214,6 +229,301 @@ __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ 
         const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * half, ko = n0 + 32 * t + i;     // accumulator row rho(r, half), column = lane
         if (mo < M && ko < K) unsafeAtomicAdd(gW + (long)mo * K + ko, v);
       }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CHAINS of Linear layers in one launch (round 4).  In lin_mfma_kernel's orientation the accumulator registers of one layer ARE the
+// B operands of the next (register 4g + j of lane (n, half) is column 8g + 4 half + j: exactly what k-step 4g + j asks of that lane),
+// so a wave carries its 32 rows through up to three layers without the activations leaving registers; every layer's output is
+// still WRITTEN (the backward needs it) but no longer re-read -- and in the backward chain the activation derivative and the dX
+// product of a whole MLP are one launch (was: one act kernel + one dX GEMM per layer).
+//   forward  chain_fwd_kernel:  b <- X (any width, streamed from global for the first layer); per layer  acc = W b (+ bias, act)
+//            -> stored to Y_k -> b (layers after the first: IN <= 64, register resident)
+//   backward chain_bwd_kernel:  d <- dY of the top layer; per layer (top first)  d *= act'(Y_k), stored as delta_k (what the dW
+//            kernel reads), then d <- W_k^T d; the last layer's product may be wider than 64 (streamed tile by tile) and is written
+//            or accumulated into dX.  `dx == 0` on the last layer: delta only.
+// Both kernels first copy the chain's weights (and biases) into LDS, zero padded to whole MFMA tiles, so that every operand read in
+// the layer loops is unconditional (a guarded global load per k-step made the first version latency bound: 99 us per launch for
+// ~25 us of HBM traffic); activations are read with unconditional dwordx4 loads whose out-of-range elements are masked with an
+// integer AND -- they may touch up to 12 bytes past a row's last column, so X / Y / dY must be WORKSPACE buffers (plan() pads).
+struct ChainLayer {
+  const float* W;      // [OUT, IN] row-major
+  const float* bias;   // forward only (null = none)
+  float* Y;            // forward: output [rows, ldy];  backward: the layer's stored output (read for act')
+  float* D;            // backward: dY of the layer, overwritten by delta
+  int ldy, ldd, IN, OUT, act, dx;
+  int S, off;          // LDS row stride of the weight copy (multiple of 4, S / 4 odd: conflict-free b128 reads) and its offset (floats)
+};
+struct ChainArgs {
+  ChainLayer l[3];
+  int n, lds_floats;
+  const float* X; int ldx;           // forward input
+  float* dX; int lddx, accumulate;   // backward output (null = none)
+  long rows;
+};
+__host__ __device__ inline int chain_stride(int IN) { int s = (IN + 3) / 4 * 4; if (((s / 4) & 1) == 0) s += 4; return s; }
+__host__ __device__ inline int chain_rows(int OUT) { return OUT > 32 ? 64 : 32; }
+
+__device__ __forceinline__ void chain_stage_weights(const ChainArgs& a, float* lds, bool with_bias) {
+  for (int i = threadIdx.x; i < a.lds_floats; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  for (int k = 0; k < a.n; ++k) {
+    const ChainLayer& L = a.l[k];
+    float* w = lds + L.off;
+    const int total = L.OUT * L.IN;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 4) {          // four independent loads in flight per thread
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = e0 + 256 * u; v[u] = L.W[e < total ? e : total - 1]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = e0 + 256 * u; if (e < total) w[(e / L.IN) * L.S + e % L.IN] = v[u]; }
+    }
+    if (with_bias && L.bias && threadIdx.x < L.OUT) w[chain_rows(L.OUT) * L.S + threadIdx.x] = L.bias[threadIdx.x];
+  }
+  __syncthreads();
+}
+// four floats p[k0 .. k0+3], elements from column K on zero (AND mask: the load itself is unconditional)
+__device__ __forceinline__ void load4_mask(const float* __restrict__ p, int k0, int K, float (&o)[4]) {
+  const int kc = k0 < K ? k0 : 0;
+  const F4U t = *reinterpret_cast<const F4U*>(p + kc);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(__float_as_uint(t.v[j]) & (k0 + j < K ? 0xffffffffu : 0u));
+}
+__device__ __forceinline__ void store4_guard(float* __restrict__ p, int c0, int C, const float (&v)[4]) {
+  if (c0 + 3 < C) { F4U o; o.v[0] = v[0]; o.v[1] = v[1]; o.v[2] = v[2]; o.v[3] = v[3]; *reinterpret_cast<F4U*>(p + c0) = o; }
+  else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (c0 + j < C) p[c0 + j] = v[j];
+  }
+}
+// CODE SIZE matters here: with the activation switch evaluated per element and one product variant per (tiles, quads) shape the
+// forward kernel was 38 000 instructions (300 KB: every wave missed the 64 KB instruction cache all the way through, 130 us per
+// launch).  Now: products in units of four quads (32 columns of k), `act` switched once per layer, the layers after the first in a
+// real loop (one copy of the code).
+// REGISTERS: the kernels are templated on QD = quads (8 columns) a wave carries per row: 4 for chains whose inner widths are all <= 32
+// (64 VGPRs, eight waves per SIMD), 8 otherwise (base_fc, geometry_fc, vis_fc's 33 outputs).  One width-64 kernel for everything ran
+// at 196 (forward) and 264 (backward) VGPRs -- one or two waves per SIMD, every load and LDS latency exposed.
+// acc[m] += W[32m + n][8q + 4 half + j] * b[q][j]  over the four quads q = Q0 .. Q0+3 (W from LDS)
+template <int QD, int MT, int Q0>
+__device__ __forceinline__ void chain_mma_fwd(const float* __restrict__ w, int S, int n, int half, const float (&b)[QD][4], f32x16t (&acc)[QD / 4]) {
+#pragma unroll
+  for (int q = Q0; q < Q0 + 4; ++q)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 a4 = *reinterpret_cast<const float4*>(w + (32 * m + n) * S + 8 * q + 4 * half);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[q][0], acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[q][1], acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[q][2], acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[q][3], acc[m], 0, 0, 0);
+    }
+}
+// acc[m] += W[8q + 4 half + j][col0 + 32 m + n] * d[q][j]  over q = Q0 .. Q0+3 (the transposed product of the backward)
+template <int QD, int MT, int Q0>
+__device__ __forceinline__ void chain_mma_bwd(const float* __restrict__ w, int S, int col0, int n, int half, const float (&d)[QD][4], f32x16t (&acc)[QD / 4]) {
+#pragma unroll
+  for (int q = Q0; q < Q0 + 4; ++q) {
+    const float* wr = w + (8 * q + 4 * half) * S + col0 + n;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j * S + 32 * m], d[q][j], acc[m], 0, 0, 0);
+  }
+}
+// the products of one layer, nk quads of k (<= QD), mt tiles of 32 outputs (<= QD / 4): uniform branches over small bodies
+template <int QD>
+__device__ __forceinline__ void chain_layer_fwd(const float* __restrict__ w, int S, int n, int half, int mt, int nk, const float (&b)[QD][4], f32x16t (&acc)[QD / 4]) {
+  if constexpr (QD == 4) {
+    chain_mma_fwd<4, 1, 0>(w, S, n, half, b, acc);
+  } else {
+    if (mt == 1) { chain_mma_fwd<8, 1, 0>(w, S, n, half, b, acc); if (nk > 4) chain_mma_fwd<8, 1, 4>(w, S, n, half, b, acc); }
+    else { chain_mma_fwd<8, 2, 0>(w, S, n, half, b, acc); if (nk > 4) chain_mma_fwd<8, 2, 4>(w, S, n, half, b, acc); }
+  }
+}
+template <int QD>
+__device__ __forceinline__ void chain_layer_bwd(const float* __restrict__ w, int S, int col0, int n, int half, int mt, int nk, const float (&d)[QD][4], f32x16t (&acc)[QD / 4]) {
+  if constexpr (QD == 4) {
+    chain_mma_bwd<4, 1, 0>(w, S, col0, n, half, d, acc);
+  } else {
+    if (mt == 1) { chain_mma_bwd<8, 1, 0>(w, S, col0, n, half, d, acc); if (nk > 4) chain_mma_bwd<8, 1, 4>(w, S, col0, n, half, d, acc); }
+    else { chain_mma_bwd<8, 2, 0>(w, S, col0, n, half, d, acc); if (nk > 4) chain_mma_bwd<8, 2, 4>(w, S, col0, n, half, d, acc); }
+  }
+}
+// b <- act(acc + bias) (zeros from column OUT on).  The softplus pair only ever closes the dist decoder (OUT <= 2): first quad only
+// (host: chain_check).
+template <int QD, int ACT>
+__device__ __forceinline__ void chain_act_fwd(const f32x16t (&acc)[QD / 4], const float* __restrict__ bias, int OUT, int half, float (&b)[QD][4]) {
+#pragma unroll
+  for (int m = 0; m < QD / 4; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c0 = 32 * m + 8 * g + 4 * half;
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + c0);
+      const float v[4] = {acc[m][4 * g] + b4.x, acc[m][4 * g + 1] + b4.y, acc[m][4 * g + 2] + b4.z, acc[m][4 * g + 3] + b4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t;
+        if ((ACT == ACT_SOFTPLUS || ACT == ACT_SOFTPLUS_B) && (m > 0 || g > 0)) t = 0.f;
+        else t = act_fwd(v[j], ACT);
+        b[4 * m + g][j] = (c0 + j < OUT) ? t : 0.f;
+      }
+    }
+}
+template <int QD, int ACT>
+__device__ __forceinline__ void chain_act_bwd(const float (&y)[QD][4], float (&d)[QD][4]) {
+#pragma unroll
+  for (int q = 0; q < QD; ++q) {
+    if ((ACT == ACT_SOFTPLUS || ACT == ACT_SOFTPLUS_B) && q > 0) break;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[q][j] *= act_grad(y[q][j], ACT);
+  }
+}
+
+template <int QD>
+__global__ void __launch_bounds__(256, QD == 4 ? 6 : 3) chain_fwd_kernel(const ChainArgs a) {
+  extern __shared__ float chain_lds[];
+  chain_stage_weights(a, chain_lds, true);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
+  const long ntiles = (a.rows + 127) / 128;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {      // (workgroups are persistent: the weights are staged once)
+    const long row = (tile * 4 + wave) * 32 + n;
+    const bool row_ok = row < a.rows;
+    const long rowc = row_ok ? row : a.rows - 1;
+    float b[QD][4];
+#pragma unroll 1
+    for (int k = 0; k < a.n; ++k) {
+      const ChainLayer& L = a.l[k];
+      const float* w = chain_lds + L.off;
+      const int S = L.S, OUT = L.OUT, IN = L.IN, mt = OUT > 32 ? 2 : 1;
+      f32x16t acc[QD / 4];
+#pragma unroll
+      for (int m = 0; m < QD / 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      if (k == 0) {
+        // first layer: any width, QD quads of the wave's rows in flight at a time
+        const float* xr = a.X + rowc * (long)a.ldx;
+        const int nq = (IN + 7) >> 3;
+        for (int q0 = 0; q0 < nq; q0 += QD) {
+#pragma unroll
+          for (int u = 0; u < QD; ++u) load4_mask(xr, 8 * (q0 + u) + 4 * half, IN, b[u]);
+          chain_layer_fwd<QD>(w + 8 * q0, S, n, half, mt, nq - q0, b, acc);
+        }
+      } else {
+        chain_layer_fwd<QD>(w, S, n, half, mt, (IN + 7) >> 3, b, acc);
+      }
+      const float* bias = w + chain_rows(OUT) * S;
+      switch (L.act) {
+        case ACT_ELU: chain_act_fwd<QD, ACT_ELU>(acc, bias, OUT, half, b); break;
+        case ACT_RELU: chain_act_fwd<QD, ACT_RELU>(acc, bias, OUT, half, b); break;
+        case ACT_SIGMOID: chain_act_fwd<QD, ACT_SIGMOID>(acc, bias, OUT, half, b); break;
+        case ACT_SOFTPLUS: chain_act_fwd<QD, ACT_SOFTPLUS>(acc, bias, OUT, half, b); break;
+        case ACT_SOFTPLUS_B: chain_act_fwd<QD, ACT_SOFTPLUS_B>(acc, bias, OUT, half, b); break;
+        default: chain_act_fwd<QD, ACT_NONE>(acc, bias, OUT, half, b); break;
+      }
+      if (row_ok) {
+        float* yr = L.Y + row * (long)L.ldy;
+#pragma unroll
+        for (int q = 0; q < QD; ++q) {
+          const int c0 = 8 * q + 4 * half;
+          if (c0 < OUT) store4_guard(yr, c0, OUT, b[q]);
+        }
+      }
+    }
+  }
+}
+
+template <int QD>
+__global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const ChainArgs a) {
+  extern __shared__ float chain_lds[];
+  chain_stage_weights(a, chain_lds, false);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
+  const long ntiles = (a.rows + 127) / 128;
+  constexpr int MTM = QD / 4;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long row = (tile * 4 + wave) * 32 + n;
+    const bool row_ok = row < a.rows;
+    const long rowc = row_ok ? row : a.rows - 1;
+    float d[QD][4];
+    {
+      const float* dr = a.l[0].D + rowc * (long)a.l[0].ldd;
+      const int OUT = a.l[0].OUT;
+#pragma unroll
+      for (int q = 0; q < QD; ++q) load4_mask(dr, 8 * q + 4 * half, OUT, d[q]);
+    }
+#pragma unroll 1
+    for (int k = 0; k < a.n; ++k) {
+      const ChainLayer& L = a.l[k];
+      const float* w = chain_lds + L.off;
+      const int S = L.S, OUT = L.OUT, IN = L.IN, nko = (OUT + 7) >> 3;
+      // delta = dY * act'(Y), stored for the weight-gradient kernel (a top layer without activation: dY is delta already)
+      if (L.act != ACT_NONE) {
+        const float* yr = L.Y + rowc * (long)L.ldy;
+        float y[QD][4];
+#pragma unroll
+        for (int q = 0; q < QD; ++q) load4_mask(yr, 8 * q + 4 * half, OUT, y[q]);
+        switch (L.act) {
+          case ACT_ELU: chain_act_bwd<QD, ACT_ELU>(y, d); break;
+          case ACT_RELU: chain_act_bwd<QD, ACT_RELU>(y, d); break;
+          case ACT_SIGMOID: chain_act_bwd<QD, ACT_SIGMOID>(y, d); break;
+          case ACT_SOFTPLUS: chain_act_bwd<QD, ACT_SOFTPLUS>(y, d); break;
+          default: chain_act_bwd<QD, ACT_SOFTPLUS_B>(y, d); break;
+        }
+      }
+      if ((L.act != ACT_NONE || k > 0) && row_ok) {
+        float* dr = L.D + row * (long)L.ldd;
+#pragma unroll
+        for (int q = 0; q < QD; ++q) {
+          const int c0 = 8 * q + 4 * half;
+          if (c0 < OUT) store4_guard(dr, c0, OUT, d[q]);
+        }
+      }
+      if (!L.dx) break;
+      const int mtiles = (IN + 31) >> 5;
+      if (k + 1 == a.n) {
+        // the chain's output: dX (=|+=) delta W, any width, QD / 4 32-column tiles at a time
+        if (!a.dX) break;
+        float* xr = a.dX + rowc * (long)a.lddx;
+        for (int m0 = 0; m0 < mtiles; m0 += MTM) {
+          f32x16t acc[MTM];
+          const int mt = mtiles - m0 >= MTM ? MTM : 1;
+#pragma unroll
+          for (int m = 0; m < MTM; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int c0 = 32 * (m0 + m) + 8 * g + 4 * half;
+              float o[4] = {0.f, 0.f, 0.f, 0.f};
+              if (a.accumulate && m < mt) load4_mask(xr, c0, IN, o);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[m][4 * g + j] = o[j];
+            }
+          chain_layer_bwd<QD>(w, S, 32 * m0, n, half, mt, nko, d, acc);
+          if (!row_ok) continue;
+#pragma unroll
+          for (int m = 0; m < MTM; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int c0 = 32 * (m0 + m) + 8 * g + 4 * half;
+              const float v[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+              if (m < mt && c0 < IN) store4_guard(xr, c0, IN, v);
+            }
+        }
+      } else {
+        // dY of the next layer down stays in registers (IN <= 8 QD)
+        f32x16t acc[MTM];
+#pragma unroll
+        for (int m = 0; m < MTM; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        chain_layer_bwd<QD>(w, S, 0, n, half, mtiles, nko, d, acc);
+#pragma unroll
+        for (int m = 0; m < MTM; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[4 * m + g][j] = (32 * m + 8 * g + 4 * half + j < IN) ? acc[m][4 * g + j] : 0.f;
+      }
+    }
   }
 }
 

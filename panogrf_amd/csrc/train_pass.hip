@@ -216,6 +216,7 @@ static size_t plan(Ws& w, long P, int V, int dn, char* base) {
   w.gb1 = take(PV * 64); w.gxin = take(PV * 207); w.gglob = take(P * 140); w.gw0 = take(PV); w.gn1 = take(PV * 8);
   w.gdfeat = take(PV * 35); w.gd1 = take(PV * 16); w.gpe_h = take(PV * 32); w.gpe_in = take(PV * 34);
   for (int m = 0; m < 4; ++m) { w.gdout[m] = take(PV * 2); w.gdh2[m] = take(PV * 32); w.gdh1[m] = take(PV * 32); }
+  (void)take(64);      // the chain kernels' dwordx4 loads may touch 12 bytes past the last row of an activation buffer
   return off;
 }
 
@@ -236,37 +237,49 @@ static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float*
   PGRF_TCHECK("train linear forward");
   return PGRF_OK;
 }
+// gW += delta^T X and gb += colsum(delta) (one launch): the reduction runs over the ROWS (sample points x views), split over gridDim.z
+// so that the launch has ~1 536 workgroups; partial tiles are summed inside a workgroup, then one atomic per element and workgroup
+static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int ldd, int rw, int rb, long rows, int IN, int OUT) {
+  float* gb = (rb >= 0) ? c.graw[rb] : nullptr;
+  if (!c.graw[rw]) {
+    if (gb) {          // bias gradient alone (the weight's is not wanted): column sums by the elementwise kernel
+      int cp = 1;
+      while (cp < OUT) cp <<= 1;
+      const long nb = (rows * cp + 256 * 8 - 1) / (256 * 8);
+      hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb))), dim3(256), 0, c.st, const_cast<float*>(delta), ldd, delta, ldd, rows, OUT, cp, (int)ACT_NONE, gb);
+    }
+    return;
+  }
+  const int nt = IN > 64 ? 4 : (IN > 32 ? 2 : 1);
+  const int gx = (IN + 32 * nt - 1) / (32 * nt), gy = (OUT + 31) / 32, groups = gx * gy;
+  const int gpw = groups >= 4 ? 4 : (groups == 2 ? 2 : 1);                  // groups per workgroup
+  const int nwg = (groups + gpw - 1) / gpw;
+  static const int target_wgs = [] { const char* e = getenv("PGRF_TRAIN_DW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();   // tuning knob (with the gradient replicas: 192: 18.6, 384: 15.9, 768: 14.5, 1536: 14.1, 3072: 14.5, 6144: 14.1 ms per 2 048-ray step)
+  long chunk = (rows * nwg / target_wgs + 63) / 64 * 64;                    // ~target_wgs workgroups per launch
+  if (chunk < 128) chunk = 128;
+  const dim3 grid(nwg, 1, (unsigned)((rows + chunk - 1) / chunk));
+  float* rep = c.grep + (size_t)rw * kGradSlot;          // this tensor's slot of replica 1 (replica r at + (r - 1) * R_COUNT * kGradSlot)
+  float* brep = gb ? c.grep + (size_t)rb * kGradSlot : nullptr;
+  c.gsize[rw] = OUT * IN;
+  if (gb) c.gsize[rb] = OUT;
+  if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.st, delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
+  else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.st, delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
+  else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.st, delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
+}
 // dY (a [rows, OUT] slice, ld lddy) is overwritten by delta = dY * act'(Y); then gW += delta^T X, gb += colsum(delta),
 // dX (=|+=) delta W
 static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ldy, float* dY, int lddy, int rw, int rb, float* dX, int lddx,
                    int acc_dx, long rows, int IN, int OUT, int act) {
-  float* gb = (rb >= 0) ? c.graw[rb] : nullptr;
-  if (act != ACT_NONE || gb)
+  if (act != ACT_NONE)
   {
     int cp = 1;
     while (cp < OUT) cp <<= 1;
     if (cp > 64) return set_error(PGRF_ERR_UNSUPPORTED, "train linear backward: %d outputs (at most 64)", OUT);
     const long nb = (rows * cp + 256 * 8 - 1) / (256 * 8);            // ~8 rows per thread
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb)))   /* (<= 1 024 same-address atomics per bias element) */, dim3(256), 0, c.st, dY, lddy, Y, ldy, rows, OUT, cp,
-                       act, gb);
+                       act, (float*)nullptr);
   }
-  if (c.graw[rw]) {
-    // gW += delta^T X: the reduction runs over the ROWS (sample points x views), split over gridDim.z so that the launch has
-    // ~1024 workgroups; partial tiles are summed inside a workgroup, then one atomic per element and workgroup
-    const int nt = IN > 64 ? 4 : (IN > 32 ? 2 : 1);
-    const int gx = (IN + 32 * nt - 1) / (32 * nt), gy = (OUT + 31) / 32, groups = gx * gy;
-    const int gpw = groups >= 4 ? 4 : (groups == 2 ? 2 : 1);                  // groups per workgroup
-    const int nwg = (groups + gpw - 1) / gpw;
-    static const int target_wgs = [] { const char* e = getenv("PGRF_TRAIN_DW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();   // tuning knob (with the gradient replicas: 192: 18.6, 384: 15.9, 768: 14.5, 1536: 14.1, 3072: 14.5, 6144: 14.1 ms per 2 048-ray step)
-    long chunk = (rows * nwg / target_wgs + 63) / 64 * 64;                    // ~target_wgs workgroups per launch
-    if (chunk < 128) chunk = 128;
-    const dim3 grid(nwg, 1, (unsigned)((rows + chunk - 1) / chunk));
-    float* rep = c.grep + (size_t)rw * kGradSlot;          // this tensor's slot of replica 1 (replica r at + (r - 1) * R_COUNT * kGradSlot)
-    c.gsize[rw] = OUT * IN;
-    if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups);
-    else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups);
-    else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.st, dY, lddy, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups);
-  }
+  L_dw(c, X, ldx, dY, lddy, rw, rb, rows, IN, OUT);
   if (dX) {
     // dX (=|+=) delta W: the same kernel with the weight read transposed (W is [OUT, IN]: "M" = IN, "K" = OUT)
     const int mt = IN > 32 ? 2 : 1;
@@ -275,6 +288,81 @@ static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ld
     else hipLaunchKernelGGL((lin_mfma_kernel<true, 1>), grid, dim3(256), 0, c.st, dY, lddy, c.raw[rw], IN, (const float*)nullptr, dX, lddx, rows, IN, OUT, (int)ACT_NONE, acc_dx);
   }
   PGRF_TCHECK("train linear backward");
+  return PGRF_OK;
+}
+
+
+// A chain of <= 3 Linear layers in one launch (train_kernels.h chain_fwd_kernel / chain_bwd_kernel).  Layer k + 1 reads layer k's
+// output; widths after the first layer's input <= 64.
+struct Lin { const float* X; int ldx; float* Y; int ldy; float* dY; int lddy; int rw, rb, IN, OUT, act; };
+static int chain_check(const Lin* l, int n) {
+  if (n < 1 || n > 3) return set_error(PGRF_ERR_ARG, "train chain: %d layers", n);
+  for (int k = 0; k < n; ++k) {
+    if ((l[k].act == ACT_SOFTPLUS || l[k].act == ACT_SOFTPLUS_B) && l[k].OUT > 4)
+      return set_error(PGRF_ERR_UNSUPPORTED, "train chain: softplus on %d outputs (at most 4)", l[k].OUT);
+    if (l[k].OUT > 64 || (k > 0 && (l[k].IN > 64 || l[k].X != l[k - 1].Y || l[k].ldx != l[k - 1].ldy || l[k].IN != l[k - 1].OUT)))
+      return set_error(PGRF_ERR_UNSUPPORTED, "train chain: layer %d does not chain (IN %d, OUT %d)", k, l[k].IN, l[k].OUT);
+  }
+  return PGRF_OK;
+}
+// LDS copy of the chain's weights: per layer chain_rows(OUT) rows of stride S, then 64 floats of bias; 64 floats of slack at the end
+static size_t chain_layout(ChainArgs& a) {
+  int off = 0;
+  for (int k = 0; k < a.n; ++k) {
+    a.l[k].S = chain_stride(a.l[k].IN);
+    a.l[k].off = off;
+    off += chain_rows(a.l[k].OUT) * a.l[k].S + 64;
+  }
+  a.lds_floats = off + 64;
+  return (size_t)a.lds_floats * 4;
+}
+// persistent workgroups: as many as fit the chip at once (LDS- or register-bound), each walking row tiles
+// every width a wave keeps in registers <= 32: the QD = 4 kernels
+static bool chain_narrow(const Lin* l, int n) {
+  for (int k = 0; k < n; ++k)
+    if (l[k].OUT > 32 || (k > 0 && l[k].IN > 32)) return false;
+  return true;
+}
+static dim3 chain_grid(long rows, size_t lds, int max_per_cu) {
+  static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  static const int per_cu_env = [] { const char* e = getenv("PGRF_TRAIN_CHAIN_WGS"); return e ? atoi(e) : 0; }();
+  int per_cu = (int)(160 * 1024 / (lds + 1024));
+  if (per_cu > max_per_cu) per_cu = max_per_cu;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu_env > 0) per_cu = per_cu_env;
+  const long tiles = (rows + 127) / 128, cap = (long)ncu * per_cu;
+  return dim3((unsigned)(tiles < cap ? tiles : cap));
+}
+static int chain_fwd(const Ctx& c, const Lin* l, int n, long rows) {
+  if (int rc = chain_check(l, n)) return rc;
+  ChainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n = n; a.X = l[0].X; a.ldx = l[0].ldx; a.rows = rows;
+  for (int k = 0; k < n; ++k)
+    a.l[k] = ChainLayer{c.raw[l[k].rw], l[k].rb >= 0 ? c.raw[l[k].rb] : nullptr, l[k].Y, nullptr, l[k].ldy, 0, l[k].IN, l[k].OUT, l[k].act, 0, 0, 0};
+  const size_t lds = chain_layout(a);
+  if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
+  if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_fwd_kernel<4>, chain_grid(rows, lds, 6), dim3(256), lds, c.st, a);
+  else hipLaunchKernelGGL(chain_fwd_kernel<8>, chain_grid(rows, lds, 3), dim3(256), lds, c.st, a);
+  PGRF_TCHECK("train chain forward");
+  return PGRF_OK;
+}
+// every layer's dY is overwritten by its delta; weight and bias gradients accumulated; dX (=|+=) the bottom layer's delta W (null: none)
+static int chain_bwd(const Ctx& c, const Lin* l, int n, long rows, float* dX, int lddx, int acc_dx) {
+  if (int rc = chain_check(l, n)) return rc;
+  ChainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n = n; a.rows = rows; a.dX = dX; a.lddx = lddx; a.accumulate = acc_dx;
+  for (int k = 0; k < n; ++k) {          // kernel order: top layer first
+    const Lin& s = l[n - 1 - k];
+    a.l[k] = ChainLayer{c.raw[s.rw], nullptr, s.Y, s.dY, s.ldy, s.lddy, s.IN, s.OUT, s.act, (k + 1 < n || dX) ? 1 : 0, 0, 0};
+  }
+  const size_t lds = chain_layout(a);
+  if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
+  if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_bwd_kernel<4>, chain_grid(rows, lds, 5), dim3(256), lds, c.st, a);
+  else hipLaunchKernelGGL(chain_bwd_kernel<8>, chain_grid(rows, lds, 2), dim3(256), lds, c.st, a);
+  for (int k = n - 1; k >= 0; --k) L_dw(c, l[k].X, l[k].ldx, l[k].dY, l[k].lddy, l[k].rw, l[k].rb, rows, l[k].IN, l[k].OUT);
+  PGRF_TCHECK("train chain backward");
   return PGRF_OK;
 }
 
@@ -352,41 +440,51 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   PGRF_TCHECK("train geometry");
 
   // ------------------------------------------------------------------ forward, every activation kept
+  // the MLPs as register-resident chains (chain_fwd_kernel); *_l arrays are reused by the backward
+  Lin dd_l[4][3];
   for (int m = 0; m < NM; ++m) {        // dist decoder MLPs on the gathered ray feature (dist_decoder.py:53-107)
-    L(lin_fwd(c, w.pe_in, 34, kDD[m][0], kDD[m][1], w.dh1[m], 32, PV, 32, 32, ACT_ELU));
-    L(lin_fwd(c, w.dh1[m], 32, kDD[m][2], kDD[m][3], w.dh2[m], 32, PV, 32, 32, ACT_ELU));
-    L(lin_fwd(c, w.dh2[m], 32, kDD[m][4], kDD[m][5], w.dout[m], 2, PV, 32, kDDout[m], kDDact[m]));
+    dd_l[m][0] = Lin{w.pe_in, 34, w.dh1[m], 32, w.gdh1[m], 32, kDD[m][0], kDD[m][1], 32, 32, ACT_ELU};
+    dd_l[m][1] = Lin{w.dh1[m], 32, w.dh2[m], 32, w.gdh2[m], 32, kDD[m][2], kDD[m][3], 32, 32, ACT_ELU};
+    dd_l[m][2] = Lin{w.dh2[m], 32, w.dout[m], 2, w.gdout[m], 2, kDD[m][4], kDD[m][5], 32, kDDout[m], kDDact[m]};
+    L(chain_fwd(c, dd_l[m], 3, PV));
   }
   ProbIO pio{w.depth_v, w.hw, frame->ref_depth_range, w.dout[0], w.dout[1], w.dout[2], use_vis ? w.dout[3] : nullptr, w.vis, w.hit};
   hipLaunchKernelGGL(prob_kernel, dim3(nblk(PV)), dim3(256), 0, st, pio, PV, V, w.pe_in);
   PGRF_TCHECK("train compute_prob");
-  L(lin_fwd(c, w.pe_in, 34, R_PE_0_W, R_PE_0_B, w.pe_h, 32, PV, 34, 32, ACT_RELU));                 // prob_embed (aggregate_net.py:53-61)
-  L(lin_fwd(c, w.pe_h, 32, R_PE_2_W, R_PE_2_B, w.xin + 175, 207, PV, 32, 32, ACT_NONE));            //   -> neuray feature, xin[:, 175:207]
-  L(lin_fwd(c, w.dd, 4, R_RD_0_W, R_RD_0_B, w.d1, 16, PV, 4, 16, ACT_ELU));                          // ray_dir_fc
-  L(lin_fwd(c, w.d1, 16, R_RD_2_W, R_RD_2_B, w.dfeat, 35, PV, 16, 35, ACT_ELU));
+  const Lin pe_l[2] = {{w.pe_in, 34, w.pe_h, 32, w.gpe_h, 32, R_PE_0_W, R_PE_0_B, 34, 32, ACT_RELU},               // prob_embed (aggregate_net.py:53-61)
+                       {w.pe_h, 32, w.xin + 175, 207, w.gxin + 175, 207, R_PE_2_W, R_PE_2_B, 32, 32, ACT_NONE}};   //   -> neuray feature, xin[:, 175:207]
+  L(chain_fwd(c, pe_l, 2, PV));
+  const Lin rd_l[2] = {{w.dd, 4, w.d1, 16, w.gd1, 16, R_RD_0_W, R_RD_0_B, 4, 16, ACT_ELU},                          // ray_dir_fc
+                       {w.d1, 16, w.dfeat, 35, w.gdfeat, 35, R_RD_2_W, R_RD_2_B, 16, 35, ACT_ELU}};
+  L(chain_fwd(c, rd_l, 2, PV));
   hipLaunchKernelGGL(rgbfeat_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.rgb, w.imf, w.dfeat, PV, w.xin);
-  L(lin_fwd(c, w.xin + 175, 207, R_NF_0_W, R_NF_0_B, w.n1, 8, PV, 32, 8, ACT_ELU));                  // neuray_fc -> weight0 (ibrnet.py:337-338)
-  L(lin_fwd(c, w.n1, 8, R_NF_2_W, R_NF_2_B, w.nfs, 1, PV, 8, 1, ACT_SIGMOID));
+  const Lin nf_l[2] = {{w.xin + 175, 207, w.n1, 8, w.gn1, 8, R_NF_0_W, R_NF_0_B, 32, 8, ACT_ELU},                   // neuray_fc -> weight0 (ibrnet.py:337-338)
+                       {w.n1, 8, w.nfs, 1, w.gw0, 1, R_NF_2_W, R_NF_2_B, 8, 1, ACT_SIGMOID}};
+  L(chain_fwd(c, nf_l, 2, PV));
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w0, 1, 0, w.nfs, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
   hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35);
   hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105);
   hipLaunchKernelGGL(bcast_kernel, dim3(nblk(PV * 140)), dim3(256), 0, st, w.xin, 207, 0, w.glob, 140, 0, PV, V, 140);
   PGRF_TCHECK("train view statistics");
-  L(lin_fwd(c, w.xin, 207, R_BASE_0_W, R_BASE_0_B, w.b1, 64, PV, 207, 64, ACT_ELU));                 // base_fc
-  L(lin_fwd(c, w.b1, 64, R_BASE_2_W, R_BASE_2_B, w.x, 32, PV, 64, 32, ACT_ELU));
+  const Lin base_l[2] = {{w.xin, 207, w.b1, 64, w.gb1, 64, R_BASE_0_W, R_BASE_0_B, 207, 64, ACT_ELU},               // base_fc
+                         {w.b1, 64, w.x, 32, w.gx, 32, R_BASE_2_W, R_BASE_2_B, 64, 32, ACT_ELU}};
+  L(chain_fwd(c, base_l, 2, PV));
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32);
-  L(lin_fwd(c, w.xw, 32, R_VF_0_W, R_VF_0_B, w.v1h, 32, PV, 32, 32, ACT_ELU));                       // vis_fc
-  L(lin_fwd(c, w.v1h, 32, R_VF_2_W, R_VF_2_B, w.xv, 33, PV, 32, 33, ACT_ELU));
+  const Lin vf_l[2] = {{w.xw, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, 32, 32, ACT_ELU},                      // vis_fc
+                       {w.v1h, 32, w.xv, 33, w.gxv, 33, R_VF_2_W, R_VF_2_B, 32, 33, ACT_ELU}};
+  L(chain_fwd(c, vf_l, 2, PV));
   hipLaunchKernelGGL(visfc_post_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.x, w.xv, PV, w.xr, w.v1);
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32);
-  L(lin_fwd(c, w.xv1, 32, R_V2_0_W, R_V2_0_B, w.f1, 32, PV, 32, 32, ACT_ELU));                       // vis_fc2 -> xr[:, 32]
-  L(lin_fwd(c, w.f1, 32, R_V2_2_W, R_V2_2_B, w.xr + 32, 37, PV, 32, 1, ACT_SIGMOID));
+  const Lin v2_l[2] = {{w.xv1, 32, w.f1, 32, w.gf1, 32, R_V2_0_W, R_V2_0_B, 32, 32, ACT_ELU},                       // vis_fc2 -> xr[:, 32]
+                       {w.f1, 32, w.xr + 32, 37, w.gxr + 32, 37, R_V2_2_W, R_V2_2_B, 32, 1, ACT_SIGMOID}};
+  L(chain_fwd(c, v2_l, 2, PV));
   hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 4)), dim3(256), 0, st, w.xr, 37, 33, w.dd, 4, 0, PV, 4, 0);
   hipLaunchKernelGGL(wgt2_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, P, V, w.wgt2, w.gin);
   hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 32)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32);
   PGRF_TCHECK("train pooled geometry feature");
-  L(lin_fwd(c, w.gin, 65, R_GEO_0_W, R_GEO_0_B, w.g1, 64, P, 65, 64, ACT_ELU));                      // geometry_fc
-  L(lin_fwd(c, w.g1, 64, R_GEO_2_W, R_GEO_2_B, w.g2, 16, P, 64, 16, ACT_ELU));
+  const Lin geo_l[2] = {{w.gin, 65, w.g1, 64, w.gg1, 64, R_GEO_0_W, R_GEO_0_B, 65, 64, ACT_ELU},                    // geometry_fc
+                        {w.g1, 64, w.g2, 16, w.ggp, 16, R_GEO_2_W, R_GEO_2_B, 64, 16, ACT_ELU}};      // (d(gp)/d(g2) = 1: the gradient arrives in ggp)
+  L(chain_fwd(c, geo_l, 2, P));
   hipLaunchKernelGGL(posenc_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.g2, w.pos, P, dn, w.gp);
   L(lin_fwd(c, w.gp, 16, R_ATT_Q_W, -1, w.q, 16, P, 16, 16, ACT_NONE));                              // ray attention
   L(lin_fwd(c, w.gp, 16, R_ATT_K_W, -1, w.k, 16, P, 16, 16, ACT_NONE));
@@ -395,11 +493,13 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   L(lin_fwd(c, w.o, 16, R_ATT_FC_W, -1, w.fo, 16, P, 16, 16, ACT_NONE));
   hipLaunchKernelGGL(slice_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.fo, 16, 0, w.gp, 16, 0, P, 16, 1);           // + residual
   hipLaunchKernelGGL(layernorm_kernel, dim3(nblk(P)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], raw_dev[R_ATT_LN_B], P, w.ln);
-  L(lin_fwd(c, w.ln, 16, R_OG_0_W, R_OG_0_B, w.og1, 16, P, 16, 16, ACT_ELU));                        // out_geometry_fc -> density
-  L(lin_fwd(c, w.og1, 16, R_OG_2_W, R_OG_2_B, w.sigma, 1, P, 16, 1, ACT_RELU));
-  L(lin_fwd(c, w.xr, 37, R_RGB_0_W, R_RGB_0_B, w.r1, 16, PV, 37, 16, ACT_ELU));                      // rgb_fc -> blending logits
-  L(lin_fwd(c, w.r1, 16, R_RGB_2_W, R_RGB_2_B, w.r2, 8, PV, 16, 8, ACT_ELU));
-  L(lin_fwd(c, w.r2, 8, R_RGB_4_W, R_RGB_4_B, w.logit, 1, PV, 8, 1, ACT_NONE));
+  const Lin og_l[2] = {{w.ln, 16, w.og1, 16, w.gog1, 16, R_OG_0_W, R_OG_0_B, 16, 16, ACT_ELU},                      // out_geometry_fc -> density
+                       {w.og1, 16, w.sigma, 1, w.gsigma, 1, R_OG_2_W, R_OG_2_B, 16, 1, ACT_RELU}};
+  L(chain_fwd(c, og_l, 2, P));
+  const Lin rgb_l[3] = {{w.xr, 37, w.r1, 16, w.gr1, 16, R_RGB_0_W, R_RGB_0_B, 37, 16, ACT_ELU},                     // rgb_fc -> blending logits
+                        {w.r1, 16, w.r2, 8, w.gr2, 8, R_RGB_2_W, R_RGB_2_B, 16, 8, ACT_ELU},
+                        {w.r2, 8, w.logit, 1, w.glogit, 1, R_RGB_4_W, R_RGB_4_B, 8, 1, ACT_NONE}};
+  L(chain_fwd(c, rgb_l, 3, PV));
   hipLaunchKernelGGL(blend_kernel, dim3(nblk(P)), dim3(256), 0, st, w.logit, w.rgb, P, V, w.blend, w.colors);
   PGRF_TCHECK("train forward tail");
   if (fwd_out) {      // the staged forward's own outputs (tests: must equal the fused kernel's to round-off)
@@ -414,11 +514,8 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
                      grad->render_depth, grad->hit_prob, grad->colors, grad->density, w.gsigma, w.gcol);
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.blend, w.rgb, w.gcol, P, V, w.glogit);
   PGRF_TCHECK("train composite backward");
-  L(lin_bwd(c, w.r2, 8, w.logit, 1, w.glogit, 1, R_RGB_4_W, R_RGB_4_B, w.gr2, 8, 0, PV, 8, 1, ACT_NONE));
-  L(lin_bwd(c, w.r1, 16, w.r2, 8, w.gr2, 8, R_RGB_2_W, R_RGB_2_B, w.gr1, 16, 0, PV, 16, 8, ACT_ELU));
-  L(lin_bwd(c, w.xr, 37, w.r1, 16, w.gr1, 16, R_RGB_0_W, R_RGB_0_B, w.gxr, 37, 0, PV, 37, 16, ACT_ELU));       // gxr written (=)
-  L(lin_bwd(c, w.og1, 16, w.sigma, 1, w.gsigma, 1, R_OG_2_W, R_OG_2_B, w.gog1, 16, 0, P, 16, 1, ACT_RELU));
-  L(lin_bwd(c, w.ln, 16, w.og1, 16, w.gog1, 16, R_OG_0_W, R_OG_0_B, w.gln, 16, 0, P, 16, 16, ACT_ELU));
+  L(chain_bwd(c, rgb_l, 3, PV, w.gxr, 37, 0));                                                                      // gxr written (=)
+  L(chain_bwd(c, og_l, 2, P, w.gln, 16, 0));
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], w.gln, P, w.gfo,
                      g_raw_dev[R_ATT_LN_W] ? g_raw_dev[R_ATT_LN_W] : w.gq /* scratch sink */, g_raw_dev[R_ATT_LN_B] ? g_raw_dev[R_ATT_LN_B] : w.gq);
   (void)hipMemcpyAsync(w.ggp, w.gfo, P * 64, hipMemcpyDeviceToDevice, st);                                            // residual branch
@@ -430,24 +527,20 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   L(lin_bwd(c, w.gp, 16, w.q, 16, w.gq, 16, R_ATT_Q_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(lin_bwd(c, w.gp, 16, w.k, 16, w.gk, 16, R_ATT_K_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(lin_bwd(c, w.gp, 16, w.v, 16, w.gv, 16, R_ATT_V_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
-  L(lin_bwd(c, w.g1, 64, w.g2, 16, w.ggp, 16, R_GEO_2_W, R_GEO_2_B, w.gg1, 64, 0, P, 64, 16, ACT_ELU));           // d(gp)/d(g2) = 1
-  L(lin_bwd(c, w.gin, 65, w.g1, 64, w.gg1, 64, R_GEO_0_W, R_GEO_0_B, w.ggin, 65, 0, P, 65, 64, ACT_ELU));
+  L(chain_bwd(c, geo_l, 2, P, w.ggin, 65, 0));
   (void)hipMemsetAsync(w.gwgt2, 0, PV * 4, st);
   hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32, w.ggin, 65, 0, 32, w.gxr,
                      37, 0, w.gwgt2);
   hipLaunchKernelGGL(wgt2_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, w.gwgt2, w.ggin, P, V, w.gxr);
   PGRF_TCHECK("train pooled geometry backward");
-  L(lin_bwd(c, w.f1, 32, w.xr + 32, 37, w.gxr + 32, 37, R_V2_2_W, R_V2_2_B, w.gf1, 32, 0, PV, 32, 1, ACT_SIGMOID));
-  L(lin_bwd(c, w.xv1, 32, w.f1, 32, w.gf1, 32, R_V2_0_W, R_V2_0_B, w.gxv1, 32, 0, PV, 32, 32, ACT_ELU));
+  L(chain_bwd(c, v2_l, 2, PV, w.gxv1, 32, 0));
   hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32, w.gxr, 37, 0, w.gv1);
   hipLaunchKernelGGL(visfc_post_bwd_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.gxr, w.gv1, w.v1, PV, w.gx, w.gxv);
-  L(lin_bwd(c, w.v1h, 32, w.xv, 33, w.gxv, 33, R_VF_2_W, R_VF_2_B, w.gv1h, 32, 0, PV, 32, 33, ACT_ELU));
-  L(lin_bwd(c, w.xw, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, w.gxw, 32, 0, PV, 32, 32, ACT_ELU));
+  L(chain_bwd(c, vf_l, 2, PV, w.gxw, 32, 0));
   hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32, w.gx, 32, 0,
                      (float*)nullptr);
   PGRF_TCHECK("train visibility backward");
-  L(lin_bwd(c, w.b1, 64, w.x, 32, w.gx, 32, R_BASE_2_W, R_BASE_2_B, w.gb1, 64, 0, PV, 64, 32, ACT_ELU));
-  L(lin_bwd(c, w.xin, 207, w.b1, 64, w.gb1, 64, R_BASE_0_W, R_BASE_0_B, w.gxin, 207, 0, PV, 207, 64, ACT_ELU));
+  L(chain_bwd(c, base_l, 2, PV, w.gxin, 207, 0));
   hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 140)), dim3(256), 0, st, w.gglob, 140, 0, w.gxin, 207, 0, P, V, 140, 0);
   (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
   hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35, w.gglob, 140, 0, 35,
@@ -457,23 +550,18 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   PGRF_TCHECK("train view statistics backward");
   // weight0 = sigmoid(neuray_fc) * wgt: the gradient enters the sigmoid output scaled by wgt
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gw0, 1, 0, w.gw0, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
-  L(lin_bwd(c, w.n1, 8, w.nfs, 1, w.gw0, 1, R_NF_2_W, R_NF_2_B, w.gn1, 8, 0, PV, 8, 1, ACT_SIGMOID));
-  L(lin_bwd(c, w.xin + 175, 207, w.n1, 8, w.gn1, 8, R_NF_0_W, R_NF_0_B, w.gxin + 175, 207, 1, PV, 32, 8, ACT_ELU));    // += onto the neuray columns
+  L(chain_bwd(c, nf_l, 2, PV, w.gxin + 175, 207, 1));                                                               // += onto the neuray columns
   hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.gdfeat, 35, 0, w.gxin, 207, 140, PV, 35, 0);
   if (g_img_feats)
     hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, g_img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.gxin, 207, 143);
-  L(lin_bwd(c, w.d1, 16, w.dfeat, 35, w.gdfeat, 35, R_RD_2_W, R_RD_2_B, w.gd1, 16, 0, PV, 16, 35, ACT_ELU));
-  L(lin_bwd(c, w.dd, 4, w.d1, 16, w.gd1, 16, R_RD_0_W, R_RD_0_B, (float*)nullptr, 0, 0, PV, 4, 16, ACT_ELU));
-  L(lin_bwd(c, w.pe_h, 32, w.xin + 175, 207, w.gxin + 175, 207, R_PE_2_W, R_PE_2_B, w.gpe_h, 32, 0, PV, 32, 32, ACT_NONE));
-  L(lin_bwd(c, w.pe_in, 34, w.pe_h, 32, w.gpe_h, 32, R_PE_0_W, R_PE_0_B, w.gpe_in, 34, 0, PV, 34, 32, ACT_RELU));
+  L(chain_bwd(c, rd_l, 2, PV, (float*)nullptr, 0, 0));
+  L(chain_bwd(c, pe_l, 2, PV, w.gpe_in, 34, 0));
   // compute_prob: gradients of (hit, vis) -> mixture parameters
   ProbGrad pg{w.gpe_in, w.gdout[0], w.gdout[1], w.gdout[2], use_vis ? w.gdout[3] : nullptr};
   hipLaunchKernelGGL(prob_bwd_kernel, dim3(nblk(PV)), dim3(256), 0, st, pio, pg, PV, V);
   PGRF_TCHECK("train compute_prob backward");
   for (int m = 0; m < NM; ++m) {
-    L(lin_bwd(c, w.dh2[m], 32, w.dout[m], 2, w.gdout[m], 2, kDD[m][4], kDD[m][5], w.gdh2[m], 32, 0, PV, 32, kDDout[m], kDDact[m]));
-    L(lin_bwd(c, w.dh1[m], 32, w.dh2[m], 32, w.gdh2[m], 32, kDD[m][2], kDD[m][3], w.gdh1[m], 32, 0, PV, 32, 32, ACT_ELU));
-    L(lin_bwd(c, w.pe_in, 34, w.dh1[m], 32, w.gdh1[m], 32, kDD[m][0], kDD[m][1], w.gpe_in, 34, 1, PV, 32, 32, ACT_ELU));       // += onto the ray feature
+    L(chain_bwd(c, dd_l[m], 3, PV, w.gpe_in, 34, 1));                                                               // += onto the ray feature
   }
   if (g_ray_feats)
     hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, g_ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.gpe_in, 34, 0);
