@@ -15,6 +15,7 @@
 #include <tuple>
 #include <vector>
 
+#include "pgrf_experiments.h"
 #include "pgrf_internal.h"
 #include "pgrf_layout.h"
 
