@@ -928,6 +928,79 @@ __global__ void __launch_bounds__(128) attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// The same for dn <= 64 and more than one source view, one single-wave workgroup per (ray, head), lane = sample (21 KB of LDS: seven of them per CU): the kernel above
+// evaluates exp(q_s k_t / 2 - max_s) four times per (s, t) (row sum, gq, and twice in the key phase) and was VALU bound (163 us for
+// 2 048 rays); here the 64 x 64 probabilities of the head are computed once into LDS (row-major, lane = key in the second phase:
+// conflict free).
+__global__ void __launch_bounds__(64) attn_bwd64_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vv,
+                                                         const float* __restrict__ o, const float* __restrict__ go, int rn, int dn,
+                                                         float* __restrict__ gq, float* __restrict__ gk, float* __restrict__ gv) {
+  __shared__ float s_p[64][65];
+  __shared__ float s_k[64][4], s_v[64][4], s_q[64][4], s_go[64][4], s_dot[64];
+  const int ray = blockIdx.x >> 2, h = blockIdx.x & 3, t = threadIdx.x;
+  const size_t me = ((size_t)ray * dn + t) * 16 + h * 4;
+  const bool ok = t < dn;
+  float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, g4 = q4, o4 = q4;
+  if (ok) {
+    q4 = *reinterpret_cast<const float4*>(q + me); k4 = *reinterpret_cast<const float4*>(k + me); v4 = *reinterpret_cast<const float4*>(vv + me);
+    g4 = *reinterpret_cast<const float4*>(go + me); o4 = *reinterpret_cast<const float4*>(o + me);
+  }
+  *reinterpret_cast<float4*>(s_q[t]) = q4; *reinterpret_cast<float4*>(s_k[t]) = k4;
+  *reinterpret_cast<float4*>(s_v[t]) = v4; *reinterpret_cast<float4*>(s_go[t]) = g4;
+  const float dot = g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
+  s_dot[t] = dot;
+  __syncthreads();
+  // phase 1, lane = query s: logits -> probabilities (stored), gq
+  {
+    const float q0 = 0.5f * q4.x, q1 = 0.5f * q4.y, q2 = 0.5f * q4.z, q3 = 0.5f * q4.w;
+    float mx = -3.0e38f;
+    for (int u = 0; u < dn; ++u) {
+      const float4 ku = *reinterpret_cast<const float4*>(s_k[u]);
+      const float lg = q0 * ku.x + q1 * ku.y + q2 * ku.z + q3 * ku.w;
+      s_p[t][u] = lg;
+      mx = fmaxf(mx, lg);
+    }
+    float l = 0.f;
+    for (int u = 0; u < dn; ++u) { const float e = expf(s_p[t][u] - mx); s_p[t][u] = e; l += e; }
+    const float rl = 1.f / l;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int u = 0; u < dn; ++u) {
+      const float p = s_p[t][u] * rl;
+      s_p[t][u] = p;
+      const float4 ku = *reinterpret_cast<const float4*>(s_k[u]), vu = *reinterpret_cast<const float4*>(s_v[u]);
+      const float gp = g4.x * vu.x + g4.y * vu.y + g4.z * vu.z + g4.w * vu.w;
+      const float gs = 0.5f * p * (gp - dot);
+      a0 += gs * ku.x; a1 += gs * ku.y; a2 += gs * ku.z; a3 += gs * ku.w;
+    }
+    if (ok) {
+      float4 r = *reinterpret_cast<const float4*>(gq + me);
+      r.x += a0; r.y += a1; r.z += a2; r.w += a3;
+      *reinterpret_cast<float4*>(gq + me) = r;
+    }
+  }
+  __syncthreads();
+  // phase 2, lane = key t: gk, gv from the stored column p[s][t]
+  {
+    float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    for (int s = 0; s < dn; ++s) {
+      const float p = s_p[s][t];
+      const float4 gs4 = *reinterpret_cast<const float4*>(s_go[s]), qs = *reinterpret_cast<const float4*>(s_q[s]);
+      v0 += p * gs4.x; v1 += p * gs4.y; v2 += p * gs4.z; v3 += p * gs4.w;
+      const float gp = gs4.x * v4.x + gs4.y * v4.y + gs4.z * v4.z + gs4.w * v4.w;
+      const float gs = 0.5f * p * (gp - s_dot[s]);
+      k0 += gs * qs.x; k1 += gs * qs.y; k2 += gs * qs.z; k3 += gs * qs.w;
+    }
+    if (ok) {
+      float4 r = *reinterpret_cast<const float4*>(gv + me);
+      r.x += v0; r.y += v1; r.z += v2; r.w += v3;
+      *reinterpret_cast<float4*>(gv + me) = r;
+      r = *reinterpret_cast<const float4*>(gk + me);
+      r.x += k0; r.y += k1; r.z += k2; r.w += k3;
+      *reinterpret_cast<float4*>(gk + me) = r;
+    }
+  }
+}
+
 // LayerNorm(16, eps 1e-6) (ibrnet.py:101): y = (x - mean) * rstd * gamma + beta
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, long P,
                                  float* __restrict__ y) {
@@ -941,34 +1014,58 @@ __global__ void layernorm_kernel(const float* __restrict__ x, const float* __res
   const float rstd = rsqrtf(sq * 0.0625f + 1e-6f);
   for (int c = 0; c < 16; ++c) y[p * 16 + c] = (x[p * 16 + c] - m) * rstd * gamma[c] + beta[c];
 }
+// (the first version added every element's term to 32 LDS words with atomics: 8 192 same-address LDS atomics per workgroup, 71 us
+//  for 8 MB of data; now each thread keeps the 32 column sums of ITS points in registers and the workgroup reduces once)
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ gy,
                                                             long P, float* __restrict__ gx, float* __restrict__ ggamma, float* __restrict__ gbeta) {
-  __shared__ float s_g[16], s_b[16];
-  if (threadIdx.x < 16) { s_g[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
-  __syncthreads();
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < P) {
+  __shared__ float s_red[4][32];
+  float sg[16], sb[16], gm[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { sg[c] = 0.f; sb[c] = 0.f; gm[c] = gamma[c]; }
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    float xv[16], gv[16];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(x + p * 16 + 4 * c4), g4 = *reinterpret_cast<const float4*>(gy + p * 16 + 4 * c4);
+      xv[4 * c4] = a4.x; xv[4 * c4 + 1] = a4.y; xv[4 * c4 + 2] = a4.z; xv[4 * c4 + 3] = a4.w;
+      gv[4 * c4] = g4.x; gv[4 * c4 + 1] = g4.y; gv[4 * c4 + 2] = g4.z; gv[4 * c4 + 3] = g4.w;
+    }
     float m = 0.f;
-    for (int c = 0; c < 16; ++c) m += x[p * 16 + c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) m += xv[c];
     m *= 0.0625f;
     float sq = 0.f;
-    for (int c = 0; c < 16; ++c) { const float d = x[p * 16 + c] - m; sq += d * d; }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { const float d = xv[c] - m; sq += d * d; }
     const float rstd = rsqrtf(sq * 0.0625f + 1e-6f);
     float a = 0.f, b = 0.f;            // mean of g*gamma, mean of g*gamma*xhat
+#pragma unroll
     for (int c = 0; c < 16; ++c) {
-      const float xh = (x[p * 16 + c] - m) * rstd, gg = gy[p * 16 + c] * gamma[c];
+      const float xh = (xv[c] - m) * rstd, gg = gv[c] * gm[c];
       a += gg; b += gg * xh;
-      atomicAdd(&s_g[c], gy[p * 16 + c] * xh);
-      atomicAdd(&s_b[c], gy[p * 16 + c]);
+      sg[c] += gv[c] * xh;
+      sb[c] += gv[c];
+      xv[c] = xh;
     }
     a *= 0.0625f; b *= 0.0625f;
-    for (int c = 0; c < 16; ++c) {
-      const float xh = (x[p * 16 + c] - m) * rstd, gg = gy[p * 16 + c] * gamma[c];
-      gx[p * 16 + c] = rstd * (gg - a - xh * b);
-    }
+    float o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = rstd * (gv[c] * gm[c] - a - xv[c] * b);
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<float4*>(gx + p * 16 + 4 * c4) = make_float4(o[4 * c4], o[4 * c4 + 1], o[4 * c4 + 2], o[4 * c4 + 3]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { sg[c] += __shfl_xor(sg[c], off, 64); sb[c] += __shfl_xor(sb[c], off, 64); }
+    if (lane == 0) { s_red[wave][c] = sg[c]; s_red[wave][16 + c] = sb[c]; }
   }
   __syncthreads();
-  if (threadIdx.x < 16) { atomicAdd(&ggamma[threadIdx.x], s_g[threadIdx.x]); atomicAdd(&gbeta[threadIdx.x], s_b[threadIdx.x]); }
+  if (threadIdx.x < 32) {
+    const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    atomicAdd(threadIdx.x < 16 ? &ggamma[threadIdx.x] : &gbeta[threadIdx.x - 16], t);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1026,36 +1123,57 @@ __global__ void composite_kernel(const float* __restrict__ sigma, const float* _
   if (pixel) { pixel[ray * 3] = c0; pixel[ray * 3 + 1] = c1; pixel[ray * 3 + 2] = c2; }
   if (rdepth) rdepth[ray] = dd;
 }
-__global__ void composite_bwd_kernel(const float* __restrict__ sigma, const float* __restrict__ colors, const float* __restrict__ depth, int rn,
+// One WAVE per ray (the first version ran a thread per ray: 32 waves on the whole chip walking 64 samples each with a scratch array,
+// 96 us for 1.5 MB of data).  Lane l owns samples [E l, E l + E), E = ceil(dn / 64) <= 2; T (exclusive prefix product of the
+// transmittance factors) and B (exclusive suffix sum of G h) by log-step shuffles.
+__global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restrict__ sigma, const float* __restrict__ colors, const float* __restrict__ depth, int rn,
                                      int dn, const float* __restrict__ g_pixel, const float* __restrict__ g_depth, const float* __restrict__ g_hit,
                                      const float* __restrict__ g_colors, const float* __restrict__ g_density, float* __restrict__ gsigma,
                                      float* __restrict__ gcol) {
-  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= rn) return;
+  constexpr int EMAX = (PGRF_MAX_DN + 63) / 64;
+  const int E = (dn + 63) >> 6;
   const float gp0 = g_pixel ? g_pixel[ray * 3] : 0.f, gp1 = g_pixel ? g_pixel[ray * 3 + 1] : 0.f, gp2 = g_pixel ? g_pixel[ray * 3 + 2] : 0.f;
   const float gd = g_depth ? g_depth[ray] : 0.f;
-  float Ts[PGRF_MAX_DN];                              // T_i = prod_{j<i} f_j, built forwards (dividing back would blow up at alpha = 1)
-  {
-    float T = 1.f;
-    for (int i = 0; i < dn; ++i) {
-      Ts[i] = T;
-      T *= 1.f - (1.f - expf(-fmaxf(sigma[(size_t)ray * dn + i], 0.f))) + 1e-10f;
-    }
+  float alpha[EMAX], f[EMAX], G[EMAX], sg[EMAX];
+  float fl = 1.f;                                        // product of this lane's factors
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    const int i = E * lane + e;
+    const bool ok = e < E && i < dn;
+    const size_t p = (size_t)ray * dn + (ok ? i : 0);
+    sg[e] = ok ? sigma[p] : 0.f;
+    alpha[e] = 1.f - expf(-fmaxf(sg[e], 0.f));
+    f[e] = ok ? 1.f - alpha[e] + 1e-10f : 1.f;
+    G[e] = ok ? (g_hit ? g_hit[p] : 0.f) + gp0 * colors[p * 3] + gp1 * colors[p * 3 + 1] + gp2 * colors[p * 3 + 2] + gd * depth[p] : 0.f;
+    fl *= f[e];
   }
-  float B = 0.f;
-  for (int i = dn - 1; i >= 0; --i) {
-    const size_t p = (size_t)ray * dn + i;
-    const float alpha = 1.f - expf(-fmaxf(sigma[p], 0.f));
-    const float f = 1.f - alpha + 1e-10f;
-    const float T = Ts[i];
-    const float h = alpha * T;
-    const float G = (g_hit ? g_hit[p] : 0.f) + gp0 * colors[p * 3] + gp1 * colors[p * 3 + 1] + gp2 * colors[p * 3 + 2] + gd * depth[p];
-    const float galpha = T * G - B / f;
-    gsigma[p] = (sigma[p] > 0.f ? (1.f - alpha) * galpha : 0.f) + (g_density ? g_density[p] : 0.f);
-    gcol[p * 3] = h * gp0 + (g_colors ? g_colors[p * 3] : 0.f);
-    gcol[p * 3 + 1] = h * gp1 + (g_colors ? g_colors[p * 3 + 1] : 0.f);
-    gcol[p * 3 + 2] = h * gp2 + (g_colors ? g_colors[p * 3 + 2] : 0.f);
-    B += G * h;
+  float incl = fl;                                       // inclusive prefix product over the lanes
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const float t = __shfl_up(incl, off, 64); if (lane >= off) incl *= t; }
+  float T = __shfl_up(incl, 1, 64);
+  if (lane == 0) T = 1.f;
+  float Tt[EMAX], h[EMAX], gl = 0.f;
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) { Tt[e] = T; h[e] = alpha[e] * T; gl += G[e] * h[e]; T *= f[e]; }
+  float sincl = gl;                                      // inclusive suffix sum over the lanes
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const float t = __shfl_down(sincl, off, 64); if (lane + off < 64) sincl += t; }
+  float B = __shfl_down(sincl, 1, 64);
+  if (lane == 63) B = 0.f;
+#pragma unroll
+  for (int e = EMAX - 1; e >= 0; --e) {
+    const int i = E * lane + e;
+    if (e < E && i < dn) {
+      const size_t p = (size_t)ray * dn + i;
+      const float galpha = Tt[e] * G[e] - B / f[e];
+      gsigma[p] = (sg[e] > 0.f ? (1.f - alpha[e]) * galpha : 0.f) + (g_density ? g_density[p] : 0.f);
+      gcol[p * 3] = h[e] * gp0 + (g_colors ? g_colors[p * 3] : 0.f);
+      gcol[p * 3 + 1] = h[e] * gp1 + (g_colors ? g_colors[p * 3 + 1] : 0.f);
+      gcol[p * 3 + 2] = h[e] * gp2 + (g_colors ? g_colors[p * 3 + 2] : 0.f);
+    }
+    B += G[e] * h[e];
   }
 }
 

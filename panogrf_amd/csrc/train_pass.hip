@@ -510,19 +510,22 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   }
 
   // ------------------------------------------------------------------ backward
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(nblk(rn, 64)), dim3(64), 0, st, w.sigma, w.colors, depth, rn, dn, grad->pixel_colors,
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(nblk(rn, 4)), dim3(256), 0, st, w.sigma, w.colors, depth, rn, dn, grad->pixel_colors,
                      grad->render_depth, grad->hit_prob, grad->colors, grad->density, w.gsigma, w.gcol);
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.blend, w.rgb, w.gcol, P, V, w.glogit);
   PGRF_TCHECK("train composite backward");
   L(chain_bwd(c, rgb_l, 3, PV, w.gxr, 37, 0));                                                                      // gxr written (=)
   L(chain_bwd(c, og_l, 2, P, w.gln, 16, 0));
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], w.gln, P, w.gfo,
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk(P, 512) > 1024 ? 1024 : nblk(P, 512)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], w.gln, P, w.gfo,
                      g_raw_dev[R_ATT_LN_W] ? g_raw_dev[R_ATT_LN_W] : w.gq /* scratch sink */, g_raw_dev[R_ATT_LN_B] ? g_raw_dev[R_ATT_LN_B] : w.gq);
   (void)hipMemcpyAsync(w.ggp, w.gfo, P * 64, hipMemcpyDeviceToDevice, st);                                            // residual branch
   L(lin_bwd(c, w.o, 16, w.fo, 16, w.gfo, 16, R_ATT_FC_W, -1, w.go, 16, 0, P, 16, 16, ACT_NONE));
   (void)hipMemsetAsync(w.gq, 0, P * 64, st); (void)hipMemsetAsync(w.gk, 0, P * 64, st); (void)hipMemsetAsync(w.gv, 0, P * 64, st);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)rn * 4), dim3(dn <= 64 ? 64 : 128), 0, st, w.q, w.k, w.v, w.o, w.go, rn, dn,
-                     V <= 1 ? 1 : 0, w.gq, w.gk, w.gv);
+  if (dn <= 64 && V > 1)      // probabilities of a (ray, head) kept in LDS: one exp per (query, key) instead of four
+    hipLaunchKernelGGL(attn_bwd64_kernel, dim3((unsigned)rn * 4), dim3(64), 0, st, w.q, w.k, w.v, w.o, w.go, rn, dn, w.gq, w.gk, w.gv);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)rn * 4), dim3(dn <= 64 ? 64 : 128), 0, st, w.q, w.k, w.v, w.o, w.go, rn, dn,
+                       V <= 1 ? 1 : 0, w.gq, w.gk, w.gv);
   PGRF_TCHECK("train attention backward");
   L(lin_bwd(c, w.gp, 16, w.q, 16, w.gq, 16, R_ATT_Q_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(lin_bwd(c, w.gp, 16, w.k, 16, w.gk, 16, R_ATT_K_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
