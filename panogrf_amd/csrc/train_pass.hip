@@ -250,7 +250,11 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
     }
     return;
   }
-  const int nt = IN > 64 ? 4 : (IN > 32 ? 2 : 1);
+  // n tiles per wave: ONE, whatever the width (measured, 2 048-ray step: base_fc.0's 207 columns as 4 / 2 / 1 tiles per wave: 8.87 / 8.82 / 8.75 ms --
+  // more and lighter waves hide the load latency better than sharing delta's rows between a wave's tiles saves traffic)
+  static const int wide_nt = [] { const char* e = getenv("PGRF_TRAIN_DW_NT"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
+  static const int mid_nt = [] { const char* e = getenv("PGRF_TRAIN_DW_NT2"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : 1; }();
+  const int nt = IN > 64 ? wide_nt : (IN > 32 ? mid_nt : 1);
   const int gx = (IN + 32 * nt - 1) / (32 * nt), gy = (OUT + 31) / 32, groups = gx * gy;
   const int gpw = groups >= 4 ? 4 : (groups == 2 ? 2 : 1);                  // groups per workgroup
   const int nwg = (groups + gpw - 1) / gpw;
