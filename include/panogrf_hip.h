@@ -326,6 +326,12 @@ int pgrf_conv3d_wino16_preferred(int Cin, int Cout, int B, int D, int H, int W);
 int pgrf_conv3d_wino16(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                        const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope,
                        const float* residual, int res_cs, int res_coff, void* stream);
+/* The same launch with a second output: pool_out (channel-last, [B, D/2, H/2, W/2, pool_cs] + pool_coff) = nn.AvgPool3d(2) of `out`.
+ * An F(2^3, 3^3) output tile is one pooling window, so the encoder levels of UNet2 (models/common_blocks.py:210-218 -> ConvBlock2 :383: two convs, then
+ * AvgPool3d(2)) get their pooled tensor from the conv's epilogue instead of one more pass over its output.  pool_out may be NULL. */
+int pgrf_conv3d_wino16_pool(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                            const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope,
+                            const float* residual, int res_cs, int res_coff, float* pool_out, int pool_cs, int pool_coff, void* stream);
 /* Narrow layers of CostRegNet (models/cost_reg.py:99-175: 8/16/32-channel convs): the same wrap-padded 3x3x3 conv,
  * but the reduction is cut into 32-deep steps over (tap, channel) (two or four taps per step when Cin is 16 or 8) and
  * `nshift` consecutive output depths share one 32-row tile (nshift * Cout <= 32; nshift > 1 needs stride 1 and

@@ -115,6 +115,8 @@ SYMBOLS = {
     "pgrf_conv3d_wino16_preferred": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pgrf_conv3d_wino16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P]),
+    "pgrf_conv3d_wino16_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_small_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pgrf_pack_conv3d_small": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_small": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,

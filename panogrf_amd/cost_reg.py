@@ -171,7 +171,30 @@ def _small16_shift(pc, x, stride):
     return 0
 
 
-def _conv(pc, x, out, stride=1, slope=0.01, residual=None):
+def _conv_wino16_applies(pc, x, stride, residual):
+    """the dispatch rule of _conv below for the second-generation Winograd kernel"""
+    if pc.cout == 1 and pc.cin >= 64 and pc.cin % 4 == 0 and stride == 1:
+        return False
+    if _small16_shift(pc, x, stride) or _small_shift(pc, x, stride):
+        return False
+    force = os.environ.get('PANOGRF_CONV_WINOGRAD') == 'force'
+    return bool(stride == 1 and residual is None and os.environ.get('PANOGRF_CONV_WINOGRAD', '1') != '0' and os.environ.get('PANOGRF_WINO', '16') != '32' and
+                (lib.pgrf_conv3d_wino16_preferred(pc.cin, pc.cout, x.B, x.D, x.H, x.W) or
+                 (force and lib.pgrf_conv3d_wino16_supported(pc.cin, pc.cout, x.D, x.H, x.W))))
+
+
+def _conv(pc, x, out, stride=1, slope=0.01, residual=None, pool_out=None):
+    """pool_out: AvgPool3d(2) of the result as well (UNet2's encoder levels) -- from the Winograd kernel's epilogue where that kernel
+    takes the layer, by pgrf_avgpool3d_2 behind any other."""
+    if pool_out is not None:
+        if _conv_wino16_applies(pc, x, stride, residual) and os.environ.get('PANOGRF_POOL_FUSE', '1') != '0':
+            lib.check(lib.pgrf_conv3d_wino16_pool(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                                  _ptr(pc.wino16()), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope), None, 0, 0,
+                                                  _ptr(pool_out.buf), pool_out.cs, pool_out.coff, _stream()))
+            return out
+        _conv(pc, x, out, stride, slope, residual)
+        _pool(out, pool_out)
+        return out
     if pc.cout == 1 and pc.cin >= 64 and pc.cin % 4 == 0 and stride == 1:
         # wide-input single-channel conv: pointwise MFMA projection onto the 27 tap vectors + 27-tap gather
         y = torch.empty(x.B, x.D, x.H, x.W, 32, dtype=torch.float32, device=x.buf.device)
@@ -362,14 +385,15 @@ class UNet2Reg(_RegBase):
         for i in range(n + 1):
             c1, c2 = pk[f'encoders.{i}.1'], pk[f'encoders.{i}.2']
             t = _conv(c1, x, E(i, c1.cout))
+            pooled = E(i + 1, c2.cout) if i < n else None       # (the pooled tensor comes out of the conv's own epilogue where it can)
             if i < n - 1:
                 # unpooled output is the skip of decoder i: write it straight into the second half of the concat buffer
                 cat = E(i, 2 * c2.cout)
                 cats[i] = cat
-                u = _conv(c2, t, cat.slice(c2.cout, c2.cout))
+                u = _conv(c2, t, cat.slice(c2.cout, c2.cout), pool_out=pooled)
             else:
-                u = _conv(c2, t, E(i, c2.cout))
-            x = _pool(u, E(i + 1, c2.cout)) if i < n else u
+                u = _conv(c2, t, E(i, c2.cout), pool_out=pooled)
+            x = pooled if i < n else u
         d = pk[f'decoders.{n - 1}.1'], pk[f'decoders.{n - 1}.2']
         x = _up(x, E(n - 1, x.C))
         x = _conv(d[1], _conv(d[0], x, E(n - 1, d[0].cout)), E(n - 1, d[1].cout))

@@ -1551,13 +1551,17 @@ __global__ void __launch_bounds__(256) cout1_gather_up_kernel(const float* __res
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int a = tap / 9, bb = (tap / 3) % 3, c = tap % 3;
-      if (zi[a] < 0 || zi[a] >= D || yi[bb] < 0 || yi[bb] >= H) continue;
+      // taps outside the volume: every load still happens (clamped address) and the term is multiplied by 0 -- a `continue` here made
+      // each tap its own branch region whose nine loads were waited for before the next tap's were issued (27 serial round trips)
+      const bool ok = zi[a] >= 0 && zi[a] < D && yi[bb] >= 0 && yi[bb] < H;
+      const int zc = min(max(zi[a], 0), D - 1), yc = min(max(yi[bb], 0), H - 1);
       const float* lo = y_lo + (long long)tap * nlow + (long long)b * Dl * Hl * Wl;
-      const long long r00 = ((long long)z0[a] * Hl + y0[bb]) * Wl, r01 = ((long long)z0[a] * Hl + y1[bb]) * Wl;
-      const long long r10 = ((long long)z1[a] * Hl + y0[bb]) * Wl, r11 = ((long long)z1[a] * Hl + y1[bb]) * Wl;
+      const int r00 = (z0[a] * Hl + y0[bb]) * Wl, r01 = (z0[a] * Hl + y1[bb]) * Wl;
+      const int r10 = (z1[a] * Hl + y0[bb]) * Wl, r11 = (z1[a] * Hl + y1[bb]) * Wl;
       const float up = lz0[a] * (ly0[bb] * (lx0[c] * lo[r00 + x0[c]] + lx1[c] * lo[r00 + x1[c]]) + ly1[bb] * (lx0[c] * lo[r01 + x0[c]] + lx1[c] * lo[r01 + x1[c]])) +
                        lz1[a] * (ly0[bb] * (lx0[c] * lo[r10 + x0[c]] + lx1[c] * lo[r10 + x1[c]]) + ly1[bb] * (lx0[c] * lo[r11 + x0[c]] + lx1[c] * lo[r11 + x1[c]]));
-      s += up + y_hi[(long long)tap * nvox + (((long long)b * D + zi[a]) * H + yi[bb]) * W + xi[c]];
+      const float term = up + y_hi[(long long)tap * nvox + (((long long)b * D + zc) * H + yc) * W + xi[c]];
+      s += ok ? term : 0.f;
     }
     if (bias0) s += bias0[0];
     s = s > 0.f ? s : s * slope;
@@ -2474,6 +2478,8 @@ int pgrf_conv3d_cout1_gather_up(const float* y_hi, const float* y_lo, const floa
   const int chunks = (Cin_hi + 31) / 32;
   const float* bias0 = has_bias ? packed_hi + (size_t)27 * chunks * 1024 + 32 + (size_t)27 * Cin_hi : nullptr;
   const long long nvox = (long long)B * D * H * W;
+  // (round 4, measured and removed: the same gather with the 27 low-resolution planes of a 2 x 2 x 64 output block staged in LDS -- 276-319 us
+  //  against 181 / 123 us: the kernel is bound by its 243 loads and ~700 VALU instructions per voxel whichever memory they come from)
   hipLaunchKernelGGL(cout1_gather_up_kernel, dim3(grid_for(nvox)), dim3(256), 0, (hipStream_t)stream, y_hi, y_lo, bias0, out, out_cs, out_coff, B, D,
                      H, W, lrelu_slope, residual, res_cs, res_coff);
   PGRF_CHECK_LAUNCH("conv3d_cout1_gather_up");

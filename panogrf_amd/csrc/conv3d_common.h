@@ -38,6 +38,8 @@ struct ConvArgs {
   int wrap_w;             // 1: circular padding along W (ERP wrap); 0: zeros (the 2-D `upconv` blocks, network/ops.py:226-233)
   int elu;                // 1: ELU instead of LeakyReLU(slope) (2-D encoder blocks)
   int res_first;          // 1: the residual is added BEFORE the activation (ResNet BasicBlock), 0: after (CostRegNet skips)
+  float* pool;            // conv3d_wino16 only: optional second output = AvgPool3d(2) of `out` (an F(2^3, 3^3) output tile IS a pooling window)
+  int pool_cs, pool_coff;
 };
 
 __device__ __forceinline__ float conv_act(const ConvArgs& a, float v) {

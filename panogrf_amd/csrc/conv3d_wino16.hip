@@ -428,21 +428,31 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
     lds_barrier();                                         // E2: partials are in LDS
     W16_TICK(6)
     {
-      // wave w finishes outputs (oz, oy) = (w >> 1, w & 1), both ox, all four output tiles: the z output transform over the four
-      // fz partials (out[oz=0] = R0 + R1 + R2, out[oz=1] = R1 - R2 - R3), LeakyReLU, stores
-      const int oz = wave >> 1, oy = wave & 1;
-      const long long ovrow = (((long long)cur.b * a.D + cur.z0 + oz) * a.H + cur.y0 + oy) * a.W + cur.x0 + 2 * n;
+      // wave w finishes the 16 output channels t = w of all eight outputs (oz, oy, ox) of its tiles: the z output transform over the
+      // four fz partials (out[oz=0] = R0 + R1 + R2, out[oz=1] = R1 - R2 - R3), LeakyReLU, stores.  (Round 4: was "wave = (oz, oy), all
+      // four channel tiles" -- the same values, stores and store widths, but this way a lane holds a whole 2 x 2 x 2 output tile of its
+      // four channels = one AvgPool3d(2) window: the pooled tensor of the encoder levels is one more store, not one more pass.)
+      const int t = wave;
+      const long long ov0 = (((long long)cur.b * a.D + cur.z0) * a.H + cur.y0) * a.W + cur.x0 + 2 * n;
+      const int coff = a.out_coff + cur.cg * 64 + t * 16 + kq * 4;
+      float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int ox = 0; ox < 2; ++ox) {
-        float* op = a.out + (ovrow + ox) * a.out_cs + a.out_coff + cur.cg * 64 + kq * 4;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float4 p1 = red[ridx(1, oy * 2 + ox, t)], p2 = red[ridx(2, oy * 2 + ox, t)], p03 = red[ridx(oz == 0 ? 0 : 3, oy * 2 + ox, t)];
-          float4 v = oz == 0 ? f4add(f4add(p03, p1), p2) : f4sub(f4sub(p1, p2), p03);
-          v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
-          v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-          *reinterpret_cast<float4*>(op + t * 16) = v;
-        }
+      for (int oyox = 0; oyox < 4; ++oyox) {
+        const float4 p0 = red[ridx(0, oyox, t)], p1 = red[ridx(1, oyox, t)], p2 = red[ridx(2, oyox, t)], p3 = red[ridx(3, oyox, t)];
+        float4 v0 = f4add(f4add(p0, p1), p2), v1 = f4sub(f4sub(p1, p2), p3);
+        v0.x = v0.x > 0.f ? v0.x : v0.x * a.slope; v0.y = v0.y > 0.f ? v0.y : v0.y * a.slope;
+        v0.z = v0.z > 0.f ? v0.z : v0.z * a.slope; v0.w = v0.w > 0.f ? v0.w : v0.w * a.slope;
+        v1.x = v1.x > 0.f ? v1.x : v1.x * a.slope; v1.y = v1.y > 0.f ? v1.y : v1.y * a.slope;
+        v1.z = v1.z > 0.f ? v1.z : v1.z * a.slope; v1.w = v1.w > 0.f ? v1.w : v1.w * a.slope;
+        const long long ov = ov0 + (long long)(oyox >> 1) * a.W + (oyox & 1);
+        *reinterpret_cast<float4*>(a.out + ov * a.out_cs + coff) = v0;
+        *reinterpret_cast<float4*>(a.out + (ov + (long long)a.H * a.W) * a.out_cs + coff) = v1;
+        pool = f4add(pool, f4add(v0, v1));
+      }
+      if (a.pool) {
+        const long long pv = (((long long)cur.b * (a.D >> 1) + (cur.z0 >> 1)) * (a.H >> 1) + (cur.y0 >> 1)) * (a.W >> 1) + (cur.x0 >> 1) + n;
+        *reinterpret_cast<float4*>(a.pool + pv * a.pool_cs + a.pool_coff + cur.cg * 64 + t * 16 + kq * 4) =
+            make_float4(pool.x * 0.125f, pool.y * 0.125f, pool.z * 0.125f, pool.w * 0.125f);
       }
     }
     W16_TICK(7)
@@ -522,6 +532,13 @@ int pgrf_conv3d_wino16_preferred(int Cin, int Cout, int B, int D, int H, int W) 
 int pgrf_conv3d_wino16(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                        const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
                        int res_cs, int res_coff, void* stream) {
+  return pgrf_conv3d_wino16_pool(in, in_cs, in_coff, Cin, out, out_cs, out_coff, Cout, packed, has_bias, B, D, H, W, lrelu_slope, residual, res_cs,
+                                 res_coff, nullptr, 0, 0, stream);
+}
+
+int pgrf_conv3d_wino16_pool(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                            const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                            int res_cs, int res_coff, float* pool_out, int pool_cs, int pool_coff, void* stream) {
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino16: null pointer");
   if (!pgrf_conv3d_wino16_supported(Cin, Cout, D, H, W))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: needs Cin a multiple of 32, Cout a multiple of 64 (<= %d), even D and H, W %% 32 == 0 "
@@ -534,7 +551,7 @@ int pgrf_conv3d_wino16(const float* in, int in_cs, int in_coff, int Cin, float* 
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: packed weights of >= 2 GiB (buffer descriptor)");
   if ((double)D * H * W * in_cs * 4.0 >= 4294967296.0)
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: one batch element of the input is >= 4 GiB (32-bit byte offsets)");
-  if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3))
+  if ((in_cs & 3) || (in_coff & 3) || (out_cs & 3) || (out_coff & 3) || (pool_out && ((pool_cs & 3) || (pool_coff & 3))))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: channel strides/offsets must be multiples of 4");
   ConvArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -543,6 +560,7 @@ int pgrf_conv3d_wino16(const float* in, int in_cs, int in_coff, int Cin, float* 
   a.chunks = Cin / 32; a.cot_total = Cout / 32;
   a.residual = residual; a.res_cs = res_cs; a.res_coff = res_coff; a.wtaps = 64; a.wrap_w = 1;
   a.wpk = packed;
+  a.pool = pool_out; a.pool_cs = pool_cs; a.pool_coff = pool_coff;
   a.bias = has_bias ? packed + (size_t)(Cout / 64) * 64 * a.chunks * 2048 : nullptr;
   const long long nrows_ll = (long long)B * (D / 2) * (H / 2) * (W / 32) * (Cout / 64);
   if (nrows_ll >= (1ll << 31)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: too many tile rows");
