@@ -45,13 +45,20 @@ __device__ __forceinline__ void load4_guard(const float* __restrict__ p, int k0,
 
 // activations of the per-point MLPs; the derivative is written in terms of the OUTPUT y (nothing else is stored)
 enum Act { ACT_NONE = 0, ACT_ELU, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_SOFTPLUS_B };   // _B: softplus + 0.05 (AddBias)
+// (the same formulas as the fused forward kernel, render_pass.h elu1 / sigmoid1 / softplus1, on v_exp_f32 / v_log_f32: the staged
+//  forward of the backward then reproduces the activations the fused kernel rendered with -- and libm's expm1f / log1pf, ~30-140
+//  instructions each with a branch, were as long as the layers' MFMAs: 96 ELUs per row of base_fc)
 __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
-    case ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case ACT_ELU: return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f);
     case ACT_RELU: return fmaxf(x, 0.f);
-    case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
-    case ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
-    case ACT_SOFTPLUS_B: return (x > 20.f ? x : log1pf(expf(x))) + 0.05f;
+    case ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+    case ACT_SOFTPLUS:
+    case ACT_SOFTPLUS_B: {
+      const float t = __builtin_amdgcn_exp2f(-fabsf(x) * 1.4426950408889634f);
+      const float sp = fmaf(__builtin_amdgcn_logf(1.f + t), 0.6931471805599453f, fmaxf(x, 0.f));
+      return act == ACT_SOFTPLUS_B ? sp + 0.05f : sp;
+    }
     default: return x;
   }
 }
@@ -283,16 +290,28 @@ __device__ __forceinline__ void chain_stage_weights(const ChainArgs& a, float* l
   }
   __syncthreads();
 }
-// four floats p[k0 .. k0+3], elements from column K on zero (AND mask: the load itself is unconditional)
-__device__ __forceinline__ void load4_mask(const float* __restrict__ p, int k0, int K, float (&o)[4]) {
-  const int kc = k0 < K ? k0 : 0;
-  const F4U t = *reinterpret_cast<const F4U*>(p + kc);
+// The lane's four floats of quad q (columns 8q + 4 half ..), elements from column K on zero.  Quads that lie inside the row for both
+// lane halves (8q + 8 <= K: a wave-uniform test) are a bare dwordx4; only the row's last quad pays for the AND masks (the load
+// itself stays unconditional there too) -- masking every quad cost 18 VALU instructions per load, as many cycles as its MFMAs.
+__device__ __forceinline__ void load4_mask(const float* __restrict__ p, int q, int half, int K, float (&o)[4]) {
+  const int k0 = 8 * q + 4 * half;
+  if (8 * q + 8 <= K) {
+    const F4U t = *reinterpret_cast<const F4U*>(p + k0);
+    o[0] = t.v[0]; o[1] = t.v[1]; o[2] = t.v[2]; o[3] = t.v[3];
+  } else {
+    const int kc = k0 < K ? k0 : 0;
+    const F4U t = *reinterpret_cast<const F4U*>(p + kc);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(__float_as_uint(t.v[j]) & (k0 + j < K ? 0xffffffffu : 0u));
+    for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(__float_as_uint(t.v[j]) & (k0 + j < K ? 0xffffffffu : 0u));
+  }
 }
-__device__ __forceinline__ void store4_guard(float* __restrict__ p, int c0, int C, const float (&v)[4]) {
-  if (c0 + 3 < C) { F4U o; o.v[0] = v[0]; o.v[1] = v[1]; o.v[2] = v[2]; o.v[3] = v[3]; *reinterpret_cast<F4U*>(p + c0) = o; }
-  else {
+// the same for stores: v -> p[8q + 4 half ..], columns < C only
+__device__ __forceinline__ void store4_guard(float* __restrict__ p, int q, int half, int C, const float (&v)[4]) {
+  const int c0 = 8 * q + 4 * half;
+  if (8 * q + 8 <= C) {
+    F4U o; o.v[0] = v[0]; o.v[1] = v[1]; o.v[2] = v[2]; o.v[3] = v[3];
+    *reinterpret_cast<F4U*>(p + c0) = o;
+  } else if (8 * q < C) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (c0 + j < C) p[c0 + j] = v[j];
   }
@@ -406,7 +425,7 @@ __global__ void __launch_bounds__(256, QD == 4 ? 6 : 3) chain_fwd_kernel(const C
         const int nq = (IN + 7) >> 3;
         for (int q0 = 0; q0 < nq; q0 += QD) {
 #pragma unroll
-          for (int u = 0; u < QD; ++u) load4_mask(xr, 8 * (q0 + u) + 4 * half, IN, b[u]);
+          for (int u = 0; u < QD; ++u) load4_mask(xr, q0 + u, half, IN, b[u]);
           chain_layer_fwd<QD>(w + 8 * q0, S, n, half, mt, nq - q0, b, acc);
         }
       } else {
@@ -425,8 +444,7 @@ __global__ void __launch_bounds__(256, QD == 4 ? 6 : 3) chain_fwd_kernel(const C
         float* yr = L.Y + row * (long)L.ldy;
 #pragma unroll
         for (int q = 0; q < QD; ++q) {
-          const int c0 = 8 * q + 4 * half;
-          if (c0 < OUT) store4_guard(yr, c0, OUT, b[q]);
+          store4_guard(yr, q, half, OUT, b[q]);
         }
       }
     }
@@ -449,7 +467,7 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
       const float* dr = a.l[0].D + rowc * (long)a.l[0].ldd;
       const int OUT = a.l[0].OUT;
 #pragma unroll
-      for (int q = 0; q < QD; ++q) load4_mask(dr, 8 * q + 4 * half, OUT, d[q]);
+      for (int q = 0; q < QD; ++q) load4_mask(dr, q, half, OUT, d[q]);
     }
 #pragma unroll 1
     for (int k = 0; k < a.n; ++k) {
@@ -461,7 +479,7 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
         const float* yr = L.Y + rowc * (long)L.ldy;
         float y[QD][4];
 #pragma unroll
-        for (int q = 0; q < QD; ++q) load4_mask(yr, 8 * q + 4 * half, OUT, y[q]);
+        for (int q = 0; q < QD; ++q) load4_mask(yr, q, half, OUT, y[q]);
         switch (L.act) {
           case ACT_ELU: chain_act_bwd<QD, ACT_ELU>(y, d); break;
           case ACT_RELU: chain_act_bwd<QD, ACT_RELU>(y, d); break;
@@ -474,8 +492,7 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
         float* dr = L.D + row * (long)L.ldd;
 #pragma unroll
         for (int q = 0; q < QD; ++q) {
-          const int c0 = 8 * q + 4 * half;
-          if (c0 < OUT) store4_guard(dr, c0, OUT, d[q]);
+          store4_guard(dr, q, half, OUT, d[q]);
         }
       }
       if (!L.dx) break;
@@ -491,9 +508,8 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
           for (int m = 0; m < MTM; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const int c0 = 32 * (m0 + m) + 8 * g + 4 * half;
               float o[4] = {0.f, 0.f, 0.f, 0.f};
-              if (a.accumulate && m < mt) load4_mask(xr, c0, IN, o);
+              if (a.accumulate && m < mt) load4_mask(xr, 4 * (m0 + m) + g, half, IN, o);
 #pragma unroll
               for (int j = 0; j < 4; ++j) acc[m][4 * g + j] = o[j];
             }
@@ -503,9 +519,8 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
           for (int m = 0; m < MTM; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const int c0 = 32 * (m0 + m) + 8 * g + 4 * half;
               const float v[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
-              if (m < mt && c0 < IN) store4_guard(xr, c0, IN, v);
+              if (m < mt) store4_guard(xr, 4 * (m0 + m) + g, half, IN, v);
             }
         }
       } else {
