@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "pgrf_internal.h"
 #include "pgrf_layout.h"
@@ -220,13 +221,59 @@ static size_t plan(Ws& w, long P, int V, int dn, char* base) {
   return off;
 }
 
+constexpr int kAux = 2;
 struct Ctx {
   hipStream_t st;
   const float* const* raw;     // device pointers, reference layouts
   float* const* graw;          // device pointers (accumulated), entries may be null = not wanted
   float* grep;                 // kGradReplicas - 1 further replicas of every weight gradient (workspace, zeroed per pass)
   int* gsize;                  // floats per raw tensor, recorded by lin_bwd for the final fold (host array)
+  // The weight-gradient launches on a SIDE STREAM: they only consume (delta, X) pairs and nothing of the pass reads their output before
+  // the final fold, and neither they nor the chain kernels they run beside fill the memory pipes alone (2-3 TB/s each).  fork(): the side
+  // stream waits for what the main stream has enqueued so far (delta of the layers about to be contracted); join(): the main stream waits
+  // for the side stream.  Null = everything on the caller's stream.
+  hipStream_t* aux;            // kAux side streams (null = none), used round robin: one per fork()
+  hipEvent_t* ev;              // ring of events (re-recording an event does not disturb waits already enqueued on it)
+  int* ev_next;
+  int ev_count;
+  int* cur;                    // side stream of the current fork
+  hipStream_t dw_stream() const { return aux ? aux[*cur] : st; }
+  void fork() const {
+    if (!aux) return;
+    *cur = (*cur + 1) % kAux;
+    hipEvent_t e = ev[(*ev_next)++ % ev_count];
+    (void)hipEventRecord(e, st);
+    (void)hipStreamWaitEvent(aux[*cur], e, 0);
+  }
+  void join() const {
+    if (!aux) return;
+    for (int i = 0; i < kAux; ++i) {
+      hipEvent_t e = ev[(*ev_next)++ % ev_count];
+      (void)hipEventRecord(e, aux[i]);
+      (void)hipStreamWaitEvent(st, e, 0);
+    }
+  }
 };
+// one side stream and event ring per device, created on first use and kept (PGRF_TRAIN_DW_STREAM=0: none)
+struct SideStream { hipStream_t s[kAux]; hipEvent_t ev[32]; int next, cur; bool ok; };
+static SideStream* side_stream() {
+  static const bool off = [] { const char* e = getenv("PGRF_TRAIN_DW_STREAM"); return e && e[0] == '0'; }();
+  if (off) return nullptr;
+  static std::mutex mu;
+  static SideStream* per_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!per_dev[dev]) {
+    SideStream* ss = new SideStream();
+    ss->next = 0; ss->cur = 0;
+    ss->ok = true;
+    for (int i = 0; ss->ok && i < kAux; ++i) ss->ok = hipStreamCreateWithFlags(&ss->s[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ss->ok && i < 32; ++i) ss->ok = hipEventCreateWithFlags(&ss->ev[i], hipEventDisableTiming) == hipSuccess;
+    per_dev[dev] = ss;
+  }
+  return per_dev[dev]->ok ? per_dev[dev] : nullptr;
+}
 
 static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float* Y, int ldy, long rows, int IN, int OUT, int act) {
   // Y = act(X W^T + b) in one launch (bias and activation in the epilogue): 128 rows per workgroup, all OUT <= 64 columns per wave
@@ -246,7 +293,7 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
       int cp = 1;
       while (cp < OUT) cp <<= 1;
       const long nb = (rows * cp + 256 * 8 - 1) / (256 * 8);
-      hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb))), dim3(256), 0, c.st, const_cast<float*>(delta), ldd, delta, ldd, rows, OUT, cp, (int)ACT_NONE, gb);
+      hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb))), dim3(256), 0, c.dw_stream(), const_cast<float*>(delta), ldd, delta, ldd, rows, OUT, cp, (int)ACT_NONE, gb);
     }
     return;
   }
@@ -266,9 +313,9 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
   float* brep = gb ? c.grep + (size_t)rb * kGradSlot : nullptr;
   c.gsize[rw] = OUT * IN;
   if (gb) c.gsize[rb] = OUT;
-  if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.st, delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
-  else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.st, delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
-  else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.st, delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
+  if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
+  else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
+  else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
 }
 // dY (a [rows, OUT] slice, ld lddy) is overwritten by delta = dY * act'(Y); then gW += delta^T X, gb += colsum(delta),
 // dX (=|+=) delta W
@@ -283,6 +330,7 @@ static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ld
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb)))   /* (<= 1 024 same-address atomics per bias element) */, dim3(256), 0, c.st, dY, lddy, Y, ldy, rows, OUT, cp,
                        act, (float*)nullptr);
   }
+  c.fork();
   L_dw(c, X, ldx, dY, lddy, rw, rb, rows, IN, OUT);
   if (dX) {
     // dX (=|+=) delta W: the same kernel with the weight read transposed (W is [OUT, IN]: "M" = IN, "K" = OUT)
@@ -365,6 +413,7 @@ static int chain_bwd(const Ctx& c, const Lin* l, int n, long rows, float* dX, in
   if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
   if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_bwd_kernel<4>, chain_grid(rows, lds, 5), dim3(256), lds, c.st, a);
   else hipLaunchKernelGGL(chain_bwd_kernel<8>, chain_grid(rows, lds, 2), dim3(256), lds, c.st, a);
+  c.fork();
   for (int k = n - 1; k >= 0; --k) L_dw(c, l[k].X, l[k].ldx, l[k].dY, l[k].lddy, l[k].rw, l[k].rb, rows, l[k].IN, l[k].OUT);
   PGRF_TCHECK("train chain backward");
   return PGRF_OK;
@@ -410,7 +459,9 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
     return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
   plan(w, P, V, dn, (char*)workspace);
   int gsize[R_COUNT] = {};
-  Ctx c{(hipStream_t)stream, raw_dev, g_raw_dev, w.grep, gsize};
+  SideStream* ss = side_stream();
+  Ctx c{(hipStream_t)stream, raw_dev, g_raw_dev, w.grep, gsize, ss ? ss->s : nullptr, ss ? ss->ev : nullptr, ss ? &ss->next : nullptr, 32, ss ? &ss->cur : nullptr};
+  struct Joiner { const Ctx& c; ~Joiner() { c.join(); } } joiner{c};      // error returns included: the caller's stream never runs ahead of the side stream
   (void)hipMemsetAsync(w.grep, 0, (size_t)(kGradReplicas - 1) * kGradSlot * R_COUNT * 4, c.st);
   hipStream_t st = c.st;
   const int NM = use_vis ? 4 : 3;
@@ -559,8 +610,10 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gw0, 1, 0, w.gw0, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
   L(chain_bwd(c, nf_l, 2, PV, w.gxin + 175, 207, 1));                                                               // += onto the neuray columns
   hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.gdfeat, 35, 0, w.gxin, 207, 140, PV, 35, 0);
-  if (g_img_feats)
-    hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, g_img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.gxin, 207, 143);
+  if (g_img_feats) {      // (nothing of the pass reads the map gradient: beside the remaining chains on a side stream)
+    c.fork();
+    hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, c.dw_stream(), g_img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.gxin, 207, 143);
+  }
   L(chain_bwd(c, rd_l, 2, PV, (float*)nullptr, 0, 0));
   L(chain_bwd(c, pe_l, 2, PV, w.gpe_in, 34, 0));
   // compute_prob: gradients of (hit, vis) -> mixture parameters
@@ -573,6 +626,7 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   if (g_ray_feats)
     hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, g_ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.gpe_in, 34, 0);
   PGRF_TCHECK("train gather backward");
+  c.join();
   {   // fold the weight-gradient replicas into the caller's buffers
     GradPtrs gp;
     for (int i = 0; i < R_COUNT; ++i) { gp.p[i] = gsize[i] > 0 ? g_raw_dev[i] : nullptr; gp.n[i] = gsize[i]; }

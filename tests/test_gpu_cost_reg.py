@@ -292,6 +292,37 @@ def test_winograd_conv_vs_oracle(cin, cout, B, D, H, W, bias, slope, monkeypatch
     assert 0.0 < d < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize('cin,cout,B,D,H,W,fused', [(32, 64, 1, 4, 4, 64, True), (64, 128, 2, 6, 8, 96, True), (64, 64, 1, 8, 8, 128, True),
+                                                    (32, 64, 1, 4, 4, 64, False)])
+def test_winograd_conv_with_pooled_output(cin, cout, B, D, H, W, fused, monkeypatch):
+    """pgrf_conv3d_wino16_pool: the conv's output AND nn.AvgPool3d(2) of it from the same launch (UNet2's encoder levels,
+    models/common_blocks.py:210-218 -- an F(2^3, 3^3) output tile is one pooling window), into a channel slice of a wider pooled buffer;
+    and the same call where the Winograd kernel does not take the layer (conv + pgrf_avgpool3d_2)."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    monkeypatch.setenv('PANOGRF_CONV_WINOGRAD', 'force' if fused else '0')
+    monkeypatch.setenv('PGRF_WINO16_WGS', '3')
+    g = torch.Generator().manual_seed(cin + cout + D * H + W)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5, 'c.bias': torch.randn(cout, generator=g) * 0.1}
+    ref = torch.nn.functional.leaky_relu(O._conv3(w, 'c', x, 1), 0.01)
+    ref_pool = torch.nn.functional.avg_pool3d(ref, 2)
+    pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
+    xin = R._Vol(R._to_ndhwc(x.cuda()), 0, cin)
+    assert R._conv_wino16_applies(pc, xin, 1, None) == fused
+    out = R._Vol.empty(B, D, H, W, cout, 'cuda')
+    wide_pool = R._Vol.empty(B, D // 2, H // 2, W // 2, cout + 8, 'cuda')
+    wide_pool.buf.fill_(7.0)
+    R._conv(pc, xin, out, pool_out=wide_pool.slice(4, cout))
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert max_abs(out.buf.permute(0, 4, 1, 2, 3).cpu(), ref) < tol
+    assert max_abs(wide_pool.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu(), ref_pool) < tol
+    assert bool((wide_pool.buf[..., :4] == 7.0).all()) and bool((wide_pool.buf[..., 4 + cout:] == 7.0).all())
+    # without a pooled output the conv writes the same values
+    out2 = R._conv(pc, xin, R._Vol.empty(B, D, H, W, cout, 'cuda'))
+    assert torch.equal(out2.buf, out.buf)
+
+
 def test_winograd_conv_rejects_what_it_cannot_do():
     import ctypes
     from panogrf_amd._lib import lib
