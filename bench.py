@@ -499,17 +499,23 @@ def main():
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
             regs = []
-            for v in D.view_shard(rank, world, V):
+            mine = list(D.view_shard(rank, world, V))
+            if mine:
+                # this rank's reference views as ONE batch, like the product stage (panogrf_amd/mvs_hip.py: B = rfn pairs in one call,
+                # network/init_net.py:164-171): the regulariser's small low-resolution layers fill the chip twice as well, same values
+                # bit for bit (2 views, one GPU: CostRegNet stage 1.80 -> 1.61 ms, UNet2 11.30 -> 11.03 ms)
+                sl = slice(mine[0], mine[-1] + 1) if mine == list(range(mine[0], mine[-1] + 1)) else mine      # (round-robin shards: index list)
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # sub-stage boundaries (roofline sub-blocks)
-                dv = cv['CV'].build_depth_volume(cv['ref_mu'][v:v + 1], cv['k'], 0.5, 0.1, 10.0, 64)
+                dv = cv['CV'].build_depth_volume(cv['ref_mu'][sl], cv['k'], 0.5, 0.1, 10.0, 64)
                 ev[0].record()
-                vol = cv['CV'].calculate_cost_volume_erp(cv['args'], cv['feats'][v:v + 1], None, cv['trans'][v:v + 1],
-                                                         cv['rots'][v:v + 1], depth_volume=dv)
+                vol = cv['CV'].calculate_cost_volume_erp(cv['args'], cv['feats'][sl], None, cv['trans'][sl],
+                                                         cv['rots'][sl], depth_volume=dv)
                 ev[1].record()
-                regs.append(cv['net'].forward_ndhwc(vol).reshape(-1))
+                regs = list(cv['net'].forward_ndhwc(vol).reshape(len(mine), -1))
                 ev[2].record()
                 if timed and rank == 0:
                     cv['sub'].append(ev)
+                    cv['sub_views'] = len(mine)
             local = torch.stack(regs, 0) if regs else torch.zeros(0, cv['reg_numel'], device=dev)
             cv['reg_all'] = D.allgather_views(local, V)
             c1.record()
@@ -602,7 +608,7 @@ def main():
         # D h w (C + 1) 4 (volume written, hypotheses read) + S h w C 4 (features read); the regulariser is f32-MFMA-bound.  UNet2's
         # wide layers run Winograd F(2x2x2, 3x3x3), which executes 1 / 3.375 of the direct convolution's multiplies: its roof
         # fraction is priced on the EXECUTED products (direct FLOPs / 3.375 against the f32 MFMA peak), not on the direct count.
-        n_sub = max(len(cv['sub']), 1)
+        n_sub = max(len(cv['sub']), 1) * cv.get('sub_views', 1)          # (the events bracket a batch of this rank's views: per view)
         build_ms = sum(e[0].elapsed_time(e[1]) for e in cv['sub']) / n_sub
         reg_ms = sum(e[1].elapsed_time(e[2]) for e in cv['sub']) / n_sub
         cv_bytes = 64 * cv['h'] * cv['w'] * (32 + 1) * 4 + 2 * cv['h'] * cv['w'] * 32 * 4
@@ -621,7 +627,7 @@ def main():
                                     'regulariser': args.reg, 'reg_direct_conv_tflops': gf_view / (reg_ms * 1e-3) / 1e12 if reg_ms > 0 else 0.0,
                                     'roofline': rl_reg, 'roofline_build': rl_build,
                                     'view_shards': min(world, V),
-                                    'note': 'hypotheses + spherical cost volume + 3-D regulariser per source view, views sharded over ranks + all-gather; included in ms_per_step/value'}
+                                    'note': 'hypotheses + spherical cost volume + 3-D regulariser per source view (a rank runs its views as one batch; the sub-block times are per view), views sharded over ranks + all-gather; included in ms_per_step/value'}
         res['config']['workload'] += f' + D=64 cost volume {cv["h"]}x{cv["w"]} + {args.reg} per view (BASELINE configs[2])'
     if rank == 0 and world == 1 and args.eager_baseline:
         eg, eout = eager_gpu_baseline(case, dev, 2048)
