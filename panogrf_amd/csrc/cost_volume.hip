@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const C
       if (opix < hw)
 #endif
       {
-        if (a.stream_stores) {                             // opt-in (PGRF_CV_STREAM_STORES=1), see launch_cost_volume
+        if (a.stream_stores) {                             // batches beyond the last-level cache (or PGRF_CV_STREAM_STORES), see pgrf_cost_volume_erp
           typedef float f32x4nt __attribute__((ext_vector_type(4)));
           const f32x4nt vv = {acc[g].x, acc[g].y, acc[g].z, acc[g].w};
           __builtin_nontemporal_store(vv, reinterpret_cast<f32x4nt*>(op + (size_t)opix * C + cg * 4));
@@ -476,10 +476,16 @@ int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const fl
   a.feats = feats; a.depth = depth_volume; a.rots = rots; a.trans = trans; a.out = out;
   a.B = B; a.S = S; a.h = h; a.w = w; a.C = C; a.D = D; a.ref_idx = ref_idx; a.n_src = n_src; a.div = src_div;
   a.cost_type = cost_type; a.dataset = dataset;
-  // Non-temporal stores: the kernel alone 75-76 -> 62 us at 128x256x64 (4.6 TB/s), but the volume then is not in the last-level
+  // Non-temporal stores: the kernel alone 75-76 -> 62 us at 128x256x64 (4.6 TB/s), but ONE such volume (268 MB) then is not in the last-level
   // cache when the regulariser's first convolution reads it right behind: cost-volume stage of bench.py 1.76-1.78 ms either way
-  // (profiles/r03_dead_ends.txt).  Opt-in for callers that consume the volume later.
-  a.stream_stores = getenv("PGRF_CV_STREAM_STORES") != nullptr && atoi(getenv("PGRF_CV_STREAM_STORES")) != 0;
+  // (profiles/r03_dead_ends.txt).  A BATCH of volumes larger than the 256 MB last-level cache does not stay resident whatever the stores do --
+  // from 384 MB on they stream by default (two views at 128x256x64, the product stage's batch: build 83 -> 73 us per view, stage 1.59 -> 1.58 ms
+  // with CostRegNet, 11.12 -> 11.01 ms with UNet2).  PGRF_CV_STREAM_STORES=0 / 1 forces either way.
+  {
+    const char* e = getenv("PGRF_CV_STREAM_STORES");
+    const double out_bytes = (double)B * D * h * w * C * 4.0;
+    a.stream_stores = e ? (atoi(e) != 0) : (out_bytes >= 384.0 * 1048576.0);
+  }
   for (int i = 0; i < kMaxSrc; ++i) {
     a.src_idx[i] = i < n_src ? src_idx_host[i] : 0;
     if (i < n_src && (src_idx_host[i] < 0 || src_idx_host[i] >= S)) return set_error(PGRF_ERR_ARG, "pgrf_cost_volume_erp: src_idx out of range");
