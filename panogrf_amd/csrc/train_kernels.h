@@ -147,7 +147,7 @@ constexpr size_t kRepStride = (size_t)68 * 13312;     // R_COUNT * kGradSlot flo
 template <int NT>
 __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ X, int ldx,
                                                       float* __restrict__ gW0, float* __restrict__ gWrep, int M, int K, long rows, int chunk,
-                                                      int gx, int groups, float* __restrict__ gb0, float* __restrict__ gbrep) {
+                                                      int gx, int groups, float* __restrict__ gb0, float* __restrict__ gbrep, int ldg, int gcol) {
   // replica of the gradient this workgroup adds into (train_pass.hip kGradReplicas): 0 = the caller's buffer
   const int rep = blockIdx.z & 7;
   float* __restrict__ gW = rep == 0 ? gW0 : gWrep + (size_t)(rep - 1) * kRepStride;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ 
         float v = acc[t][r];
         for (int k = 1; k < wpg; ++k) v += red[wave + k - 1][t][r][lane];
         const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * half, ko = n0 + 32 * t + i;     // accumulator row rho(r, half), column = lane
-        if (mo < M && ko < K) unsafeAtomicAdd(gW + (long)mo * K + ko, v);
+        if (mo < M && ko < K) unsafeAtomicAdd(gW + (long)mo * ldg + gcol + ko, v);     // (ldg, gcol: a column block of a wider weight)
       }
   }
 }
@@ -261,11 +261,14 @@ struct ChainLayer {
   float* D;            // backward: dY of the layer, overwritten by delta
   int ldy, ldd, IN, OUT, act, dx;
   int S, off;          // LDS row stride of the weight copy (multiple of 4, S / 4 odd: conflict-free b128 reads) and its offset (floats)
+  int ldw;             // row stride of W in memory (IN, or the full width when the layer is a column block of a wider weight)
 };
 struct ChainArgs {
   ChainLayer l[3];
   int n, lds_floats;
   const float* X; int ldx;           // forward input
+  const float* add; int ldadd, addV; // forward, first layer: + add[row / addV][0 .. OUT) before the activation (a term shared by the addV
+                                     // consecutive rows of a point: base_fc.0's product with the view-independent statistics)
   float* dX; int lddx, accumulate;   // backward output (null = none)
   long rows;
 };
@@ -282,7 +285,7 @@ __device__ __forceinline__ void chain_stage_weights(const ChainArgs& a, float* l
     for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 4) {          // four independent loads in flight per thread
       float v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int e = e0 + 256 * u; v[u] = L.W[e < total ? e : total - 1]; }
+      for (int u = 0; u < 4; ++u) { int e = e0 + 256 * u; e = e < total ? e : total - 1; v[u] = L.W[(long)(e / L.IN) * L.ldw + e % L.IN]; }
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int e = e0 + 256 * u; if (e < total) w[(e / L.IN) * L.S + e % L.IN] = v[u]; }
     }
@@ -430,6 +433,18 @@ __global__ void __launch_bounds__(256, QD == 4 ? 6 : 3) chain_fwd_kernel(const C
         }
       } else {
         chain_layer_fwd<QD>(w, S, n, half, mt, (IN + 7) >> 3, b, acc);
+      }
+      if (k == 0 && a.add) {
+        const float* ar = a.add + (rowc / a.addV) * (long)a.ldadd;
+#pragma unroll
+        for (int m = 0; m < QD / 4; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float o[4];
+            load4_mask(ar, 4 * m + g, half, OUT, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m][4 * g + j] += o[j];
+          }
       }
       const float* bias = w + chain_rows(OUT) * S;
       switch (L.act) {

@@ -182,11 +182,11 @@ struct Ws {
   // forward activations
   float *pe_in, *imf;
   float *dh1[4], *dh2[4], *dout[4];
-  float *vis, *hit, *pe_h, *d1, *dfeat, *n1, *nfs, *w0, *glob, *xin, *b1, *x, *xw, *v1h, *xv, *v1, *xr, *xv1, *f1, *wgt2;
+  float *vis, *hit, *pe_h, *d1, *dfeat, *n1, *nfs, *w0, *glob, *hb, *xin, *b1, *x, *xw, *v1h, *xv, *v1, *xr, *xv1, *f1, *wgt2;
   float *gin, *g1, *g2, *gp, *q, *k, *v, *o, *fo, *ln, *og1, *sigma, *r1, *r2, *logit, *blend, *colors;
   // gradients
   float *gsigma, *gcol, *glogit, *gr2, *gr1, *gxr, *gog1, *gln, *gfo, *go, *gq, *gk, *gv, *ggp, *gg1, *ggin, *gwgt2, *gf1, *gxv1, *gv1,
-      *gx, *gxv, *gv1h, *gxw, *gb1, *gxin, *gglob, *gw0, *gn1, *gdfeat, *gd1, *gpe_h, *gpe_in, *gdout[4], *gdh2[4], *gdh1[4];
+      *gx, *gxv, *gv1h, *gxw, *gb1, *ghb, *gxin, *gglob, *gw0, *gn1, *gdfeat, *gd1, *gpe_h, *gpe_in, *gdout[4], *gdh2[4], *gdh1[4];
 };
 
 static size_t plan(Ws& w, long P, int V, int dn, char* base) {
@@ -204,7 +204,7 @@ static size_t plan(Ws& w, long P, int V, int dn, char* base) {
   w.pe_in = take(PV * 34); w.imf = take(PV * 32);
   for (int m = 0; m < 4; ++m) { w.dh1[m] = take(PV * 32); w.dh2[m] = take(PV * 32); w.dout[m] = take(PV * 2); }
   w.vis = take(PV); w.hit = take(PV); w.pe_h = take(PV * 32); w.d1 = take(PV * 16); w.dfeat = take(PV * 35); w.n1 = take(PV * 8);
-  w.nfs = take(PV); w.w0 = take(PV); w.glob = take(P * 140); w.xin = take(PV * 207); w.b1 = take(PV * 64); w.x = take(PV * 32);
+  w.nfs = take(PV); w.w0 = take(PV); w.glob = take(P * 140); w.hb = take(P * 64); w.xin = take(PV * 207); w.b1 = take(PV * 64); w.x = take(PV * 32);
   w.xw = take(PV * 32); w.v1h = take(PV * 32); w.xv = take(PV * 33); w.v1 = take(PV); w.xr = take(PV * 37); w.xv1 = take(PV * 32);
   w.f1 = take(PV * 32); w.wgt2 = take(PV);
   w.gin = take(P * 65); w.g1 = take(P * 64); w.g2 = take(P * 16); w.gp = take(P * 16); w.q = take(P * 16); w.k = take(P * 16);
@@ -214,7 +214,7 @@ static size_t plan(Ws& w, long P, int V, int dn, char* base) {
   w.gog1 = take(P * 16); w.gln = take(P * 16); w.gfo = take(P * 16); w.go = take(P * 16); w.gq = take(P * 16); w.gk = take(P * 16);
   w.gv = take(P * 16); w.ggp = take(P * 16); w.gg1 = take(P * 64); w.ggin = take(P * 65); w.gwgt2 = take(PV); w.gf1 = take(PV * 32);
   w.gxv1 = take(PV * 32); w.gv1 = take(PV); w.gx = take(PV * 32); w.gxv = take(PV * 33); w.gv1h = take(PV * 32); w.gxw = take(PV * 32);
-  w.gb1 = take(PV * 64); w.gxin = take(PV * 207); w.gglob = take(P * 140); w.gw0 = take(PV); w.gn1 = take(PV * 8);
+  w.gb1 = take(PV * 64); w.ghb = take(P * 64); w.gxin = take(PV * 207); w.gglob = take(P * 140); w.gw0 = take(PV); w.gn1 = take(PV * 8);
   w.gdfeat = take(PV * 35); w.gd1 = take(PV * 16); w.gpe_h = take(PV * 32); w.gpe_in = take(PV * 34);
   for (int m = 0; m < 4; ++m) { w.gdout[m] = take(PV * 2); w.gdh2[m] = take(PV * 32); w.gdh1[m] = take(PV * 32); }
   (void)take(64);      // the chain kernels' dwordx4 loads may touch 12 bytes past the last row of an activation buffer
@@ -286,7 +286,7 @@ static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float*
 }
 // gW += delta^T X and gb += colsum(delta) (one launch): the reduction runs over the ROWS (sample points x views), split over gridDim.z
 // so that the launch has ~1 536 workgroups; partial tiles are summed inside a workgroup, then one atomic per element and workgroup
-static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int ldd, int rw, int rb, long rows, int IN, int OUT) {
+static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int ldd, int rw, int rb, long rows, int IN, int OUT, int wld = 0, int wcol = 0) {
   float* gb = (rb >= 0) ? c.graw[rb] : nullptr;
   if (!c.graw[rw]) {
     if (gb) {          // bias gradient alone (the weight's is not wanted): column sums by the elementwise kernel
@@ -311,11 +311,12 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
   const dim3 grid(nwg, 1, (unsigned)((rows + chunk - 1) / chunk));
   float* rep = c.grep + (size_t)rw * kGradSlot;          // this tensor's slot of replica 1 (replica r at + (r - 1) * R_COUNT * kGradSlot)
   float* brep = gb ? c.grep + (size_t)rb * kGradSlot : nullptr;
-  c.gsize[rw] = OUT * IN;
+  const int ldg = wld ? wld : IN;
+  c.gsize[rw] = OUT * ldg;
   if (gb) c.gsize[rb] = OUT;
-  if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
-  else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
-  else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep);
+  if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
+  else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
+  else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
 }
 // dY (a [rows, OUT] slice, ld lddy) is overwritten by delta = dY * act'(Y); then gW += delta^T X, gb += colsum(delta),
 // dX (=|+=) delta W
@@ -346,7 +347,7 @@ static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ld
 
 // A chain of <= 3 Linear layers in one launch (train_kernels.h chain_fwd_kernel / chain_bwd_kernel).  Layer k + 1 reads layer k's
 // output; widths after the first layer's input <= 64.
-struct Lin { const float* X; int ldx; float* Y; int ldy; float* dY; int lddy; int rw, rb, IN, OUT, act; };
+struct Lin { const float* X; int ldx; float* Y; int ldy; float* dY; int lddy; int rw, rb, IN, OUT, act; int wcol = 0, wld = 0; };     // wcol / wld: columns [wcol, wcol + IN) of a weight with wld columns
 static int chain_check(const Lin* l, int n) {
   if (n < 1 || n > 3) return set_error(PGRF_ERR_ARG, "train chain: %d layers", n);
   for (int k = 0; k < n; ++k) {
@@ -385,13 +386,15 @@ static dim3 chain_grid(long rows, size_t lds, int max_per_cu) {
   const long tiles = (rows + 127) / 128, cap = (long)ncu * per_cu;
   return dim3((unsigned)(tiles < cap ? tiles : cap));
 }
-static int chain_fwd(const Ctx& c, const Lin* l, int n, long rows) {
+static int chain_fwd(const Ctx& c, const Lin* l, int n, long rows, const float* add = nullptr, int ldadd = 0, int addV = 1) {
   if (int rc = chain_check(l, n)) return rc;
   ChainArgs a;
   std::memset(&a, 0, sizeof(a));
   a.n = n; a.X = l[0].X; a.ldx = l[0].ldx; a.rows = rows;
   for (int k = 0; k < n; ++k)
-    a.l[k] = ChainLayer{c.raw[l[k].rw], l[k].rb >= 0 ? c.raw[l[k].rb] : nullptr, l[k].Y, nullptr, l[k].ldy, 0, l[k].IN, l[k].OUT, l[k].act, 0, 0, 0};
+    a.l[k] = ChainLayer{c.raw[l[k].rw] + l[k].wcol, l[k].rb >= 0 ? c.raw[l[k].rb] : nullptr, l[k].Y, nullptr, l[k].ldy, 0, l[k].IN, l[k].OUT, l[k].act, 0, 0, 0,
+                        l[k].wld ? l[k].wld : l[k].IN};
+  a.add = add; a.ldadd = ldadd; a.addV = addV > 0 ? addV : 1;
   const size_t lds = chain_layout(a);
   if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
   if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_fwd_kernel<4>, chain_grid(rows, lds, 6), dim3(256), lds, c.st, a);
@@ -407,14 +410,14 @@ static int chain_bwd(const Ctx& c, const Lin* l, int n, long rows, float* dX, in
   a.n = n; a.rows = rows; a.dX = dX; a.lddx = lddx; a.accumulate = acc_dx;
   for (int k = 0; k < n; ++k) {          // kernel order: top layer first
     const Lin& s = l[n - 1 - k];
-    a.l[k] = ChainLayer{c.raw[s.rw], nullptr, s.Y, s.dY, s.ldy, s.lddy, s.IN, s.OUT, s.act, (k + 1 < n || dX) ? 1 : 0, 0, 0};
+    a.l[k] = ChainLayer{c.raw[s.rw] + s.wcol, nullptr, s.Y, s.dY, s.ldy, s.lddy, s.IN, s.OUT, s.act, (k + 1 < n || dX) ? 1 : 0, 0, 0, s.wld ? s.wld : s.IN};
   }
   const size_t lds = chain_layout(a);
   if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
   if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_bwd_kernel<4>, chain_grid(rows, lds, 5), dim3(256), lds, c.st, a);
   else hipLaunchKernelGGL(chain_bwd_kernel<8>, chain_grid(rows, lds, 2), dim3(256), lds, c.st, a);
   c.fork();
-  for (int k = n - 1; k >= 0; --k) L_dw(c, l[k].X, l[k].ldx, l[k].dY, l[k].lddy, l[k].rw, l[k].rb, rows, l[k].IN, l[k].OUT);
+  for (int k = n - 1; k >= 0; --k) L_dw(c, l[k].X, l[k].ldx, l[k].dY, l[k].lddy, l[k].rw, l[k].rb, rows, l[k].IN, l[k].OUT, l[k].wld, l[k].wcol);
   PGRF_TCHECK("train chain backward");
   return PGRF_OK;
 }
@@ -519,11 +522,16 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w0, 1, 0, w.nfs, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
   hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35);
   hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105);
-  hipLaunchKernelGGL(bcast_kernel, dim3(nblk(PV * 140)), dim3(256), 0, st, w.xin, 207, 0, w.glob, 140, 0, PV, V, 140);
   PGRF_TCHECK("train view statistics");
-  const Lin base_l[2] = {{w.xin, 207, w.b1, 64, w.gb1, 64, R_BASE_0_W, R_BASE_0_B, 207, 64, ACT_ELU},               // base_fc
+  // base_fc.0 in two column blocks, like the fused kernel's L_BG / L_BV: the 140 view statistics are the SAME for the V views of a point,
+  // so their product with W[:, 0:140] is formed once per point (hb, P rows) and enters the per-view layer -- W[:, 140:207] on the 67
+  // per-view columns -- as an additive term.  The broadcast copy of the statistics into xin[:, 0:140] (147 MB per pass), its columns of the
+  // layer's dX and their reduction over the views, and 140 of the 207 columns of the (point x view)-row dW are gone.
+  const Lin glob_l[1] = {{w.glob, 140, w.hb, 64, w.ghb, 64, R_BASE_0_W, -1, 140, 64, ACT_NONE, 0, 207}};
+  L(chain_fwd(c, glob_l, 1, P));
+  const Lin base_l[2] = {{w.xin + 140, 207, w.b1, 64, w.gb1, 64, R_BASE_0_W, R_BASE_0_B, 67, 64, ACT_ELU, 140, 207},    // base_fc
                          {w.b1, 64, w.x, 32, w.gx, 32, R_BASE_2_W, R_BASE_2_B, 64, 32, ACT_ELU}};
-  L(chain_fwd(c, base_l, 2, PV));
+  L(chain_fwd(c, base_l, 2, PV, w.hb, 64, V));
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32);
   const Lin vf_l[2] = {{w.xw, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, 32, 32, ACT_ELU},                      // vis_fc
                        {w.v1h, 32, w.xv, 33, w.gxv, 33, R_VF_2_W, R_VF_2_B, 32, 33, ACT_ELU}};
@@ -598,8 +606,9 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32, w.gx, 32, 0,
                      (float*)nullptr);
   PGRF_TCHECK("train visibility backward");
-  L(chain_bwd(c, base_l, 2, PV, w.gxin, 207, 0));
-  hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 140)), dim3(256), 0, st, w.gglob, 140, 0, w.gxin, 207, 0, P, V, 140, 0);
+  L(chain_bwd(c, base_l, 2, PV, w.gxin + 140, 207, 0));                                  // d / d(per-view columns); delta of base_fc.0 left in gb1
+  hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 64)), dim3(256), 0, st, w.ghb, 64, 0, w.gb1, 64, 0, P, V, 64, 0);      // d hb = sum over the views
+  L(chain_bwd(c, glob_l, 1, P, w.gglob, 140, 0));                                         // d glob = d hb W[:, 0:140]  (+ that block's dW, P rows)
   (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
   hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35, w.gglob, 140, 0, 35,
                      w.gxin, 207, 140, w.gw0);
