@@ -46,15 +46,21 @@ def _close(a, b, rel, floor):
     return float((a - b).abs().max()) / scale
 
 
-@pytest.mark.parametrize('name', STAGE_FIXTURES)
-def test_backward_vs_autograd_through_the_oracle(name):
+@pytest.mark.parametrize('name,rn_sub,dn_sub', [(n, None, None) for n in STAGE_FIXTURES] +
+                         # ragged batches: (point x view) row counts that are not multiples of the kernels' 128-row workgroup tiles (448),
+                         # nor of a wave's 32 rows (310, 435, 203), nor of a 64-lane ray chunk
+                         [('render_stages_v2_dn32', 7, 32), ('render_stages_v2_dn32', 5, 31), ('render_stages_v3_vis', 5, 29),
+                          ('render_stages_v1_dn32', 7, 29)])
+def test_backward_vs_autograd_through_the_oracle(name, rn_sub, dn_sub):
     from panogrf_amd import engine as E
     frame, w, cfg, g = FX.load(name)
     fr = _frame(E, frame)
     use_vis = cfg['dist_decoder_cfg']['use_vis']
-    coords = frame['coords']
+    coords = frame['coords'] if rn_sub is None else frame['coords'][:rn_sub].contiguous()
     for tag, dd, ag, seed in [('coarse', 'dist_decoder', 'agg_net', 1), ('fine', 'fine_dist_decoder', 'fine_agg_net', 2)]:
         depth = g[tag]['depth']
+        if rn_sub is not None:
+            depth = depth[:rn_sub, :dn_sub].contiguous()
         rn, dn = depth.shape
         up = _upstream(rn, dn, seed)
         gw_ref, gif_ref, grf_ref, out_ref = _oracle_grads(w, dd, ag, frame, coords, depth, use_vis, up)
@@ -62,9 +68,10 @@ def test_backward_vs_autograd_through_the_oracle(name):
         g_raw, g_if, g_rf, fwd = E.render_pass_backward(fr, raw, use_vis, coords, depth, up, want_forward=True)
         # the rematerialised forward is the fused kernel's forward (and the reference's)
         blob = E.pack_pass_weights(w, dd, ag, use_vis).cuda()
-        fused = E.render_pass(fr, blob, use_vis, coords, depth)
+        fused = E.render_pass(fr, blob, use_vis, coords, depth) if dn in (32, 64, 128) else None      # (the fused kernel's sample counts)
         for k in ('pixel_colors_nr', 'hit_prob_nr', 'density_nr', 'colors_nr', 'render_depth'):
-            assert FX.max_abs(fwd[k].cpu(), fused[k].cpu()) < 2e-5 * max(1.0, float(fused[k].abs().max())), (name, tag, k)
+            if fused is not None:
+                assert FX.max_abs(fwd[k].cpu(), fused[k].cpu()) < 2e-5 * max(1.0, float(fused[k].abs().max())), (name, tag, k)
             assert FX.max_abs(fwd[k].cpu(), out_ref[k]) < 1e-4 * max(1.0, float(out_ref[k].abs().max())), (name, tag, k)
         # weight gradients, in the reference's state_dict layout
         names = E.raw_names()
