@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
 __global__ void bias_act_kernel(float* __restrict__ Y, int ldy, const float* __restrict__ bias, long rows, int cols, int act) {
   const long n = rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cols; const int c = (int)(i % cols);
+    const unsigned iu = (unsigned)i; const long r = iu / (unsigned)cols; const int c = (int)(iu % (unsigned)cols);      // (n < 2^32: host guard; a 64-bit divide is ~100 instructions)
     float* y = Y + r * ldy + c;
     *y = act_fwd(*y + (bias ? bias[c] : 0.f), act);
   }
@@ -610,7 +610,7 @@ __global__ void slice_kernel(float* __restrict__ dst, int ldd, int dc, const flo
                              int accumulate) {
   const long n = rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cols; const int c = (int)(i % cols);
+    const unsigned iu = (unsigned)i; const long r = iu / (unsigned)cols; const int c = (int)(iu % (unsigned)cols);      // (n < 2^32: host guard; a 64-bit divide is ~100 instructions)
     const float v = src[r * lds + sc + c];
     float* d = dst + r * ldd + dc + c;
     *d = accumulate ? *d + v : v;
@@ -825,7 +825,7 @@ __global__ void stats_kernel(const float* __restrict__ x, int ldx, int xc, const
                              float* __restrict__ out, int ldo, int mc, int vc) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P * F) return;
-  const long p = i / F; const int j = (int)(i % F);
+  const unsigned iu = (unsigned)i; const long p = iu / (unsigned)F; const int j = (int)(iu % (unsigned)F);
   float m = 0.f;
   for (int v = 0; v < V; ++v) m += x[(p * V + v) * ldx + xc + j] * w[p * V + v];
   float var = 0.f;

@@ -41,20 +41,25 @@ __global__ void bcast_kernel(float* __restrict__ dst, int ldd, int dc, const flo
                              int cols) {
   const long n = rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cols; const int c = (int)(i % cols);
+    const unsigned iu = (unsigned)i; const long r = iu / (unsigned)cols; const int c = (int)(iu % (unsigned)cols);      // (n < 2^32: host guard; a 64-bit divide is ~100 instructions)
     dst[r * ldd + dc + c] = src[(r / div) * lds + sc + c];
   }
 }
-// dst[p, dc + c] (=|+=) sum_v src[p * V + v, sc + c]
+// dst[p, dc + c] (=|+=) sum_v src[p * V + v, sc + c]     (four columns per thread: cols, strides and offsets multiples of 4)
 __global__ void reduce_views_kernel(float* __restrict__ dst, int ldd, int dc, const float* __restrict__ src, int lds, int sc, long P, int V,
                                     int cols, int accumulate) {
-  const long n = P * cols;
+  const int c4 = cols >> 2;
+  const long n = P * c4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const long p = i / cols; const int c = (int)(i % cols);
-    float s = 0.f;
-    for (int v = 0; v < V; ++v) s += src[(p * V + v) * lds + sc + c];
-    float* d = dst + p * ldd + dc + c;
-    *d = accumulate ? *d + s : s;
+    const unsigned iu = (unsigned)i; const long p = iu / (unsigned)c4; const int c = 4 * (int)(iu % (unsigned)c4);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = 0; v < V; ++v) {
+      const float4 t = *reinterpret_cast<const float4*>(src + (p * V + v) * lds + sc + c);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    float4* d = reinterpret_cast<float4*>(dst + p * ldd + dc + c);
+    if (accumulate) { const float4 o = *d; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    *d = s;
   }
 }
 // y[r, yc + c] = x[r, xc + c] * (s ? s[r * sstride] : cst)
@@ -62,7 +67,7 @@ __global__ void rowscale_kernel(float* __restrict__ y, int ldy, int yc, const fl
                                 int sstride, float cst, long rows, int cols) {
   const long n = rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cols; const int c = (int)(i % cols);
+    const unsigned iu = (unsigned)i; const long r = iu / (unsigned)cols; const int c = (int)(iu % (unsigned)cols);      // (n < 2^32: host guard; a 64-bit divide is ~100 instructions)
     y[r * ldy + yc + c] = x[r * ldx + xc + c] * (s ? s[r * sstride] : cst);
   }
 }
@@ -91,14 +96,14 @@ __global__ void __launch_bounds__(256) rowscale_bwd_kernel(const float* __restri
 __global__ void rgbfeat_kernel(const float* __restrict__ rgb, const float* __restrict__ imf, const float* __restrict__ dfeat, long PV,
                                float* __restrict__ xin) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 35; i += (long)gridDim.x * blockDim.x) {
-    const long pv = i / 35; const int c = (int)(i % 35);
+    const unsigned iu = (unsigned)i; const long pv = iu / 35u; const int c = (int)(iu % 35u);
     xin[pv * 207 + 140 + c] = (c < 3 ? rgb[pv * 3 + c] : imf[pv * 32 + c - 3]) + dfeat[pv * 35 + c];
   }
 }
 // x2 = x + x_res, v1 = sigmoid(xv[32])  (ibrnet.py:347-350); x2 -> xr[:, 0:32]
 __global__ void visfc_post_kernel(const float* __restrict__ x, const float* __restrict__ xv, long PV, float* __restrict__ xr, float* __restrict__ v1) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 33; i += (long)gridDim.x * blockDim.x) {
-    const long pv = i / 33; const int c = (int)(i % 33);
+    const unsigned iu = (unsigned)i; const long pv = iu / 33u; const int c = (int)(iu % 33u);
     if (c < 32) xr[pv * 37 + c] = x[pv * 32 + c] + xv[pv * 33 + c];
     else v1[pv] = 1.f / (1.f + expf(-xv[pv * 33 + 32]));
   }
@@ -107,7 +112,7 @@ __global__ void visfc_post_kernel(const float* __restrict__ x, const float* __re
 __global__ void visfc_post_bwd_kernel(const float* __restrict__ gxr, const float* __restrict__ gv1, const float* __restrict__ v1, long PV,
                                       float* __restrict__ gx, float* __restrict__ gxv) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 33; i += (long)gridDim.x * blockDim.x) {
-    const long pv = i / 33; const int c = (int)(i % 33);
+    const unsigned iu = (unsigned)i; const long pv = iu / 33u; const int c = (int)(iu % 33u);
     if (c < 32) { const float g = gxr[pv * 37 + c]; gx[pv * 32 + c] = g; gxv[pv * 33 + c] = g; }
     else gxv[pv * 33 + 32] = gv1[pv] * v1[pv] * (1.f - v1[pv]);
   }
@@ -607,7 +612,7 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
                      (float*)nullptr);
   PGRF_TCHECK("train visibility backward");
   L(chain_bwd(c, base_l, 2, PV, w.gxin + 140, 207, 0));                                  // d / d(per-view columns); delta of base_fc.0 left in gb1
-  hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 64)), dim3(256), 0, st, w.ghb, 64, 0, w.gb1, 64, 0, P, V, 64, 0);      // d hb = sum over the views
+  hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.ghb, 64, 0, w.gb1, 64, 0, P, V, 64, 0);      // d hb = sum over the views
   L(chain_bwd(c, glob_l, 1, P, w.gglob, 140, 0));                                         // d glob = d hb W[:, 0:140]  (+ that block's dW, P rows)
   (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
   hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35, w.gglob, 140, 0, 35,
