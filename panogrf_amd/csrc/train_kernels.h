@@ -239,6 +239,106 @@ __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ 
   }
 }
 
+// The same product with its operands staged through LDS (round 4, NT = 1).  The kernel above loads one float per lane and k-step: 256
+// bytes per load instruction, and with the number of vector-memory instructions a CU keeps in flight that is ~1.7 TB/s however many of
+// them are launched (33 products of a pass as ONE grid: 1.34 GB in 0.78 ms).  Here a wave fetches 32 rows x 32 columns of delta and of X
+// with four `dwordx4` loads each (8 lanes per row: 1 KB per instruction), parks them in a private LDS tile (row stride 32: the two lane
+// halves of a k-step read rows 2s and 2s + 1 = all 64 banks) and reads its MFMA operands from there; the next stage's loads are in flight
+// while a stage is multiplied.  Out-of-range columns / rows are AND-masked after an unconditional load (the load may touch up to 124
+// bytes past a row's end: workspace buffers, plan() pads).  Epilogue as above (the tiles' memory is reused for the cross-wave sum).
+__global__ void __launch_bounds__(256) dw_lds_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ X, int ldx,
+                                                     float* __restrict__ gW0, float* __restrict__ gWrep, int M, int K, long rows, int chunk,
+                                                     int gx, int groups, float* __restrict__ gb0, float* __restrict__ gbrep, int ldg, int gcol) {
+  const int rep = blockIdx.z & 7;
+  float* __restrict__ gW = rep == 0 ? gW0 : gWrep + (size_t)(rep - 1) * kRepStride;
+  float* __restrict__ gb = gb0 ? (rep == 0 ? gb0 : gbrep + (size_t)(rep - 1) * kRepStride) : nullptr;
+  __shared__ float tiles[4][2][32 * 32];                     // per wave: [delta | X] tile; later red[3][16][64] (12 KB of the 32)
+  __shared__ float cs_red[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, half = lane >> 5;
+  const int wpg = groups >= 4 ? 1 : (groups == 2 ? 2 : 4);           // waves per group
+  const int grp = blockIdx.x * (4 / wpg) + wave / wpg, sub = wave % wpg;
+  const bool grp_ok = grp < groups;
+  const int m0 = (grp_ok ? grp / gx : 0) * 32, n0 = (grp_ok ? grp % gx : 0) * 32;
+  const long r_beg = (long)blockIdx.z * chunk, r_end = (r_beg + chunk < rows) ? r_beg + chunk : rows;
+  // the sub-waves of a group take contiguous shares of the chunk's rows, in stages of 32
+  const long per = (((r_end - r_beg) + wpg - 1) / wpg + 31) / 32 * 32;
+  const long my_beg = r_beg + (long)sub * per, my_end = (my_beg + per < r_end) ? my_beg + per : r_end;
+  // load mapping: 8 lanes per row, 4 columns each; load j covers rows lr + 8j of the stage
+  const int lr = lane >> 3, c4 = (lane & 7) * 4;
+  unsigned dmask[4], xmask[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    dmask[e] = (grp_ok && m0 + c4 + e < M) ? 0xffffffffu : 0u;
+    xmask[e] = (grp_ok && n0 + c4 + e < K) ? 0xffffffffu : 0u;
+  }
+  const float* dcol = D + ((grp_ok && m0 + c4 < M) ? m0 + c4 : 0);
+  const float* xcol = X + ((grp_ok && n0 + c4 < K) ? n0 + c4 : 0);
+  float* tD = tiles[wave][0];
+  float* tX = tiles[wave][1];
+  f32x16t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colsum = 0.f;
+  F4U dreg[4], xreg[4];
+  auto fetch = [&](long s0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long row = s0 + lr + 8 * j;
+      row = row < rows ? row : rows - 1;                      // (rows past the share are masked at the LDS write)
+      dreg[j] = *reinterpret_cast<const F4U*>(dcol + row * ldd);
+      xreg[j] = *reinterpret_cast<const F4U*>(xcol + row * ldx);
+    }
+  };
+  if (my_beg < my_end) fetch(my_beg);
+  for (long s0 = my_beg; s0 < my_end; s0 += 32) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned rm = (s0 + lr + 8 * j < my_end) ? 0xffffffffu : 0u;
+      float4 dv, xv;
+      dv.x = __uint_as_float(__float_as_uint(dreg[j].v[0]) & dmask[0] & rm); dv.y = __uint_as_float(__float_as_uint(dreg[j].v[1]) & dmask[1] & rm);
+      dv.z = __uint_as_float(__float_as_uint(dreg[j].v[2]) & dmask[2] & rm); dv.w = __uint_as_float(__float_as_uint(dreg[j].v[3]) & dmask[3] & rm);
+      xv.x = __uint_as_float(__float_as_uint(xreg[j].v[0]) & xmask[0] & rm); xv.y = __uint_as_float(__float_as_uint(xreg[j].v[1]) & xmask[1] & rm);
+      xv.z = __uint_as_float(__float_as_uint(xreg[j].v[2]) & xmask[2] & rm); xv.w = __uint_as_float(__float_as_uint(xreg[j].v[3]) & xmask[3] & rm);
+      *reinterpret_cast<float4*>(tD + (lr + 8 * j) * 32 + c4) = dv;
+      *reinterpret_cast<float4*>(tX + (lr + 8 * j) * 32 + c4) = xv;
+    }
+    if (s0 + 32 < my_end) fetch(s0 + 32);                    // in flight under this stage's products
+    __builtin_amdgcn_wave_barrier();                         // (one wave, in-order LDS: the reads below see the writes above)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float a = tD[(2 * ks + half) * 32 + i], b = tX[(2 * ks + half) * 32 + i];
+      colsum += a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (gb) {      // both lane halves walked different rows of column i; then the sub-waves of the group
+    colsum += __shfl_xor(colsum, 32, 64);
+    if (half == 0) cs_red[wave][i] = colsum;
+  }
+  __syncthreads();                                           // every wave is done with its tiles: their memory becomes the reduction buffer
+  float* red = &tiles[0][0][0];                              // [3][16][64]
+  if (wpg > 1 && sub > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (gb && sub == 0 && grp_ok && n0 == 0 && half == 0 && m0 + i < M) {
+    float t = cs_red[wave][i];
+    for (int k = 1; k < wpg; ++k) t += cs_red[wave + k][i];
+    if (t != 0.f) unsafeAtomicAdd(gb + m0 + i, t);
+  }
+  if (sub == 0 && grp_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r];
+      for (int k = 1; k < wpg; ++k) v += red[((wave + k - 1) * 16 + r) * 64 + lane];
+      const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * half, ko = n0 + i;
+      if (mo < M && ko < K) unsafeAtomicAdd(gW + (long)mo * ldg + gcol + ko, v);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // CHAINS of Linear layers in one launch (round 4).  In lin_mfma_kernel's orientation the accumulator registers of one layer ARE the
 // B operands of the next (register 4g + j of lane (n, half) is column 8g + 4 half + j: exactly what k-step 4g + j asks of that lane),

@@ -319,6 +319,11 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
   const int ldg = wld ? wld : IN;
   c.gsize[rw] = OUT * ldg;
   if (gb) c.gsize[rb] = OUT;
+  static const bool use_lds = [] { const char* e = getenv("PGRF_TRAIN_DW_LDS"); return !(e && e[0] == '0'); }();
+  if (nt == 1 && use_lds) {
+    hipLaunchKernelGGL(dw_lds_kernel, grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
+    return;
+  }
   if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
   else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
   else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
