@@ -310,7 +310,7 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
   const int gx = (IN + 32 * nt - 1) / (32 * nt), gy = (OUT + 31) / 32, groups = gx * gy;
   const int gpw = groups >= 4 ? 4 : (groups == 2 ? 2 : 1);                  // groups per workgroup
   const int nwg = (groups + gpw - 1) / gpw;
-  static const int target_wgs = [] { const char* e = getenv("PGRF_TRAIN_DW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();   // tuning knob (with the gradient replicas: 192: 18.6, 384: 15.9, 768: 14.5, 1536: 14.1, 3072: 14.5, 6144: 14.1 ms per 2 048-ray step)
+  static const int target_wgs = [] { const char* e = getenv("PGRF_TRAIN_DW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();   // tuning knob (LDS-staged kernel: 768: 6.74, 1024: 6.82, 1536: 6.85, 2048: 6.98 ms per step; the dword-load kernel it replaced: (with the gradient replicas: 192: 18.6, 384: 15.9, 768: 14.5, 1536: 14.1, 3072: 14.5, 6144: 14.1 ms per 2 048-ray step)
   long chunk = (rows * nwg / target_wgs + 63) / 64 * 64;                    // ~target_wgs workgroups per launch
   if (chunk < 128) chunk = 128;
   const dim3 grid(nwg, 1, (unsigned)((rows + chunk - 1) / chunk));
