@@ -329,6 +329,13 @@ int pgrf_conv3d_wino16(const float* in, int in_cs, int in_coff, int Cin, float* 
 /* The same launch with a second output: pool_out (channel-last, [B, D/2, H/2, W/2, pool_cs] + pool_coff) = nn.AvgPool3d(2) of `out`.
  * An F(2^3, 3^3) output tile is one pooling window, so the encoder levels of UNet2 (models/common_blocks.py:210-218 -> ConvBlock2 :383: two convs, then
  * AvgPool3d(2)) get their pooled tensor from the conv's epilogue instead of one more pass over its output.  pool_out may be NULL. */
+/* Layers with few rows (low-resolution levels of UNet2: < ~1.5 rows per CU where the kernel wants two workgroups per CU): every row as
+ * `ksplit` work items over shares of the 32-channel input blocks, raw partial sums into `scratch` (ksplit * B*D*H*W*Cout floats), bias +
+ * LeakyReLU in a small reduce kernel behind.  pgrf_conv3d_wino16_ksplit() returns the split the host should use (0: none). */
+int pgrf_conv3d_wino16_ksplit(int Cin, int Cout, int B, int D, int H, int W);
+int pgrf_conv3d_wino16_splitk(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                              const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, int ksplit,
+                              float* scratch, size_t scratch_floats, void* stream);
 int pgrf_conv3d_wino16_pool(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                             const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope,
                             const float* residual, int res_cs, int res_coff, float* pool_out, int pool_cs, int pool_coff, void* stream);

@@ -115,6 +115,9 @@ SYMBOLS = {
     "pgrf_conv3d_wino16_preferred": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pgrf_conv3d_wino16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P]),
+    "pgrf_conv3d_wino16_ksplit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pgrf_conv3d_wino16_splitk": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P, C.c_size_t, _P]),
     "pgrf_conv3d_wino16_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "pgrf_conv3d_small_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -183,11 +183,23 @@ def _conv_wino16_applies(pc, x, stride, residual):
                  (force and lib.pgrf_conv3d_wino16_supported(pc.cin, pc.cout, x.D, x.H, x.W))))
 
 
+def _wino16_ksplit(pc, x, stride, residual):
+    """split of the input-channel blocks for layers with too few rows to fill the chip (pgrf_conv3d_wino16_splitk), 0 = none"""
+    if stride != 1 or residual is not None or os.environ.get('PANOGRF_CONV_WINOGRAD', '1') == '0' or os.environ.get('PANOGRF_WINO', '16') == '32':
+        return 0
+    if os.environ.get('PANOGRF_WINO_KSPLIT', '1') == '0' or (pc.cout == 1 and pc.cin >= 64):
+        return 0
+    if _small16_shift(pc, x, stride) or _small_shift(pc, x, stride):
+        return 0
+    return int(lib.pgrf_conv3d_wino16_ksplit(pc.cin, pc.cout, x.B, x.D, x.H, x.W))
+
+
 def _conv(pc, x, out, stride=1, slope=0.01, residual=None, pool_out=None):
     """pool_out: AvgPool3d(2) of the result as well (UNet2's encoder levels) -- from the Winograd kernel's epilogue where that kernel
     takes the layer, by pgrf_avgpool3d_2 behind any other."""
     if pool_out is not None:
-        if _conv_wino16_applies(pc, x, stride, residual) and os.environ.get('PANOGRF_POOL_FUSE', '1') != '0':
+        if (_conv_wino16_applies(pc, x, stride, residual) and os.environ.get('PANOGRF_POOL_FUSE', '1') != '0' and
+                not _wino16_ksplit(pc, x, stride, residual)):
             lib.check(lib.pgrf_conv3d_wino16_pool(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
                                                   _ptr(pc.wino16()), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope), None, 0, 0,
                                                   _ptr(pool_out.buf), pool_out.cs, pool_out.coff, _stream()))
@@ -220,6 +232,14 @@ def _conv(pc, x, out, stride=1, slope=0.01, residual=None, pool_out=None):
                                         _ptr(residual.buf) if residual is not None else None,
                                         residual.cs if residual is not None else 0,
                                         residual.coff if residual is not None else 0, _stream()))
+        return out
+    ks = _wino16_ksplit(pc, x, stride, residual)
+    if ks >= 2:
+        # few rows (the low-resolution levels): every row as `ks` work items over shares of the input-channel blocks, partial sums reduced behind
+        scratch = torch.empty(ks * x.B * x.D * x.H * x.W * pc.cout, dtype=torch.float32, device=x.buf.device)
+        lib.check(lib.pgrf_conv3d_wino16_splitk(_ptr(x.buf), x.cs, x.coff, pc.cin, _ptr(out.buf), out.cs, out.coff, pc.cout,
+                                                _ptr(pc.wino16()), int(pc.has_bias), x.B, x.D, x.H, x.W, float(slope), ks,
+                                                _ptr(scratch), scratch.numel(), _stream()))
         return out
     force = os.environ.get('PANOGRF_CONV_WINOGRAD') == 'force'
     if (stride == 1 and residual is None and os.environ.get('PANOGRF_CONV_WINOGRAD', '1') != '0' and os.environ.get('PANOGRF_WINO', '16') != '32' and

@@ -40,6 +40,8 @@ struct ConvArgs {
   int res_first;          // 1: the residual is added BEFORE the activation (ResNet BasicBlock), 0: after (CostRegNet skips)
   float* pool;            // conv3d_wino16 only: optional second output = AvgPool3d(2) of `out` (an F(2^3, 3^3) output tile IS a pooling window)
   int pool_cs, pool_coff;
+  int ksplit;             // conv3d_wino16 only: > 1 = every row is `ksplit` work items, each over a range of the 32-channel input blocks,
+  long long ksplit_stride;//   writing its raw partial sums (no bias, slope 1) to out + item * ksplit_stride floats (pgrf_conv3d_wino16_splitk)
 };
 
 __device__ __forceinline__ float conv_act(const ConvArgs& a, float v) {

@@ -108,10 +108,14 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
   struct Row {               // wave-uniform
     unsigned zyok;           // bit dz*4+dy: that patch row is inside the volume
     int b, z0, y0, x0, cg;
+    int c0, c1, split;       // input channel blocks [c0, c1) of this work item (the whole range unless a.ksplit > 1)
   };
+  const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
   auto setup = [&](int rowi) {
     Row r;
     int g = rowi;
+    r.split = g % ksplit; g /= ksplit;
+    r.c0 = (int)((long long)a.chunks * r.split / ksplit); r.c1 = (int)((long long)a.chunks * (r.split + 1) / ksplit);
     r.cg = g % cgroups; g /= cgroups;
     const int txg = g % Wg; g /= Wg;
     const int ty = g % Ht; g /= Ht;
@@ -202,12 +206,12 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
     };
     Row cur = setup(rowi);
 #ifndef PGRF_WINO_ABL_NOB       // timing experiment (wrong results): the loader waves only keep the barrier protocol
-    prefetch(cur, 0);
+    prefetch(cur, cur.c0);
 #endif
     while (true) {
       const int nrow = rowi + gridDim.x;
       const bool has_next = nrow < nrows;
-      for (int blk = 0; blk < a.chunks; ++blk) {
+      for (int blk = cur.c0; blk < cur.c1; ++blk) {
 #ifndef PGRF_WINO_ABL_NOB
         *reinterpret_cast<float4*>(stage + (hitem * 16 + hzy) * 4) = ((cur.zyok >> hzy) & 1u) ? hraw : make_float4(0.f, 0.f, 0.f, 0.f);
         transform(cur.zyok);
@@ -224,8 +228,8 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
 #endif
         lds_barrier();                                     // B2
 #ifndef PGRF_WINO_ABL_NOB
-        if (blk + 1 < a.chunks) prefetch(cur, blk + 1);
-        else if (has_next) prefetch(setup(nrow), 0);
+        if (blk + 1 < cur.c1) prefetch(cur, blk + 1);
+        else if (has_next) { const Row nr = setup(nrow); prefetch(nr, nr.c0); }
 #endif
       }
       lds_barrier();                                       // E1
@@ -275,11 +279,12 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
 #pragma unroll
   for (int st = 0; st < PGRF_W16_RING; ++st)
 #pragma unroll
-    for (int g = 0; g < 2; ++g) A[st][g] = a_load(a_off(cur.cg, 0, 0) + st * 2048 + g * 1024);
+    for (int g = 0; g < 2; ++g) A[st][g] = a_load(a_off(cur.cg, cur.c0, 0) + st * 2048 + g * 1024);
   while (true) {
     const int nrow = rowi + gridDim.x;
     const bool has_next = nrow < nrows;
-    const int ncg = has_next ? setup(nrow).cg : cur.cg;
+    const Row nxt = has_next ? setup(nrow) : cur;
+    const int ncg = nxt.cg, nc0 = nxt.c0;
     // The bias enters through the accumulators of the fz = 1 wave: R1 appears with + in both z outputs.
     f32x4v R[2][2][4];                                     // [oy][ox][output tile]
 #pragma unroll
@@ -294,8 +299,8 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox) R[oy][ox][t] = binit;
     }
-    for (int blk = 0; blk < a.chunks; ++blk) {
-      const bool lastblk = blk + 1 == a.chunks;
+    for (int blk = cur.c0; blk < cur.c1; ++blk) {
+      const bool lastblk = blk + 1 == cur.c1;
       W16_TICK(0)
       lds_barrier();                                       // B1
       W16_TICK(1)
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
       W16_TICK(2)
       const unsigned abase = a_off(cur.cg, blk, 0);
       const unsigned astride = (unsigned)a.chunks * (unsigned)kABlockBytes;
-      const unsigned anext = lastblk ? a_off(ncg, 0, 0) : abase + (unsigned)kABlockBytes;
+      const unsigned anext = lastblk ? a_off(ncg, nc0, 0) : abase + (unsigned)kABlockBytes;
       // 64 steps (frequency fyfx = s >> 2, output tile t = s & 3), software-pipelined by hand:
       //   * step s issues its 8 chained MFMAs into M[s & 1]; the output-transform adds of step s - 1 (VALU reads of an MFMA result)
       //     come AFTER them, so that no wait states are needed in front of the adds (the first version did the adds right behind
@@ -435,6 +440,7 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
       const int t = wave;
       const long long ov0 = (((long long)cur.b * a.D + cur.z0) * a.H + cur.y0) * a.W + cur.x0 + 2 * n;
       const int coff = a.out_coff + cur.cg * 64 + t * 16 + kq * 4;
+      float* const outp = a.out + (long long)cur.split * a.ksplit_stride;       // (split-K: this item's partial-sum buffer)
       float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int oyox = 0; oyox < 4; ++oyox) {
@@ -445,8 +451,8 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
         v1.x = v1.x > 0.f ? v1.x : v1.x * a.slope; v1.y = v1.y > 0.f ? v1.y : v1.y * a.slope;
         v1.z = v1.z > 0.f ? v1.z : v1.z * a.slope; v1.w = v1.w > 0.f ? v1.w : v1.w * a.slope;
         const long long ov = ov0 + (long long)(oyox >> 1) * a.W + (oyox & 1);
-        *reinterpret_cast<float4*>(a.out + ov * a.out_cs + coff) = v0;
-        *reinterpret_cast<float4*>(a.out + (ov + (long long)a.H * a.W) * a.out_cs + coff) = v1;
+        *reinterpret_cast<float4*>(outp + ov * a.out_cs + coff) = v0;
+        *reinterpret_cast<float4*>(outp + (ov + (long long)a.H * a.W) * a.out_cs + coff) = v1;
         pool = f4add(pool, f4add(v0, v1));
       }
       if (a.pool) {
@@ -472,6 +478,24 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
 }  // namespace pgrf
 
 using namespace pgrf;
+
+// split-K epilogue: out = LeakyReLU(sum_s partial[s] + bias) over channel-last voxels (four channels per thread)
+__global__ void __launch_bounds__(256) wino16_splitk_reduce_kernel(const float* __restrict__ part, long long stride, int S, const float* __restrict__ bias,
+                                                                   float* __restrict__ out, int out_cs, int out_coff, long long nvox, int Cout, float slope) {
+  const int c4n = Cout >> 2;
+  const long long n = nvox * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long v = i / c4n; const int c = 4 * (int)(i % c4n);
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+      const float4 p = *reinterpret_cast<const float4*>(part + s * stride + v * Cout + c);
+      acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
+    acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
+    *reinterpret_cast<float4*>(out + v * out_cs + out_coff + c) = acc;
+  }
+}
 
 static constexpr int kMaxDevices16 = 64;
 
@@ -536,9 +560,43 @@ int pgrf_conv3d_wino16(const float* in, int in_cs, int in_coff, int Cin, float* 
                                  res_coff, nullptr, 0, 0, stream);
 }
 
+int pgrf_conv3d_wino16_ksplit(int Cin, int Cout, int B, int D, int H, int W) {
+  if (!pgrf_conv3d_wino16_supported(Cin, Cout, D, H, W)) return 0;
+  // rows (16 tiles x 64 output channels) are the kernel's unit of work and it wants two workgroups per CU: a layer with fewer than ~1.5 rows
+  // per CU gives every row to several work items, each over a share of the 32-channel input blocks
+  const long long rows = (long long)B * (D / 2) * (H / 2) * (W / 32) * (Cout / 64);
+  const int chunks = Cin / 32;
+  if (rows <= 0 || rows >= 384) return 0;
+  long long s = 512 / rows;
+  if (s > chunks) s = chunks;
+  if (s > 8) s = 8;
+  return s >= 2 ? (int)s : 0;
+}
+
+static int wino16_launch(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                         const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                         int res_cs, int res_coff, float* pool_out, int pool_cs, int pool_coff, int ksplit, float* scratch, void* stream);
+
 int pgrf_conv3d_wino16_pool(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
                             const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
                             int res_cs, int res_coff, float* pool_out, int pool_cs, int pool_coff, void* stream) {
+  return wino16_launch(in, in_cs, in_coff, Cin, out, out_cs, out_coff, Cout, packed, has_bias, B, D, H, W, lrelu_slope, residual, res_cs, res_coff,
+                       pool_out, pool_cs, pool_coff, 1, nullptr, stream);
+}
+
+int pgrf_conv3d_wino16_splitk(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                              const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, int ksplit,
+                              float* scratch, size_t scratch_floats, void* stream) {
+  if (ksplit < 2 || ksplit > Cin / 32) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino16_splitk: ksplit %d outside [2, Cin / 32 = %d]", ksplit, Cin / 32);
+  const size_t need = (size_t)ksplit * B * D * H * W * Cout;
+  if (!scratch || scratch_floats < need) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino16_splitk: scratch of %zu floats needed", need);
+  return wino16_launch(in, in_cs, in_coff, Cin, out, out_cs, out_coff, Cout, packed, has_bias, B, D, H, W, lrelu_slope, nullptr, 0, 0,
+                       nullptr, 0, 0, ksplit, scratch, stream);
+}
+
+static int wino16_launch(const float* in, int in_cs, int in_coff, int Cin, float* out, int out_cs, int out_coff, int Cout,
+                         const float* packed, int has_bias, int B, int D, int H, int W, float lrelu_slope, const float* residual,
+                         int res_cs, int res_coff, float* pool_out, int pool_cs, int pool_coff, int ksplit, float* scratch, void* stream) {
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino16: null pointer");
   if (!pgrf_conv3d_wino16_supported(Cin, Cout, D, H, W))
     return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: needs Cin a multiple of 32, Cout a multiple of 64 (<= %d), even D and H, W %% 32 == 0 "
@@ -562,7 +620,13 @@ int pgrf_conv3d_wino16_pool(const float* in, int in_cs, int in_coff, int Cin, fl
   a.wpk = packed;
   a.pool = pool_out; a.pool_cs = pool_cs; a.pool_coff = pool_coff;
   a.bias = has_bias ? packed + (size_t)(Cout / 64) * 64 * a.chunks * 2048 : nullptr;
-  const long long nrows_ll = (long long)B * (D / 2) * (H / 2) * (W / 32) * (Cout / 64);
+  const float* bias_dev = a.bias;
+  const long long nvox = (long long)B * D * H * W;
+  if (ksplit > 1) {          // raw partial sums into the scratch buffers; bias and activation in the reduce kernel behind
+    a.out = scratch; a.out_cs = Cout; a.out_coff = 0; a.slope = 1.f; a.bias = nullptr; a.pool = nullptr;
+    a.ksplit = ksplit; a.ksplit_stride = nvox * Cout;
+  }
+  const long long nrows_ll = (long long)B * (D / 2) * (H / 2) * (W / 32) * (Cout / 64) * (ksplit > 1 ? ksplit : 1);
   if (nrows_ll >= (1ll << 31)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: too many tile rows");
   const int nrows = (int)nrows_ll;
   int dev = 0;
@@ -588,6 +652,13 @@ int pgrf_conv3d_wino16_pool(const float* in, int in_cs, int in_coff, int Cin, fl
   dim3 grid((unsigned)(nrows < wgs ? nrows : wgs));
   hipLaunchKernelGGL(conv3d_wino16_kernel, grid, dim3(w16::kThreads), w16::kLdsBytes, (hipStream_t)stream, a, nrows);
   PGRF_CHECK_LAUNCH("conv3d_wino16");
+  if (ksplit > 1) {
+    const long long n4 = nvox * (Cout / 4);
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino16_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, a.ksplit_stride, ksplit, bias_dev, out, out_cs,
+                       out_coff, nvox, Cout, lrelu_slope);
+    PGRF_CHECK_LAUNCH("conv3d_wino16 split-K reduce");
+  }
   return PGRF_OK;
 }
 

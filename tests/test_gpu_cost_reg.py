@@ -323,6 +323,38 @@ def test_winograd_conv_with_pooled_output(cin, cout, B, D, H, W, fused, monkeypa
     assert torch.equal(out2.buf, out.buf)
 
 
+@pytest.mark.parametrize('cin,cout,B,D,H,W', [(64, 128, 1, 4, 4, 32), (512, 128, 1, 16, 16, 32), (256, 512, 1, 8, 16, 32), (96, 128, 2, 2, 4, 64),
+                                              (128, 128, 1, 6, 2, 32)])
+def test_winograd_split_k_vs_oracle(cin, cout, B, D, H, W, monkeypatch):
+    """pgrf_conv3d_wino16_splitk: layers with few rows (the low-resolution levels of UNet2) run every row as several work items over shares
+    of the 32-channel input blocks, partial sums reduced with bias + LeakyReLU behind.  Same tolerance as the unsplit kernel; the host rule
+    (pgrf_conv3d_wino16_ksplit) must pick a split for these shapes, and every split up to the block count must give the same result."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_reg as R
+    from panogrf_amd._lib import lib
+    g = torch.Generator().manual_seed(cin + 3 * cout + D + H)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5, 'c.bias': torch.randn(cout, generator=g) * 0.1}
+    ref = torch.nn.functional.leaky_relu(O._conv3(w, 'c', x, 1), 0.01)
+    pc = R._PackedConv(w['c.weight'], w['c.bias'], 'cuda')
+    xin = R._Vol(R._to_ndhwc(x.cuda()), 0, cin)
+    ks = lib.pgrf_conv3d_wino16_ksplit(cin, cout, B, D, H, W)
+    assert 2 <= ks <= cin // 32 and R._wino16_ksplit(pc, xin, 1, None) == ks
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    out = R._conv(pc, xin, R._Vol.empty(B, D, H, W, cout, 'cuda'))                    # the host's own choice
+    assert max_abs(out.buf.permute(0, 4, 1, 2, 3).cpu(), ref) < tol
+    for s_ in sorted({2, cin // 32}):                                                  # the extremes, into a channel slice of a wider tensor
+        wide = R._Vol.empty(B, D, H, W, cout + 8, 'cuda')
+        wide.buf.fill_(7.0)
+        scratch = torch.empty(s_ * B * D * H * W * cout, device='cuda')
+        lib.check(lib.pgrf_conv3d_wino16_splitk(R._ptr(xin.buf), xin.cs, xin.coff, cin, R._ptr(wide.buf), wide.cs, 4, cout, R._ptr(pc.wino16()), 1,
+                                                B, D, H, W, 0.01, s_, R._ptr(scratch), scratch.numel(), R._stream()))
+        assert max_abs(wide.buf[..., 4:4 + cout].permute(0, 4, 1, 2, 3).cpu(), ref) < tol
+        assert bool((wide.buf[..., :4] == 7.0).all()) and bool((wide.buf[..., 4 + cout:] == 7.0).all())
+    assert lib.pgrf_conv3d_wino16_splitk(R._ptr(xin.buf), xin.cs, xin.coff, cin, R._ptr(out.buf), out.cs, 0, cout, R._ptr(pc.wino16()), 1,
+                                         B, D, H, W, 0.01, cin // 32 + 1, R._ptr(out.buf), 10 ** 9, None) != 0          # more items than blocks
+
+
 def test_winograd_conv_rejects_what_it_cannot_do():
     import ctypes
     from panogrf_amd._lib import lib
