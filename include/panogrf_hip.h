@@ -317,7 +317,8 @@ int pgrf_conv3d_wino(const float* in, int in_cs, int in_coff, int Cin, float* ou
 /* The same algorithm, second kernel generation (round 4; csrc/conv3d_wino16.hip): rows of 16 tiles, v_mfma_f32_16x16x4_f32, TWO
  * independent 8-wave workgroups per CU (78 KB of LDS each) instead of one 16-wave workgroup -- one's barriers, epilogue and operand
  * formation run under the other's MFMAs.  Own packing (k permutation of the 16-row MFMA, bias in natural order).  Needs
- * Cin % 32 == 0, Cout % 64 == 0 (<= 1024), even D and H, W % 32 == 0.  Environment switch of the Python host: PANOGRF_WINO=32
+ * Cin % 32 == 0, Cout % 64 == 0 (<= 1024), even D and H, W % 32 == 0 or W == 16 (a 32-voxel row then walks the circular volume twice and
+ * stores its first half).  Environment switch of the Python host: PANOGRF_WINO=32
  * selects the first generation where both apply. */
 size_t pgrf_conv3d_wino16_packed_floats(int Cout, int Cin);
 int pgrf_pack_conv3d_wino16(const float* w_host, const float* bias_host, int Cout, int Cin, float* packed_host);

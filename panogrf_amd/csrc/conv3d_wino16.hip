@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
   float* lbias = lds + kTFloats + kStageFloats;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;                         // waves 4..7 feed LDS, waves 0..3 run the MFMAs
-  const int Wg = a.W / (2 * TX), Ht = a.H >> 1, Dt = a.D >> 1, cgroups = a.cot_total >> 1;
+  const int Wg = (a.W + 2 * TX - 1) / (2 * TX), Ht = a.H >> 1, Dt = a.D >> 1, cgroups = a.cot_total >> 1;
   const long long rowstride = (long long)a.W * a.in_cs;              // floats between consecutive y
   const long long planestride = rowstride * a.H;
 
@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
     auto prefetch = [&](const Row& r, int blk) {
       const char* eb = reinterpret_cast<const char*>(a.in + (long long)r.b * a.D * planestride + a.in_coff);
       int xm = r.x0 - 1 + ip;
-      xm = xm < 0 ? xm + a.W : (xm >= a.W ? xm - a.W : xm);
+      xm = xm < 0 ? xm + a.W : xm;
+      while (xm >= a.W) xm -= a.W;                         // (W = 16: a 32-voxel row walks the circular volume twice; its second half is not stored)
       const unsigned moff = ((unsigned)xm * (unsigned)a.in_cs + icq * 4 + blk * 32) * 4u;
 #pragma unroll
       for (int zy = 0; zy < 16; ++zy) {
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
         raw[zy] = sload16(eb + ((unsigned)zc * ps4 + (unsigned)yc * rs4), moff);
       }
       int xh = r.x0 + 2 * TX - 1 + hp;
-      xh = xh >= a.W ? xh - a.W : xh;
+      while (xh >= a.W) xh -= a.W;
       const int hz = min(max(r.z0 - 1 + (hzy >> 2), 0), a.D - 1), hy = min(max(r.y0 - 1 + (hzy & 3), 0), a.H - 1);
       const unsigned hoff = (unsigned)hz * ps4 + (unsigned)hy * rs4 + ((unsigned)xh * (unsigned)a.in_cs + hcq * 4 + blk * 32) * 4u;
       hraw = sload16(eb, hoff);
@@ -440,6 +441,7 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
       const int t = wave;
       const long long ov0 = (((long long)cur.b * a.D + cur.z0) * a.H + cur.y0) * a.W + cur.x0 + 2 * n;
       const int coff = a.out_coff + cur.cg * 64 + t * 16 + kq * 4;
+      const bool x_in = cur.x0 + 2 * n < a.W;               // (W = 16: tiles 8..15 of the row are the wrapped repeat of tiles 0..7)
       float* const outp = a.out + (long long)cur.split * a.ksplit_stride;       // (split-K: this item's partial-sum buffer)
       float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -451,11 +453,13 @@ __global__ void __launch_bounds__(w16::kThreads, 4) conv3d_wino16_kernel(const C
         v1.x = v1.x > 0.f ? v1.x : v1.x * a.slope; v1.y = v1.y > 0.f ? v1.y : v1.y * a.slope;
         v1.z = v1.z > 0.f ? v1.z : v1.z * a.slope; v1.w = v1.w > 0.f ? v1.w : v1.w * a.slope;
         const long long ov = ov0 + (long long)(oyox >> 1) * a.W + (oyox & 1);
-        *reinterpret_cast<float4*>(outp + ov * a.out_cs + coff) = v0;
-        *reinterpret_cast<float4*>(outp + (ov + (long long)a.H * a.W) * a.out_cs + coff) = v1;
+        if (x_in) {
+          *reinterpret_cast<float4*>(outp + ov * a.out_cs + coff) = v0;
+          *reinterpret_cast<float4*>(outp + (ov + (long long)a.H * a.W) * a.out_cs + coff) = v1;
+        }
         pool = f4add(pool, f4add(v0, v1));
       }
-      if (a.pool) {
+      if (a.pool && x_in) {
         const long long pv = (((long long)cur.b * (a.D >> 1) + (cur.z0 >> 1)) * (a.H >> 1) + (cur.y0 >> 1)) * (a.W >> 1) + (cur.x0 >> 1) + n;
         *reinterpret_cast<float4*>(a.pool + pv * a.pool_cs + a.pool_coff + cur.cg * 64 + t * 16 + kq * 4) =
             make_float4(pool.x * 0.125f, pool.y * 0.125f, pool.z * 0.125f, pool.w * 0.125f);
@@ -542,14 +546,14 @@ int pgrf_pack_conv3d_wino16(const float* w_host, const float* bias_host, int Cou
 }
 
 int pgrf_conv3d_wino16_supported(int Cin, int Cout, int D, int H, int W) {
-  return (Cin % 32 == 0) && (Cout % 64 == 0) && (Cout <= w16::kBiasFloats) && (D % 2 == 0) && (H % 2 == 0) && (W % 32 == 0) && D >= 2 && H >= 2 && W >= 32;
+  return (Cin % 32 == 0) && (Cout % 64 == 0) && (Cout <= w16::kBiasFloats) && (D % 2 == 0) && (H % 2 == 0) && (W % 32 == 0 || W == 16) && D >= 2 && H >= 2 && W >= 16;
 }
 
 int pgrf_conv3d_wino16_preferred(int Cin, int Cout, int B, int D, int H, int W) {
   if (!pgrf_conv3d_wino16_supported(Cin, Cout, D, H, W)) return 0;
   // persistent, two workgroups per CU, a row (16 tiles x 64 output channels) is the unit of work: below ~200 rows most of the
   // chip idles and the split-K direct kernel wins
-  const long long rows = (long long)B * (D / 2) * (H / 2) * (W / 32) * (Cout / 64);
+  const long long rows = (long long)B * (D / 2) * (H / 2) * ((W + 31) / 32) * (Cout / 64);
   return rows >= 192 ? 1 : 0;
 }
 
@@ -564,7 +568,7 @@ int pgrf_conv3d_wino16_ksplit(int Cin, int Cout, int B, int D, int H, int W) {
   if (!pgrf_conv3d_wino16_supported(Cin, Cout, D, H, W)) return 0;
   // rows (16 tiles x 64 output channels) are the kernel's unit of work and it wants two workgroups per CU: a layer with fewer than ~1.5 rows
   // per CU gives every row to several work items, each over a share of the 32-channel input blocks
-  const long long rows = (long long)B * (D / 2) * (H / 2) * (W / 32) * (Cout / 64);
+  const long long rows = (long long)B * (D / 2) * (H / 2) * ((W + 31) / 32) * (Cout / 64);
   const int chunks = Cin / 32;
   if (rows <= 0 || rows >= 384) return 0;
   long long s = 512 / rows;
@@ -599,7 +603,7 @@ static int wino16_launch(const float* in, int in_cs, int in_coff, int Cin, float
                          int res_cs, int res_coff, float* pool_out, int pool_cs, int pool_coff, int ksplit, float* scratch, void* stream) {
   if (!in || !out || !packed) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino16: null pointer");
   if (!pgrf_conv3d_wino16_supported(Cin, Cout, D, H, W))
-    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: needs Cin a multiple of 32, Cout a multiple of 64 (<= %d), even D and H, W %% 32 == 0 "
+    return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: needs Cin a multiple of 32, Cout a multiple of 64 (<= %d), even D and H, W %% 32 == 0 or W == 16 "
                      "(got Cin %d Cout %d D %d H %d W %d); use pgrf_conv3d_wrap", w16::kBiasFloats, Cin, Cout, D, H, W);
   if (B < 1) return set_error(PGRF_ERR_ARG, "pgrf_conv3d_wino16: bad dims");
 #ifndef PGRF_WINO_TIMING
@@ -626,7 +630,7 @@ static int wino16_launch(const float* in, int in_cs, int in_coff, int Cin, float
     a.out = scratch; a.out_cs = Cout; a.out_coff = 0; a.slope = 1.f; a.bias = nullptr; a.pool = nullptr;
     a.ksplit = ksplit; a.ksplit_stride = nvox * Cout;
   }
-  const long long nrows_ll = (long long)B * (D / 2) * (H / 2) * (W / 32) * (Cout / 64) * (ksplit > 1 ? ksplit : 1);
+  const long long nrows_ll = (long long)B * (D / 2) * (H / 2) * ((W + 31) / 32) * (Cout / 64) * (ksplit > 1 ? ksplit : 1);
   if (nrows_ll >= (1ll << 31)) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_conv3d_wino16: too many tile rows");
   const int nrows = (int)nrows_ll;
   int dev = 0;

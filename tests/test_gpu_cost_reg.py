@@ -258,7 +258,7 @@ def test_interior_wave_pipeline_vs_oracle(cin, cout, nt, split, monkeypatch):
                                                          (128, 64, 1, 2, 4, 64, False, 1.0), (64, 128, 1, 6, 2, 64, True, 0.2),
                                                          (32, 64, 1, 8, 8, 128, True, 0.01), (96, 192, 1, 2, 2, 64, True, 0.01),
                                                          (32, 64, 1, 4, 4, 32, True, 0.01), (64, 128, 2, 6, 8, 96, True, 0.01),
-                                                         (128, 64, 1, 2, 12, 32, False, 0.2)])
+                                                         (128, 64, 1, 2, 12, 32, False, 0.2), (32, 64, 1, 4, 4, 16, True, 0.01)])
 def test_winograd_conv_vs_oracle(cin, cout, B, D, H, W, bias, slope, monkeypatch):
     """pgrf_conv3d_wino (Winograd F(2x2x2, 3x3x3), csrc/conv3d_wino.hip) against F.conv3d of the oracle: volume faces
     (zero padding along D and H), the circular W seam, interior rows (D = H = 8), several channel blocks and cout groups,
@@ -269,7 +269,7 @@ def test_winograd_conv_vs_oracle(cin, cout, B, D, H, W, bias, slope, monkeypatch
     from panogrf_amd._lib import lib
     monkeypatch.setenv('PANOGRF_CONV_WINOGRAD', 'force')         # also for layers with too few rows to be preferred
     monkeypatch.setenv('PGRF_WINO_WGS', '3')                     # few workgroups: every one loops over several rows
-    assert lib.pgrf_conv3d_wino_supported(cin, cout, D, H, W) == 1
+    assert lib.pgrf_conv3d_wino16_supported(cin, cout, D, H, W) == 1
     g = torch.Generator().manual_seed(cin * 31 + cout * 7 + D + H + W)
     x = torch.randn(B, cin, D, H, W, generator=g)
     w = {'c.weight': torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5}
@@ -324,7 +324,7 @@ def test_winograd_conv_with_pooled_output(cin, cout, B, D, H, W, fused, monkeypa
 
 
 @pytest.mark.parametrize('cin,cout,B,D,H,W', [(64, 128, 1, 4, 4, 32), (512, 128, 1, 16, 16, 32), (256, 512, 1, 8, 16, 32), (96, 128, 2, 2, 4, 64),
-                                              (128, 128, 1, 6, 2, 32)])
+                                              (128, 128, 1, 6, 2, 32), (256, 512, 1, 8, 8, 16), (64, 128, 2, 4, 6, 16)])
 def test_winograd_split_k_vs_oracle(cin, cout, B, D, H, W, monkeypatch):
     """pgrf_conv3d_wino16_splitk: layers with few rows (the low-resolution levels of UNet2) run every row as several work items over shares
     of the 32-channel input blocks, partial sums reduced with bias + LeakyReLU behind.  Same tolerance as the unsplit kernel; the host rule
