@@ -570,8 +570,10 @@ int pgrf_conv3d_wino16_ksplit(int Cin, int Cout, int B, int D, int H, int W) {
   // per CU gives every row to several work items, each over a share of the 32-channel input blocks
   const long long rows = (long long)B * (D / 2) * (H / 2) * ((W + 31) / 32) * (Cout / 64);
   const int chunks = Cin / 32;
-  if (rows <= 0 || rows >= 384) return 0;
-  long long s = 512 / rows;
+  static const long long max_rows = [] { const char* e = getenv("PGRF_WINO16_KSPLIT_ROWS"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 384; }();   // tuning knobs (measured: rows < 384 / 512 items 5.42 | 1.62 ms, < 640 / 1024: 5.46 | 1.67, < 1100 / 2048: 5.58 | 1.77 -- UNet2 at 128x256x64 | 64x128x64)
+  static const long long items = [] { const char* e = getenv("PGRF_WINO16_KSPLIT_ITEMS"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 512; }();
+  if (rows <= 0 || rows >= max_rows) return 0;
+  long long s = (items + rows - 1) / rows;
   if (s > chunks) s = chunks;
   if (s > 8) s = 8;
   return s >= 2 ? (int)s : 0;
