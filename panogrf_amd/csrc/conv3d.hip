@@ -2432,6 +2432,63 @@ int pgrf_conv3d_upbrick(const float* in, int in_cs, int in_coff, int Cin, float*
   return PGRF_OK;
 }
 
+// Pointwise projection of a 64-channel volume onto the 27 tap vectors, streaming form (round 4): the general kernel in its pointwise mode
+// reads 537 MB and writes 226 MB in 244 us at 64x128x256 (3.1 TB/s).  Here the 27 x 64 weights live in registers for the whole launch (A
+// operands of `v_mfma_f32_32x32x2_f32`: row = tap), a persistent wave takes 32 consecutive voxels per step -- lane (n, half) loads its voxel's
+// channels 8q + 4 half .. with eight `dwordx4`, the next step's loads in flight under this step's 32 MFMAs -- and the accumulator layout
+// (lane = voxel, register = tap) makes every plane store 32 consecutive voxels per lane half.  Rows 27..31 of the plane block are not written.
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) cout1_project64_kernel(const float* __restrict__ in, int in_cs, int in_coff, const float* __restrict__ wlin,
+                                                              float* __restrict__ y, long long nvox) {
+  const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * 256) >> 6;
+  const long long ntiles = (nvox + 31) / 32;
+  float4 a[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    a[q] = n < 27 ? *reinterpret_cast<const float4*>(wlin + n * 64 + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](long long tile, float4 (&x)[8]) {
+    long long v = tile * 32 + n;
+    v = v < nvox ? v : nvox - 1;
+    const float* p = in + v * in_cs + in_coff + 4 * half;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const float4*>(p + 8 * q);
+  };
+  float4 xa[8], xb[8];
+  auto step = [&](long long tile, float4 (&x)[8]) {
+    f32x16p acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, x[q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, x[q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, x[q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, x[q].w, acc, 0, 0, 0);
+    }
+    const long long v = tile * 32 + n;
+    if (v < nvox) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (tap < 27) y[(long long)tap * nvox + v] = acc[r];
+      }
+    }
+  };
+  long long t = wave;
+  if (t < ntiles) fetch(t, xa);
+  while (t < ntiles) {
+    const long long t1 = t + nwaves;
+    if (t1 < ntiles) fetch(t1, xb);
+    step(t, xa);
+    if (t1 >= ntiles) break;
+    const long long t2 = t1 + nwaves;
+    if (t2 < ntiles) fetch(t2, xa);
+    step(t1, xb);
+    t = t2;
+  }
+}
+
 // Cout == 1 convolution in two passes (fast path for wide inputs): y[B,D,H,W,32] = per-voxel projections onto the 27
 // tap vectors (MFMA, pointwise), then a 27-tap gather.  y is caller-owned scratch of B*D*H*W*32 floats.
 int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, const float* packed, float* y, int B,
@@ -2445,6 +2502,16 @@ int pgrf_conv3d_cout1_project(const float* in, int in_cs, int in_coff, int Cin, 
   a.B = B; a.D = D; a.H = H; a.W = W; a.stride = 1; a.slope = 1.f; a.Do = D; a.Ho = H; a.Wo = W;
   a.chunks = (Cin + 31) / 32; a.cot_total = 1; a.residual = nullptr; a.res_cs = 0; a.res_coff = 0; a.wtaps = 1; a.tapmajor = 1; a.wrap_w = 1; a.elu = 0; a.res_first = 0;
   const size_t a_floats = (size_t)27 * a.chunks * 1024;
+  static const bool no_stream = [] { const char* e = getenv("PGRF_COUT1_PROJECT_STREAM"); return e && e[0] == '0'; }();
+  if (Cin == 64 && !no_stream) {
+    static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const long long nvox = (long long)B * D * H * W, tiles = (nvox + 31) / 32;
+    long long blocks = (tiles + 3) / 4;
+    if (blocks > 3LL * ncu) blocks = 3LL * ncu;             // persistent: three 4-wave workgroups per CU (~130 registers)
+    hipLaunchKernelGGL(cout1_project64_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, in_cs, in_coff, packed + a_floats + 32, y, nvox);
+    PGRF_CHECK_LAUNCH("conv3d_cout1_project (streaming)");
+    return PGRF_OK;
+  }
   a.wpk = packed + a_floats + 32 + (((size_t)27 * Cin + 1 + 3) & ~(size_t)3);
   a.bias = nullptr;
   const long long tiles = ((long long)B * D * H * W + 31) / 32;
