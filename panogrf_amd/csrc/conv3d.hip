@@ -2438,7 +2438,7 @@ int pgrf_conv3d_upbrick(const float* in, int in_cs, int in_coff, int Cin, float*
 // channels 8q + 4 half .. with eight `dwordx4`, the next step's loads in flight under this step's 32 MFMAs -- and the accumulator layout
 // (lane = voxel, register = tap) makes every plane store 32 consecutive voxels per lane half.  Rows 27..31 of the plane block are not written.
 typedef float f32x16p __attribute__((ext_vector_type(16)));
-__global__ void __launch_bounds__(256) cout1_project64_kernel(const float* __restrict__ in, int in_cs, int in_coff, const float* __restrict__ wlin,
+__global__ void __launch_bounds__(256, 3) cout1_project64_kernel(const float* __restrict__ in, int in_cs, int in_coff, const float* __restrict__ wlin,
                                                               float* __restrict__ y, long long nvox) {
   const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
   const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * 256) >> 6;
