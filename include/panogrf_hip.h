@@ -205,6 +205,15 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
                               const float* depth, int rn, int dn, const PgrfPassGrad* grad, float* const* g_raw_dev,
                               float* g_img_feats, float* g_ray_feats, const PgrfPassOut* fwd_out, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* The same in two calls, for training loops that can hold a pass's activations between forward and backward (the workspace: ~9 KB per
+ * (ray, sample, view)): phase 1 = the staged forward alone (fills `workspace`, writes `fwd_out`; grad / g_* may be NULL) -- its outputs ARE the
+ * pass's outputs, equal to pgrf_render_pass's to round-off, so the autograd forward needs no fused launch; phase 2 = the reverse sweep over a
+ * workspace a phase-1 call with the same frame, weights, coords and depth left behind (the weights must not have changed in between: the
+ * reference's autograd has the same rule for its saved tensors).  phase 0 = both = pgrf_render_pass_backward. */
+int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* raw_dev, int n_raw, int use_vis, const float* coords,
+                                    const float* depth, int rn, int dn, const PgrfPassGrad* grad, float* const* g_raw_dev,
+                                    float* g_img_feats, float* g_ray_feats, const PgrfPassOut* fwd_out, void* workspace,
+                                    size_t workspace_bytes, void* stream, int phase);
 
 /* `render_c2f_all` (network/renderer.py:484-518): one composite over the sorted union of the
  * coarse and fine samples.  Inputs [rn,dn_c]/[rn,dn_f]; outputs sized dn_c+dn_f. */

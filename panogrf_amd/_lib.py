@@ -95,6 +95,9 @@ SYMBOLS = {
     "pgrf_render_pass_backward": (C.c_int, [C.POINTER(PgrfFrame), C.POINTER(_P), C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
                                             C.POINTER(PgrfPassGrad), C.POINTER(_P), _P, _P, C.POINTER(PgrfPassOut), _P,
                                             C.c_size_t, _P]),
+    "pgrf_render_pass_backward_phase": (C.c_int, [C.POINTER(PgrfFrame), C.POINTER(_P), C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
+                                                  C.POINTER(PgrfPassGrad), C.POINTER(_P), _P, _P, C.POINTER(PgrfPassOut), _P,
+                                                  C.c_size_t, _P, C.c_int]),
     "pgrf_depth_hypotheses": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, _P,
                                         C.c_int, _P, _P]),
     "pgrf_cost_volume_erp": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -449,8 +449,19 @@ size_t pgrf_render_pass_backward_workspace_bytes(int rfn, int rn, int dn) {
 int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_dev, int n_raw, int use_vis, const float* coords,
                               const float* depth, int rn, int dn, const PgrfPassGrad* grad, float* const* g_raw_dev, float* g_img_feats,
                               float* g_ray_feats, const PgrfPassOut* fwd_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return pgrf_render_pass_backward_phase(frame, raw_dev, n_raw, use_vis, coords, depth, rn, dn, grad, g_raw_dev, g_img_feats, g_ray_feats, fwd_out, workspace,
+                                         workspace_bytes, stream, 0);
+}
+
+int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* raw_dev, int n_raw, int use_vis, const float* coords,
+                                    const float* depth, int rn, int dn, const PgrfPassGrad* grad, float* const* g_raw_dev, float* g_img_feats,
+                                    float* g_ray_feats, const PgrfPassOut* fwd_out, void* workspace, size_t workspace_bytes, void* stream, int phase) {
+  if (phase < 0 || phase > 2) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward_phase: phase %d (0 both, 1 staged forward, 2 backward sweep)", phase);
+  const bool do_fwd = phase != 2, do_bwd = phase != 1;
   if (rn == 0) return PGRF_OK;             // empty batch: nothing to add to the gradients
-  if (!frame || !raw_dev || !coords || !depth || !grad || !g_raw_dev) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: null pointer");
+  static float* const kNoGrads[R_COUNT] = {};
+  if (!do_bwd && !g_raw_dev) g_raw_dev = kNoGrads;       // (the forward phase reads no gradient pointers)
+  if (!frame || !raw_dev || !coords || !depth || (do_bwd && !grad) || !g_raw_dev) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: null pointer");
   if (n_raw != R_COUNT) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: expected %d raw tensors, got %d", R_COUNT, n_raw);
   if (frame->rfn < 1 || frame->rfn > PGRF_MAX_VIEWS) return set_error(PGRF_ERR_ARG, "pgrf_render_pass_backward: rfn=%d not in [1,%d]", frame->rfn, PGRF_MAX_VIEWS);
   if (dn < 3 || dn > PGRF_MAX_DN) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_render_pass_backward: dn=%d outside [3,%d]", dn, PGRF_MAX_DN);
@@ -475,7 +486,7 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   SideStream* ss = side_stream();
   Ctx c{(hipStream_t)stream, raw_dev, g_raw_dev, w.grep, gsize, ss ? ss->s : nullptr, ss ? ss->ev : nullptr, ss ? &ss->next : nullptr, 32, ss ? &ss->cur : nullptr};
   struct Joiner { const Ctx& c; ~Joiner() { c.join(); } } joiner{c};      // error returns included: the caller's stream never runs ahead of the side stream
-  (void)hipMemsetAsync(w.grep, 0, (size_t)(kGradReplicas - 1) * kGradSlot * R_COUNT * 4, c.st);
+  if (do_bwd) (void)hipMemsetAsync(w.grep, 0, (size_t)(kGradReplicas - 1) * kGradSlot * R_COUNT * 4, c.st);
   hipStream_t st = c.st;
   const int NM = use_vis ? 4 : 3;
   static const int kDD[4][6] = {{R_DD_MEAN_0_W, R_DD_MEAN_0_B, R_DD_MEAN_2_W, R_DD_MEAN_2_B, R_DD_MEAN_4_W, R_DD_MEAN_4_B},
@@ -499,12 +510,12 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
   a.H = frame->H; a.W = frame->W; a.hf = frame->hf; a.wf = frame->wf; a.hr = frame->hr; a.wr = frame->wr;
   a.coords = coords; a.depth = depth; a.rn = rn;
   GeomOut go{w.tap_rf_o, w.tap_rf_w, w.tap_if_o, w.tap_if_w, w.rgb, w.dd, w.depth_v, w.hw};
-  hipLaunchKernelGGL(geometry_kernel, dim3(nblk(PV)), dim3(256), 0, st, a, dn, V, go);
-  hipLaunchKernelGGL(fill_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w1, wgt, PV);
-  hipLaunchKernelGGL(posenc_table_kernel, dim3(nblk((long)dn * 16)), dim3(256), 0, st, w.pos, dn);
+  if (do_fwd) hipLaunchKernelGGL(geometry_kernel, dim3(nblk(PV)), dim3(256), 0, st, a, dn, V, go);
+  if (do_fwd) hipLaunchKernelGGL(fill_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w1, wgt, PV);
+  if (do_fwd) hipLaunchKernelGGL(posenc_table_kernel, dim3(nblk((long)dn * 16)), dim3(256), 0, st, w.pos, dn);
   const long rf_stride = (long)frame->hr * frame->wr * 32, if_stride = (long)frame->hf * frame->wf * 32;
-  hipLaunchKernelGGL(gather32_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.pe_in, 34, 0);
-  hipLaunchKernelGGL(gather32_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.imf, 32, 0);
+  if (do_fwd) hipLaunchKernelGGL(gather32_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.pe_in, 34, 0);
+  if (do_fwd) hipLaunchKernelGGL(gather32_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.imf, 32, 0);
   PGRF_TCHECK("train geometry");
 
   // ------------------------------------------------------------------ forward, every activation kept
@@ -514,75 +525,76 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
     dd_l[m][0] = Lin{w.pe_in, 34, w.dh1[m], 32, w.gdh1[m], 32, kDD[m][0], kDD[m][1], 32, 32, ACT_ELU};
     dd_l[m][1] = Lin{w.dh1[m], 32, w.dh2[m], 32, w.gdh2[m], 32, kDD[m][2], kDD[m][3], 32, 32, ACT_ELU};
     dd_l[m][2] = Lin{w.dh2[m], 32, w.dout[m], 2, w.gdout[m], 2, kDD[m][4], kDD[m][5], 32, kDDout[m], kDDact[m]};
-    L(chain_fwd(c, dd_l[m], 3, PV));
+    if (do_fwd) L(chain_fwd(c, dd_l[m], 3, PV));
   }
   ProbIO pio{w.depth_v, w.hw, frame->ref_depth_range, w.dout[0], w.dout[1], w.dout[2], use_vis ? w.dout[3] : nullptr, w.vis, w.hit};
-  hipLaunchKernelGGL(prob_kernel, dim3(nblk(PV)), dim3(256), 0, st, pio, PV, V, w.pe_in);
+  if (do_fwd) hipLaunchKernelGGL(prob_kernel, dim3(nblk(PV)), dim3(256), 0, st, pio, PV, V, w.pe_in);
   PGRF_TCHECK("train compute_prob");
   const Lin pe_l[2] = {{w.pe_in, 34, w.pe_h, 32, w.gpe_h, 32, R_PE_0_W, R_PE_0_B, 34, 32, ACT_RELU},               // prob_embed (aggregate_net.py:53-61)
                        {w.pe_h, 32, w.xin + 175, 207, w.gxin + 175, 207, R_PE_2_W, R_PE_2_B, 32, 32, ACT_NONE}};   //   -> neuray feature, xin[:, 175:207]
-  L(chain_fwd(c, pe_l, 2, PV));
+  if (do_fwd) L(chain_fwd(c, pe_l, 2, PV));
   const Lin rd_l[2] = {{w.dd, 4, w.d1, 16, w.gd1, 16, R_RD_0_W, R_RD_0_B, 4, 16, ACT_ELU},                          // ray_dir_fc
                        {w.d1, 16, w.dfeat, 35, w.gdfeat, 35, R_RD_2_W, R_RD_2_B, 16, 35, ACT_ELU}};
-  L(chain_fwd(c, rd_l, 2, PV));
-  hipLaunchKernelGGL(rgbfeat_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.rgb, w.imf, w.dfeat, PV, w.xin);
+  if (do_fwd) L(chain_fwd(c, rd_l, 2, PV));
+  if (do_fwd) hipLaunchKernelGGL(rgbfeat_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.rgb, w.imf, w.dfeat, PV, w.xin);
   const Lin nf_l[2] = {{w.xin + 175, 207, w.n1, 8, w.gn1, 8, R_NF_0_W, R_NF_0_B, 32, 8, ACT_ELU},                   // neuray_fc -> weight0 (ibrnet.py:337-338)
                        {w.n1, 8, w.nfs, 1, w.gw0, 1, R_NF_2_W, R_NF_2_B, 8, 1, ACT_SIGMOID}};
-  L(chain_fwd(c, nf_l, 2, PV));
-  hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w0, 1, 0, w.nfs, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
-  hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35);
-  hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105);
+  if (do_fwd) L(chain_fwd(c, nf_l, 2, PV));
+  if (do_fwd) hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w0, 1, 0, w.nfs, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
+  if (do_fwd) hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35);
+  if (do_fwd) hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105);
   PGRF_TCHECK("train view statistics");
   // base_fc.0 in two column blocks, like the fused kernel's L_BG / L_BV: the 140 view statistics are the SAME for the V views of a point,
   // so their product with W[:, 0:140] is formed once per point (hb, P rows) and enters the per-view layer -- W[:, 140:207] on the 67
   // per-view columns -- as an additive term.  The broadcast copy of the statistics into xin[:, 0:140] (147 MB per pass), its columns of the
   // layer's dX and their reduction over the views, and 140 of the 207 columns of the (point x view)-row dW are gone.
   const Lin glob_l[1] = {{w.glob, 140, w.hb, 64, w.ghb, 64, R_BASE_0_W, -1, 140, 64, ACT_NONE, 0, 207}};
-  L(chain_fwd(c, glob_l, 1, P));
+  if (do_fwd) L(chain_fwd(c, glob_l, 1, P));
   const Lin base_l[2] = {{w.xin + 140, 207, w.b1, 64, w.gb1, 64, R_BASE_0_W, R_BASE_0_B, 67, 64, ACT_ELU, 140, 207},    // base_fc
                          {w.b1, 64, w.x, 32, w.gx, 32, R_BASE_2_W, R_BASE_2_B, 64, 32, ACT_ELU}};
-  L(chain_fwd(c, base_l, 2, PV, w.hb, 64, V));
-  hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32);
+  if (do_fwd) L(chain_fwd(c, base_l, 2, PV, w.hb, 64, V));
+  if (do_fwd) hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32);
   const Lin vf_l[2] = {{w.xw, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, 32, 32, ACT_ELU},                      // vis_fc
                        {w.v1h, 32, w.xv, 33, w.gxv, 33, R_VF_2_W, R_VF_2_B, 32, 33, ACT_ELU}};
-  L(chain_fwd(c, vf_l, 2, PV));
-  hipLaunchKernelGGL(visfc_post_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.x, w.xv, PV, w.xr, w.v1);
-  hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32);
+  if (do_fwd) L(chain_fwd(c, vf_l, 2, PV));
+  if (do_fwd) hipLaunchKernelGGL(visfc_post_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.x, w.xv, PV, w.xr, w.v1);
+  if (do_fwd) hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32);
   const Lin v2_l[2] = {{w.xv1, 32, w.f1, 32, w.gf1, 32, R_V2_0_W, R_V2_0_B, 32, 32, ACT_ELU},                       // vis_fc2 -> xr[:, 32]
                        {w.f1, 32, w.xr + 32, 37, w.gxr + 32, 37, R_V2_2_W, R_V2_2_B, 32, 1, ACT_SIGMOID}};
-  L(chain_fwd(c, v2_l, 2, PV));
-  hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 4)), dim3(256), 0, st, w.xr, 37, 33, w.dd, 4, 0, PV, 4, 0);
-  hipLaunchKernelGGL(wgt2_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, P, V, w.wgt2, w.gin);
-  hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 32)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32);
+  if (do_fwd) L(chain_fwd(c, v2_l, 2, PV));
+  if (do_fwd) hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 4)), dim3(256), 0, st, w.xr, 37, 33, w.dd, 4, 0, PV, 4, 0);
+  if (do_fwd) hipLaunchKernelGGL(wgt2_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, P, V, w.wgt2, w.gin);
+  if (do_fwd) hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 32)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32);
   PGRF_TCHECK("train pooled geometry feature");
   const Lin geo_l[2] = {{w.gin, 65, w.g1, 64, w.gg1, 64, R_GEO_0_W, R_GEO_0_B, 65, 64, ACT_ELU},                    // geometry_fc
                         {w.g1, 64, w.g2, 16, w.ggp, 16, R_GEO_2_W, R_GEO_2_B, 64, 16, ACT_ELU}};      // (d(gp)/d(g2) = 1: the gradient arrives in ggp)
-  L(chain_fwd(c, geo_l, 2, P));
-  hipLaunchKernelGGL(posenc_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.g2, w.pos, P, dn, w.gp);
-  L(lin_fwd(c, w.gp, 16, R_ATT_Q_W, -1, w.q, 16, P, 16, 16, ACT_NONE));                              // ray attention
-  L(lin_fwd(c, w.gp, 16, R_ATT_K_W, -1, w.k, 16, P, 16, 16, ACT_NONE));
-  L(lin_fwd(c, w.gp, 16, R_ATT_V_W, -1, w.v, 16, P, 16, 16, ACT_NONE));
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk((long)rn * 4 * dn)), dim3(256), 0, st, w.q, w.k, w.v, rn, dn, V <= 1 ? 1 : 0, w.o);
-  L(lin_fwd(c, w.o, 16, R_ATT_FC_W, -1, w.fo, 16, P, 16, 16, ACT_NONE));
-  hipLaunchKernelGGL(slice_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.fo, 16, 0, w.gp, 16, 0, P, 16, 1);           // + residual
-  hipLaunchKernelGGL(layernorm_kernel, dim3(nblk(P)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], raw_dev[R_ATT_LN_B], P, w.ln);
+  if (do_fwd) L(chain_fwd(c, geo_l, 2, P));
+  if (do_fwd) hipLaunchKernelGGL(posenc_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.g2, w.pos, P, dn, w.gp);
+  if (do_fwd) L(lin_fwd(c, w.gp, 16, R_ATT_Q_W, -1, w.q, 16, P, 16, 16, ACT_NONE));                              // ray attention
+  if (do_fwd) L(lin_fwd(c, w.gp, 16, R_ATT_K_W, -1, w.k, 16, P, 16, 16, ACT_NONE));
+  if (do_fwd) L(lin_fwd(c, w.gp, 16, R_ATT_V_W, -1, w.v, 16, P, 16, 16, ACT_NONE));
+  if (do_fwd) hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk((long)rn * 4 * dn)), dim3(256), 0, st, w.q, w.k, w.v, rn, dn, V <= 1 ? 1 : 0, w.o);
+  if (do_fwd) L(lin_fwd(c, w.o, 16, R_ATT_FC_W, -1, w.fo, 16, P, 16, 16, ACT_NONE));
+  if (do_fwd) hipLaunchKernelGGL(slice_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.fo, 16, 0, w.gp, 16, 0, P, 16, 1);           // + residual
+  if (do_fwd) hipLaunchKernelGGL(layernorm_kernel, dim3(nblk(P)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], raw_dev[R_ATT_LN_B], P, w.ln);
   const Lin og_l[2] = {{w.ln, 16, w.og1, 16, w.gog1, 16, R_OG_0_W, R_OG_0_B, 16, 16, ACT_ELU},                      // out_geometry_fc -> density
                        {w.og1, 16, w.sigma, 1, w.gsigma, 1, R_OG_2_W, R_OG_2_B, 16, 1, ACT_RELU}};
-  L(chain_fwd(c, og_l, 2, P));
+  if (do_fwd) L(chain_fwd(c, og_l, 2, P));
   const Lin rgb_l[3] = {{w.xr, 37, w.r1, 16, w.gr1, 16, R_RGB_0_W, R_RGB_0_B, 37, 16, ACT_ELU},                     // rgb_fc -> blending logits
                         {w.r1, 16, w.r2, 8, w.gr2, 8, R_RGB_2_W, R_RGB_2_B, 16, 8, ACT_ELU},
                         {w.r2, 8, w.logit, 1, w.glogit, 1, R_RGB_4_W, R_RGB_4_B, 8, 1, ACT_NONE}};
-  L(chain_fwd(c, rgb_l, 3, PV));
-  hipLaunchKernelGGL(blend_kernel, dim3(nblk(P)), dim3(256), 0, st, w.logit, w.rgb, P, V, w.blend, w.colors);
+  if (do_fwd) L(chain_fwd(c, rgb_l, 3, PV));
+  if (do_fwd) hipLaunchKernelGGL(blend_kernel, dim3(nblk(P)), dim3(256), 0, st, w.logit, w.rgb, P, V, w.blend, w.colors);
   PGRF_TCHECK("train forward tail");
-  if (fwd_out) {      // the staged forward's own outputs (tests: must equal the fused kernel's to round-off)
-    hipLaunchKernelGGL(composite_kernel, dim3(nblk(rn, 64)), dim3(64), 0, st, w.sigma, w.colors, depth, rn, dn, fwd_out->hit_prob,
+  if (fwd_out && do_fwd) {      // the staged forward's own outputs (tests: must equal the fused kernel's to round-off)
+    if (do_fwd) hipLaunchKernelGGL(composite_kernel, dim3(nblk(rn, 64)), dim3(64), 0, st, w.sigma, w.colors, depth, rn, dn, fwd_out->hit_prob,
                        fwd_out->pixel_colors, fwd_out->render_depth);
     if (fwd_out->density) (void)hipMemcpyAsync(fwd_out->density, w.sigma, P * 4, hipMemcpyDeviceToDevice, st);
     if (fwd_out->colors) (void)hipMemcpyAsync(fwd_out->colors, w.colors, P * 12, hipMemcpyDeviceToDevice, st);
   }
 
   // ------------------------------------------------------------------ backward
+  if (do_bwd) {
   hipLaunchKernelGGL(composite_bwd_kernel, dim3(nblk(rn, 4)), dim3(256), 0, st, w.sigma, w.colors, depth, rn, dn, grad->pixel_colors,
                      grad->render_depth, grad->hit_prob, grad->colors, grad->density, w.gsigma, w.gcol);
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.blend, w.rgb, w.gcol, P, V, w.glogit);
@@ -652,6 +664,7 @@ int pgrf_render_pass_backward(const PgrfFrame* frame, const float* const* raw_de
     hipLaunchKernelGGL(reduce_replicas_kernel, dim3(13, R_COUNT), dim3(256), 0, st, w.grep, gp);
     PGRF_TCHECK("train replica fold");
   }
+  }   // do_bwd
 #undef L
   return PGRF_OK;
 }

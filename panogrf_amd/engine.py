@@ -4,6 +4,7 @@ torch is used for device memory and streams only; every tensor handed to the lib
 caller-owned, contiguous float32 CUDA(HIP) tensor passed as a raw pointer.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -334,7 +335,28 @@ def raw_weight_tensors(state_dict, dd_prefix, agg_prefix, use_vis, device):
     return out
 
 
-def render_pass_backward(frame, raw, use_vis, coords, depth, grads, want_maps=True, want_forward=False):
+def render_pass_staged_forward(frame, raw, use_vis, coords, depth):
+    """Phase 1 of pgrf_render_pass_backward_phase: the staged forward of one pass with every activation kept.  -> (outputs dict, workspace
+    tensor) -- hand the workspace to render_pass_backward(..., workspace=ws) for the reverse sweep (same frame / raw / coords / depth)."""
+    _require_gpu()
+    dev = frame.device
+    coords, depth = _f32c(coords, dev), _f32c(depth, dev)
+    rn, dn = depth.shape
+    n = len(raw)
+    raw_arr = (C.c_void_p * n)()
+    for i, t in enumerate(raw):
+        raw_arr[i] = None if t is None else t.data_ptr()
+    fs = frame.c_struct()
+    fwd_t, fwd_s = _alloc_out(rn, dn, dev)
+    nws = lib.pgrf_render_pass_backward_workspace_bytes(frame.rfn, rn, dn)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+    if rn > 0:
+        lib.check(lib.pgrf_render_pass_backward_phase(C.byref(fs), raw_arr, n, int(bool(use_vis)), _ptr(coords), _ptr(depth), rn, dn,
+                                                      None, None, None, None, C.byref(fwd_s), _ptr(ws), C.c_size_t(nws), _stream(), 1))
+    return fwd_t, ws
+
+
+def render_pass_backward(frame, raw, use_vis, coords, depth, grads, want_maps=True, want_forward=False, workspace=None):
     """Backward of one network pass (pgrf_render_pass_backward).  raw: list from raw_weight_tensors; grads: dict with any of
     'pixel_colors_nr' [rn,3], 'render_depth' [rn], 'hit_prob_nr' [rn,dn], 'colors_nr' [rn,dn,3], 'density_nr' [rn,dn].
     -> (list of weight gradients in raw order (None where raw is None), g_img_feats [rfn,32,hf,wf], g_ray_feats [rfn,32,hr,wr]
@@ -368,10 +390,17 @@ def render_pass_backward(frame, raw, use_vis, coords, depth, grads, want_maps=Tr
     if want_forward:
         fwd_t, fwd_s = _alloc_out(rn, dn, dev)
     nws = lib.pgrf_render_pass_backward_workspace_bytes(frame.rfn, rn, dn)
-    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    lib.check(lib.pgrf_render_pass_backward(C.byref(fs), raw_arr, n, int(bool(use_vis)), _ptr(coords), _ptr(depth), rn, dn,
-                                            C.byref(pg), g_arr, _ptr(g_if), _ptr(g_rf), C.byref(fwd_s) if want_forward else None,
-                                            _ptr(ws), C.c_size_t(nws), _stream()))
+    if workspace is not None:
+        # the reverse sweep alone, over the activations render_pass_staged_forward left in `workspace`
+        if workspace.numel() < nws:
+            raise PgrfError('render_pass_backward: workspace smaller than the pass needs')
+        lib.check(lib.pgrf_render_pass_backward_phase(C.byref(fs), raw_arr, n, int(bool(use_vis)), _ptr(coords), _ptr(depth), rn, dn,
+                                                      C.byref(pg), g_arr, _ptr(g_if), _ptr(g_rf), None, _ptr(workspace), C.c_size_t(nws), _stream(), 2))
+    else:
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        lib.check(lib.pgrf_render_pass_backward(C.byref(fs), raw_arr, n, int(bool(use_vis)), _ptr(coords), _ptr(depth), rn, dn,
+                                                C.byref(pg), g_arr, _ptr(g_if), _ptr(g_rf), C.byref(fwd_s) if want_forward else None,
+                                                _ptr(ws), C.c_size_t(nws), _stream()))
     to_nchw = lambda t: None if t is None else t.permute(0, 3, 1, 2)
     return g_raw, to_nchw(g_if), to_nchw(g_rf), fwd_t
 
@@ -412,12 +441,23 @@ class RenderPassFunction(torch.autograd.Function):
         if frame is None:
             frame = Frame(imgs, img_feats.detach(), ray_feats.detach(), w2c, ref_dr, que_c2w, que_dr, device=imgs.device, **frame_kw)
             F_._store(F_._frames, f_ts, f_extra, frame, keep=1)
-        blob = F_._lookup(F_._blobs, list(raw), bool(use_vis))
-        if blob is None:
-            names = raw_names()
-            blob = pack_pass_weights({n: t.detach() for n, t in zip(names, raw) if t is not None}, 'dist_decoder', 'agg_net', use_vis).to(frame.device)
-            F_._store(F_._blobs, list(raw), bool(use_vis), blob, keep=4)
-        out = render_pass(frame, blob, use_vis, coords, depth, precision=precision)
+        # Training keeps a pass's activations between forward and backward (PANOGRF_TRAIN_KEEP_ACTS=0: the fused kernel forward + a
+        # rematerialising backward, ~9 KB less memory per (ray, sample, view) held): the staged forward's outputs ARE the pass's outputs
+        # (equal to the fused kernel's to 2e-5, tests/test_gpu_train_backward.py), so the fused launch and the second forward are saved.
+        rn = coords.shape[0]
+        keep = os.environ.get('PANOGRF_TRAIN_KEEP_ACTS', '1') != '0' and precision in (None, 'f32') and rn > 0 and \
+            lib.pgrf_render_pass_backward_workspace_bytes(frame.rfn, rn, depth.shape[1]) <= int(float(os.environ.get('PANOGRF_TRAIN_KEEP_ACTS_MAX_GB', '16')) * 2 ** 30)
+        ctx.ws = None
+        if keep:
+            raw_now = [(t.detach().to(frame.device, torch.float32).contiguous() if t is not None else None) for t in raw]
+            out, ctx.ws = render_pass_staged_forward(frame, raw_now, use_vis, coords, depth)
+        else:
+            blob = F_._lookup(F_._blobs, list(raw), bool(use_vis))
+            if blob is None:
+                names = raw_names()
+                blob = pack_pass_weights({n: t.detach() for n, t in zip(names, raw) if t is not None}, 'dist_decoder', 'agg_net', use_vis).to(frame.device)
+                F_._store(F_._blobs, list(raw), bool(use_vis), blob, keep=4)
+            out = render_pass(frame, blob, use_vis, coords, depth, precision=precision)
         ctx.frame, ctx.use_vis = frame, use_vis
         ctx.coords, ctx.depth = coords.detach(), depth.detach()
         # the weights go through save_for_backward: an in-place update between forward and backward (an optimiser step) is then
@@ -432,7 +472,9 @@ class RenderPassFunction(torch.autograd.Function):
         grads = {'pixel_colors_nr': g_pixel, 'render_depth': g_depth, 'hit_prob_nr': g_hit, 'colors_nr': g_colors, 'density_nr': g_density}
         saved = iter(ctx.saved_tensors)
         raw = [(next(saved).detach().to(ctx.frame.device, torch.float32).contiguous() if p else None) for p in ctx.present]
-        g_raw, g_if, g_rf, _ = render_pass_backward(ctx.frame, raw, ctx.use_vis, ctx.coords, ctx.depth, grads, want_maps=ctx.need_maps)
+        g_raw, g_if, g_rf, _ = render_pass_backward(ctx.frame, raw, ctx.use_vis, ctx.coords, ctx.depth, grads, want_maps=ctx.need_maps,
+                                                    workspace=ctx.ws)
+        ctx.ws = None
         return (None, None, None, g_if, g_rf) + tuple(g_raw)
 
 

@@ -96,6 +96,39 @@ def test_backward_vs_autograd_through_the_oracle(name, rn_sub, dn_sub):
         assert float(grf_ref.abs().max()) > 0 and float(gif_ref.abs().max()) > 0
 
 
+@pytest.mark.parametrize('name', ['render_stages_v2_dn32', 'render_stages_v3_vis'])
+def test_autograd_function_kept_activations_equal_rematerialised(name, monkeypatch):
+    """RenderPassFunction in its two modes: staged forward kept for the reverse sweep (default: pgrf_render_pass_backward_phase 1 / 2)
+    against the fused forward + rematerialising backward (PANOGRF_TRAIN_KEEP_ACTS=0).  Outputs equal to round-off (two different forward
+    kernels), gradients equal to ~1e-5 of their scale (the same sweep over the same activations, atomics in a different order)."""
+    from panogrf_amd import engine as E
+    frame, w, cfg, g = FX.load(name)
+    use_vis = cfg['dist_decoder_cfg']['use_vis']
+    depth = g['coarse']['depth'].cuda()
+    coords = frame['coords'].cuda()
+    rn, dn = depth.shape
+    up = {k: v.cuda() for k, v in _upstream(rn, dn, 5).items()}
+    res = []
+    for keep in ('1', '0'):
+        monkeypatch.setenv('PANOGRF_TRAIN_KEEP_ACTS', keep)
+        params = {k: torch.nn.Parameter(v.cuda().clone()) for k, v in w.items()}
+        imf = frame['img_feats'].cuda().clone().requires_grad_(True)
+        rf = frame['ray_feats'].cuda().clone().requires_grad_(True)
+        out = E.render_pass_autograd(frame['imgs'].cuda(), imf, rf, frame['w2c'].cuda(), frame['ref_depth_range'].cuda(), frame['que_c2w'],
+                                     frame['que_depth_range'], params, 'dist_decoder', 'agg_net', use_vis, coords, depth)
+        loss = sum((out[k] * up[k]).sum() for k in up)
+        loss.backward()
+        res.append(({k: v.detach().clone() for k, v in out.items()}, {k: p.grad.clone() for k, p in params.items() if p.grad is not None},
+                    imf.grad.clone(), rf.grad.clone()))
+    (o1, g1, i1, r1), (o0, g0, i0, r0) = res
+    for k in o1:
+        assert FX.max_abs(o1[k].cpu(), o0[k].cpu()) < 2e-5 * max(1.0, float(o0[k].abs().max())), k
+    assert g1.keys() == g0.keys() and len(g1) >= 62
+    for k in g1:
+        assert FX.max_abs(g1[k].cpu(), g0[k].cpu()) < 2e-4 * max(float(g0[k].abs().max()), 1e-3), k
+    assert FX.max_abs(i1.cpu(), i0.cpu()) < 2e-4 * float(i0.abs().max()) and FX.max_abs(r1.cpu(), r0.cpu()) < 2e-4 * float(r0.abs().max())
+
+
 def test_backward_argument_validation():
     import ctypes as C
     from panogrf_amd import engine as E
