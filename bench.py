@@ -259,8 +259,8 @@ def train_bench(args, dev, rank, world, distributed):
     """one TRAINING step of the per-ray networks as the reference's trainer runs it through
     network/renderer.py:567-633 -- coarse pass, importance sampling from the detached weights, fine pass, a photometric loss on
     both images, backward to every per-ray weight and to the two feature maps, Adam.  The 2-D encoders that produce the maps are
-    torch modules outside this path (their outputs are leaf tensors here).  Forward = the fused HIP kernel, backward =
-    pgrf_render_pass_backward (rematerialising).  Ranks are data-parallel: each its own rays, gradients all-reduced (RCCL)."""
+    torch modules outside this path (their outputs are leaf tensors here).  Forward = the staged HIP forward with its activations kept, backward = the
+    reverse sweep over them (pgrf_render_pass_backward_phase 1 / 2).  Ranks are data-parallel: each its own rays, gradients all-reduced (RCCL)."""
     from panogrf_amd import engine as E
     H, W, V, dn, rays = args.height, args.width, args.views, args.samples, args.train_rays
     case = synthetic_case(H, W, V, dn, seed=0, fine=True)
@@ -335,9 +335,9 @@ def train_bench(args, dev, rank, world, distributed):
                                   f'samples; gradients to all per-ray weights and to img_feats / ray_feats; Adam; encoders outside',
                       'rays_per_step_per_rank': rays, 'parallelism': f'data-parallel x{world}, gradient all-reduce'},
            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                        'traffic': None, 'kernel': 'whole step on the stream (2 fused forward passes, 2 staged forwards + backwards, sampler, loss, Adam)',
+                        'traffic': None, 'kernel': 'whole step on the stream (2 staged forward passes with their activations kept, 2 reverse sweeps, sampler, loss, Adam)',
                         'kernel_ms': gpu_ms, 'flop_per_ray': 3 * flop_per_ray(V, dn, 2), 'rays_per_launch': rays,
-                        'note': 'algorithmic = 3 x forward FLOPs (the rematerialising backward executes 4 x)'},
+                        'note': 'algorithmic = 3 x forward FLOPs = what the step executes (PANOGRF_TRAIN_KEEP_ACTS=0: fused forward + rematerialising backward, 4 x)'},
            'loss_first_last': [float(losses[0].detach()), float(losses[-1].detach())]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the eager-autograd port on the same GPU: the oracle's torch ops (the reference's graph) under torch.autograd, same rays
