@@ -1236,22 +1236,49 @@ __global__ void blend_bwd_kernel(const float* __restrict__ blend, const float* _
 //   alpha = 1 - exp(-relu(sigma)), T_i = prod_{j<i} (1 - alpha_j + 1e-10), hit_i = alpha_i T_i
 // backward: with G_i = d/d hit_i (own gradient + through the pixel colour and the depth) and B_i = sum_{k>i} G_k hit_k:
 //   d/d alpha_i = T_i G_i - B_i / (1 - alpha_i + 1e-10),  d/d sigma_i = (1 - alpha_i) d/d alpha_i,  d/d colour_i = hit_i g_pixel
-__global__ void composite_kernel(const float* __restrict__ sigma, const float* __restrict__ colors, const float* __restrict__ depth, int rn,
+// One wave per ray, like the backward below (lane l owns samples [E l, E l + E); the transmittance by a log-step prefix product, the
+// pixel / depth sums by a wave reduction): the thread-per-ray loop was 29 us on the path between the coarse pass and the sampler.
+__global__ void __launch_bounds__(256) composite_kernel(const float* __restrict__ sigma, const float* __restrict__ colors, const float* __restrict__ depth, int rn,
                                  int dn, float* __restrict__ hit, float* __restrict__ pixel, float* __restrict__ rdepth) {
-  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= rn) return;
-  float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dd = 0.f;
-  for (int i = 0; i < dn; ++i) {
-    const size_t p = (size_t)ray * dn + i;
-    const float alpha = 1.f - expf(-fmaxf(sigma[p], 0.f));
-    const float h = alpha * T;
-    if (hit) hit[p] = h;
-    c0 += h * colors[p * 3]; c1 += h * colors[p * 3 + 1]; c2 += h * colors[p * 3 + 2];
-    dd += h * depth[p];
-    T *= 1.f - alpha + 1e-10f;
+  constexpr int EMAX = (PGRF_MAX_DN + 63) / 64;
+  const int E = (dn + 63) >> 6;
+  float alpha[EMAX], f[EMAX], fl = 1.f;
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    const int i = E * lane + e;
+    const bool ok = e < E && i < dn;
+    alpha[e] = ok ? 1.f - expf(-fmaxf(sigma[(size_t)ray * dn + i], 0.f)) : 0.f;
+    f[e] = ok ? 1.f - alpha[e] + 1e-10f : 1.f;
+    fl *= f[e];
   }
-  if (pixel) { pixel[ray * 3] = c0; pixel[ray * 3 + 1] = c1; pixel[ray * 3 + 2] = c2; }
-  if (rdepth) rdepth[ray] = dd;
+  float incl = fl;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const float t = __shfl_up(incl, off, 64); if (lane >= off) incl *= t; }
+  float T = __shfl_up(incl, 1, 64);
+  if (lane == 0) T = 1.f;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, dd = 0.f;
+#pragma unroll
+  for (int e = 0; e < EMAX; ++e) {
+    const int i = E * lane + e;
+    if (e < E && i < dn) {
+      const size_t p = (size_t)ray * dn + i;
+      const float h = alpha[e] * T;
+      if (hit) hit[p] = h;
+      c0 += h * colors[p * 3]; c1 += h * colors[p * 3 + 1]; c2 += h * colors[p * 3 + 2];
+      dd += h * depth[p];
+    }
+    T *= f[e];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    c0 += __shfl_xor(c0, off, 64); c1 += __shfl_xor(c1, off, 64); c2 += __shfl_xor(c2, off, 64); dd += __shfl_xor(dd, off, 64);
+  }
+  if (lane == 0) {
+    if (pixel) { pixel[ray * 3] = c0; pixel[ray * 3 + 1] = c1; pixel[ray * 3 + 2] = c2; }
+    if (rdepth) rdepth[ray] = dd;
+  }
 }
 // One WAVE per ray (the first version ran a thread per ray: 32 waves on the whole chip walking 64 samples each with a scratch array,
 // 96 us for 1.5 MB of data).  Lane l owns samples [E l, E l + E), E = ceil(dn / 64) <= 2; T (exclusive prefix product of the

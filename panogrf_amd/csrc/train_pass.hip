@@ -587,7 +587,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   if (do_fwd) hipLaunchKernelGGL(blend_kernel, dim3(nblk(P)), dim3(256), 0, st, w.logit, w.rgb, P, V, w.blend, w.colors);
   PGRF_TCHECK("train forward tail");
   if (fwd_out && do_fwd) {      // the staged forward's own outputs (tests: must equal the fused kernel's to round-off)
-    if (do_fwd) hipLaunchKernelGGL(composite_kernel, dim3(nblk(rn, 64)), dim3(64), 0, st, w.sigma, w.colors, depth, rn, dn, fwd_out->hit_prob,
+    if (do_fwd) hipLaunchKernelGGL(composite_kernel, dim3(nblk(rn, 4)), dim3(256), 0, st, w.sigma, w.colors, depth, rn, dn, fwd_out->hit_prob,
                        fwd_out->pixel_colors, fwd_out->render_depth);
     if (fwd_out->density) (void)hipMemcpyAsync(fwd_out->density, w.sigma, P * 4, hipMemcpyDeviceToDevice, st);
     if (fwd_out->colors) (void)hipMemcpyAsync(fwd_out->colors, w.colors, P * 12, hipMemcpyDeviceToDevice, st);
