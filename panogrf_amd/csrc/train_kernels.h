@@ -996,6 +996,34 @@ __global__ void attn_fwd_kernel(const float* __restrict__ q, const float* __rest
   float* op = o + ((size_t)ray * dn + s) * 16 + h * 4;
   op[0] = a0 / l; op[1] = a1 / l; op[2] = a2 / l; op[3] = a3 / l;
 }
+// The same for dn <= 64 and more than one source view with the head's keys and values in LDS: one single-wave workgroup per (ray, head), lane =
+// query; the kernel above reads k and v through eight broadcast global loads per key and pass (1 024 vector-memory instructions per wave, 61 us).
+__global__ void __launch_bounds__(64) attn_fwd64_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vv, int rn,
+                                                        int dn, float* __restrict__ o) {
+  __shared__ float s_k[64][4], s_v[64][4];
+  const int ray = blockIdx.x >> 2, h = blockIdx.x & 3, s = threadIdx.x;
+  const size_t me = ((size_t)ray * dn + s) * 16 + h * 4;
+  const bool ok = s < dn;
+  float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
+  if (ok) { q4 = *reinterpret_cast<const float4*>(q + me); k4 = *reinterpret_cast<const float4*>(k + me); v4 = *reinterpret_cast<const float4*>(vv + me); }
+  *reinterpret_cast<float4*>(s_k[s]) = k4;
+  *reinterpret_cast<float4*>(s_v[s]) = v4;
+  __syncthreads();
+  const float q0 = q4.x * 0.5f, q1 = q4.y * 0.5f, q2 = q4.z * 0.5f, q3 = q4.w * 0.5f;
+  float mx = -3.0e38f;
+  for (int t = 0; t < dn; ++t) {
+    const float4 kt = *reinterpret_cast<const float4*>(s_k[t]);
+    mx = fmaxf(mx, q0 * kt.x + q1 * kt.y + q2 * kt.z + q3 * kt.w);
+  }
+  float l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int t = 0; t < dn; ++t) {
+    const float4 kt = *reinterpret_cast<const float4*>(s_k[t]), vt = *reinterpret_cast<const float4*>(s_v[t]);
+    const float e = expf(q0 * kt.x + q1 * kt.y + q2 * kt.z + q3 * kt.w - mx);
+    l += e;
+    a0 += e * vt.x; a1 += e * vt.y; a2 += e * vt.z; a3 += e * vt.w;
+  }
+  if (ok) *reinterpret_cast<float4*>(o + me) = make_float4(a0 / l, a1 / l, a2 / l, a3 / l);
+}
 // Backward of the attention of ONE (ray, head) per workgroup, thread = sample index (dn <= 128), no atomics:
 //   P_st = softmax_t(q_s k_t / 2);  gP_st = <go_s, v_t>;  gS_st = P_st (gP_st - <go_s, o_s>)
 //   phase 1 (thread = query s): row maximum / sum, <go_s, o_s>, and gq_s = 0.5 sum_t gS_st k_t

@@ -573,7 +573,10 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   if (do_fwd) L(lin_fwd(c, w.gp, 16, R_ATT_Q_W, -1, w.q, 16, P, 16, 16, ACT_NONE));                              // ray attention
   if (do_fwd) L(lin_fwd(c, w.gp, 16, R_ATT_K_W, -1, w.k, 16, P, 16, 16, ACT_NONE));
   if (do_fwd) L(lin_fwd(c, w.gp, 16, R_ATT_V_W, -1, w.v, 16, P, 16, 16, ACT_NONE));
-  if (do_fwd) hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk((long)rn * 4 * dn)), dim3(256), 0, st, w.q, w.k, w.v, rn, dn, V <= 1 ? 1 : 0, w.o);
+  if (do_fwd) {
+    if (dn <= 64 && V > 1) hipLaunchKernelGGL(attn_fwd64_kernel, dim3((unsigned)rn * 4), dim3(64), 0, st, w.q, w.k, w.v, rn, dn, w.o);
+    else hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk((long)rn * 4 * dn)), dim3(256), 0, st, w.q, w.k, w.v, rn, dn, V <= 1 ? 1 : 0, w.o);
+  }
   if (do_fwd) L(lin_fwd(c, w.o, 16, R_ATT_FC_W, -1, w.fo, 16, P, 16, 16, ACT_NONE));
   if (do_fwd) hipLaunchKernelGGL(slice_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.fo, 16, 0, w.gp, 16, 0, P, 16, 1);           // + residual
   if (do_fwd) hipLaunchKernelGGL(layernorm_kernel, dim3(nblk(P)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], raw_dev[R_ATT_LN_B], P, w.ln);
