@@ -657,15 +657,6 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
   }
 }
 
-// Y[r, c] = act(Y[r, c] + bias[c])  (epilogue of the forward GEMM)
-__global__ void bias_act_kernel(float* __restrict__ Y, int ldy, const float* __restrict__ bias, long rows, int cols, int act) {
-  const long n = rows * cols;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const unsigned iu = (unsigned)i; const long r = iu / (unsigned)cols; const int c = (int)(iu % (unsigned)cols);      // (n < 2^32: host guard; a 64-bit divide is ~100 instructions)
-    float* y = Y + r * ldy + c;
-    *y = act_fwd(*y + (bias ? bias[c] : 0.f), act);
-  }
-}
 // dY[r, c] *= act'(Y[r, c]);  gbias[c] += sum_r dY[r, c].  cols <= 64: thread = (column, row slot), the column sum stays in a register
 // over the block's rows, then one LDS reduction over the row slots and ONE atomic per column and block (the first version did an
 // LDS atomic per element: 2.4 ms of a 16 ms training step).

@@ -36,15 +36,6 @@ struct GradPtrs { float* p[R_COUNT]; int n[R_COUNT]; };
   } while (0)
 
 // ---- small glue kernels ----------------------------------------------------------------------------------------------
-// dst[r, dc + c] = src[r / div, sc + c]   (per-point values repeated for the views of the point)
-__global__ void bcast_kernel(float* __restrict__ dst, int ldd, int dc, const float* __restrict__ src, int lds, int sc, long rows, int div,
-                             int cols) {
-  const long n = rows * cols;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const unsigned iu = (unsigned)i; const long r = iu / (unsigned)cols; const int c = (int)(iu % (unsigned)cols);      // (n < 2^32: host guard; a 64-bit divide is ~100 instructions)
-    dst[r * ldd + dc + c] = src[(r / div) * lds + sc + c];
-  }
-}
 // dst[p, dc + c] (=|+=) sum_v src[p * V + v, sc + c]     (four columns per thread: cols, strides and offsets multiples of 4)
 __global__ void reduce_views_kernel(float* __restrict__ dst, int ldd, int dc, const float* __restrict__ src, int lds, int sc, long P, int V,
                                     int cols, int accumulate) {
