@@ -347,10 +347,14 @@ __global__ void __launch_bounds__(64) fine_depth_lane_kernel(const float* __rest
 
 int launch_fine_depth(const float* depth, const float* hit, float qnear, float qfar, int use_disp, int use_all, int rn,
                       int dn, int fdn, const float* urand, float* out, void* stream, int rows_equal) {
-  const char* knob = getenv("PGRF_FINE_DEPTH");          // "wave": the wave-per-ray kernel for every shape (A/B, tests)
+  const char* knob = getenv("PGRF_FINE_DEPTH");          // "wave" / "lane" / "noshare": one kernel for every shape (A/B, tests)
   const bool wave_only = knob && !strcmp(knob, "wave");
   const bool aligned = (((uintptr_t)depth | (uintptr_t)hit | (uintptr_t)out) & 15) == 0;
-  if (!wave_only && dn == fdn && (dn == 32 || dn == 64) && aligned && rn > 0) {
+  // The lane-per-ray kernel is a throughput form: 64 rays per wave, each lane a long serial run (~225 us whatever the batch while its
+  // waves fit the chip at once).  A training batch of 2 048 rays is 32 such waves; the wave-per-ray kernel (1.7 ns per ray) finishes
+  // it in a few microseconds.  Crossover ~130 k rays; both give the same bits.
+  const bool small = rn < 131072 && !(knob && (!strcmp(knob, "lane") || !strcmp(knob, "noshare")));
+  if (!wave_only && !small && dn == fdn && (dn == 32 || dn == 64) && aligned && rn > 0) {
     const int blocks = (rn + 63) / 64;
     const bool shared = rows_equal && !use_all && !(knob && !strcmp(knob, "noshare"));
 #define PGRF_FD(DN_, SH_) hipLaunchKernelGGL((fine_depth_lane_kernel<DN_, SH_>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, \

@@ -519,8 +519,9 @@ def test_lane_per_ray_sampler_equals_wave_per_ray_sampler(monkeypatch):
                 for draws in (None, u):
                     monkeypatch.setenv('PGRF_FINE_DEPTH', 'wave')
                     want = E.sample_fine_depth(depth, hit, (0.5, 15.0), dn, use_all=use_all, u=draws)
-                    monkeypatch.delenv('PGRF_FINE_DEPTH')
+                    monkeypatch.setenv('PGRF_FINE_DEPTH', 'lane')          # (small batches take the wave kernel by default)
                     got = E.sample_fine_depth(depth, hit, (0.5, 15.0), dn, use_all=use_all, u=draws)
+                    monkeypatch.delenv('PGRF_FINE_DEPTH')
                     assert got.shape == want.shape == (rn, dn * (2 if use_all else 1))
                     assert torch.equal(got, want), (dn, rn, use_all, draws is not None)
     # inside pgrf_render_rays the eval-mode coarse depths are one row for all rays: the sampler then keeps that row once
@@ -533,14 +534,14 @@ def test_lane_per_ray_sampler_equals_wave_per_ray_sampler(monkeypatch):
         ys, xs = torch.meshgrid(torch.arange(16, dtype=torch.float32), torch.arange(40, dtype=torch.float32), indexing='ij')
         coords = torch.stack([xs, ys], -1).reshape(-1, 2)[:637]
         outs = {}
-        for knob in (None, 'noshare', 'wave'):
+        for knob in (None, 'lane', 'noshare', 'wave'):
             if knob is None:
                 monkeypatch.delenv('PGRF_FINE_DEPTH', raising=False)
             else:
                 monkeypatch.setenv('PGRF_FINE_DEPTH', knob)
             outs[knob] = rr.render_rays(fr, coords)
         monkeypatch.delenv('PGRF_FINE_DEPTH', raising=False)
-        for knob in ('noshare', 'wave'):
+        for knob in ('lane', 'noshare', 'wave'):
             for k in ('depth_fine', 'pixel_colors_nr_fine', 'render_depth_fine'):
                 assert torch.equal(outs[None][k], outs[knob][k]), (dn, knob, k)
 
