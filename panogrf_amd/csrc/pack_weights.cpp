@@ -62,6 +62,28 @@ void pack_small(float* A, float* B, const float* W, int in_dim, const float* bia
   }
 }
 
+// "w16" block for the 16x16x4 MFMA path (pgrf_layout.h): in_feat / out_row as for the layer's 32-row tile (tile `m`)
+void pack_w16(float* A, float* B, const float* W, int in_dim, const float* bias, int ks, int m, const InMap& in_feat, const OutMap& out_row) {
+  const int k4 = w16_k4(ks), c4 = (k4 + 3) / 4;
+  for (int j = 0; j < c4 * 4; ++j)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int kk = lane >> 4, s = 2 * j + (kk & 1);
+      float v = 0.f;
+      if (j < k4 && s < ks && W) {
+        const int row = out_row(m, w16_row(lane & 15));
+        const int col = in_feat(s, kk >> 1);
+        if (row >= 0 && col >= 0) v = W[(size_t)row * in_dim + col];
+      }
+      A[((size_t)(j / 4) * 64 + lane) * 4 + (j & 3)] = v;
+    }
+  if (B)
+    for (int q = 0; q < 4; ++q)
+      for (int r = 0; r < 4; ++r) {
+        const int row = out_row(m, w16_row(4 * q + r));
+        B[q * 4 + r] = (row >= 0 && bias) ? bias[row] : 0.f;
+      }
+}
+
 // head block [half][R]: value = w[col(r, half)]
 void pack_head(float* dst, const float* w, int R, const std::function<int(int, int)>& col) {
   for (int h = 0; h < 2; ++h)
@@ -273,6 +295,23 @@ static void pack_permute(const float* const* raw, int use_vis, int max_dn, float
   pack_small(blob + OFF_S_RDC_A, blob + OFF_S_RDC_B, raw[R_RD_2_W], 16, raw[R_RD_2_B], 8, 1, 3, 0, ident_in);
   pack_small(blob + OFF_S_RGB2_A, blob + OFF_S_RGB2_B, raw[R_RGB_2_W], 16, raw[R_RGB_2_B], 8, 2, 8, 0, ident_in);
   for (int o = 0; o < 8; ++o) blob[OFF_S_RGB2_H + o] = raw[R_RGB_4_W][o];
+  // ---- 16-row layers for the 16x16x4 MFMA path (pgrf_layout.h: OFF_W16_*): the same maps as their 32-row tiles above
+  {
+    const OutMap rows16 = [](int, int r) { return r < 16 ? r : -1; };
+    pack_w16(blob + OFF_W16_RGB1, blob + OFF_W16B_RGB1, raw[R_RGB_0_W], 37, raw[R_RGB_0_B], 19, 0,
+             [](int s, int h) {
+               if (s < 16) return rho(s, h);
+               const int c = 32 + 2 * (s - 16) + h;
+               return c < 37 ? c : -1;
+             }, rows16);
+    pack_w16(blob + OFF_W16_G2, blob + OFF_W16B_G2, raw[R_GEO_2_W], 64, raw[R_GEO_2_B], 32, 0,
+             [](int s, int h) { return s < 16 ? rho(s, h) : 32 + rho(s - 16, h); }, rows16);
+    pack_w16(blob + OFF_W16_V, nullptr, raw[R_ATT_V_W], 16, nullptr, 8, 0, ident_in,
+             [](int, int r) { return r < 16 ? attn_feat(r) : -1; });
+    pack_w16(blob + OFF_W16_FC, nullptr, raw[R_ATT_FC_W], 16, nullptr, 8, 0,
+             [](int s, int h) { return 4 * (s >> 1) + 2 * (s & 1) + h; }, rows16);
+    pack_w16(blob + OFF_W16_OG1, blob + OFF_W16B_OG1, raw[R_OG_0_W], 16, raw[R_OG_0_B], 8, 0, ident_in, rows16);
+  }
   // ---- split-f16 copies of all A blocks (pgrf_layout.h: layer_h_off) ----------------------------
   for (int id = 0; id < L_COUNT; ++id) {
     const int ks = kKS[id], mt = kMT[id], ks4 = (ks + 3) / 4, G = h_groups(ks);

@@ -91,9 +91,14 @@ constexpr int OFF_RGBH_B = OFF_RGBH_W + 8;
 // LayerNorm gamma, beta: [half][8] each
 constexpr int OFF_LN_G = OFF_RGBH_B + 4;
 constexpr int OFF_LN_B = OFF_LN_G + 16;
+// bias blocks of the 16-row layers on v_mfma_f32_16x16x4_f32 ("w16" blocks below): [lane >> 4][4], kept inside the head region so
+// that they ride in the LDS image
+constexpr int OFF_W16B_RGB1 = OFF_LN_B + 16;
+constexpr int OFF_W16B_G2 = OFF_W16B_RGB1 + 16;
+constexpr int OFF_W16B_OG1 = OFF_W16B_G2 + 16;
 // positional encoding [PGRF_MAX_DN][half][8]
 constexpr int kMaxDn = 128;
-constexpr int OFF_POS = OFF_LN_B + 16;
+constexpr int OFF_POS = OFF_W16B_OG1 + 16;
 // Per-pixel projection of the ray_feats maps (done once per pass and frame, see project_ray_feats_kernel):
 // the first layers that consume the gathered ray feature — dist-decoder layer 0 of every MLP and the 32
 // ray-feature columns of prob_embed.0 — are linear, and bilinear interpolation is linear with weights summing
@@ -131,7 +136,26 @@ constexpr int OFF_S_RGB2_A = OFF_S_RDC_B + s_b_size(1);
 constexpr int OFF_S_RGB2_B = OFF_S_RGB2_A + s_a_size(8, 2);
 constexpr int OFF_S_RGB2_H = OFF_S_RGB2_B + s_b_size(2);     // [8] head weights
 constexpr int OFF_S_END = OFF_S_RGB2_H + 8;
-constexpr int OFF_H_BASE = OFF_S_END;
+// ---- "w16" layers (f32 mode): layers with 16 outputs waste half of a 32-row tile.  They run on v_mfma_f32_16x16x4_f32 instead
+// (16 rows x 16 points x 4 features in 32 cycles: twice the useful work per cycle).  Two B-operand registers X = b[2j], Y = b[2j+1] of
+// the 32-point layout (feature in_feat(s, 0) in lanes 0-31, in_feat(s, 1) in lanes 32-63) become, through ONE v_permlane16_swap,
+// the B operands of k4-step j for points 0-15 (X') and 16-31 (Y'): lane group kk = lane >> 4 carries feature
+//   f16(j, kk) = in_feat(2j + (kk & 1), kk >> 1).
+// D (4 registers, rows 4 (lane >> 4) + r of point lane & 15) of the two point groups goes back to the 32-point layout by one
+// v_permlane16_swap per register pair; MFMA row i is given the logical output row  w16_row(i)  (bits 2 and 3 exchanged) so that the
+// 8 result registers are exactly registers 0..7 of the padded 32-row tile: nothing downstream changes.
+//   w16 A block: [c4][lane 0..63][4]   value(j = 4 c4 + e, lane) = W[out_row(w16_row(lane & 15))][f16(j, lane >> 4)]
+//   w16 bias   : [lane >> 4][4]        value(q, r) = b[out_row(w16_row(4 q + r))]      (OFF_W16B_*, head region)
+constexpr int w16_row(int i) { return (i & 3) + 4 * ((i >> 3) & 1) + 8 * ((i >> 2) & 1); }
+constexpr int w16_k4(int ks) { return (ks + 1) / 2; }
+constexpr int w16_a_size(int ks) { return ((w16_k4(ks) + 3) / 4) * 256; }
+constexpr int OFF_W16_RGB1 = OFF_S_END;                              // rgb_fc.0          37 -> 16
+constexpr int OFF_W16_G2 = OFF_W16_RGB1 + w16_a_size(19);            // geometry_fc.2     64 -> 16
+constexpr int OFF_W16_V = OFF_W16_G2 + w16_a_size(32);               // w_vs              16 -> 16
+constexpr int OFF_W16_FC = OFF_W16_V + w16_a_size(8);                // ray_attention.fc  16 -> 16
+constexpr int OFF_W16_OG1 = OFF_W16_FC + w16_a_size(8);              // out_geometry_fc.0 16 -> 16
+constexpr int OFF_W16_END = OFF_W16_OG1 + w16_a_size(8);
+constexpr int OFF_H_BASE = OFF_W16_END;
 constexpr int layer_h_off(int id) {
   int off = OFF_H_BASE;
   for (int i = 0; i < id; ++i) off += h_size(kKS[i], kMT[i]);

@@ -52,6 +52,9 @@ namespace PGRF_PREC_NS {
 
 constexpr int kPrec = PGRF_PREC;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef PGRF_ABL_WLDS
+__shared__ float4 g_abl_w[512];
+#endif
 
 
 
@@ -314,6 +317,8 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
     for (int s4 = 0; s4 < KS4; ++s4) {
 #ifdef PGRF_ABL_WEIGHTS   // ablation (timing only): every weight load hits the same 1 KiB -> L1 resident
       const float4 a = reinterpret_cast<const float4*>(A)[lane + ((m * KS4 + s4) & 1) * 64];
+#elif defined(PGRF_ABL_WLDS)   // ablation (timing only): every weight load from 8 KB of LDS (what an LDS-resident blob would cost)
+      const float4 a = g_abl_w[lane + ((m * KS4 + s4) & 7) * 64];
 #else
       const float4 a = (Limg && limg_full)          ? reinterpret_cast<const float4*>(Limg)[(m * KS4 + s4) * 64 + lane]
                        : (Limg && limg_a > 0 && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
@@ -376,6 +381,55 @@ __device__ __forceinline__ void mfma_small(const float* __restrict__ S, const fl
 #pragma unroll
       for (int i = 0; i < 4; ++i) out[t][4 * g + i] = xsum(acc[t][g][i]);
 }
+
+// Layer with 16 outputs on v_mfma_f32_16x16x4_f32 (pgrf_layout.h "w16" layers): the B registers of two k-steps become the operands of
+// one k4-step for points 0-15 and 16-31 through one v_permlane16_swap; the results come back to registers 0..7 of the 32-point layout
+// the same way.  Half the matrix-pipe time of the padded 32-row tile (2 x 32 cycles per 4 features against 2 x 64), for KS/2 + 4
+// cross-lane swaps.  Two accumulators per point tile alternate, so the 40-cycle dependent latency of this MFMA never shows.
+template <int KS, int NT>
+__device__ __forceinline__ void mfma_layer16(const float* __restrict__ A16, const float* __restrict__ B16, int lane,
+                                             const float (&b)[NT][KS], float (&out)[NT][8]) {
+  constexpr int K4 = (KS + 1) / 2, C4 = (K4 + 3) / 4;
+  f32x4 d[NT][2];
+  {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (B16) { const float4 bb = reinterpret_cast<const float4*>(B16)[lane >> 4]; bv = (f32x4){bb.x, bb.y, bb.z, bb.w}; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) d[t][0] = d[t][1] = bv;
+  }
+#pragma unroll
+  for (int c = 0; c < C4; ++c) {
+    const float4 a = reinterpret_cast<const float4*>(A16)[c * 64 + lane];
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = c * 4 + e;
+      if (j < K4) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float x = b[t][2 * j], y = (2 * j + 1 < KS) ? b[t][2 * j + 1 < KS ? 2 * j + 1 : 0] : 0.f;
+          const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+          d[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], __uint_as_float(r[0]), d[t][0], 0, 0, 0);
+          d[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], __uint_as_float(r[1]), d[t][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[t][0][i]), __float_as_uint(d[t][1][i]), false, false);
+      out[t][i] = __uint_as_float(r[0]);
+      out[t][4 + i] = __uint_as_float(r[1]);
+    }
+}
+// 16-row layers on the 16x16x4 MFMA: f32 mode (-DPGRF_NO_W16 = the padded 32-row tiles)
+#ifdef PGRF_NO_W16
+constexpr bool kW16 = false;
+#else
+constexpr bool kW16 = (kPrec == 0);
+#endif
 
 // partial dot over this lane half's R features (no cross-half sum)
 template <int R>
@@ -1033,12 +1087,21 @@ __device__ __forceinline__ void stage_rgb(const PassArgs& p, const float* LI, co
     b19[t][18] = half ? 0.f : vs[v].dd[3];
   }
   f32x16 a1[NT][1], a2[NT][1];
-  mfma_layer<19, 1, NT, true>(W + layer_a_off(L_RGB1), W + layer_b_off(L_RGB1), lane, b19, a1, W + layer_h_off(L_RGB1), PGRF_LIMG(L_RGB1));
   float b8[NT][8];
+  if constexpr (kW16) {
+    float o16[NT][8];
+    mfma_layer16<19, NT>(W + OFF_W16_RGB1, PGRF_LHEAD(OFF_W16B_RGB1), lane, b19, o16);
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
+      for (int s = 0; s < 8; ++s) b8[t][s] = elu1(o16[t][s]);
+  } else {
+    mfma_layer<19, 1, NT, true>(W + layer_a_off(L_RGB1), W + layer_b_off(L_RGB1), lane, b19, a1, W + layer_h_off(L_RGB1), PGRF_LIMG(L_RGB1));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) b8[t][s] = elu1(a1[t][0][s]);
+  }
   if constexpr (kSmallV<V>) {
     float o8[NT][8];
     mfma_small<8, 2, NT>(W + OFF_S_RGB2_A, W + OFF_S_RGB2_B, lane, b8, o8);
@@ -1098,7 +1161,14 @@ __device__ __forceinline__ float point_tail(const PassArgs& p, const float* LI, 
 #pragma unroll
   for (int s = 0; s < 16; ++s) { b32[0][s] = elu1(g1[0][0][s]); b32[0][16 + s] = elu1(g1[0][1][s]); }
   f32x16 g2[1][1];
-  mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2, W + layer_h_off(L_G2), PGRF_LIMG(L_G2));
+  if constexpr (kW16) {
+    float o16[1][8];
+    mfma_layer16<32, 1>(W + OFF_W16_G2, PGRF_LHEAD(OFF_W16B_G2), lane, b32, o16);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) g2[0][0][r] = o16[0][r];
+  } else {
+    mfma_layer<32, 1, 1, true>(W + layer_a_off(L_G2), W + layer_b_off(L_G2), lane, b32, g2, W + layer_h_off(L_G2), PGRF_LIMG(L_G2));
+  }
   float gp[1][8];     // geometry feature + positional encoding (ibrnet.py:356-358)
   {
     const float4* pp = reinterpret_cast<const float4*>(W + OFF_POS + si * 16 + half * 8);
@@ -1116,7 +1186,19 @@ __device__ __forceinline__ float point_tail(const PassArgs& p, const float* LI, 
   f32x16 qkv[1][2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { qkv[0][0][r] = 0.f; qkv[0][1][r] = 0.f; }   // no bias on w_qs/w_ks/w_vs
-  mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv, W + layer_h_off(L_QKV), PGRF_LIMG(L_QKV));
+  if constexpr (kW16) {       // q | k on the 32-row tile, v (16 rows) on the 16x16x4 MFMA
+    f32x16 qk[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qk[0][0][r] = 0.f;
+    mfma_layer<8, 1, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qk, W + layer_h_off(L_QKV), PGRF_LIMG(L_QKV));
+    qkv[0][0] = qk[0][0];
+    float v8[1][8];
+    mfma_layer16<8, 1>(W + OFF_W16_V, nullptr, lane, gp, v8);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) qkv[0][1][r] = v8[0][r];
+  } else {
+    mfma_layer<8, 2, 1, false>(W + layer_a_off(L_QKV), nullptr, lane, gp, qkv, W + layer_h_off(L_QKV), PGRF_LIMG(L_QKV));
+  }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     if (HSEL != 1) lds_k[pt_local * kKStride + 2 * r + half] = qkv[0][0][8 + r];
@@ -1225,7 +1307,14 @@ __device__ __forceinline__ float point_tail(const PassArgs& p, const float* LI, 
   f32x16 fo[1][1];
 #pragma unroll
   for (int r = 0; r < 16; ++r) fo[0][0][r] = (r < 8) ? gp[0][r < 8 ? r : 0] : 0.f;     // residual as the initial accumulator
-  mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo, W + layer_h_off(L_FC), PGRF_LIMG(L_FC));
+  if constexpr (kW16) {       // (fc(x) first, then the residual: the reference's order, ibrnet.py:95-98)
+    float o16[1][8];
+    mfma_layer16<8, 1>(W + OFF_W16_FC, nullptr, lane, bo, o16);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) fo[0][0][r] = o16[0][r] + gp[0][r];
+  } else {
+    mfma_layer<8, 1, 1, false>(W + layer_a_off(L_FC), nullptr, lane, bo, fo, W + layer_h_off(L_FC), PGRF_LIMG(L_FC));
+  }
   float ln[1][8];
   {
     float sum = 0.f;
@@ -1250,7 +1339,14 @@ __device__ __forceinline__ float point_tail(const PassArgs& p, const float* LI, 
   }
   // out_geometry_fc 16 -> 16 elu -> 1 relu  (ibrnet.py:361)
   f32x16 og[1][1];
-  mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og, W + layer_h_off(L_OG1), PGRF_LIMG(L_OG1));
+  if constexpr (kW16) {
+    float o16[1][8];
+    mfma_layer16<8, 1>(W + OFF_W16_OG1, PGRF_LHEAD(OFF_W16B_OG1), lane, ln, o16);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) og[0][0][r] = o16[0][r];
+  } else {
+    mfma_layer<8, 1, 1, true>(W + layer_a_off(L_OG1), W + layer_b_off(L_OG1), lane, ln, og, W + layer_h_off(L_OG1), PGRF_LIMG(L_OG1));
+  }
 #pragma unroll
   for (int r = 0; r < 8; ++r) og[0][0][r] = elu1(og[0][0][r]);
   return fmaxf(head_dot<8>(PGRF_LHEAD(OFF_OGH_W), half, og[0][0]) + W[OFF_OGH_B], 0.f);
@@ -1344,6 +1440,10 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
   }
 
   const int lane = threadIdx.x & 63;
+#ifdef PGRF_ABL_WLDS
+  g_abl_w[threadIdx.x] = g_abl_w[threadIdx.x + 256] = make_float4(0.01f, -0.02f, 0.03f, 0.005f);
+  __syncthreads();
+#endif
 #ifdef PGRF_ONE_WG_PER_CU   // experiment: 84 KB of LDS ballast -> one workgroup (one wave per SIMD) per CU
   __shared__ float lds_ballast[21000];
   if (p.rn < 0) lds_ballast[threadIdx.x * 80] = 1.f;
