@@ -52,6 +52,14 @@ namespace PGRF_PREC_NS {
 
 constexpr int kPrec = PGRF_PREC;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Every f32 instance carries an LDS image (kHasImg below).  The layer functions decide "image or blob" on this CONSTANT, never on the
+// pointer: a run-time select between an LDS and a global pointer is a generic pointer, its loads are flat_load_dwordx4 (52 per tile:
+// every layer's bias block) and each of those waits for vmcnt(0) AND lgkmcnt(0) -- draining the gathers in flight at every layer start.
+#ifdef PGRF_NO_LDS_IMG
+constexpr bool kImg = false;
+#else
+constexpr bool kImg = (kPrec == 0);
+#endif
 #ifdef PGRF_ABL_WLDS
 __shared__ float4 g_abl_w[512];
 #endif
@@ -199,7 +207,7 @@ __device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, con
   if (INIT_BIAS) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
+      const float4* bp = reinterpret_cast<const float4*>((kImg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       const f32x16 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
 #pragma unroll
@@ -220,7 +228,7 @@ __device__ __forceinline__ void mfma_layer_h(const float* __restrict__ Hblk, con
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       H8 a1, a2;
-      if (Limg && m == 0 && g == 0) {
+      if (kImg && m == 0 && g == 0) {
         a1.u = reinterpret_cast<const uint4*>(Limg)[lane];
         a2.u = reinterpret_cast<const uint4*>(Limg)[64 + lane];
       } else {
@@ -261,8 +269,8 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
     constexpr int Q = MT * KS4, PD = (PGRF_A_PREFETCH) < Q ? (PGRF_A_PREFETCH) : Q;
     auto load_a = [&](int q) {
       const int m = q / KS4, s4 = q % KS4;
-      return (Limg && limg_full)          ? reinterpret_cast<const float4*>(Limg)[(m * KS4 + s4) * 64 + lane]
-             : (Limg && limg_a > 0 && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
+      return (kImg && limg_full)          ? reinterpret_cast<const float4*>(Limg)[(m * KS4 + s4) * 64 + lane]
+             : (kImg && limg_a > 0 && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
                                            : reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
     };
     float4 ring[PD + 1];
@@ -282,7 +290,7 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
       const float av[4] = {a.x, a.y, a.z, a.w};
       f32x16 bv;
       if (INIT_BIAS && s4 == 0) {
-        const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
+        const float4* bp = reinterpret_cast<const float4*>((kImg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
         const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
         bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
       }
@@ -309,7 +317,7 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
   for (int m = 0; m < MT; ++m) {
     f32x16 bv;
     if (INIT_BIAS) {
-      const float4* bp = reinterpret_cast<const float4*>((Limg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
+      const float4* bp = reinterpret_cast<const float4*>((kImg ? Limg + limg_a : B) + m * 32 + (lane >> 5) * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
     }
@@ -320,8 +328,8 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ A, const fl
 #elif defined(PGRF_ABL_WLDS)   // ablation (timing only): every weight load from 8 KB of LDS (what an LDS-resident blob would cost)
       const float4 a = g_abl_w[lane + ((m * KS4 + s4) & 7) * 64];
 #else
-      const float4 a = (Limg && limg_full)          ? reinterpret_cast<const float4*>(Limg)[(m * KS4 + s4) * 64 + lane]
-                       : (Limg && limg_a > 0 && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
+      const float4 a = (kImg && limg_full)          ? reinterpret_cast<const float4*>(Limg)[(m * KS4 + s4) * 64 + lane]
+                       : (kImg && limg_a > 0 && m == 0 && s4 == 0) ? reinterpret_cast<const float4*>(Limg)[lane]
                                                      : reinterpret_cast<const float4*>(A)[(m * KS4 + s4) * 64 + lane];
 #endif
       const float av[4] = {a.x, a.y, a.z, a.w};
@@ -452,6 +460,12 @@ __device__ __forceinline__ float pair_mine(float s0, float s1) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// LDS word that must really be re-read (values parked there to shorten their live range): a volatile access through the LDS address
+// space.  (`*(volatile float*)&lds[..]` is a GENERIC volatile access: flat_load_dword sc0 sc1, which waits for vmcnt AND lgkmcnt.)
+typedef __attribute__((address_space(3))) float lds_f32;
+__device__ __forceinline__ float lds_reload(const float* p) { return *(volatile lds_f32*)p; }
+__device__ __forceinline__ void lds_restore(float* p, float v) { *(volatile lds_f32*)p = v; }
+
 struct Bilin {
   int o00, o01, o10, o11;   // pixel offsets (pixels, not floats) of the 4 taps inside one view's map
   float wnw, wne, wsw, wse;
@@ -525,6 +539,9 @@ __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const 
       out[4 * q + 3] = t[q][0].w * b.wnw + t[q][1].w * b.wne + t[q][2].w * b.wsw + t[q][3].w * b.wse;
     }
   } else {
+    // (tried: the blend on v_pk_mul_f32 / v_pk_fma_f32 with the tap weight broadcast through op_sel -- half the VALU instructions,
+    // 36.35 against 35.95 ms per frame: two dependent chains per quad instead of four, and hipcc's pre-emit peephole splits the
+    // packed ops that land behind an MFMA back into VOP3 pairs; as inline asm 37.07 ms.  profiles/r05_dead_ends.txt)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 a = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * STRIDE + q * 8);
@@ -573,7 +590,11 @@ __device__ unsigned long long g_stage_cycles[32];
 #ifndef PGRF_FENCE_MASK
 #define PGRF_FENCE_MASK ((V == 3 || (PGRF_KT == 1 && V == 2)) ? 0u : 0xffffffffu)      // bit i = stage boundary i is a fence (tuning knob)
 #endif
+#ifdef PGRF_STAGE_MARK   // ISA census builds (tools/isa_stage_census.py): a comment line per stage boundary in the assembly
+#define PGRF_TICK(i) do { if (((PGRF_FENCE_MASK) >> (i)) & 1u) { __builtin_amdgcn_sched_barrier(0); asm volatile("; PGRF_STAGE_END %0" :: "i"(i)); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
 #define PGRF_TICK(i) do { if (((PGRF_FENCE_MASK) >> (i)) & 1u) __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 #endif
 
 struct ViewState {
@@ -762,7 +783,13 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #pragma unroll
       for (int s = 0; s < 16; ++s) b2[t][s] = elu1(a1[s]);
     }
+#ifdef PGRF_DD_FENCE     // experiment: all 16 blended + activated operands of both views first, then the layer's MFMAs back to back
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     mfma_layer<16, 1, NT, true>(W + layer_a_off(L_DD2_0 + m), W + layer_b_off(L_DD2_0 + m), lane, b2, a2, W + layer_h_off(L_DD2_0 + m), PGRF_LIMG(L_DD2_0 + m));
+#if defined(PGRF_DD_FENCE) && PGRF_DD_FENCE >= 2
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if constexpr (kDedupe) {
       // heads of the view this lane half owns (half 0: view V0, half 1: view V0+1): activation and everything after it
       // is computed once per view instead of in both halves
@@ -1451,7 +1478,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
 #ifdef PGRF_STAGE_TIMING
   unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform: the ray index arithmetic runs on the SALU
   const int half = lane >> 5;
   const int pl = lane & 31;
   const int ray_local = wave / KT;
@@ -1573,7 +1600,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
   // feature j of view v's tile: from the registers, or (kLdsState) from the LDS rows of the pair that is parked there
   auto fa_at = [&](int v, int j, int parked_pair) -> float {
     if constexpr (kLdsState<V>) {
-      if ((v >> 1) == parked_pair) return *(volatile float*)&lds_state[(v & 1) * 16 + j][threadIdx.x];
+      if ((v >> 1) == parked_pair) return lds_reload(&lds_state[(v & 1) * 16 + j][threadIdx.x]);
     }
     return vs[v].fa[j];
   };
@@ -1628,8 +1655,8 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
     for (int v = 0; v < 2; ++v)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        vs[v].fa[j] = *(volatile float*)&lds_state[v * 16 + j][threadIdx.x];     // pair 0's inputs back into registers ...
-        *(volatile float*)&lds_state[v * 16 + j][threadIdx.x] = vs[2 + v].fa[j]; // ... pair 1's outputs into their rows
+        vs[v].fa[j] = lds_reload(&lds_state[v * 16 + j][threadIdx.x]);     // pair 0's inputs back into registers ...
+        lds_restore(&lds_state[v * 16 + j][threadIdx.x], vs[2 + v].fa[j]); // ... pair 1's outputs into their rows
       }
     __builtin_amdgcn_sched_barrier(0);
     stage_mid<V, 0, 2, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
@@ -1688,9 +1715,9 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
 #pragma unroll
       for (int v = 0; v < V; ++v) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) vs[v].dd[c] = *(volatile float*)&lds_park[v * 7 + c][park_col];
+        for (int c = 0; c < 4; ++c) vs[v].dd[c] = lds_reload(&lds_park[v * 7 + c][park_col]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) vs[v].rgb[c] = *(volatile float*)&lds_park[v * 7 + 4 + c][park_col];
+        for (int c = 0; c < 3; ++c) vs[v].rgb[c] = lds_reload(&lds_park[v * 7 + 4 + c][park_col]);
       }
     }
     stage_rgb<V, 0, kNT0<V>>(p, LI, vs, lane, logit);
@@ -1699,7 +1726,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
 #pragma unroll
       for (int v = 0; v < 2; ++v)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) vs[2 + v].fa[j] = *(volatile float*)&lds_state[v * 16 + j][threadIdx.x];
+        for (int j = 0; j < 16; ++j) vs[2 + v].fa[j] = lds_reload(&lds_state[v * 16 + j][threadIdx.x]);
     }
     if constexpr (V > kNT0<V>) stage_rgb<V, 2, V - 2>(p, LI, vs, lane, logit);
     float mx = logit[0];
@@ -2051,9 +2078,9 @@ __global__ void __launch_bounds__(256, 2) render_pass_pair_kernel(const PassArgs
 #pragma unroll
     for (int v = 0; v < V; ++v) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) vs[v].dd[c] = *(volatile float*)&lds_park[v * 7 + c][park_col];
+      for (int c = 0; c < 4; ++c) vs[v].dd[c] = lds_reload(&lds_park[v * 7 + c][park_col]);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) vs[v].rgb[c] = *(volatile float*)&lds_park[v * 7 + 4 + c][park_col];
+      for (int c = 0; c < 3; ++c) vs[v].rgb[c] = lds_reload(&lds_park[v * 7 + 4 + c][park_col]);
     }
     float lg[V];
     stage_rgb<V, 0, 2>(p, LI, vs, lane, lg);
