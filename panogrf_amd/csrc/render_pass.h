@@ -542,6 +542,29 @@ __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const 
     // (tried: the blend on v_pk_mul_f32 / v_pk_fma_f32 with the tap weight broadcast through op_sel -- half the VALU instructions,
     // 36.35 against 35.95 ms per frame: two dependent chains per quad instead of four, and hipcc's pre-emit peephole splits the
     // packed ops that land behind an MFMA back into VOP3 pairs; as inline asm 37.07 ms.  profiles/r05_dead_ends.txt)
+#ifndef PGRF_GATHER_QUAD_MAJOR
+    // tap-major (35.82 -> 35.62 ms against quad-major, -DPGRF_GATHER_QUAD_MAJOR): the four 16-byte pieces a lane reads of ONE texel's 128-byte line are requested back to back (one L1 miss, three
+    // hits under it) and folded into the 16 accumulators as they arrive; per channel the same mul, fma, fma, fma in the same order
+    {
+      const int offs[4] = {b.o00, b.o01, b.o10, b.o11};
+      const float ws[4] = {b.wnw, b.wne, b.wsw, b.wse};
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        float4 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4*>(base + (size_t)offs[tap] * STRIDE + q * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (tap == 0) {
+            out[4 * q + 0] = t[q].x * ws[0]; out[4 * q + 1] = t[q].y * ws[0]; out[4 * q + 2] = t[q].z * ws[0]; out[4 * q + 3] = t[q].w * ws[0];
+          } else {
+            out[4 * q + 0] = fmaf(t[q].x, ws[tap], out[4 * q + 0]); out[4 * q + 1] = fmaf(t[q].y, ws[tap], out[4 * q + 1]);
+            out[4 * q + 2] = fmaf(t[q].z, ws[tap], out[4 * q + 2]); out[4 * q + 3] = fmaf(t[q].w, ws[tap], out[4 * q + 3]);
+          }
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 a = *reinterpret_cast<const float4*>(base + (size_t)b.o00 * STRIDE + q * 8);
@@ -553,6 +576,7 @@ __device__ __forceinline__ f32x16 gather32(const float* __restrict__ map, const 
       out[4 * q + 2] = a.z * b.wnw + c.z * b.wne + d.z * b.wsw + e.z * b.wse;
       out[4 * q + 3] = a.w * b.wnw + c.w * b.wne + d.w * b.wsw + e.w * b.wse;
     }
+#endif
   }
 #ifdef PGRF_ABL_GATHER
 #undef b
