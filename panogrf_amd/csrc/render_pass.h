@@ -607,12 +607,15 @@ __device__ unsigned long long g_stage_cycles[32];
 #elif defined(PGRF_NO_STAGE_FENCE)
 #define PGRF_TICK(i) do {} while (0)
 #else
-// stage boundaries are scheduling fences: measured 47.5 -> 46.3 ms/frame (fewer live ranges crossing stages)
-// Per view count: with 3 views the fences cost more than they save (53.6 -> 52.7 ms without them, although 26 instead of 6
-// registers spill), with 2 views x 32 samples as well (19.09 -> 18.91 ms); 2 views x 64: +-0.2 %, 4 views: 77.9 -> 79.0 ms
-// without.  (V is in scope wherever a stage ends.)
+// Stage boundaries as scheduling fences, per instance as measured.  Round 1: 47.5 -> 46.3 ms with them (fewer live ranges crossing
+// stages, while the kernel still spilled).  Round 5, after the 16-row layers moved to the 16x16x4 MFMA and the flat loads went (225
+// registers, nothing spilled): WITHOUT them 2 views x 64 samples 35.45 -> 34.72 ms and the 4-view pair kernel 65.2 -> 64.5 ms -- the
+// scheduler slides one stage's loads and VALU work under the previous stage's MFMAs; 3 views the other way round now (fences on:
+// 50.57 -> 50.13 ms although 8-15 registers spill), one view as well (21.57 -> 21.36 ms).  32 and 128 samples follow the 64-sample
+// kernels (2 views x 32: 17.66 vs 17.83 ms with fences, x 128: 72.2 vs 73.7; 4 views x 32: 33.35 vs 33.8).  (V is in scope wherever
+// a stage ends.)
 #ifndef PGRF_FENCE_MASK
-#define PGRF_FENCE_MASK ((V == 3 || (PGRF_KT == 1 && V == 2)) ? 0u : 0xffffffffu)      // bit i = stage boundary i is a fence (tuning knob)
+#define PGRF_FENCE_MASK ((V == 3 || V == 1) ? 0xffffffffu : 0u)      // bit i = stage boundary i is a fence (tuning knob)
 #endif
 #ifdef PGRF_STAGE_MARK   // ISA census builds (tools/isa_stage_census.py): a comment line per stage boundary in the assembly
 #define PGRF_TICK(i) do { if (((PGRF_FENCE_MASK) >> (i)) & 1u) { __builtin_amdgcn_sched_barrier(0); asm volatile("; PGRF_STAGE_END %0" :: "i"(i)); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -668,8 +671,9 @@ __device__ __forceinline__ void stage_front(const PassArgs& p, const float* LI, 
 #ifdef PGRF_NO_LAZY_TAPS
   constexpr bool kLazyTaps = false;
 #else
-  constexpr bool kLazyTaps = (kTwoWave<V> && kPrec == 0 && V != 3);   // 3 views in one group: 118 -> 6 spilled registers and
-                                                                       // 60.1 -> 55.3 ms WITHOUT it (allocator behaviour, measured)
+  // (round 5: with the register pressure down the 2-view kernels for 32 and 64 samples are faster when they KEEP the setups, 34.72 ->
+  // 34.62 and 17.66 -> 17.46 ms; 128 samples (72.2 vs 72.8 ms) and the pair kernel's V = 2 stages (64.5 vs 65.2 ms) still recompute)
+  constexpr bool kLazyTaps = (kTwoWave<V> && kPrec == 0 && V != 3 && !(PGRF_KT <= 2 && PGRF_V == 2));
 #endif
   // gathers with all their loads in flight behind scheduling fences (see gather32): measured SLOWER for the second view pair of
   // the 4-view kernel (78.4 -> 79.7 ms, both pairs 80.5 ms; 163 -> 187 spilled registers) although that pair's gathers are
