@@ -6,7 +6,7 @@
 // Include this header first in every kernel translation unit (before the defaults of the tunables are defined).
 #pragma once
 
-#if defined(PGRF_ABL_ELU) || defined(PGRF_ABL_GATHER) || defined(PGRF_ABL_WEIGHTS) || defined(PGRF_ABL_WLDS) || defined(PGRF_NO_W16) || defined(PGRF_STAGE_MARK) || defined(PGRF_GATHER_QUAD_MAJOR) || defined(PGRF_DD_FENCE) || defined(PGRF_NO_BARRIER) ||             \
+#if defined(PGRF_ABL_ELU) || defined(PGRF_ABL_GATHER) || defined(PGRF_ABL_WEIGHTS) || defined(PGRF_ABL_WLDS) || defined(PGRF_NO_W16) || defined(PGRF_STAGE_MARK) || defined(PGRF_MID_FENCE) || defined(PGRF_GATHER_QUAD_MAJOR) || defined(PGRF_DD_FENCE) || defined(PGRF_NO_BARRIER) ||             \
     defined(PGRF_STAGE_TIMING) || defined(PGRF_NO_DEDUPE) || defined(PGRF_NO_FULL_IMG) || defined(PGRF_NO_LAZY_TAPS) ||        \
     defined(PGRF_NO_LDS_IMG) || defined(PGRF_NO_PARK) || defined(PGRF_NO_RECOMPUTE_NF) || defined(PGRF_NO_SMALL) ||           \
     defined(PGRF_NO_STAGE_FENCE) || defined(PGRF_NO_XCD_REMAP) || defined(PGRF_NT_ALL) || defined(PGRF_NT_PAIRS) ||           \

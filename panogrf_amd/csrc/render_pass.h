@@ -615,7 +615,8 @@ __device__ unsigned long long g_stage_cycles[32];
 // kernels (2 views x 32: 17.66 vs 17.83 ms with fences, x 128: 72.2 vs 73.7; 4 views x 32: 33.35 vs 33.8).  (V is in scope wherever
 // a stage ends.)
 #ifndef PGRF_FENCE_MASK
-#define PGRF_FENCE_MASK ((V == 3 || V == 1) ? 0xffffffffu : 0u)      // bit i = stage boundary i is a fence (tuning knob)
+// (2 views x 64 samples: fences after neuray_fc, stage B and the density head only -- single-fence sweep + combinations, 34.8 -> 34.25 ms)
+#define PGRF_FENCE_MASK ((V == 3 || V == 1) ? 0xffffffffu : ((PGRF_KT == 2 && PGRF_V == 2) ? 0x100084u : 0u))      // bit i = stage boundary i is a fence (tuning knob)
 #endif
 #ifdef PGRF_STAGE_MARK   // ISA census builds (tools/isa_stage_census.py): a comment line per stage boundary in the assembly
 #define PGRF_TICK(i) do { if (((PGRF_FENCE_MASK) >> (i)) & 1u) { __builtin_amdgcn_sched_barrier(0); asm volatile("; PGRF_STAGE_END %0" :: "i"(i)); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -1193,6 +1194,12 @@ template <int V> constexpr int kNT0 = V < 2 ? V : 2;
 template <int V> constexpr int kNT0 = (V <= 3 || !kTwoWave<V>) ? V : 2;
 #endif
 #endif
+// the two fences between view groups (after stage A's and stage C's first group), which for <= 2 views are simply two more stage fences
+#ifdef PGRF_MID_FENCE
+template <int V> constexpr bool kMidFence = (PGRF_MID_FENCE) != 0;
+#else
+template <int V> constexpr bool kMidFence = true;
+#endif
 constexpr int kKStride = 17;   // K rows in LDS: odd stride -> conflict-free column reads (A operand)
 constexpr int kVStride = 20;   // V rows: 16-byte aligned rows for broadcast float4 reads
 
@@ -1617,7 +1624,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
       for (int j = 0; j < 16; ++j) lds_state[v * 16 + j][threadIdx.x] = vs[v].fa[j];
     if constexpr (kPark) park_views(0, 2);           // (and its directions / colours: not carried through pair 1's stage A)
   }
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (kMidFence<V>) __builtin_amdgcn_sched_barrier(0);
   if constexpr (V > kNT0<V>) stage_front<V, 2, V - 2, DBG, GEN>(p, LI, g, vs, lane, pt, npts, store_ok, sdbg
 #ifdef PGRF_STAGE_TIMING
                                            , t_prev
@@ -1690,7 +1697,7 @@ __global__ void __launch_bounds__(256, (kTwoWave<V> ? 2 : 1)) render_pass_kernel
     stage_mid<V, 0, 2, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
   } else {
   stage_mid<V, 0, kNT0<V>, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (kMidFence<V>) __builtin_amdgcn_sched_barrier(0);
   if constexpr (V > kNT0<V>) stage_mid<V, 2, V - 2, DBG>(p, LI, G[0], vs, lane, pt, store_ok, sdbg);
   }
   PGRF_TICK(3);   // stage C
