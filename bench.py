@@ -449,6 +449,13 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # the RCCL build the collectives run on (torch's "nccl" backend IS RCCL on ROCm), recorded with every distributed line
+    rccl_version = None
+    if distributed and backend == 'nccl':
+        try:
+            rccl_version = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001 -- a record field, never a reason to fail the bench
+            rccl_version = 'unknown (%s)' % type(e).__name__
 
     from panogrf_amd import engine as E
     from panogrf_amd import dist as D
@@ -595,7 +602,8 @@ def main():
                                + ' (BASELINE configs[1])' * (not args.fine and (H, W, V, dn) == (512, 1024, 2, 64)),
                    'rays_per_step': H * W, 'ray_tiles': world, 'parallelism': f'ray-tile x{world} + all-gather',
                    'gathered_image_max_abs_diff_vs_unsharded': gather_diff,
-                   'collectives': (None if not distributed else backend + (', forced at world size 1' if world == 1 else ''))},
+                   'collectives': (None if not distributed else backend + (', forced at world size 1' if world == 1 else '')),
+                   'rccl_version': rccl_version},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
                      'frac': achieved / peak_tf, 'traffic': traffic, 'traffic_source': traffic_source,
                      'kernel': 'render_pass_kernel', 'kernel_ms': k_ms / launches,

@@ -173,8 +173,11 @@ int pgrf_render_pass(const PgrfFrame* frame, const float* blob, int flags, const
 typedef struct PgrfUniqueId { char internal[128]; } PgrfUniqueId;      /* = ncclUniqueId */
 int pgrf_comm_unique_id(PgrfUniqueId* id);
 int pgrf_comm_init(const PgrfUniqueId* id, int rank, int nranks, void** comm);
-/* shard: `count` floats of this rank; full: nranks * count floats, rank-major (equal shards: H % nranks == 0) */
+/* shard: `count` floats of this rank; full: nranks * count floats, rank-major (equal shards: H % nranks == 0).  In place when
+ * shard == full + rank * count (the rank rendered straight into its rows of the frame buffer: SURVEY.md 8e), as ncclAllGather allows. */
 int pgrf_allgather_image(void* comm, const float* shard, float* full, size_t count, void* stream);
+/* NCCL_VERSION_CODE of the RCCL library this process resolved (major * 10000 + minor * 100 + patch), for run records */
+int pgrf_comm_rccl_version(int* version);
 int pgrf_comm_destroy(void* comm);
 
 /* ------------------------------------------------------------------ training: backward of one pass --- */

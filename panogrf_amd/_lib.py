@@ -91,6 +91,7 @@ SYMBOLS = {
     "pgrf_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "pgrf_allgather_image": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "pgrf_comm_destroy": (C.c_int, [_P]),
+    "pgrf_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
     "pgrf_render_pass_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pgrf_render_pass_backward": (C.c_int, [C.POINTER(PgrfFrame), C.POINTER(_P), C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
                                             C.POINTER(PgrfPassGrad), C.POINTER(_P), _P, _P, C.POINTER(PgrfPassOut), _P,

@@ -19,6 +19,7 @@ struct Rccl {
   int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;   // ncclAllGather(send, recv, count, dtype, comm, stream)
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;                                     // ncclGetVersion(int*)
 };
 
 Rccl g_rccl;
@@ -55,7 +56,8 @@ bool load_rccl() {
   }
   // the id is passed BY VALUE (128 bytes): refuse a library whose ABI this was not written against
   static_assert(sizeof(PgrfUniqueId) == 128, "ncclUniqueId is 128 bytes");
-  if (auto ver = reinterpret_cast<int (*)(int*)>(dlsym(so, "ncclGetVersion"))) {
+  r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(so, "ncclGetVersion"));
+  if (auto ver = r.GetVersion) {
     int v = 0;
     if (ver(&v) == 0 && v > 0 && v < 20000) {          // NCCL_VERSION_CODE = major * 10000 + ...: RCCL 2.x and later
       std::snprintf(g_why, sizeof(g_why), "RCCL version code %d is older than 2.0", v);
@@ -101,6 +103,15 @@ int pgrf_allgather_image(void* comm, const float* shard, float* full, size_t cou
   const int kFloat32 = 7;                                      // ncclFloat32
   const int rc = g_rccl.AllGather(shard, full, count, kFloat32, comm, stream);
   if (rc) return set_error(PGRF_ERR_LAUNCH, "ncclAllGather failed: %s", rccl_err(rc));
+  return PGRF_OK;
+}
+
+int pgrf_comm_rccl_version(int* version) {
+  if (!version) return set_error(PGRF_ERR_ARG, "pgrf_comm_rccl_version: null pointer");
+  if (!load_rccl()) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_comm_rccl_version: %s", g_why);
+  if (!g_rccl.GetVersion) return set_error(PGRF_ERR_UNSUPPORTED, "pgrf_comm_rccl_version: the RCCL library has no ncclGetVersion");
+  const int rc = g_rccl.GetVersion(version);
+  if (rc) return set_error(PGRF_ERR_LAUNCH, "ncclGetVersion failed: %s", rccl_err(rc));
   return PGRF_OK;
 }
 

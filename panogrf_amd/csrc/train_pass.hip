@@ -250,11 +250,19 @@ struct Ctx {
     }
   }
 };
+// Debug mode PGRF_TRAIN_DETERMINISTIC=1 (tests/test_grad_fixtures.py): every weight-gradient element is produced by ONE workgroup that
+// walks all rows in index order and adds once into a zeroed buffer -- no replicas, no side streams, one block for the bias column sums
+// and LayerNorm's parameter sums: the result no longer depends on the order in which float atomics happen to land.  Several times
+// slower (one 32 x 32 tile = one wave group over all rows); never the default.
+static bool train_deterministic() {
+  static const bool on = [] { const char* e = getenv("PGRF_TRAIN_DETERMINISTIC"); return e && e[0] == '1'; }();
+  return on;
+}
 // one side stream and event ring per device, created on first use and kept (PGRF_TRAIN_DW_STREAM=0: none)
 struct SideStream { hipStream_t s[kAux]; hipEvent_t ev[32]; int next, cur; bool ok; };
 static SideStream* side_stream() {
   static const bool off = [] { const char* e = getenv("PGRF_TRAIN_DW_STREAM"); return e && e[0] == '0'; }();
-  if (off) return nullptr;
+  if (off || train_deterministic()) return nullptr;
   static std::mutex mu;
   static SideStream* per_dev[64] = {};
   int dev = 0;
@@ -289,7 +297,7 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
       int cp = 1;
       while (cp < OUT) cp <<= 1;
       const long nb = (rows * cp + 256 * 8 - 1) / (256 * 8);
-      hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb))), dim3(256), 0, c.dw_stream(), const_cast<float*>(delta), ldd, delta, ldd, rows, OUT, cp, (int)ACT_NONE, gb);
+      hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(train_deterministic() ? 1 : (nb < 1 ? 1 : (nb > 1024 ? 1024 : nb)))), dim3(256), 0, c.dw_stream(), const_cast<float*>(delta), ldd, delta, ldd, rows, OUT, cp, (int)ACT_NONE, gb);
     }
     return;
   }
@@ -304,6 +312,7 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
   static const int target_wgs = [] { const char* e = getenv("PGRF_TRAIN_DW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();   // tuning knob (LDS-staged kernel: 768: 6.74, 1024: 6.82, 1536: 6.85, 2048: 6.98 ms per step; the dword-load kernel it replaced: (with the gradient replicas: 192: 18.6, 384: 15.9, 768: 14.5, 1536: 14.1, 3072: 14.5, 6144: 14.1 ms per 2 048-ray step)
   long chunk = (rows * nwg / target_wgs + 63) / 64 * 64;                    // ~target_wgs workgroups per launch
   if (chunk < 128) chunk = 128;
+  if (train_deterministic()) chunk = (rows + 63) / 64 * 64;                 // one workgroup per output tile, rows in index order
   const dim3 grid(nwg, 1, (unsigned)((rows + chunk - 1) / chunk));
   float* rep = c.grep + (size_t)rw * kGradSlot;          // this tensor's slot of replica 1 (replica r at + (r - 1) * R_COUNT * kGradSlot)
   float* brep = gb ? c.grep + (size_t)rb * kGradSlot : nullptr;
@@ -595,7 +604,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   PGRF_TCHECK("train composite backward");
   L(chain_bwd(c, rgb_l, 3, PV, w.gxr, 37, 0));                                                                      // gxr written (=)
   L(chain_bwd(c, og_l, 2, P, w.gln, 16, 0));
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk(P, 512) > 1024 ? 1024 : nblk(P, 512)), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], w.gln, P, w.gfo,
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(train_deterministic() ? 1 : (nblk(P, 512) > 1024 ? 1024 : nblk(P, 512))), dim3(256), 0, st, w.fo, raw_dev[R_ATT_LN_W], w.gln, P, w.gfo,
                      g_raw_dev[R_ATT_LN_W] ? g_raw_dev[R_ATT_LN_W] : w.gq /* scratch sink */, g_raw_dev[R_ATT_LN_B] ? g_raw_dev[R_ATT_LN_B] : w.gq);
   (void)hipMemcpyAsync(w.ggp, w.gfo, P * 64, hipMemcpyDeviceToDevice, st);                                            // residual branch
   L(lin_bwd(c, w.o, 16, w.fo, 16, w.gfo, 16, R_ATT_FC_W, -1, w.go, 16, 0, P, 16, 16, ACT_NONE));

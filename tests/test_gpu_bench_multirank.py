@@ -85,6 +85,7 @@ def test_bench_distributed_path_on_rccl_with_one_rank():
     assert d['n_gpus'] == 1 and d['value'] > 0
     assert d['config']['gathered_image_max_abs_diff_vs_unsharded'] == 0.0
     assert d['config']['collectives'] == 'nccl, forced at world size 1'
+    assert isinstance(d['config']['rccl_version'], str) and d['config']['rccl_version'][0].isdigit()      # what the run was on, for the first real 8-GPU record
 
 
 def test_plain_bench_gpus_2_launches_its_own_ranks():
@@ -167,6 +168,15 @@ lib.check(lib.pgrf_allgather_image(comm, C.c_void_p(shard.data_ptr()), C.c_void_
 torch.cuda.synchronize()
 assert torch.equal(full, shard)
 assert lib.pgrf_allgather_image(None, C.c_void_p(shard.data_ptr()), C.c_void_p(full.data_ptr()), 4, None) != 0
+# in place, as SURVEY.md 8(e) words the collective: the rank rendered into ITS rows of the frame buffer (shard == full + rank * count)
+frame = torch.rand(64 * 128, 3, device='cuda'); want = frame.clone()
+lib.check(lib.pgrf_allgather_image(comm, C.c_void_p(frame.data_ptr()), C.c_void_p(frame.data_ptr()), frame.numel(), C.c_void_p(st)))
+torch.cuda.synchronize()
+assert torch.equal(frame, want)
+ver = C.c_int(0)
+lib.check(lib.pgrf_comm_rccl_version(C.byref(ver)))
+assert ver.value >= 20000, ver.value
+print('rccl version code', ver.value)
 lib.check(lib.pgrf_comm_destroy(comm))
 print('cabi rccl allgather ok')
 '''
