@@ -6,8 +6,10 @@ parameter names (`image_encoder`, `vis_encoder`, `dist_decoder`, `agg_net.agg_im
 works unchanged, and `renderer(data)` / `render(que_imgs_info, ref_imgs_info, is_train)` return the same
 dict keys and shapes (network/renderer.py:635-686, 777-786).  The per-frame 2-D encoders run on stock
 PyTorch-ROCm; everything per ray goes to the HIP library.  The Linear layers below are parameter HOLDERS:
-their forward is never called.  Inference; training mode (`'eval' not in data`) is forward-only: the reference's
-random sampling and extra outputs, no backward pass.
+their forward is never called.  Training mode (`'eval' not in data`): the reference's random sampling and
+extra outputs; under autograd the per-ray passes are torch.autograd Functions whose backward is `pgrf_render_pass_backward`
+(panogrf_amd.engine), the 2-D encoders train on torch.  `name2network['neuray_ft']` is the per-scene fine-tuning module
+(network/renderer.py:788-1200) on the same fast path; the reference's losses are in panogrf_amd/loss.py.
 """
 import itertools
 import math
@@ -253,6 +255,8 @@ class NeuralRayBaseRenderer(nn.Module):
             gt_key = 'imgs' if 'imgs' in que_imgs_info else ('cube_imgs' if 'cube_imgs' in que_imgs_info else None)
             if gt_key is not None:      # ground-truth colours of the query pixels (renderer.py:277-288)
                 res['pixel_colors_gt' + suffix] = _interpolate_feats(que_imgs_info[gt_key], que_imgs_info['coords'])
+                if c.get('use_polar_weighted_loss') and suffix == '' and gt_key == 'imgs':       # renderer.py:283-285
+                    res['polar_weights'] = _interpolate_feats(que_imgs_info['polar_weights'], que_imgs_info['coords'])
             if c['use_ray_mask']:
                 ok = (imgs.shape[0] >= c['ray_mask_view_num']) and (dn > c['ray_mask_point_num'])
                 res['ray_mask' + suffix] = torch.full((1, rn), bool(ok), dtype=torch.bool, device=dev)
@@ -709,7 +713,175 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         return self.render_call(que, ref, is_train, src, is_perspec)
 
 
+def imgs_info_slice(imgs_info, indices):
+    """utils/imgs_info.py:273-277"""
+    return {k: v[indices] for k, v in imgs_info.items()}
+
+
+def get_coords_mask(que_mask, train_ray_num, foreground_ratio):
+    """Training pixels of a query view (utils/base_utils.py:585-604): `train_ray_num * foreground_ratio` random pixels inside the
+    mask, the rest from everything left; draws from np.random like the reference."""
+    min_pos_num = int(train_ray_num * foreground_ratio)
+    y0, x0 = np.nonzero(que_mask)
+    y1, x1 = np.nonzero(~que_mask)
+    xy0 = np.stack([x0, y0], 1).astype(np.float32)
+    xy1 = np.stack([x1, y1], 1).astype(np.float32)
+    idx = np.arange(xy0.shape[0])
+    np.random.shuffle(idx)
+    xy0 = xy0[idx]
+    coords0 = xy0[:min_pos_num]
+    if min_pos_num < train_ray_num:
+        xy1 = np.concatenate([xy1, xy0[min_pos_num:]], 0)
+        idx = np.arange(xy1.shape[0])
+        np.random.shuffle(idx)
+        return np.concatenate([coords0, xy1[idx[:(train_ray_num - min_pos_num)]]], 0)
+    return coords0
+
+
+class NeuralRayFtRenderer(NeuralRayBaseRenderer):
+    """Per-scene fine-tuning (network/renderer.py:788-1200): the source panoramas' raw visibility features `ray_feats` are
+    PARAMETERS (one [1, dim, h/8, w/8] tensor per source view, initialised by the generalisable model's init net or from noise) and
+    are optimised together with the encoders and the per-ray networks; `renderer(data)` without 'eval' is `train_step()` (a random
+    source view becomes the query, `train_ray_num` of its pixels are rendered from the others), with 'eval' `validate_step(index)`.
+
+    The reference reads its scene from a Habitat / Replica database inside the constructor (:826-871; datasets are out of scope, SURVEY.md
+    section 2): here the scene is GIVEN -- `ref_imgs_info` (the source views in `ref_ids` order) and optionally `val_imgs_info`, dicts
+    as built by panogrf_amd.imgs_info.build_imgs_info (`imgs, w2c, c2w, depth_range, masks`, ...; numpy or torch) -- and the
+    generalisable model as an object (`gen_renderer=`, a NeuralRayGenRenderer with its init net) instead of a checkpoint path."""
+    default_cfg = {
+        'gen_cfg': None, 'use_validation': True, 'validate_initialization': False, 'init_src_view_num': 1, 'train_include_self': False,
+        'ft_include_self': False, 'include_self_prob': 0.01, 'train_ray_num': 512, 'foreground_ratio': 1.0, 'ray_feats_res': [64, 128],
+        'ray_feats_dim': 32, 'depth_guided_ray_sampling': False, 'has_depth': True,
+    }
+
+    def __init__(self, cfg, ref_imgs_info=None, val_imgs_info=None, gen_renderer=None):
+        cfg = {**self.default_cfg, **cfg}
+        cfg['ray_feats_res'] = [cfg['height'] // 8, cfg['width'] // 8]                       # :822
+        super().__init__(cfg)
+        if ref_imgs_info is None:
+            raise PgrfError('NeuralRayFtRenderer: the scene is passed in as ref_imgs_info= (see class docstring); the reference\'s '
+                            'Habitat / Replica readers are out of scope')
+        for key in ('depth_guided_ray_sampling', 'use_self_hit_prob'):
+            if self.cfg.get(key):
+                raise PgrfError(f"cfg['{key}'] is not implemented on the HIP path")
+        from .imgs_info import imgs_info_to_torch
+        self.ref_imgs_info = imgs_info_to_torch(dict(ref_imgs_info))
+        n_ref = self.ref_imgs_info['imgs'].shape[0]
+        self.ref_ids = np.arange(n_ref)
+        if self.cfg['use_validation'] and val_imgs_info is not None:
+            self.val_imgs_info = imgs_info_to_torch(dict(val_imgs_info))
+            self.val_num = self.val_imgs_info['imgs'].shape[0]
+        else:
+            self.val_imgs_info, self.val_num = None, 0
+        self._initialization(gen_renderer)
+
+    # ---- initialisation (network/renderer.py:918-1028)
+    def _init_by_cost_volume(self, ref_i, init_net):
+        ref = imgs_info_slice(self.ref_imgs_info, torch.tensor([ref_i]))
+        src_index = [i for i in range(len(self.ref_ids)) if i != ref_i]
+        src = imgs_info_slice(self.ref_imgs_info, torch.tensor(src_index))
+        dev = next(init_net.parameters()).device
+        with torch.no_grad():
+            ret = init_net({k: v.to(dev) for k, v in ref.items()}, {k: v.to(dev) for k, v in src.items()}, False)
+        out = [ret['ray_feats'].detach().cpu(), ret['mvs_depth'].detach().cpu()]
+        if self.cfg.get('render_uncert'):
+            out.append(ret['mvs_uncert'].detach().cpu())
+        return out
+
+    def _initialization(self, gen_renderer):
+        self.ray_feats = nn.ParameterList()
+        self.mvs_depths, self.mvs_uncert = [], []
+        if gen_renderer is not None:
+            gen_renderer = gen_renderer.eval()
+            for ref_i in range(len(self.ref_ids)):
+                got = self._init_by_cost_volume(ref_i, gen_renderer.init_net)
+                self.ray_feats.append(nn.Parameter(got[0]))
+                self.mvs_depths.append(got[1])
+                if self.cfg.get('render_uncert'):
+                    self.mvs_uncert.append(got[2])
+            for name in ('vis_encoder', 'dist_decoder', 'agg_net', 'sph_fitter', 'image_encoder'):
+                getattr(self, name).load_state_dict(getattr(gen_renderer, name).state_dict())
+            if self.cfg['use_hierarchical_sampling'] and not self.cfg.get('one_mlp'):
+                self.fine_dist_decoder.load_state_dict(gen_renderer.fine_dist_decoder.state_dict())
+                self.fine_agg_net.load_state_dict(gen_renderer.fine_agg_net.state_dict())
+        else:                                   # 'init from scratch !' (:1021-1027)
+            fh, fw = self.cfg['ray_feats_res']
+            for _ in range(len(self.ref_ids)):
+                self.ray_feats.append(nn.Parameter(torch.randn(1, self.cfg['ray_feats_dim'], fh, fw)))
+
+    # ---- batches (network/renderer.py:1029-1107)
+    def slice_imgs_info(self, ref_idx, val_idx, is_train):
+        dev = self.ray_feats[0].device
+        ref = {k: v.to(dev) for k, v in imgs_info_slice(self.ref_imgs_info, torch.as_tensor(np.asarray(ref_idx)).long()).items()}
+        ref['ray_feats'] = torch.cat([self.ray_feats[i] for i in ref_idx], 0)
+        if self.mvs_depths:
+            ref['mvs_depth'] = torch.cat([self.mvs_depths[i] for i in ref_idx], 0).to(dev)
+            if self.cfg.get('render_uncert'):
+                ref['mvs_uncert'] = torch.cat([self.mvs_uncert[i] for i in ref_idx], 0).to(dev)
+        if is_train:
+            que = imgs_info_slice(self.ref_imgs_info, torch.tensor([val_idx]))
+            if self.cfg.get('my_debug'):
+                _, _, hn, wn = que['imgs'].shape
+                coords = np.stack(np.meshgrid(np.arange(wn), np.arange(hn)), -1).reshape([1, -1, 2]).astype(np.float32)
+            else:
+                mask = que['masks'][0, 0].cpu().numpy() > 0
+                coords = get_coords_mask(mask, self.cfg['train_ray_num'], self.cfg['foreground_ratio']).reshape([1, -1, 2])
+        else:
+            if self.val_imgs_info is None:
+                raise PgrfError('NeuralRayFtRenderer: no validation views (val_imgs_info=)')
+            que = imgs_info_slice(self.val_imgs_info, torch.tensor([val_idx]))
+            _, _, hn, wn = que['imgs'].shape
+            coords = np.stack(np.meshgrid(np.arange(wn), np.arange(hn)), -1).reshape([1, -1, 2]).astype(np.float32)
+        que = {k: v.to(dev) for k, v in que.items()}
+        que['coords'] = torch.from_numpy(coords).to(dev)
+        if is_train and self.mvs_depths:
+            que['mvs_depth'] = self.mvs_depths[val_idx]
+            if self.cfg.get('render_uncert'):
+                que['mvs_uncert'] = self.mvs_uncert[val_idx]
+        return ref, que
+
+    def validate_step(self, val_idx, step=0):
+        ref_idx = list(range(len(self.ref_ids)))
+        ref, que = self.slice_imgs_info(ref_idx, val_idx, False)
+        with torch.no_grad():
+            out = self.render(dict(que), dict(ref), False)
+        ref.pop('ray_feats')
+        out.update({'ref_imgs_info': ref, 'que_imgs_info': que})
+        return out
+
+    def train_step(self):
+        n = len(self.ref_ids)
+        que_i = np.random.randint(0, n)
+        others = [i for i in range(n) if i != que_i]
+        if self.cfg['ft_include_self'] and not (np.random.random() > self.cfg['include_self_prob']):
+            ref_idx = list(range(n))
+            np.random.shuffle(ref_idx)
+        else:
+            ref_idx = others
+        ref, que = self.slice_imgs_info(ref_idx, que_i, True)
+        out = self.render(dict(que), dict(ref), True)
+        out.update({'que_imgs_info': que, 'ref_imgs_info': ref, 'que_id': que_i, 'all_info': self.ref_imgs_info})
+        return out
+
+    def render_pose(self, render_imgs_info, is_perspec=False):
+        """Arbitrary query poses from all source views (network/renderer.py:1162-1187; render_cube_pose = is_perspec=True)."""
+        dev = self.ray_feats[0].device
+        ref = {k: v.to(dev) for k, v in self.ref_imgs_info.items()}
+        ref['ray_feats'] = torch.cat(list(self.ray_feats), 0)
+        with torch.no_grad():
+            return self.render(render_imgs_info, ref, False, is_perspec=is_perspec)
+
+    def render_cube_pose(self, render_imgs_info):
+        return self.render_pose(render_imgs_info, is_perspec=True)
+
+    def forward(self, data, is_perspec=False):
+        if 'eval' not in data:
+            return self.train_step()
+        return self.validate_step(data['index'], data.get('step', 0))
+
+
 name2network = {
     'neuray_gen': NeuralRayGenRenderer,
+    'neuray_ft': NeuralRayFtRenderer,
     'neuray_base': NeuralRayBaseRenderer,
 }

@@ -1,0 +1,131 @@
+"""`name2network['neuray_ft']` (network/renderer.py:788-1200) on the HIP fast path: 20 fine-tuning steps -- the per-scene `ray_feats`
+parameters, both 2-D encoders and the coarse + fine per-ray networks under Adam, the reference's RenderLoss (network/loss.py:55-165,
+panogrf_amd/loss.py) reduced as the trainer does (train/trainer.py:377-394) -- against the SAME training loop built from the oracle's
+torch ops (oracle/render_oracle.py + oracle/loss_oracle.py) on an identically initialised copy with the same random draws."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import fixtures as FX
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(H, W, n, seed):
+    """n panoramas on a small circle around the origin: smooth textures (sums of low-frequency sinusoids), y-up w2c poses"""
+    g = np.random.RandomState(seed)
+    th, ph = np.meshgrid((np.arange(W) + 0.5) / W * 2 * math.pi, (np.arange(H) + 0.5) / H * math.pi)
+    imgs = np.zeros((n, 3, H, W), np.float32)
+    for v in range(n):
+        for c in range(3):
+            acc = np.zeros((H, W))
+            for _ in range(6):
+                a, b, p0 = g.randint(1, 4), g.randint(1, 3), g.uniform(0, 6.28)
+                acc += g.uniform(0.3, 1.0) * np.sin(a * th + b * ph + p0 + 0.2 * v)
+            imgs[v, c] = (acc - acc.min()) / (acc.max() - acc.min())
+    w2c = np.zeros((n, 3, 4))
+    for v in range(n):
+        w2c[v, :3, :3] = np.eye(3)
+        w2c[v, :, 3] = [-0.4 * math.cos(2 * math.pi * v / n), 0.0, -0.4 * math.sin(2 * math.pi * v / n)]
+    return imgs, w2c, np.tile(np.array([[0.5, 15.0]], np.float32), (n, 1))
+
+
+# The reference trains with either optimiser (train/trainer.py:38,242-245: cfg optimizer_type 'adam' | 'sgd').  The 1e-4 bar on the
+# loss curve is a statement about GRADIENTS, so it is held under SGD, whose update is proportional to them.  Adam's first updates are
+# lr * sign(g) whatever |g| is: a coordinate whose gradient is at round-off level moves by +-lr on both sides independently, and the
+# two trajectories separate at the per-cent level within a few steps even between two fp32 implementations of the same graph
+# (measured: step 0 equal to the last digit, 2e-6 at step 1, 4e-3 by step 5) -- there the bar is 2 %.
+@pytest.mark.parametrize('opt_name,lr,bar', [('sgd', 2e-3, 1e-4), ('sgd', 5e-3, 1e-4), ('adam', 1e-4, 2e-2)])
+def test_neuray_ft_twenty_steps_match_the_oracle_training_loop(opt_name, lr, bar):
+    from oracle import loss_oracle as LO
+    from oracle import render_oracle as O
+    from panogrf_amd import engine as E
+    from panogrf_amd import loss as PL
+    from panogrf_amd.imgs_info import build_imgs_info
+    from panogrf_amd.renderer import name2network
+
+    _, _, cfg, _ = FX.load('render_full_v2_dn32')
+    H, W, n_ref, rays = 64, 128, 3, 128
+    cfg = dict(cfg, height=H, width=W, train_ray_num=rays, use_nr_fine_loss=True, fix_all=False, fix_coarse=False, network='neuray_ft',
+               use_validation=False, ft_include_self=False)
+    imgs, w2c, dr = _scene(H, W, n_ref, 5)
+    info = build_imgs_info(imgs, w2c, dr)
+    torch.manual_seed(0)
+    net_h = name2network['neuray_ft'](dict(cfg), ref_imgs_info=info)
+    # seeded weights with live densities (default init gives alpha ~ 0: nothing to fit), the same state for both copies
+    shapes = [(k, tuple(v.shape)) for k, v in net_h.state_dict().items() if not k.startswith('ray_feats')]
+    sd = FX.seeded_renderer_state(shapes, 800)
+    # per-scene visibility features: smooth fields (what an init net leaves), not the white noise of the from-scratch branch -- with
+    # white-noise maps a 1e-6 shift of a fine sample changes the gathered feature at the per-cent level and two fp32 implementations
+    # of one graph part ways within five steps
+    gsm = torch.Generator().manual_seed(7)
+    for k, v in net_h.state_dict().items():
+        if k.startswith('ray_feats'):
+            low = torch.randn(1, v.shape[1], 3, 4, generator=gsm)
+            sd[k] = torch.nn.functional.interpolate(low, size=v.shape[-2:], mode='bicubic', align_corners=True)
+    net_h.load_state_dict(sd)
+    net_o = copy.deepcopy(net_h)
+    net_h, net_o = net_h.cuda().train(), net_o.cuda().train()
+    assert len(net_h.ray_feats) == n_ref and net_h.ray_feats[0].shape == (1, 32, H // 8, W // 8)
+    loss_fn = PL.name2loss['render'](cfg)
+    mk = (lambda ps: torch.optim.SGD(ps, lr=lr)) if opt_name == 'sgd' else (lambda ps: torch.optim.Adam(ps, lr=lr))
+    opt_h, opt_o = mk(net_h.parameters()), mk(net_o.parameters())
+    uv = cfg['dist_decoder_cfg']['use_vis']
+    dn, fdn = cfg['depth_sample_num'], cfg['fine_depth_sample_num']
+    curve_h, curve_o = [], []
+    for step in range(20):
+        # ---- HIP fast path: renderer(data) without 'eval' = train_step() (network/renderer.py:1116-1157, 1188-1200)
+        np.random.seed(1000 + step)
+        torch.manual_seed(step)
+        opt_h.zero_grad()
+        out = net_h({'index': 0})
+        assert out['pixel_colors_nr_fine'].requires_grad and out['pixel_colors_gt'].shape == (1, rays, 3) and out['que_id'] in (0, 1, 2)
+        loss_h = PL.total_loss(loss_fn(out, None, step))
+        loss_h.backward()
+        opt_h.step()
+        curve_h.append(float(loss_h.detach()))
+        # ---- the same step from the oracle's ops: same view / pixel draws, same importance-sampling draws
+        np.random.seed(1000 + step)
+        torch.manual_seed(step)
+        opt_o.zero_grad()
+        que_i = np.random.randint(0, n_ref)
+        assert que_i == out['que_id']
+        ref, que = net_o.slice_imgs_info([i for i in range(n_ref) if i != que_i], que_i, True)
+        assert torch.equal(que['coords'], out['que_imgs_info']['coords'])
+        feats, rf = net_o._torch_encoders(ref['imgs'], ref['ray_feats'])
+        w = dict(net_o.named_parameters())
+        fr = dict(imgs=ref['imgs'], img_feats=feats, ray_feats=rf, w2c=ref['w2c'], ref_depth_range=ref['depth_range'],
+                  que_c2w=que['c2w'][0], que_depth_range=que['depth_range'][0])
+        coords = que['coords'][0]
+        depth_c = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rays, dn, cfg.get('use_disp', True), 'cuda')
+        oc = O.render_pass(w, 'dist_decoder', 'agg_net', fr, coords, depth_c, {'use_vis': uv})
+        u = torch.rand([1, rays, fdn])[0].cuda()
+        fd = E.sample_fine_depth(depth_c, oc['hit_prob_nr'].detach(), que['depth_range'][0].cpu(), fdn, use_disp=cfg.get('use_disp', True), u=u)
+        of = O.render_pass(w, 'fine_dist_decoder', 'fine_agg_net', fr, coords, fd, {'use_vis': cfg['fine_dist_decoder_cfg']['use_vis']})
+        h, wd = que['imgs'].shape[-2:]
+        grid = torch.stack([coords[:, 0] / (wd - 1) * 2 - 1, coords[:, 1] / (h - 1) * 2 - 1], -1)[None, None]
+        gt = torch.nn.functional.grid_sample(que['imgs'], grid, mode='bilinear', padding_mode='zeros', align_corners=True)[0, :, 0].t()[None]
+        data_pr = {'pixel_colors_nr': oc['pixel_colors_nr'][None], 'pixel_colors_nr_fine': of['pixel_colors_nr'][None], 'pixel_colors_gt': gt,
+                   'ray_mask': torch.ones(1, rays, dtype=torch.bool, device='cuda')}
+        loss_o = LO.total_loss(LO.render_loss(data_pr, cfg))
+        loss_o.backward()
+        opt_o.step()
+        curve_o.append(float(loss_o.detach()))
+    print('HIP   ', ['%.6f' % x for x in curve_h])
+    print('oracle', ['%.6f' % x for x in curve_o])
+    for a, b in zip(curve_h, curve_o):
+        assert abs(a - b) <= bar * abs(b), (curve_h, curve_o)
+    # the fit moves: mean loss of the last five steps below the first five (views differ step to step, so compare windows)
+    assert sum(curve_h[-5:]) < sum(curve_h[:5])
+    # every trainable group received updates, the per-scene ray_feats included
+    for k, p in net_h.named_parameters():
+        if k.startswith(('ray_feats.', 'image_encoder.conv1', 'vis_encoder.', 'agg_net.agg_impl.base_fc.0', 'fine_dist_decoder.mean_decoder.0')):
+            assert not torch.equal(p.detach().cpu(), sd[k].cpu()), k
+    # validation / free-pose rendering run on the fused inference path with the trained parameters
+    pose = {k: torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v for k, v in
+            __import__('panogrf_amd.imgs_info', fromlist=['x']).build_render_imgs_info(w2c[0], (H, W), (0.5, 15.0)).items()}
+    img = net_h.render_pose(pose)['pixel_colors_nr_fine']
+    assert img.shape == (1, H * W, 3) and bool(torch.isfinite(img).all())
