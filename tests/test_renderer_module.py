@@ -204,3 +204,37 @@ def test_bench_refuses_gpu_count_mismatch():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], capture_output=True, text=True,
                        timeout=300, cwd=root, env=env)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+def test_neuray_ft_module_surface_on_cpu():
+    """name2network['neuray_ft'] (network/renderer.py:788-1200): per-scene `ray_feats` parameters [1, dim, h/8, w/8] per source view
+    (:822, :1021-1027), `slice_imgs_info` batches with the reference's keys (:1029-1107), `get_coords_mask` pixel draws
+    (utils/base_utils.py:585-604); the scene is passed in, the Habitat readers are out of scope."""
+    import numpy as np
+    from panogrf_amd.imgs_info import build_imgs_info
+    from panogrf_amd.renderer import name2network, get_coords_mask
+    H, W, n = 32, 64, 3
+    g = np.random.RandomState(0)
+    info = build_imgs_info(g.rand(n, 3, H, W).astype(np.float32), np.tile(np.eye(3, 4)[None], (n, 1, 1)), np.tile([[0.5, 15.0]], (n, 1)))
+    cfg = dict(use_wrap_padding=True, dataset_name='m3d', height=H, width=W, min_depth=0.5, max_depth=15.0, use_hierarchical_sampling=True,
+               depth_sample_num=32, fine_depth_sample_num=32, sample_num=32, train_ray_num=50, use_validation=False,
+               dist_decoder_cfg={'use_vis': False}, fine_dist_decoder_cfg={'use_vis': False})
+    with pytest.raises(Exception):
+        name2network['neuray_ft'](dict(cfg))                                   # no scene given
+    with pytest.raises(Exception):
+        name2network['neuray_ft'](dict(cfg, use_self_hit_prob=True), ref_imgs_info=info)
+    net = name2network['neuray_ft'](dict(cfg), ref_imgs_info=info)
+    assert len(net.ray_feats) == n and all(p.shape == (1, 32, H // 8, W // 8) and p.requires_grad for p in net.ray_feats)
+    assert any(k.startswith('ray_feats.') for k, _ in net.named_parameters())
+    np.random.seed(3)
+    ref, que = net.slice_imgs_info([0, 2], 1, True)
+    assert ref['imgs'].shape == (2, 3, H, W) and ref['ray_feats'].shape == (2, 32, H // 8, W // 8) and ref['w2c'].shape == (2, 3, 4)
+    assert que['coords'].shape == (1, 50, 2) and que['imgs'].shape == (1, 3, H, W) and que['c2w'].shape == (1, 3, 4)
+    c = que['coords'][0].numpy()
+    assert len({(x, y) for x, y in c.tolist()}) == 50 and c[:, 0].max() < W and c[:, 1].max() < H       # distinct pixels of the view
+    mask = np.zeros((H, W), bool); mask[:4] = True
+    np.random.seed(1)
+    cc = get_coords_mask(mask, 40, 0.5)
+    assert cc.shape == (40, 2) and (cc[:20, 1] < 4).all()                      # the foreground share comes from inside the mask first
+    with pytest.raises(Exception):
+        net.slice_imgs_info([0, 1, 2], 0, False)                               # no validation views were given
