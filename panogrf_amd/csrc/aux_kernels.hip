@@ -352,7 +352,7 @@ int launch_fine_depth(const float* depth, const float* hit, float qnear, float q
   const bool aligned = (((uintptr_t)depth | (uintptr_t)hit | (uintptr_t)out) & 15) == 0;
   // The lane-per-ray kernel is a throughput form: 64 rays per wave, each lane a long serial run (45-225 us whatever the batch while its
   // waves fit the chip at once: 225 us with per-ray random draws, the training call).  A training batch of 2 048 rays is 32 such waves;
-  // the wave-per-ray kernel (1.9 ns per ray) finishes it in 14 us.  Measured crossover (tools/scratch/sampler_ab.py, dn 64): 16 k rays
+  // the wave-per-ray kernel (1.9 ns per ray) finishes it in 14 us.  Measured crossover (tools/sampler_ab.py, dn 64): 16 k rays
   // 36 | 46 us, 32 k rays 66 | 49 us (wave | lane); both give the same bits.
   const bool small = rn < 24576 && !(knob && (!strcmp(knob, "lane") || !strcmp(knob, "noshare")));
   if (!wave_only && !small && dn == fdn && (dn == 32 || dn == 64) && aligned && rn > 0) {

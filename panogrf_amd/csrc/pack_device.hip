@@ -6,7 +6,7 @@
 // The blob layout is NOT restated here: pack_weights.cpp's build_pack_maps() probes the host packer once per (device, use_vis,
 // max_dn) and returns, per 32-bit blob word, where it comes from -- a f32 copy of element e of tensor t, two split-f16 halves, or a
 // constant.  The kernel below evaluates that map; the four folded tensors (prob_embed.2 into base_fc.0 / neuray_fc.0) are computed
-// on the fly in the host's order of operations (double accumulation, index order: bit-identical, tests/test_gpu_pack_device.py).
+// on the fly in the host's order of operations (double accumulation, index order: bit-identical, tests/test_pack_device.py).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

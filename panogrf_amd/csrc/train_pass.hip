@@ -232,17 +232,21 @@ struct Ctx {
   hipEvent_t* ev;              // ring of events (re-recording an event does not disturb waits already enqueued on it)
   int* ev_next;
   int ev_count;
-  int* cur;                    // side stream of the current fork
-  hipStream_t dw_stream() const { return aux ? aux[*cur] : st; }
+  std::mutex* ev_mu;           // the event ring is shared by every pass on the device: slot choice + record + wait are one critical section
+                               // (two host threads -- an autograd backward thread and the main thread -- may run passes on one device)
+  mutable int cur = 0;         // side stream of the current fork: per-call state (this Ctx), not per-device
+  hipStream_t dw_stream() const { return aux ? aux[cur] : st; }
   void fork() const {
     if (!aux) return;
-    *cur = (*cur + 1) % kAux;
+    cur = (cur + 1) % kAux;
+    std::lock_guard<std::mutex> lock(*ev_mu);
     hipEvent_t e = ev[(*ev_next)++ % ev_count];
     (void)hipEventRecord(e, st);
-    (void)hipStreamWaitEvent(aux[*cur], e, 0);
+    (void)hipStreamWaitEvent(aux[cur], e, 0);
   }
   void join() const {
     if (!aux) return;
+    std::lock_guard<std::mutex> lock(*ev_mu);
     for (int i = 0; i < kAux; ++i) {
       hipEvent_t e = ev[(*ev_next)++ % ev_count];
       (void)hipEventRecord(e, aux[i]);
@@ -259,7 +263,7 @@ static bool train_deterministic() {
   return on;
 }
 // one side stream and event ring per device, created on first use and kept (PGRF_TRAIN_DW_STREAM=0: none)
-struct SideStream { hipStream_t s[kAux]; hipEvent_t ev[32]; int next, cur; bool ok; };
+struct SideStream { hipStream_t s[kAux]; hipEvent_t ev[32]; int next; bool ok; std::mutex mu; };
 static SideStream* side_stream() {
   static const bool off = [] { const char* e = getenv("PGRF_TRAIN_DW_STREAM"); return e && e[0] == '0'; }();
   if (off || train_deterministic()) return nullptr;
@@ -270,7 +274,7 @@ static SideStream* side_stream() {
   std::lock_guard<std::mutex> lock(mu);
   if (!per_dev[dev]) {
     SideStream* ss = new SideStream();
-    ss->next = 0; ss->cur = 0;
+    ss->next = 0;
     ss->ok = true;
     for (int i = 0; ss->ok && i < kAux; ++i) ss->ok = hipStreamCreateWithFlags(&ss->s[i], hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ss->ok && i < 32; ++i) ss->ok = hipEventCreateWithFlags(&ss->ev[i], hipEventDisableTiming) == hipSuccess;
@@ -484,7 +488,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   plan(w, P, V, dn, (char*)workspace);
   int gsize[R_COUNT] = {};
   SideStream* ss = side_stream();
-  Ctx c{(hipStream_t)stream, raw_dev, g_raw_dev, w.grep, gsize, ss ? ss->s : nullptr, ss ? ss->ev : nullptr, ss ? &ss->next : nullptr, 32, ss ? &ss->cur : nullptr};
+  Ctx c{(hipStream_t)stream, raw_dev, g_raw_dev, w.grep, gsize, ss ? ss->s : nullptr, ss ? ss->ev : nullptr, ss ? &ss->next : nullptr, 32, ss ? &ss->mu : nullptr};
   struct Joiner { const Ctx& c; ~Joiner() { c.join(); } } joiner{c};      // error returns included: the caller's stream never runs ahead of the side stream
   if (do_bwd) (void)hipMemsetAsync(w.grep, 0, (size_t)(kGradReplicas - 1) * kGradSlot * R_COUNT * 4, c.st);
   hipStream_t st = c.st;

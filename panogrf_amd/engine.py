@@ -5,6 +5,7 @@ caller-owned, contiguous float32 CUDA(HIP) tensor passed as a raw pointer.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -417,9 +418,13 @@ class RenderPassFunction(torch.autograd.Function):
     # the same tensors does not (was: ~70 device->host copies and two map re-layouts per pass).
     _frames, _blobs = [], []
 
+    _lock = threading.Lock()
+
     @staticmethod
     def _lookup(cache, ts, extra):
-        for ent_ts, ent_ver, ent_extra, val in cache:
+        with RenderPassFunction._lock:
+            entries = list(cache)
+        for ent_ts, ent_ver, ent_extra, val in entries:
             if ent_extra == extra and len(ent_ts) == len(ts) and all((a is b) or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype) for a, b in zip(ent_ts, ts)) and \
                     ent_ver == [None if t is None else t._version for t in ts]:
                 return val
@@ -427,8 +432,17 @@ class RenderPassFunction(torch.autograd.Function):
 
     @staticmethod
     def _store(cache, ts, extra, val, keep):
-        del cache[:max(0, len(cache) - keep + 1)]
-        cache.append((list(ts), [None if t is None else t._version for t in ts], extra, val))
+        # detached aliases as keys: same storage address and version counter (the lookup still matches, the address still cannot be
+        # recycled under the cache), but no grad_fn -- the encoders' autograd graph is not kept alive by the cache
+        with RenderPassFunction._lock:
+            del cache[:max(0, len(cache) - keep + 1)]
+            cache.append(([None if t is None else t.detach() for t in ts], [None if t is None else t._version for t in ts], extra, val))
+
+    @staticmethod
+    def clear_caches():
+        """Drop the cached channel-last Frame and packed weight blobs (after training / validation, or to release their memory)."""
+        with RenderPassFunction._lock:
+            del RenderPassFunction._frames[:], RenderPassFunction._blobs[:]
 
     @staticmethod
     def forward(ctx, meta, coords, depth, img_feats, ray_feats, *raw):
@@ -445,7 +459,9 @@ class RenderPassFunction(torch.autograd.Function):
         # rematerialising backward, ~9 KB less memory per (ray, sample, view) held): the staged forward's outputs ARE the pass's outputs
         # (equal to the fused kernel's to 2e-5, tests/test_gpu_train_backward.py), so the fused launch and the second forward are saved.
         rn = coords.shape[0]
-        keep = os.environ.get('PANOGRF_TRAIN_KEEP_ACTS', '1') != '0' and precision in (None, 'f32') and rn > 0 and \
+        # (only when some differentiable input needs a gradient: grad mode is always off inside Function.forward, so a caller under
+        # torch.no_grad() or with frozen inputs would otherwise pay the staged forward and its workspace for nothing)
+        keep = any(ctx.needs_input_grad[3:]) and os.environ.get('PANOGRF_TRAIN_KEEP_ACTS', '1') != '0' and precision in (None, 'f32') and rn > 0 and \
             lib.pgrf_render_pass_backward_workspace_bytes(frame.rfn, rn, depth.shape[1]) <= int(float(os.environ.get('PANOGRF_TRAIN_KEEP_ACTS_MAX_GB', '16')) * 2 ** 30)
         ctx.ws = None
         if keep:

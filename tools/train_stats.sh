@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel statistics of the training bench (rocprofv3 --kernel-trace --stats), the top N kernels:   bash tools/train_stats.sh [N]
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the gpurun box exports it) or run from the repo root with GRAFT_REPO_ROOT=$PWD}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/trs
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trs -- python3 $R/bench.py --train --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1

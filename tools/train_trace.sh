@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-launch durations of one kernel family in the LAST training step of the bench (launch order):   bash tools/train_trace.sh chain_fwd [count]
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the gpurun box exports it) or run from the repo root with GRAFT_REPO_ROOT=$PWD}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/trt
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trt -- python3 $R/bench.py --train --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
