@@ -173,6 +173,7 @@ def cpu_baseline(case, budget_s=15.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    avail = cores
     cores = max(1, min(cores, int(os.environ.get('PGRF_CPU_BASELINE_THREADS', '16'))))
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(cores)
@@ -193,7 +194,9 @@ def cpu_baseline(case, budget_s=15.0):
     torch.set_num_threads(prev_threads)
     return dict(value=n / dt, unit='rays/s', cores=cores, kind='port',
                 sample=f'{n} random rays of the same frame through oracle.render_oracle.render_rays '
-                       f'({dt:.1f} s, torch CPU fp32)'), coords, out
+                       f'({dt:.1f} s, torch CPU fp32; {cores} of the {avail} CPUs the affinity mask shows: GPU boxes expose far more '
+                       f'logical CPUs than their cgroup quota runs, and torch with every one of them as a thread is slower than with 16 '
+                       f'-- PGRF_CPU_BASELINE_THREADS overrides)'), coords, out
 
 
 def eager_gpu_baseline(case, dev, ray_batch_num=2048, frames=1):
