@@ -1952,8 +1952,11 @@ static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, fl
   if (const char* e = getenv("PGRF_CONV_SPLIT")) split = (nt == 1) && atoi(e) != 0;                       // tuning knob
   if (split) {
     // tuning knobs: one cout tile per workgroup (twice the workgroups, half the chain per wave) / the two-wave LEAN instantiation
-    int smt = mt;
-    if (const char* e = getenv("PGRF_CONV_SPLIT_MT")) { if (atoi(e) == 1) smt = 1; }
+    // 2-D layers (depth-1 volumes: the per-frame encoders and the MVS feature nets, a few thousand output pixels): ONE cout tile per workgroup --
+    // twice the workgroups (two waves per SIMD instead of one) and half the dependent MFMA chain per wave: encoders 1.44 -> 1.22 ms,
+    // init net 5.51 -> 5.10 ms (round 5).  3-D layers keep two tiles per workgroup (UNet2's low-resolution levels: 587 vs 675 us, round 3).
+    int smt = (a.D == 1) ? 1 : mt;
+    if (const char* e = getenv("PGRF_CONV_SPLIT_MT")) { const int v = atoi(e); if (v == 1) smt = 1; else if (v == 2) smt = mt; }
     bool slean = false;
     if (const char* e = getenv("PGRF_CONV_SPLIT_LEAN")) slean = atoi(e) != 0 && (Cin & 31) == 0 && a.wtaps == 27;
     dim3 sgrid((unsigned)tiles, (unsigned)(a.cot_total / smt));
