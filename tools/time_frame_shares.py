@@ -35,15 +35,20 @@ src = imgs_info_to_torch(build_imgs_info(imgs[::-1].copy(), np.stack([pose(-0.5)
 que = imgs_info_to_torch(build_render_imgs_info(pose(0.0), (H, W), [0.5, 15.0]), 'cuda')
 
 
-def timeit(fn, n=10, warm=3):
+def timeit(fn, n=10, warm=3, reps=3):
+    """median over `reps` batches of the mean of n calls (a single batch now and then catches a clock dip: one of eight equal row
+    tiles read 9.6 ms against 8.7-8.8 for its neighbours in the first round-5 collection)"""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    vals = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        vals.append((time.perf_counter() - t0) / n * 1e3)
+    return sorted(vals)[len(vals) // 2]
 
 
 with torch.no_grad():
