@@ -3,7 +3,9 @@
 // mixture-of-logistics visibility decoder -> IBRNet-with-NeuRay aggregation (all Linear layers on
 // v_mfma_f32_32x32x2_f32, transposed so activations stay in registers: see pgrf_layout.h) ->
 // 4-head attention over the samples of the ray (QK^T on MFMA, K/V staged in LDS) -> density,
-// colour blending -> alpha compositing (wave scan through LDS).
+// colour blending -> alpha compositing (transmittance = inclusive product scan over the wave's 32 samples by __shfl_up,
+// the totals of a ray's earlier waves through LDS; pixel colour / depth by wave-shuffle reduction).
+// The 16-output layers run on v_mfma_f32_16x16x4_f32 (mfma_layer16), the <= 8-output layers on v_mfma_f32_4x4x1_16b_f32 (mfma_small).
 //
 // Work decomposition: workgroup = 4 waves = 128 sample points = 128/DN rays.  A wave owns 32
 // consecutive samples of one ray for ALL source views; lane l holds point (l & 31); lanes l and
