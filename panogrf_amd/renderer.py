@@ -223,10 +223,8 @@ class NeuralRayBaseRenderer(nn.Module):
     def _check_train(self, is_train):
         """Training mode: the reference's random importance samples and hit_prob_* outputs; with autograd
         enabled the per-ray passes run as torch.autograd Functions whose backward is pgrf_render_pass_backward
-        (panogrf_amd.engine.RenderPassFunction) and the 2-D encoders stay on torch.  What has no backward is refused."""
+        (panogrf_amd.engine.RenderPassFunction) and the 2-D encoders stay on torch.  What has no backward (the split-f16 mode) is refused."""
         if is_train and torch.is_grad_enabled():
-            if self.cfg.get('render_c2f_all') and self.cfg.get('render_uncert'):
-                raise NotImplementedError("cfg['render_c2f_all'] together with cfg['render_uncert'] has no backward pass")
             if self.cfg.get('hip_precision', 'f32') != 'f32':
                 raise NotImplementedError("training runs in exact fp32 (cfg['hip_precision']='f32')")
 
@@ -305,6 +303,9 @@ class NeuralRayBaseRenderer(nn.Module):
             fine['depth'] = fd
             if c.get('render_c2f_all'):      # one composite over the sorted union of both passes' samples (renderer.py:484-518)
                 fine.update(E.merge_c2f_autograd(depth, out['colors_nr'], out['density_nr'], fd, fine['colors_nr'], fine['density_nr']))
+                # the merged composite's depths (constants of the graph): what render_uncert below pairs with the merged hit
+                # probabilities (renderer.py:492,515); equal depths give equal terms, so the order among ties does not matter
+                fine['depth'] = torch.sort(torch.cat([depth, fd], -1), dim=-1, stable=True)[0]
             for k, v in fine.items():
                 out[k + '_fine'] = v
         if c.get('render_uncert'):        # renderer.py:305-312, in torch so that it stays differentiable

@@ -236,3 +236,76 @@ def test_module_training_step_matches_autograd_through_the_oracle():
     out2 = net({'que_imgs_info': dict(que), 'ref_imgs_info': mk_ref()})
     after = float(loss_of({k: v[0] for k, v in out2.items() if v.dtype == torch.float32}).detach())
     assert after < before, (before, after)
+
+
+def test_c2f_all_with_render_uncert_backward_vs_autograd_of_the_oracle():
+    """cfg render_c2f_all + render_uncert under autograd (network/renderer.py:484-518: the merged composite's uncertainty
+    sum_i w_i (z_i - depth)^2 + 1e-5 over the sorted union of both passes' samples).  The module's training path (two HIP passes,
+    MergeC2fFunction, the uncertainty in torch on the merged hit probabilities) against the same graph from the oracle's ops
+    (render_pass x 2 + merge_c2f_all(uncert=True)) on the SAME sample depths: loss and every gradient."""
+    import numpy as np
+    from oracle import render_oracle as O
+    from panogrf_amd import engine as E
+    from panogrf_amd.renderer import name2network
+    frame, _, cfg, g = FX.load('render_full_v2_dn32')
+    z = np.load(FX.GOLDEN + '/render_full_v2_dn32.npz')
+    shapes = []
+    for ln in bytes(z['state.keys']).decode().split('\n'):
+        k, s_ = ln.split(':')
+        shapes.append((k, tuple(int(t) for t in s_.split(',')) if s_ else ()))
+    cfg = dict(cfg, render_c2f_all=True, render_uncert=True, render_depth=True, sample_num=64, depth_sample_num=32, fine_depth_sample_num=32)
+    # (the merged composite has 64 samples; the per-pass networks keep 32: the positional table is per pass)
+    cfg['sample_num'] = 32
+    net = name2network['neuray_base'](dict(cfg))
+    net.load_state_dict(FX.seeded_renderer_state(shapes, 800))
+    net = net.cuda().train()
+    H, W = frame['imgs'].shape[-2:]
+    gsel = torch.Generator().manual_seed(5)
+    idx = torch.randperm(H * W, generator=gsel)[:80]
+    coords = torch.stack([(idx % W).float(), (idx // W).float()], -1)
+    target = torch.rand(80, 3, generator=gsel).cuda()
+    que = {'c2w': frame['que_c2w'][None].cuda(), 'coords': coords[None].cuda(), 'depth_range': frame['que_depth_range'][None].cuda()}
+    mk_ref = lambda: {'imgs': frame['imgs'].cuda(), 'w2c': frame['w2c'].cuda(), 'depth_range': frame['ref_depth_range'].cuda(),
+                      'ray_feats': frame['ray_feats'].cuda()}
+
+    def loss_of(out):
+        return ((out['pixel_colors_nr_fine'] - target) ** 2).mean() + 0.3 * out['render_uncert_fine'].mean() + 0.1 * out['render_uncert'].mean() + \
+            0.05 * out['render_depth_fine'].mean()
+
+    net.zero_grad()
+    torch.manual_seed(13)
+    out = net({'que_imgs_info': dict(que), 'ref_imgs_info': mk_ref()})
+    assert out['render_uncert_fine'].requires_grad and out['render_uncert_fine'].shape == (1, 80) and out['hit_prob_nr_fine'].shape == (1, 80, 64)
+    loss = loss_of({k: v[0] for k, v in out.items() if v.dtype == torch.float32})
+    loss.backward()
+    mine = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    net.zero_grad()
+    torch.manual_seed(13)
+    u = torch.rand([1, 80, 32])[0].cuda()
+    ref = mk_ref()
+    feats, rf = net._torch_encoders(ref['imgs'], ref['ray_feats'])
+    w = {k: p for k, p in net.named_parameters()}
+    fr = dict(imgs=ref['imgs'], img_feats=feats, ray_feats=rf, w2c=ref['w2c'], ref_depth_range=ref['depth_range'],
+              que_c2w=frame['que_c2w'].cuda(), que_depth_range=frame['que_depth_range'].cuda())
+    depth_c = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], 80, 32, cfg.get('use_disp', True), 'cuda')
+    fd = E.sample_fine_depth(depth_c, out['hit_prob_nr'][0].detach(), frame['que_depth_range'], 32, use_disp=cfg.get('use_disp', True), u=u)
+    uv = cfg['dist_decoder_cfg']['use_vis']
+    oc = O.render_pass(w, 'dist_decoder', 'agg_net', fr, coords.cuda(), depth_c, {'use_vis': uv})
+    of = O.render_pass(w, 'fine_dist_decoder', 'fine_agg_net', fr, coords.cuda(), fd, {'use_vis': cfg['fine_dist_decoder_cfg']['use_vis']})
+    m = O.merge_c2f_all(depth_c, oc, fd, of, uncert=True)
+    oout = {'pixel_colors_nr_fine': m['pixel_colors_nr'], 'render_uncert_fine': m['render_uncert'], 'render_depth_fine': m['render_depth'],
+            'render_uncert': O.depth_uncertainty(depth_c, oc['render_depth'], oc['hit_prob_nr'])}
+    oloss = loss_of(oout)
+    oloss.backward()
+    theirs = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 2e-5 * max(1.0, abs(float(oloss.detach())))
+    assert FX.max_abs(out['render_uncert_fine'][0].detach().cpu(), m['render_uncert'].detach().cpu()) < 2e-5 * max(1.0, float(m["render_uncert"].detach().abs().max()))
+    assert set(mine) == set(theirs)
+    num = den = 0.0
+    for k in theirs:
+        a, b = mine[k].double().flatten(), theirs[k].double().flatten()
+        num, den = num + float((a - b).norm()) ** 2, den + float(b.norm()) ** 2
+        if float(b.norm()) > 1e-7:
+            assert float((a - b).norm()) / float(b.norm()) < (5e-3 if b.numel() >= 512 else 2e-2), (k, float((a - b).norm()) / float(b.norm()))
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
