@@ -603,7 +603,11 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
           default: chain_act_bwd<QD, ACT_SOFTPLUS_B>(y, d); break;
         }
       }
+#ifdef PGRF_TRAIN_ABL_NO_DELTA   // timing experiment: delta is not written (what a fusion of the dW products into this kernel would save)
+      if (false) {
+#else
       if ((L.act != ACT_NONE || k > 0) && row_ok) {
+#endif
         float* dr = L.D + row * (long)L.ldd;
 #pragma unroll
         for (int q = 0; q < QD; ++q) {

@@ -296,6 +296,9 @@ static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float*
 // so that the launch has ~1 536 workgroups; partial tiles are summed inside a workgroup, then one atomic per element and workgroup
 static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int ldd, int rw, int rb, long rows, int IN, int OUT, int wld = 0, int wcol = 0) {
   float* gb = (rb >= 0) ? c.graw[rb] : nullptr;
+#ifdef PGRF_TRAIN_ABL_NO_DW   // timing experiment: no weight-gradient products at all (the bound of any fusion of them into the chains)
+  return;
+#endif
   if (!c.graw[rw]) {
     if (gb) {          // bias gradient alone (the weight's is not wanted): column sums by the elementwise kernel
       int cp = 1;
