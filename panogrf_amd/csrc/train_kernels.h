@@ -854,6 +854,80 @@ __global__ void gather32_bwd_kernel(float* __restrict__ gmap, long view_stride, 
   }
 }
 
+// The same scatter with the taps of a RAY merged before they reach memory (round 5).  The kernel above issues one 128-byte atomic per
+// (sample, view, tap): 33.5 M float atomics for 2 048 rays x 64 samples x 2 views, ~206 us whatever the launch shape (device-scope
+// float atomics execute beyond the XCD's L2).  But the samples of a ray project onto an epipolar CURVE of the source map: consecutive
+// samples share most of their four texels.  Here one wave = one (ray, view), lane & 31 = channel, and the two lane halves walk the two
+// halves of the ray's samples in order, each keeping the last kGE texels it touched as (texel, partial sum) pairs in registers (a FIFO:
+// a miss flushes the oldest pair with ONE atomic and shifts); everything is flushed at the end of the walk.  The taps of kGB samples
+// are fetched together (a walk of dependent loads would be one memory round trip per sample).  Same products, the sum of a texel's
+// contributions merely associates per ray first.
+#ifndef PGRF_SCATTER_GE
+#define PGRF_SCATTER_GE 6
+#endif
+#ifndef PGRF_SCATTER_GB
+#define PGRF_SCATTER_GB 4
+#endif
+#ifndef PGRF_SCATTER_GW
+#define PGRF_SCATTER_GW 1
+#endif
+constexpr int kGE = PGRF_SCATTER_GE, kGB = PGRF_SCATTER_GB, kGW = PGRF_SCATTER_GW;     // FIFO depth, samples fetched together, waves per (ray, view)
+__global__ void __launch_bounds__(256) gather32_bwd_ray_kernel(float* __restrict__ gmap, long view_stride, const int* __restrict__ to,
+                                                               const float* __restrict__ tw, int rn, int dn, int V,
+                                                               const float* __restrict__ g, int ldg, int gc) {
+  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wv >= (long)rn * V * kGW) return;
+  const int part = (int)(wv % kGW), v = (int)((wv / kGW) % V), ray = (int)(wv / ((long)kGW * V));
+  const int lane = threadIdx.x & 63, c = lane & 31, half = lane >> 5;
+  const int seg = (dn + 2 * kGW - 1) / (2 * kGW), s0 = (part * 2 + half) * seg, s1 = (s0 + seg < dn) ? s0 + seg : dn;
+  float* __restrict__ mb = gmap + (size_t)v * view_stride + c;
+  int key[kGE];
+  float val[kGE];
+#pragma unroll
+  for (int e = 0; e < kGE; ++e) { key[e] = -1; val[e] = 0.f; }
+  for (int sb = s0; sb < s1; sb += kGB) {
+    float gv[kGB];
+    int4 o4[kGB];
+    float4 w4[kGB];
+#pragma unroll
+    for (int u = 0; u < kGB; ++u) {
+      const int s = (sb + u < s1) ? sb + u : s1 - 1;
+      const long pv = ((long)ray * dn + s) * V + v;
+      gv[u] = g[pv * ldg + gc + c];
+      o4[u] = *reinterpret_cast<const int4*>(to + pv * 4);
+      w4[u] = *reinterpret_cast<const float4*>(tw + pv * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < kGB; ++u) {
+      const bool live = sb + u < s1;
+      const int o[4] = {o4[u].x, o4[u].y, o4[u].z, o4[u].w};
+      const float wt[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (live && wt[t] != 0.f) {                 // (zero weight: a tap outside the map; uniform over the half)
+          const float contrib = gv[u] * wt[t];
+          bool hit = false;
+#pragma unroll
+          for (int e = 0; e < kGE; ++e) {
+            const bool m = key[e] == o[t];
+            val[e] += m ? contrib : 0.f;
+            hit = hit || m;
+          }
+          if (!hit) {
+            if (key[kGE - 1] >= 0 && val[kGE - 1] != 0.f) unsafeAtomicAdd(mb + (size_t)key[kGE - 1] * 32, val[kGE - 1]);
+#pragma unroll
+            for (int e = kGE - 1; e > 0; --e) { key[e] = key[e - 1]; val[e] = val[e - 1]; }
+            key[0] = o[t]; val[0] = contrib;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < kGE; ++e)
+    if (key[e] >= 0 && val[e] != 0.f) unsafeAtomicAdd(mb + (size_t)key[e] * 32, val[e]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // compute_prob (dist_decoder.py:6-51 is_ref branch, :109-140): mixture of two logistics -> visibility, hit probability
 struct ProbIO {
@@ -928,40 +1002,79 @@ __global__ void stats_kernel(const float* __restrict__ x, int ldx, int xc, const
   out[p * ldo + mc + j] = m;
   out[p * ldo + vc + j] = var;
 }
-// gx[PV, .] += ..., gw[PV] += ...   One WAVE per point, lane = feature (F <= 64, V <= 4): every access is a run of F consecutive
+// gx[PV, .] += ..., gw[PV] += ...   A WAVE per point, lane = feature (F <= 64, V <= 4): every access is a run of F consecutive
 // floats (the first version gave a thread one (point, view) row and walked the features at a stride of ld floats: 744 us per call
 // for 262 144 rows against ~25 us of traffic); the per-view weight gradient is a wave reduction.
-__global__ void __launch_bounds__(256) stats_bwd_kernel(const float* __restrict__ x, int ldx, int xc, const float* __restrict__ w, int V, int F,
-                                                        long P, const float* __restrict__ stat, int lds, int mc, int vc,
-                                                        const float* __restrict__ g, int ldg, int gmc, int gvc, float* __restrict__ gx, int ldgx,
-                                                        int gxc, float* __restrict__ gw) {
-  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+// Round 5: (i) NS = 2 statistics of the SAME rows under two weightings (ibrnet.py:128-137: weight0 from neuray_fc, weight1 uniform) in one
+// sweep -- x is read and gx read-modified-written once, the two terms added in the order the two launches added them: 2 x 100 us -> 139 us;
+// (ii) PGRF_STAT_PTS points per wave, two in flight (measured per 2 048-ray training step, tools/ab_train_variants.sh: 1 point 5.95 ms,
+// 2 points 5.89, 4 points 6.07: the kernel is bound by the round trips of short rows at a 207-float stride, and wants waves, not long ones).
+struct StatSet { const float* w; int mc, vc, gmc, gvc; float* gw; };    // weights [PV], stat / g columns of (mean, var), gw [PV] or null
+#ifndef PGRF_STAT_PTS
+#define PGRF_STAT_PTS 2
+#endif
+constexpr int kStatPts = PGRF_STAT_PTS, kStatFly = kStatPts >= 2 ? 2 : 1;      // points per wave, points in flight
+template <int NS>
+__global__ void __launch_bounds__(256) stats_bwd_kernel(const float* __restrict__ x, int ldx, int xc, int V, int F, long P,
+                                                        const float* __restrict__ stat, int lds, const float* __restrict__ g, int ldg,
+                                                        float* __restrict__ gx, int ldgx, int gxc, StatSet s0, StatSet s1) {
+  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int j = threadIdx.x & 63;
-  if (p >= P) return;
   const bool on = j < F;
   const int jj = on ? j : 0;
-  const float m = stat[p * lds + mc + jj], gm = g[p * ldg + gmc + jj], gvar = g[p * ldg + gvc + jj];
-  float xs[4], ws[4], S = 0.f;              // S = sum_u w_u (x_u - m): zero only when the weights sum to one
+  const long p_beg = wv * kStatPts, p_end = (p_beg + kStatPts < P) ? p_beg + kStatPts : P;
+  for (long p0 = p_beg; p0 < p_end; p0 += kStatFly) {
+    float xs[kStatFly][4], go[kStatFly][4], ws[kStatFly][NS][4], m[kStatFly][NS], gm[kStatFly][NS], gvar[kStatFly][NS];
+    bool ok[kStatFly];
+    // every load of the two points first
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (u < V) {
-      ws[u] = w[p * V + u];
-      xs[u] = x[(p * V + u) * ldx + xc + jj];
-      S += ws[u] * (xs[u] - m);
-    }
-  }
-  const float gmt = gm - 2.f * S * gvar;    // total gradient reaching the mean
+    for (int e = 0; e < kStatFly; ++e) {
+      ok[e] = p0 + e < p_end;
+      const long p = ok[e] ? p0 + e : p0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (u < V) {
-      const float d = xs[u] - m;
-      if (on) gx[(p * V + u) * ldgx + gxc + j] += ws[u] * gmt + 2.f * ws[u] * d * gvar;
-      if (gw) {
-        float part = on ? xs[u] * gmt + d * d * gvar : 0.f;
+      for (int u = 0; u < 4; ++u)
+        if (u < V) {
+          xs[e][u] = x[(p * V + u) * ldx + xc + jj];
+          go[e][u] = gx[(p * V + u) * ldgx + gxc + jj];
+        }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
-        if (j == 0) gw[p * V + u] += part;
+      for (int k = 0; k < NS; ++k) {
+        const StatSet& S = k == 0 ? s0 : s1;
+        m[e][k] = stat[p * lds + S.mc + jj]; gm[e][k] = g[p * ldg + S.gmc + jj]; gvar[e][k] = g[p * ldg + S.gvc + jj];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < V) ws[e][k][u] = S.w[p * V + u];
       }
+    }
+#pragma unroll
+    for (int e = 0; e < kStatFly; ++e) {
+      if (!ok[e]) break;                      // (wave-uniform)
+      const long p = p0 + e;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const StatSet& S = k == 0 ? s0 : s1;
+        float Sw = 0.f;                       // sum_u w_u (x_u - m): zero only when the weights sum to one
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < V) Sw += ws[e][k][u] * (xs[e][u] - m[e][k]);
+        const float gmt = gm[e][k] - 2.f * Sw * gvar[e][k];    // total gradient reaching the mean
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u < V) {
+            const float d = xs[e][u] - m[e][k];
+            go[e][u] += ws[e][k][u] * gmt + 2.f * ws[e][k][u] * d * gvar[e][k];
+            if (S.gw) {
+              float part = on ? xs[e][u] * gmt + d * d * gvar[e][k] : 0.f;
+#pragma unroll
+              for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+              if (j == 0) S.gw[p * V + u] += part;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < V && on) gx[(p * V + u) * ldgx + gxc + j] = go[e][u];
     }
   }
 }

@@ -283,6 +283,13 @@ static SideStream* side_stream() {
   return per_dev[dev]->ok ? per_dev[dev] : nullptr;
 }
 
+// map gradient += transpose of the bilinear gather: the per-ray merging kernel (PGRF_TRAIN_SCATTER_RAY=0: one atomic per sample and tap)
+static void scatter32(hipStream_t st, float* gmap, long view_stride, const int* to, const float* tw, int rn, int dn, int V, const float* g, int ldg, int gc) {
+  static const bool per_ray = [] { const char* e = getenv("PGRF_TRAIN_SCATTER_RAY"); return !(e && e[0] == '0'); }();
+  const long PV = (long)rn * dn * V;
+  if (per_ray) hipLaunchKernelGGL(gather32_bwd_ray_kernel, dim3(nblk((long)rn * V * kGW, 4)), dim3(256), 0, st, gmap, view_stride, to, tw, rn, dn, V, g, ldg, gc);
+  else hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, gmap, view_stride, to, tw, PV, V, g, ldg, gc);
+}
 static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float* Y, int ldy, long rows, int IN, int OUT, int act) {
   // Y = act(X W^T + b) in one launch (bias and activation in the epilogue): 128 rows per workgroup, all OUT <= 64 columns per wave
   const dim3 grid((unsigned)((rows + 127) / 128), 1, 1);
@@ -627,8 +634,8 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   L(lin_bwd(c, w.gp, 16, w.v, 16, w.gv, 16, R_ATT_V_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(chain_bwd(c, geo_l, 2, P, w.ggin, 65, 0));
   (void)hipMemsetAsync(w.gwgt2, 0, PV * 4, st);
-  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32, w.ggin, 65, 0, 32, w.gxr,
-                     37, 0, w.gwgt2);
+  hipLaunchKernelGGL(stats_bwd_kernel<1>, dim3(nblk(P, 4 * kStatPts)), dim3(256), 0, st, w.xr, 37, 0, V, 32, P, w.gin, 65, w.ggin, 65, w.gxr, 37, 0,
+                     StatSet{w.wgt2, 0, 32, 0, 32, w.gwgt2}, StatSet{});
   hipLaunchKernelGGL(wgt2_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, w.gwgt2, w.ggin, P, V, w.gxr);
   PGRF_TCHECK("train pooled geometry backward");
   L(chain_bwd(c, v2_l, 2, PV, w.gxv1, 32, 0));
@@ -642,10 +649,9 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.ghb, 64, 0, w.gb1, 64, 0, P, V, 64, 0);      // d hb = sum over the views
   L(chain_bwd(c, glob_l, 1, P, w.gglob, 140, 0));                                         // d glob = d hb W[:, 0:140]  (+ that block's dW, P rows)
   (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
-  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35, w.gglob, 140, 0, 35,
-                     w.gxin, 207, 140, w.gw0);
-  hipLaunchKernelGGL(stats_bwd_kernel, dim3(nblk(P, 4)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105, w.gglob, 140, 70, 105,
-                     w.gxin, 207, 140, (float*)nullptr);
+  // both weightings of the per-view features (weight0 = sigmoid(neuray_fc) / V with a gradient, weight1 = 1 / V without) in one sweep
+  hipLaunchKernelGGL(stats_bwd_kernel<2>, dim3(nblk(P, 4 * kStatPts)), dim3(256), 0, st, w.xin, 207, 140, V, 35, P, w.glob, 140, w.gglob, 140, w.gxin, 207, 140,
+                     StatSet{w.w0, 0, 35, 0, 35, w.gw0}, StatSet{w.w1, 70, 105, 70, 105, nullptr});
   PGRF_TCHECK("train view statistics backward");
   // weight0 = sigmoid(neuray_fc) * wgt: the gradient enters the sigmoid output scaled by wgt
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gw0, 1, 0, w.gw0, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
@@ -653,7 +659,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.gdfeat, 35, 0, w.gxin, 207, 140, PV, 35, 0);
   if (g_img_feats) {      // (nothing of the pass reads the map gradient: beside the remaining chains on a side stream)
     c.fork();
-    hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, c.dw_stream(), g_img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.gxin, 207, 143);
+    scatter32(c.dw_stream(), g_img_feats, if_stride, w.tap_if_o, w.tap_if_w, rn, dn, V, w.gxin, 207, 143);
   }
   L(chain_bwd(c, rd_l, 2, PV, (float*)nullptr, 0, 0));
   L(chain_bwd(c, pe_l, 2, PV, w.gpe_in, 34, 0));
@@ -665,7 +671,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
     L(chain_bwd(c, dd_l[m], 3, PV, w.gpe_in, 34, 1));                                                               // += onto the ray feature
   }
   if (g_ray_feats)
-    hipLaunchKernelGGL(gather32_bwd_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, g_ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.gpe_in, 34, 0);
+    scatter32(st, g_ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, rn, dn, V, w.gpe_in, 34, 0);
   PGRF_TCHECK("train gather backward");
   c.join();
   {   // fold the weight-gradient replicas into the caller's buffers
