@@ -309,3 +309,29 @@ def test_c2f_all_with_render_uncert_backward_vs_autograd_of_the_oracle():
         if float(b.norm()) > 1e-7:
             assert float((a - b).norm()) / float(b.norm()) < (5e-3 if b.numel() >= 512 else 2e-2), (k, float((a - b).norm()) / float(b.norm()))
     assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+
+
+def test_map_gradient_scatter_per_ray_merge_equals_one_atomic_per_tap():
+    """gather32_bwd_ray_kernel (a ray's taps merged in registers before the atomics, round 5) against the plain scatter
+    (PGRF_TRAIN_SCATTER_RAY=0) on shapes around its segmentation: the minimum of 3 samples, odd counts, more waves' worth of samples
+    than a FIFO holds, 1-4 views.  Same products; only the association of a texel's sum differs."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    cases = ['5x3x1', '7x5x3', '3x128x4', '9x64x2', '33x31x2']
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ('0', '1'):
+            out = os.path.join(td, 's%s.pt' % mode)
+            env = dict(os.environ, PGRF_TRAIN_SCATTER_RAY=mode)
+            r = subprocess.run([sys.executable, os.path.join(here, 'gpu_scatter_modes.py'), out] + cases, capture_output=True, text=True,
+                               timeout=600, env=env)
+            assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2500:])
+            res[mode] = torch.load(out)
+    assert set(res['0']) == set(res['1']) and len(res['0']) == 2 * len(cases)
+    for k in res['0']:
+        a, b = res['1'][k], res['0'][k]
+        assert float(b.abs().max()) > 0, k
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
