@@ -18,7 +18,7 @@
     defined(PGRF_CV_ABL_GATHER) || defined(PGRF_CV_ABL_GEOM) || defined(PGRF_CV_ABL_STORE) || defined(PGRF_CV_MINITEMS) ||    \
     defined(PGRF_CV_WAVES) ||                                                                                                \
     defined(PGRF_WINO_ABL_NOA) || defined(PGRF_WINO_ABL_NOADD) || defined(PGRF_WINO_ABL_NOALOAD) ||                           \
-    defined(PGRF_TRAIN_ABL_NO_DW) || defined(PGRF_STAT_PTS) || defined(PGRF_SCATTER_GE) || defined(PGRF_SCATTER_GB) || defined(PGRF_SCATTER_GW) || defined(PGRF_TRAIN_ABL_NO_DELTA) || defined(PGRF_WINO_ABL_NOB) || defined(PGRF_WINO_ABL_NOLDS) || defined(PGRF_WINO_TIMING) || defined(PGRF_WINO_TV_PINGPONG)
+    defined(PGRF_TRAIN_ABL_NO_DW) || defined(PGRF_TRAIN_ABL_NO_STAGE) || defined(PGRF_STAT_PTS) || defined(PGRF_SCATTER_GE) || defined(PGRF_SCATTER_GB) || defined(PGRF_SCATTER_GW) || defined(PGRF_TRAIN_ABL_NO_DELTA) || defined(PGRF_WINO_ABL_NOB) || defined(PGRF_WINO_ABL_NOLDS) || defined(PGRF_WINO_TIMING) || defined(PGRF_WINO_TV_PINGPONG)
 #ifndef PGRF_ABLATION_BUILD
 #error "experiment switch (-DPGRF_ABL_* / PGRF_NO_* / PGRF_*_TIMING / tunable override) without -DPGRF_ABLATION_BUILD: use tools/build_variant*.sh, never the product Makefile"
 #endif

@@ -376,18 +376,21 @@ __host__ __device__ inline int chain_stride(int IN) { int s = (IN + 3) / 4 * 4; 
 __host__ __device__ inline int chain_rows(int OUT) { return OUT > 32 ? 64 : 32; }
 
 __device__ __forceinline__ void chain_stage_weights(const ChainArgs& a, float* lds, bool with_bias) {
-  for (int i = threadIdx.x; i < a.lds_floats; i += 256) lds[i] = 0.f;
+#ifdef PGRF_TRAIN_ABL_NO_STAGE   // timing experiment: the weights are not staged (the products then read whatever the LDS holds)
+  return;
+#endif
+  // (round 5: 16-byte zero stores and a (row, column) walk without integer division -- the staging of a chain's few KB was 0.22 ms of a
+  //  5.6 ms training step, 52 chain launches of ~1 300 workgroups each)
+  for (int i = threadIdx.x * 4; i < a.lds_floats; i += 256 * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // (lds_floats % 4 == 0)
   __syncthreads();
+  const int r0 = threadIdx.x >> 5, c0 = threadIdx.x & 31;          // 8 rows x 32 columns per sweep: a row's columns are consecutive addresses
   for (int k = 0; k < a.n; ++k) {
     const ChainLayer& L = a.l[k];
     float* w = lds + L.off;
-    const int total = L.OUT * L.IN;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 4) {          // four independent loads in flight per thread
-      float v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { int e = e0 + 256 * u; e = e < total ? e : total - 1; v[u] = L.W[(long)(e / L.IN) * L.ldw + e % L.IN]; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int e = e0 + 256 * u; if (e < total) w[(e / L.IN) * L.S + e % L.IN] = v[u]; }
+    for (int r = r0; r < L.OUT; r += 8) {
+      const float* src = L.W + (long)r * L.ldw;
+      float* dst = w + r * L.S;
+      for (int c = c0; c < L.IN; c += 32) dst[c] = src[c];
     }
     if (with_bias && L.bias && threadIdx.x < L.OUT) w[chain_rows(L.OUT) * L.S + threadIdx.x] = L.bias[threadIdx.x];
   }
