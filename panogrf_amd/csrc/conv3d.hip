@@ -31,14 +31,17 @@ namespace pgrf {
 // LEAN: two waves per SIMD (<= 256 registers): ONE operand buffer of half a step (16 of the chunk's 32 channels),
 // refilled in place behind the MFMAs that read it, for interior AND boundary waves (the latter with masked operands).
 // Needs Cin % 32 == 0 and the 27-tap mode; everything else takes the LEAN = false instantiations.
-template <int MT, int NT, bool SPLIT, bool LEAN = false>
+// SW (with SPLIT): waves sharing one output tile -- 4 (the whole workgroup, one tile) or 2 (two tiles per workgroup, a wave pair each)
+template <int MT, int NT, bool SPLIT, bool LEAN = false, int SW = 4>
 __global__ void __launch_bounds__(256, LEAN ? 2 : PGRF_CONV_WAVES) conv3d_wrap_kernel(const ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[SPLIT ? 3 * MT * NT * 16 * 64 : 4];
+  static_assert(SW == 4 || SW == 2, "split ways");
+  __shared__ __attribute__((aligned(16))) float red[SPLIT ? (4 / SW) * (SW - 1) * MT * NT * 16 * 64 : 4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 31, kk = lane >> 5;
   const long long nvox = (long long)a.B * a.Do * a.Ho * a.Wo;
-  const long long tile0 = SPLIT ? (long long)blockIdx.x * NT : ((long long)blockIdx.x * 4 + wave) * NT;
+  const int sgrp = SPLIT ? wave / SW : 0, ssub = SPLIT ? wave % SW : 0;      // tile of the workgroup, share of its reduction
+  const long long tile0 = SPLIT ? ((long long)blockIdx.x * (4 / SW) + sgrp) * NT : ((long long)blockIdx.x * 4 + wave) * NT;
   const int cot0 = blockIdx.y * MT;
   if (!SPLIT && tile0 * 32 >= nvox) return;
 
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(256, LEAN ? 2 : PGRF_CONV_WAVES) conv3d_wrap_k
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 bv;
-    if (a.bias && (!SPLIT || wave == 0)) {
+    if (a.bias && (!SPLIT || ssub == 0)) {
       const float4* bp = reinterpret_cast<const float4*>(a.bias + (cot0 + m) * 32 + kk * 16);
       const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
       bv = (f32x16){b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
@@ -298,9 +301,9 @@ __global__ void __launch_bounds__(256, LEAN ? 2 : PGRF_CONV_WAVES) conv3d_wrap_k
   };
   auto advance = [&]() {
     next1();
-    if (SPLIT) while (row >= 0 && (midx & 3) != wave) next1();       // this wave's quarter of the macro steps
+    if (SPLIT) while (row >= 0 && (midx & (SW - 1)) != ssub) next1();       // this wave's share of the macro steps
   };
-  if (SPLIT) while (row >= 0 && (midx & 3) != wave) next1();
+  if (SPLIT) while (row >= 0 && (midx & (SW - 1)) != ssub) next1();
   typedef std::integral_constant<int, 0> DX0;
   typedef std::integral_constant<int, 1> DX1;
   typedef std::integral_constant<int, 2> DX2;
@@ -477,27 +480,28 @@ __global__ void __launch_bounds__(256, LEAN ? 2 : PGRF_CONV_WAVES) conv3d_wrap_k
   }
   }
   if (SPLIT) {
-    if (wave > 0) {
+    float* rg = red + sgrp * (SW - 1) * MT * NT * 16 * 64;           // this tile's partial buffers
+    if (ssub > 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(&red[((((wave - 1) * NT + t) * MT + m) * 4 + q) * 256 + lane * 4]) =
+            *reinterpret_cast<float4*>(&rg[((((ssub - 1) * NT + t) * MT + m) * 4 + q) * 256 + lane * 4]) =
                 make_float4(acc[t][m][q * 4], acc[t][m][q * 4 + 1], acc[t][m][q * 4 + 2], acc[t][m][q * 4 + 3]);
     }
     __syncthreads();
-    if (wave > 0) return;
+    if (ssub > 0) return;
 #pragma unroll
-    for (int w = 0; w < 3; ++w)
+    for (int w = 0; w < SW - 1; ++w)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(&red[(((w * NT + t) * MT + m) * 4 + q) * 256 + lane * 4]);
+            const float4 v = *reinterpret_cast<const float4*>(&rg[(((w * NT + t) * MT + m) * 4 + q) * 256 + lane * 4]);
             acc[t][m][q * 4] += v.x; acc[t][m][q * 4 + 1] += v.y; acc[t][m][q * 4 + 2] += v.z; acc[t][m][q * 4 + 3] += v.w;
           }
   }
@@ -1959,6 +1963,25 @@ static int conv3d_wrap_impl(const float* in, int in_cs, int in_coff, int Cin, fl
     if (const char* e = getenv("PGRF_CONV_SPLIT_MT")) { const int v = atoi(e); if (v == 1) smt = 1; else if (v == 2) smt = mt; }
     bool slean = false;
     if (const char* e = getenv("PGRF_CONV_SPLIT_LEAN")) slean = atoi(e) != 0 && (Cin & 31) == 0 && a.wtaps == 27;
+    // 2-D layers (round 5): the reduction of a (tile, cout tile) pair is shared by 4 waves only when the layer has fewer than 512 pairs; from 512
+    // pairs on by TWO waves (two tiles per workgroup), from 2 048 on one wave owns a pair (the plain kernel with one cout tile per wave): a wave's
+    // fixed cost (index set-up, first operands, the LDS sum and its barrier) is spread over 2-4 x the MFMAs.  tools/ab_mvs_env.sh, two rounds:
+    // encoders 1.24 -> 1.19 ms, Equi feature net 1.04 -> 0.96 ms, MVS stage 5.17 -> 5.06 ms.  (Summation order per shape is fixed: results
+    // are reproducible, and differ from the 4-way sums in the last bits only.)
+    static const int sw2_min = [] { const char* e = getenv("PGRF_CONV_SPLIT_SW2_MIN"); return e ? atoi(e) : 512; }();      // tuning knob
+    static const int sw1_min = [] { const char* e = getenv("PGRF_CONV_SPLIT_SW1_MIN"); return e ? atoi(e) : 2048; }();     // tuning knob
+    if (a.D == 1 && smt == 1 && !slean && tiles * a.cot_total >= sw1_min) {
+      dim3 g1((unsigned)((tiles + 3) / 4), (unsigned)a.cot_total);
+      hipLaunchKernelGGL((conv3d_wrap_kernel<1, 1, false, false>), g1, dim3(256), 0, (hipStream_t)stream, a);
+      PGRF_CHECK_LAUNCH("conv3d_wrap(one wave per tile)");
+      return PGRF_OK;
+    }
+    if (a.D == 1 && smt == 1 && !slean && tiles * a.cot_total >= sw2_min) {
+      dim3 g2((unsigned)((tiles + 1) / 2), (unsigned)a.cot_total);
+      hipLaunchKernelGGL((conv3d_wrap_kernel<1, 1, true, false, 2>), g2, dim3(256), 0, (hipStream_t)stream, a);
+      PGRF_CHECK_LAUNCH("conv3d_wrap(split 2)");
+      return PGRF_OK;
+    }
     dim3 sgrid((unsigned)tiles, (unsigned)(a.cot_total / smt));
     if (smt == 2 && slean) hipLaunchKernelGGL((conv3d_wrap_kernel<2, 1, true, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
     else if (smt == 2) hipLaunchKernelGGL((conv3d_wrap_kernel<2, 1, true>), sgrid, dim3(256), 0, (hipStream_t)stream, a);
