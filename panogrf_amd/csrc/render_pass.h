@@ -618,7 +618,9 @@ __device__ unsigned long long g_stage_cycles[32];
 // a stage ends.)
 #ifndef PGRF_FENCE_MASK
 // (2 views x 64 samples: fences after neuray_fc, stage B and the density head only -- single-fence sweep + combinations, 34.8 -> 34.25 ms)
-#define PGRF_FENCE_MASK ((V == 3 || V == 1) ? 0xffffffffu : ((PGRF_KT == 2 && PGRF_V == 2) ? 0x100084u : 0u))      // bit i = stage boundary i is a fence (tuning knob)
+// (4 views x 64 samples, the pair kernel: fences after the projection / tap set-up and after neuray_fc of each pair -- single-fence sweep,
+//  every other boundary within +-0.3 %: 63.97 -> 63.45 ms)
+#define PGRF_FENCE_MASK ((V == 3 || V == 1) ? 0xffffffffu : ((PGRF_KT == 2 && PGRF_V == 2) ? 0x100084u : ((PGRF_KT == 2 && PGRF_V == 4) ? 0x110000u : 0u)))      // bit i = stage boundary i is a fence (tuning knob)
 #endif
 #ifdef PGRF_STAGE_MARK   // ISA census builds (tools/isa_stage_census.py): a comment line per stage boundary in the assembly
 #define PGRF_TICK(i) do { if (((PGRF_FENCE_MASK) >> (i)) & 1u) { __builtin_amdgcn_sched_barrier(0); asm volatile("; PGRF_STAGE_END %0" :: "i"(i)); __builtin_amdgcn_sched_barrier(0); } } while (0)
