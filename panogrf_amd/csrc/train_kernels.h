@@ -147,7 +147,7 @@ constexpr size_t kRepStride = (size_t)68 * 13312;     // R_COUNT * kGradSlot flo
 template <int NT>
 __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ X, int ldx,
                                                       float* __restrict__ gW0, float* __restrict__ gWrep, int M, int K, long rows, int chunk,
-                                                      int gx, int groups, float* __restrict__ gb0, float* __restrict__ gbrep, int ldg, int gcol) {
+                                                      int gx, int groups, float* __restrict__ gb0, float* __restrict__ gbrep, int ldg, int gcol, float oscale) {
   // replica of the gradient this workgroup adds into (train_pass.hip kGradReplicas): 0 = the caller's buffer
   const int rep = blockIdx.z & 7;
   float* __restrict__ gW = rep == 0 ? gW0 : gWrep + (size_t)(rep - 1) * kRepStride;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ 
         float v = acc[t][r];
         for (int k = 1; k < wpg; ++k) v += red[wave + k - 1][t][r][lane];
         const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * half, ko = n0 + 32 * t + i;     // accumulator row rho(r, half), column = lane
-        if (mo < M && ko < K) unsafeAtomicAdd(gW + (long)mo * ldg + gcol + ko, v);     // (ldg, gcol: a column block of a wider weight)
+        if (mo < M && ko < K) unsafeAtomicAdd(gW + (long)mo * ldg + gcol + ko, v * oscale);     // (ldg, gcol: a column block of a wider weight; oscale: the layer read s * X)
       }
   }
 }
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) dw_mfma_kernel(const float* __restrict__ 
 // bytes past a row's end: workspace buffers, plan() pads).  Epilogue as above (the tiles' memory is reused for the cross-wave sum).
 __global__ void __launch_bounds__(256) dw_lds_kernel(const float* __restrict__ D, int ldd, const float* __restrict__ X, int ldx,
                                                      float* __restrict__ gW0, float* __restrict__ gWrep, int M, int K, long rows, int chunk,
-                                                     int gx, int groups, float* __restrict__ gb0, float* __restrict__ gbrep, int ldg, int gcol) {
+                                                     int gx, int groups, float* __restrict__ gb0, float* __restrict__ gbrep, int ldg, int gcol, float oscale) {
   const int rep = blockIdx.z & 7;
   float* __restrict__ gW = rep == 0 ? gW0 : gWrep + (size_t)(rep - 1) * kRepStride;
   float* __restrict__ gb = gb0 ? (rep == 0 ? gb0 : gbrep + (size_t)(rep - 1) * kRepStride) : nullptr;
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) dw_lds_kernel(const float* __restrict__ D
       float v = acc[r];
       for (int k = 1; k < wpg; ++k) v += red[((wave + k - 1) * 16 + r) * 64 + lane];
       const int mo = m0 + (r & 3) + 8 * (r >> 2) + 4 * half, ko = n0 + i;
-      if (mo < M && ko < K) unsafeAtomicAdd(gW + (long)mo * ldg + gcol + ko, v);
+      if (mo < M && ko < K) unsafeAtomicAdd(gW + (long)mo * ldg + gcol + ko, v * oscale);
     }
   }
 }
@@ -371,6 +371,7 @@ struct ChainArgs {
                                      // consecutive rows of a point: base_fc.0's product with the view-independent statistics)
   float* dX; int lddx, accumulate;   // backward output (null = none)
   long rows;
+  float xscale;                      // the first layer reads xscale * X (forward); the chain's dX is xscale * (delta W) (backward)
 };
 __host__ __device__ inline int chain_stride(int IN) { int s = (IN + 3) / 4 * 4; if (((s / 4) & 1) == 0) s += 4; return s; }
 __host__ __device__ inline int chain_rows(int OUT) { return OUT > 32 ? 64 : 32; }
@@ -532,6 +533,12 @@ __global__ void __launch_bounds__(256, QD == 4 ? 6 : 3) chain_fwd_kernel(const C
         for (int q0 = 0; q0 < nq; q0 += QD) {
 #pragma unroll
           for (int u = 0; u < QD; ++u) load4_mask(xr, q0 + u, half, IN, b[u]);
+          if (a.xscale != 1.f) {
+#pragma unroll
+            for (int u = 0; u < QD; ++u)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) b[u][j] *= a.xscale;
+          }
           chain_layer_fwd<QD>(w + 8 * q0, S, n, half, mt, nq - q0, b, acc);
         }
       } else {
@@ -622,6 +629,12 @@ __global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const C
       if (k + 1 == a.n) {
         // the chain's output: dX (=|+=) delta W, any width, QD / 4 32-column tiles at a time
         if (!a.dX) break;
+        if (a.xscale != 1.f) {
+#pragma unroll
+          for (int q = 0; q < QD; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[q][j] *= a.xscale;
+        }
         float* xr = a.dX + rowc * (long)a.lddx;
         for (int m0 = 0; m0 < mtiles; m0 += MTM) {
           f32x16t acc[MTM];
@@ -993,17 +1006,35 @@ __global__ void prob_bwd_kernel(ProbIO io, ProbGrad gr, long PV, int V) {
 // ---------------------------------------------------------------------------------------------------------------
 // weighted mean / variance over the views of a point (ibrnet.py:112-116): mean = sum_v w x, var = sum_v w (x - mean)^2
 // x [PV, ldx] (columns xc .. xc+F), w [PV] -> out [P, ldo]: mean at column mc, var at column vc
-__global__ void stats_kernel(const float* __restrict__ x, int ldx, int xc, const float* __restrict__ w, int V, int F, long P,
-                             float* __restrict__ out, int ldo, int mc, int vc) {
+// (round 5: NS weightings of the same rows in one launch -- x is read once)
+struct StatFwd { const float* w; int mc, vc; };
+template <int NS>
+__global__ void stats_kernel(const float* __restrict__ x, int ldx, int xc, int V, int F, long P, float* __restrict__ out, int ldo, StatFwd s0, StatFwd s1) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P * F) return;
   const unsigned iu = (unsigned)i; const long p = iu / (unsigned)F; const int j = (int)(iu % (unsigned)F);
-  float m = 0.f;
-  for (int v = 0; v < V; ++v) m += x[(p * V + v) * ldx + xc + j] * w[p * V + v];
-  float var = 0.f;
-  for (int v = 0; v < V; ++v) { const float d = x[(p * V + v) * ldx + xc + j] - m; var += w[p * V + v] * (d * d); }
-  out[p * ldo + mc + j] = m;
-  out[p * ldo + vc + j] = var;
+  float xs[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+    if (v < V) xs[v] = x[(p * V + v) * ldx + xc + j];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const StatFwd& S = k == 0 ? s0 : s1;
+    float ws[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (v < V) ws[v] = S.w[p * V + v];
+    float m = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (v < V) m += xs[v] * ws[v];
+    float var = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (v < V) { const float d = xs[v] - m; var += ws[v] * (d * d); }
+    out[p * ldo + S.mc + j] = m;
+    out[p * ldo + S.vc + j] = var;
+  }
 }
 // gx[PV, .] += ..., gw[PV] += ...   A WAVE per point, lane = feature (F <= 64, V <= 4): every access is a run of F consecutive
 // floats (the first version gave a thread one (point, view) row and walked the features at a stride of ld floats: 744 us per call
@@ -1241,11 +1272,7 @@ __global__ void __launch_bounds__(64) attn_bwd64_kernel(const float* __restrict_
       const float gs = 0.5f * p * (gp - dot);
       a0 += gs * ku.x; a1 += gs * ku.y; a2 += gs * ku.z; a3 += gs * ku.w;
     }
-    if (ok) {
-      float4 r = *reinterpret_cast<const float4*>(gq + me);
-      r.x += a0; r.y += a1; r.z += a2; r.w += a3;
-      *reinterpret_cast<float4*>(gq + me) = r;
-    }
+    if (ok) *reinterpret_cast<float4*>(gq + me) = make_float4(a0, a1, a2, a3);      // (written, not accumulated: every (sample, head) has one owner)
   }
   __syncthreads();
   // phase 2, lane = key t: gk, gv from the stored column p[s][t]
@@ -1260,12 +1287,8 @@ __global__ void __launch_bounds__(64) attn_bwd64_kernel(const float* __restrict_
       k0 += gs * qs.x; k1 += gs * qs.y; k2 += gs * qs.z; k3 += gs * qs.w;
     }
     if (ok) {
-      float4 r = *reinterpret_cast<const float4*>(gv + me);
-      r.x += v0; r.y += v1; r.z += v2; r.w += v3;
-      *reinterpret_cast<float4*>(gv + me) = r;
-      r = *reinterpret_cast<const float4*>(gk + me);
-      r.x += k0; r.y += k1; r.z += k2; r.w += k3;
-      *reinterpret_cast<float4*>(gk + me) = r;
+      *reinterpret_cast<float4*>(gv + me) = make_float4(v0, v1, v2, v3);
+      *reinterpret_cast<float4*>(gk + me) = make_float4(k0, k1, k2, k3);
     }
   }
 }

@@ -301,7 +301,7 @@ static int lin_fwd(const Ctx& c, const float* X, int ldx, int rw, int rb, float*
 }
 // gW += delta^T X and gb += colsum(delta) (one launch): the reduction runs over the ROWS (sample points x views), split over gridDim.z
 // so that the launch has ~1 536 workgroups; partial tiles are summed inside a workgroup, then one atomic per element and workgroup
-static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int ldd, int rw, int rb, long rows, int IN, int OUT, int wld = 0, int wcol = 0) {
+static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int ldd, int rw, int rb, long rows, int IN, int OUT, int wld = 0, int wcol = 0, float xscale = 1.f) {
   float* gb = (rb >= 0) ? c.graw[rb] : nullptr;
 #ifdef PGRF_TRAIN_ABL_NO_DW   // timing experiment: no weight-gradient products at all (the bound of any fusion of them into the chains)
   return;
@@ -335,12 +335,12 @@ static void L_dw(const Ctx& c, const float* X, int ldx, const float* delta, int 
   if (gb) c.gsize[rb] = OUT;
   static const bool use_lds = [] { const char* e = getenv("PGRF_TRAIN_DW_LDS"); return !(e && e[0] == '0'); }();
   if (nt == 1 && use_lds) {
-    hipLaunchKernelGGL(dw_lds_kernel, grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
+    hipLaunchKernelGGL(dw_lds_kernel, grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol, xscale);
     return;
   }
-  if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
-  else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
-  else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol);
+  if (nt == 4) hipLaunchKernelGGL((dw_mfma_kernel<4>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol, xscale);
+  else if (nt == 2) hipLaunchKernelGGL((dw_mfma_kernel<2>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol, xscale);
+  else hipLaunchKernelGGL((dw_mfma_kernel<1>), grid, dim3(256), 0, c.dw_stream(), delta, ldd, X, ldx, c.graw[rw], rep, OUT, IN, rows, (int)chunk, gx, groups, gb, brep, ldg, wcol, xscale);
 }
 // dY (a [rows, OUT] slice, ld lddy) is overwritten by delta = dY * act'(Y); then gW += delta^T X, gb += colsum(delta),
 // dX (=|+=) delta W
@@ -371,7 +371,7 @@ static int lin_bwd(const Ctx& c, const float* X, int ldx, const float* Y, int ld
 
 // A chain of <= 3 Linear layers in one launch (train_kernels.h chain_fwd_kernel / chain_bwd_kernel).  Layer k + 1 reads layer k's
 // output; widths after the first layer's input <= 64.
-struct Lin { const float* X; int ldx; float* Y; int ldy; float* dY; int lddy; int rw, rb, IN, OUT, act; int wcol = 0, wld = 0; };     // wcol / wld: columns [wcol, wcol + IN) of a weight with wld columns
+struct Lin { const float* X; int ldx; float* Y; int ldy; float* dY; int lddy; int rw, rb, IN, OUT, act; int wcol = 0, wld = 0; float xscale = 1.f; };     // wcol / wld: columns [wcol, wcol + IN) of a weight with wld columns
 static int chain_check(const Lin* l, int n) {
   if (n < 1 || n > 3) return set_error(PGRF_ERR_ARG, "train chain: %d layers", n);
   for (int k = 0; k < n; ++k) {
@@ -414,7 +414,7 @@ static int chain_fwd(const Ctx& c, const Lin* l, int n, long rows, const float* 
   if (int rc = chain_check(l, n)) return rc;
   ChainArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.n = n; a.X = l[0].X; a.ldx = l[0].ldx; a.rows = rows;
+  a.n = n; a.X = l[0].X; a.ldx = l[0].ldx; a.rows = rows; a.xscale = l[0].xscale;
   for (int k = 0; k < n; ++k)
     a.l[k] = ChainLayer{c.raw[l[k].rw] + l[k].wcol, l[k].rb >= 0 ? c.raw[l[k].rb] : nullptr, l[k].Y, nullptr, l[k].ldy, 0, l[k].IN, l[k].OUT, l[k].act, 0, 0, 0,
                         l[k].wld ? l[k].wld : l[k].IN};
@@ -431,7 +431,7 @@ static int chain_bwd(const Ctx& c, const Lin* l, int n, long rows, float* dX, in
   if (int rc = chain_check(l, n)) return rc;
   ChainArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.n = n; a.rows = rows; a.dX = dX; a.lddx = lddx; a.accumulate = acc_dx;
+  a.n = n; a.rows = rows; a.dX = dX; a.lddx = lddx; a.accumulate = acc_dx; a.xscale = l[0].xscale;
   for (int k = 0; k < n; ++k) {          // kernel order: top layer first
     const Lin& s = l[n - 1 - k];
     a.l[k] = ChainLayer{c.raw[s.rw] + s.wcol, nullptr, s.Y, s.dY, s.ldy, s.lddy, s.IN, s.OUT, s.act, (k + 1 < n || dX) ? 1 : 0, 0, 0, s.wld ? s.wld : s.IN};
@@ -441,7 +441,7 @@ static int chain_bwd(const Ctx& c, const Lin* l, int n, long rows, float* dX, in
   if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_bwd_kernel<4>, chain_grid(rows, lds, 5), dim3(256), lds, c.st, a);
   else hipLaunchKernelGGL(chain_bwd_kernel<8>, chain_grid(rows, lds, 2), dim3(256), lds, c.st, a);
   c.fork();
-  for (int k = n - 1; k >= 0; --k) L_dw(c, l[k].X, l[k].ldx, l[k].dY, l[k].lddy, l[k].rw, l[k].rb, rows, l[k].IN, l[k].OUT, l[k].wld, l[k].wcol);
+  for (int k = n - 1; k >= 0; --k) L_dw(c, l[k].X, l[k].ldx, l[k].dY, l[k].lddy, l[k].rw, l[k].rb, rows, l[k].IN, l[k].OUT, l[k].wld, l[k].wcol, l[k].xscale);
   PGRF_TCHECK("train chain backward");
   return PGRF_OK;
 }
@@ -555,8 +555,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
                        {w.n1, 8, w.nfs, 1, w.gw0, 1, R_NF_2_W, R_NF_2_B, 8, 1, ACT_SIGMOID}};
   if (do_fwd) L(chain_fwd(c, nf_l, 2, PV));
   if (do_fwd) hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.w0, 1, 0, w.nfs, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
-  if (do_fwd) hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w0, V, 35, P, w.glob, 140, 0, 35);
-  if (do_fwd) hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, w.w1, V, 35, P, w.glob, 140, 70, 105);
+  if (do_fwd) hipLaunchKernelGGL(stats_kernel<2>, dim3(nblk(P * 35)), dim3(256), 0, st, w.xin, 207, 140, V, 35, P, w.glob, 140, StatFwd{w.w0, 0, 35}, StatFwd{w.w1, 70, 105});
   PGRF_TCHECK("train view statistics");
   // base_fc.0 in two column blocks, like the fused kernel's L_BG / L_BV: the 140 view statistics are the SAME for the V views of a point,
   // so their product with W[:, 0:140] is formed once per point (hb, P rows) and enters the per-view layer -- W[:, 140:207] on the 67
@@ -567,8 +566,9 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   const Lin base_l[2] = {{w.xin + 140, 207, w.b1, 64, w.gb1, 64, R_BASE_0_W, R_BASE_0_B, 67, 64, ACT_ELU, 140, 207},    // base_fc
                          {w.b1, 64, w.x, 32, w.gx, 32, R_BASE_2_W, R_BASE_2_B, 64, 32, ACT_ELU}};
   if (do_fwd) L(chain_fwd(c, base_l, 2, PV, w.hb, 64, V));
-  if (do_fwd) hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32);
-  const Lin vf_l[2] = {{w.xw, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, 32, 32, ACT_ELU},                      // vis_fc
+  // vis_fc reads x * weight (ibrnet.py:343, weight = 1 / V here): the scale rides in the chain's first-layer load, in its dX and in its dW
+  // (it was a [PV, 32] copy forward and a read-modify-write kernel backward)
+  const Lin vf_l[2] = {{w.x, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, 32, 32, ACT_ELU, 0, 0, wgt},                      // vis_fc
                        {w.v1h, 32, w.xv, 33, w.gxv, 33, R_VF_2_W, R_VF_2_B, 32, 33, ACT_ELU}};
   if (do_fwd) L(chain_fwd(c, vf_l, 2, PV));
   if (do_fwd) hipLaunchKernelGGL(visfc_post_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.x, w.xv, PV, w.xr, w.v1);
@@ -578,7 +578,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   if (do_fwd) L(chain_fwd(c, v2_l, 2, PV));
   if (do_fwd) hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 4)), dim3(256), 0, st, w.xr, 37, 33, w.dd, 4, 0, PV, 4, 0);
   if (do_fwd) hipLaunchKernelGGL(wgt2_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, P, V, w.wgt2, w.gin);
-  if (do_fwd) hipLaunchKernelGGL(stats_kernel, dim3(nblk(P * 32)), dim3(256), 0, st, w.xr, 37, 0, w.wgt2, V, 32, P, w.gin, 65, 0, 32);
+  if (do_fwd) hipLaunchKernelGGL(stats_kernel<1>, dim3(nblk(P * 32)), dim3(256), 0, st, w.xr, 37, 0, V, 32, P, w.gin, 65, StatFwd{w.wgt2, 0, 32}, StatFwd{});
   PGRF_TCHECK("train pooled geometry feature");
   const Lin geo_l[2] = {{w.gin, 65, w.g1, 64, w.gg1, 64, R_GEO_0_W, R_GEO_0_B, 65, 64, ACT_ELU},                    // geometry_fc
                         {w.g1, 64, w.g2, 16, w.ggp, 16, R_GEO_2_W, R_GEO_2_B, 64, 16, ACT_ELU}};      // (d(gp)/d(g2) = 1: the gradient arrives in ggp)
@@ -622,12 +622,13 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
                      g_raw_dev[R_ATT_LN_W] ? g_raw_dev[R_ATT_LN_W] : w.gq /* scratch sink */, g_raw_dev[R_ATT_LN_B] ? g_raw_dev[R_ATT_LN_B] : w.gq);
   (void)hipMemcpyAsync(w.ggp, w.gfo, P * 64, hipMemcpyDeviceToDevice, st);                                            // residual branch
   L(lin_bwd(c, w.o, 16, w.fo, 16, w.gfo, 16, R_ATT_FC_W, -1, w.go, 16, 0, P, 16, 16, ACT_NONE));
-  (void)hipMemsetAsync(w.gq, 0, P * 64, st); (void)hipMemsetAsync(w.gk, 0, P * 64, st); (void)hipMemsetAsync(w.gv, 0, P * 64, st);
-  if (dn <= 64 && V > 1)      // probabilities of a (ray, head) kept in LDS: one exp per (query, key) instead of four
+  if (dn <= 64 && V > 1)      // probabilities of a (ray, head) kept in LDS: one exp per (query, key) instead of four; gq / gk / gv are WRITTEN
     hipLaunchKernelGGL(attn_bwd64_kernel, dim3((unsigned)rn * 4), dim3(64), 0, st, w.q, w.k, w.v, w.o, w.go, rn, dn, w.gq, w.gk, w.gv);
-  else
+  else {
+    (void)hipMemsetAsync(w.gq, 0, P * 64, st); (void)hipMemsetAsync(w.gk, 0, P * 64, st); (void)hipMemsetAsync(w.gv, 0, P * 64, st);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)rn * 4), dim3(dn <= 64 ? 64 : 128), 0, st, w.q, w.k, w.v, w.o, w.go, rn, dn,
                        V <= 1 ? 1 : 0, w.gq, w.gk, w.gv);
+  }
   PGRF_TCHECK("train attention backward");
   L(lin_bwd(c, w.gp, 16, w.q, 16, w.gq, 16, R_ATT_Q_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(lin_bwd(c, w.gp, 16, w.k, 16, w.gk, 16, R_ATT_K_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
@@ -641,9 +642,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   L(chain_bwd(c, v2_l, 2, PV, w.gxv1, 32, 0));
   hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32, w.gxr, 37, 0, w.gv1);
   hipLaunchKernelGGL(visfc_post_bwd_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.gxr, w.gv1, w.v1, PV, w.gx, w.gxv);
-  L(chain_bwd(c, vf_l, 2, PV, w.gxw, 32, 0));
-  hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxw, 32, 0, w.x, 32, 0, (const float*)nullptr, 0, wgt, PV, 32, w.gx, 32, 0,
-                     (float*)nullptr);
+  L(chain_bwd(c, vf_l, 2, PV, w.gx, 32, 1));                                             // gx += wgt * (delta W)
   PGRF_TCHECK("train visibility backward");
   L(chain_bwd(c, base_l, 2, PV, w.gxin + 140, 207, 0));                                  // d / d(per-view columns); delta of base_fc.0 left in gb1
   hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.ghb, 64, 0, w.gb1, 64, 0, P, V, 64, 0);      // d hb = sum over the views

@@ -106,7 +106,11 @@ def test_neuray_ft_twenty_steps_match_the_oracle_training_loop(lr):
         depth_c = O.sample_coarse_depth(cfg['min_depth'], cfg['max_depth'], rays, dn, cfg.get('use_disp', True), 'cuda')
         oc = O.render_pass(w, 'dist_decoder', 'agg_net', fr, coords, depth_c, {'use_vis': uv})
         u = torch.rand([1, rays, fdn])[0].cuda()
-        fd = E.sample_fine_depth(depth_c, oc['hit_prob_nr'].detach(), que['depth_range'][0].cpu(), fdn, use_disp=cfg.get('use_disp', True), u=u)
+        # the fine samples from the FAST path's coarse hit probabilities (its own 'hit_prob_nr' output): the inverse-CDF sampler is piecewise
+        # -- a 1e-6 difference between the two coarse passes moves a sample across a bin edge now and then, and the two fine passes then
+        # look at different points of that ray (a whole-gradient deviation of 1e-2 .. 4e-1 at such a step, ~1 step in 100)
+        assert float((oc['hit_prob_nr'].detach() - out['hit_prob_nr'][0].detach()).abs().max()) < 1e-4
+        fd = E.sample_fine_depth(depth_c, out['hit_prob_nr'][0].detach(), que['depth_range'][0].cpu(), fdn, use_disp=cfg.get('use_disp', True), u=u)
         of = O.render_pass(w, 'fine_dist_decoder', 'fine_agg_net', fr, coords, fd, {'use_vis': cfg['fine_dist_decoder_cfg']['use_vis']})
         h, wd = que['imgs'].shape[-2:]
         grid = torch.stack([coords[:, 0] / (wd - 1) * 2 - 1, coords[:, 1] / (h - 1) * 2 - 1], -1)[None, None]
@@ -141,13 +145,13 @@ def test_neuray_ft_twenty_steps_match_the_oracle_training_loop(lr):
     print('oracle', ['%.6f' % x for x in curve_o])
     print('whole-gradient relative L2 error per step:', ['%.1e' % t for t in totals])
     print('per tensor: worst %.2e (>= 512 elements), %.2e (smaller); %d of %d tensor-steps beyond 2e-2 / 5e-2' % (worst_grad, worst_small, per_tensor_bad, per_tensor_n))
-    # ReLU kinks (prob_embed's ReLU, the density's max(., 0), masked softmaxes): where a pre-activation sits within the two forwards' 1e-6
-    # of zero, its derivative is 0 on one side and 1 on the other -- a step that contains such a sample shows a whole-gradient deviation
-    # of a few 1e-3 (one or two of the 20 steps; which ones varies from run to run with the order of the float atomics) where the
-    # typical step agrees to 1e-6 .. 1e-4.  Hence: the median step within 1e-3, every step within
-    # 1e-2, and at most 1 % of the (tensor, step) pairs beyond the per-tensor bars.
+    # With the sampler's discontinuity taken out (above) the whole gradient of a step agrees to 1e-6 .. 1.3e-4 (30 runs observed).  ReLU kinks
+    # (prob_embed's ReLU, the density's max(., 0), masked softmaxes) remain: where a pre-activation sits within the two forwards' 1e-6 of
+    # zero its derivative is 0 on one side and 1 on the other, and which samples do varies from run to run with the order of the float
+    # atomics.  Hence: the median step within 3e-4, every step but at most ONE within 2e-3 (none beyond 2e-2), and at most 1 % of the
+    # (tensor, step) pairs beyond the per-tensor bars.
     st = sorted(totals)
-    assert st[len(st) // 2] < 1e-3 and st[-1] < 1e-2, totals
+    assert st[len(st) // 2] < 3e-4 and st[-2] < 2e-3 and st[-1] < 2e-2, totals
     assert per_tensor_bad <= per_tensor_n // 100, (per_tensor_bad, per_tensor_n)
     for a, b in zip(curve_h, curve_o):
         assert abs(a - b) <= 1e-4 * abs(b), (curve_h, curve_o)
