@@ -382,13 +382,13 @@ __device__ __forceinline__ void chain_stage_weights(const ChainArgs& a, float* l
 #endif
   // (round 5: 16-byte zero stores and a (row, column) walk without integer division -- the staging of a chain's few KB was 0.22 ms of a
   //  5.6 ms training step, 52 chain launches of ~1 300 workgroups each)
-  for (int i = threadIdx.x * 4; i < a.lds_floats; i += 256 * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // (lds_floats % 4 == 0)
+  for (int i = threadIdx.x * 4; i < a.lds_floats; i += blockDim.x * 4) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // (lds_floats % 4 == 0)
   __syncthreads();
-  const int r0 = threadIdx.x >> 5, c0 = threadIdx.x & 31;          // 8 rows x 32 columns per sweep: a row's columns are consecutive addresses
+  const int r0 = threadIdx.x >> 5, c0 = threadIdx.x & 31, rstep = blockDim.x >> 5;          // rstep rows x 32 columns per sweep: a row's columns are consecutive addresses
   for (int k = 0; k < a.n; ++k) {
     const ChainLayer& L = a.l[k];
     float* w = lds + L.off;
-    for (int r = r0; r < L.OUT; r += 8) {
+    for (int r = r0; r < L.OUT; r += rstep) {
       const float* src = L.W + (long)r * L.ldw;
       float* dst = w + r * L.S;
       for (int c = c0; c < L.IN; c += 32) dst[c] = src[c];
@@ -505,14 +505,15 @@ __device__ __forceinline__ void chain_act_bwd(const float (&y)[QD][4], float (&d
   }
 }
 
-template <int QD>
-__global__ void __launch_bounds__(256, QD == 4 ? 6 : 3) chain_fwd_kernel(const ChainArgs a) {
+// WPB: waves per workgroup (4 or 8): 8 halves the number of workgroups and with it the weight stagings of a launch
+template <int QD, int WPB = 4>
+__global__ void __launch_bounds__(64 * WPB, (QD == 4 ? 6 : 3) * 4 / WPB) chain_fwd_kernel(const ChainArgs a) {
   extern __shared__ float chain_lds[];
   chain_stage_weights(a, chain_lds, true);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
-  const long ntiles = (a.rows + 127) / 128;
+  const long ntiles = (a.rows + 32 * WPB - 1) / (32 * WPB);
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {      // (workgroups are persistent: the weights are staged once)
-    const long row = (tile * 4 + wave) * 32 + n;
+    const long row = (tile * WPB + wave) * 32 + n;
     const bool row_ok = row < a.rows;
     const long rowc = row_ok ? row : a.rows - 1;
     float b[QD][4];
@@ -576,15 +577,15 @@ __global__ void __launch_bounds__(256, QD == 4 ? 6 : 3) chain_fwd_kernel(const C
   }
 }
 
-template <int QD>
-__global__ void __launch_bounds__(256, QD == 4 ? 5 : 2) chain_bwd_kernel(const ChainArgs a) {
+template <int QD, int WPB = 4>
+__global__ void __launch_bounds__(64 * WPB, QD == 4 ? (WPB == 4 ? 5 : 3) : (WPB == 4 ? 2 : 1)) chain_bwd_kernel(const ChainArgs a) {
   extern __shared__ float chain_lds[];
   chain_stage_weights(a, chain_lds, false);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, half = lane >> 5;
-  const long ntiles = (a.rows + 127) / 128;
+  const long ntiles = (a.rows + 32 * WPB - 1) / (32 * WPB);
   constexpr int MTM = QD / 4;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long row = (tile * 4 + wave) * 32 + n;
+    const long row = (tile * WPB + wave) * 32 + n;
     const bool row_ok = row < a.rows;
     const long rowc = row_ok ? row : a.rows - 1;
     float d[QD][4];

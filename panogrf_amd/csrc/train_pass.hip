@@ -400,14 +400,17 @@ static bool chain_narrow(const Lin* l, int n) {
     if (l[k].OUT > 32 || (k > 0 && l[k].IN > 32)) return false;
   return true;
 }
+static int chain_wpb() { static const int v = [] { const char* e = getenv("PGRF_TRAIN_CHAIN_WPB"); return (e && atoi(e) == 4) ? 4 : 8; }(); return v; }   // waves per chain workgroup (8: half the workgroups = half the weight stagings of a launch: 5.45 -> 5.39 ms per step; 4 = round 4)
 static dim3 chain_grid(long rows, size_t lds, int max_per_cu) {
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   static const int per_cu_env = [] { const char* e = getenv("PGRF_TRAIN_CHAIN_WGS"); return e ? atoi(e) : 0; }();
+  const int wpb = chain_wpb();
+  if (wpb == 8) max_per_cu = (max_per_cu + 1) / 2;          // (max_per_cu counts four-wave workgroups: the register-bound occupancy)
   int per_cu = (int)(160 * 1024 / (lds + 1024));
   if (per_cu > max_per_cu) per_cu = max_per_cu;
   if (per_cu < 1) per_cu = 1;
   if (per_cu_env > 0) per_cu = per_cu_env;
-  const long tiles = (rows + 127) / 128, cap = (long)ncu * per_cu;
+  const long tiles = (rows + 32 * wpb - 1) / (32 * wpb), cap = (long)ncu * per_cu;
   return dim3((unsigned)(tiles < cap ? tiles : cap));
 }
 static int chain_fwd(const Ctx& c, const Lin* l, int n, long rows, const float* add = nullptr, int ldadd = 0, int addV = 1) {
@@ -421,7 +424,10 @@ static int chain_fwd(const Ctx& c, const Lin* l, int n, long rows, const float* 
   a.add = add; a.ldadd = ldadd; a.addV = addV > 0 ? addV : 1;
   const size_t lds = chain_layout(a);
   if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
-  if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_fwd_kernel<4>, chain_grid(rows, lds, 6), dim3(256), lds, c.st, a);
+  if (chain_wpb() == 8) {
+    if (chain_narrow(l, n)) hipLaunchKernelGGL((chain_fwd_kernel<4, 8>), chain_grid(rows, lds, 6), dim3(512), lds, c.st, a);
+    else hipLaunchKernelGGL((chain_fwd_kernel<8, 8>), chain_grid(rows, lds, 3), dim3(512), lds, c.st, a);
+  } else if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_fwd_kernel<4>, chain_grid(rows, lds, 6), dim3(256), lds, c.st, a);
   else hipLaunchKernelGGL(chain_fwd_kernel<8>, chain_grid(rows, lds, 3), dim3(256), lds, c.st, a);
   PGRF_TCHECK("train chain forward");
   return PGRF_OK;
@@ -438,7 +444,10 @@ static int chain_bwd(const Ctx& c, const Lin* l, int n, long rows, float* dX, in
   }
   const size_t lds = chain_layout(a);
   if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
-  if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_bwd_kernel<4>, chain_grid(rows, lds, 5), dim3(256), lds, c.st, a);
+  if (chain_wpb() == 8) {
+    if (chain_narrow(l, n)) hipLaunchKernelGGL((chain_bwd_kernel<4, 8>), chain_grid(rows, lds, 5), dim3(512), lds, c.st, a);
+    else hipLaunchKernelGGL((chain_bwd_kernel<8, 8>), chain_grid(rows, lds, 2), dim3(512), lds, c.st, a);
+  } else if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_bwd_kernel<4>, chain_grid(rows, lds, 5), dim3(256), lds, c.st, a);
   else hipLaunchKernelGGL(chain_bwd_kernel<8>, chain_grid(rows, lds, 2), dim3(256), lds, c.st, a);
   c.fork();
   for (int k = n - 1; k >= 0; --k) L_dw(c, l[k].X, l[k].ldx, l[k].dY, l[k].lddy, l[k].rw, l[k].rb, rows, l[k].IN, l[k].OUT, l[k].wld, l[k].wcol, l[k].xscale);
