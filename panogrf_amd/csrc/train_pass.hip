@@ -62,27 +62,6 @@ __global__ void rowscale_kernel(float* __restrict__ y, int ldy, int yc, const fl
     y[r * ldy + yc + c] = x[r * ldx + xc + c] * (s ? s[r * sstride] : cst);
   }
 }
-// gx[r, gxc + c] += gy[r, gyc + c] * scale_r ;  gs[r] (=) sum_c gy[r, gyc + c] * x[r, xc + c]
-__global__ void __launch_bounds__(256) rowscale_bwd_kernel(const float* __restrict__ gy, int ldgy, int gyc, const float* __restrict__ x, int ldx,
-                                                           int xc, const float* __restrict__ s, int sstride, float cst, long rows, int cols,
-                                                           float* __restrict__ gx, int ldgx, int gxc, float* __restrict__ gs) {
-  // 32 lanes per row (coalesced column runs; one thread per row walked its columns at a stride of ld floats: 515 us per call)
-  const long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int c0 = threadIdx.x & 31;
-  if (r >= rows) return;
-  const float sc = s ? s[r * sstride] : cst;
-  float acc = 0.f;
-  for (int c = c0; c < cols; c += 32) {
-    const float g = gy[r * ldgy + gyc + c];
-    gx[r * ldgx + gxc + c] += g * sc;
-    acc += g * x[r * ldx + xc + c];
-  }
-  if (gs) {
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 32);
-    if (c0 == 0) gs[r] = acc;
-  }
-}
 // rgb_feat = [rgb | img_feats] + dir_feat  (ibrnet.py:325-327) -> xin[:, 140:175]
 __global__ void rgbfeat_kernel(const float* __restrict__ rgb, const float* __restrict__ imf, const float* __restrict__ dfeat, long PV,
                                float* __restrict__ xin) {
@@ -91,22 +70,34 @@ __global__ void rgbfeat_kernel(const float* __restrict__ rgb, const float* __res
     xin[pv * 207 + 140 + c] = (c < 3 ? rgb[pv * 3 + c] : imf[pv * 32 + c - 3]) + dfeat[pv * 35 + c];
   }
 }
-// x2 = x + x_res, v1 = sigmoid(xv[32])  (ibrnet.py:347-350); x2 -> xr[:, 0:32]
-__global__ void visfc_post_kernel(const float* __restrict__ x, const float* __restrict__ xv, long PV, float* __restrict__ xr, float* __restrict__ v1) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 33; i += (long)gridDim.x * blockDim.x) {
-    const unsigned iu = (unsigned)i; const long pv = iu / 33u; const int c = (int)(iu % 33u);
-    if (c < 32) xr[pv * 37 + c] = x[pv * 32 + c] + xv[pv * 33 + c];
-    else v1[pv] = 1.f / (1.f + expf(-xv[pv * 33 + 32]));
-  }
+// x2 = x + x_res, v1 = sigmoid(xv[32])  (ibrnet.py:347-350); x2 -> xr[:, 0:32]; xv1 = x2 * v1 (vis_fc2's input) in the same sweep
+// (round 5: was this kernel + a row-scale launch).  32 lanes per row.
+__global__ void __launch_bounds__(256) visfc_post_kernel(const float* __restrict__ x, const float* __restrict__ xv, long PV, float* __restrict__ xr,
+                                                         float* __restrict__ v1, float* __restrict__ xv1) {
+  const long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int c = threadIdx.x & 31;
+  if (r >= PV) return;
+  const float s = 1.f / (1.f + expf(-xv[r * 33 + 32]));
+  const float t = x[r * 32 + c] + xv[r * 33 + c];
+  xr[r * 37 + c] = t;
+  xv1[r * 32 + c] = t * s;
+  if (c == 0) v1[r] = s;
 }
-// backward of the line above: gx = gxr[:, :32]; gxv[:, :32] = gxr[:, :32]; gxv[:, 32] = gv1 * v1 (1 - v1)
-__global__ void visfc_post_bwd_kernel(const float* __restrict__ gxr, const float* __restrict__ gv1, const float* __restrict__ v1, long PV,
-                                      float* __restrict__ gx, float* __restrict__ gxv) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 33; i += (long)gridDim.x * blockDim.x) {
-    const unsigned iu = (unsigned)i; const long pv = iu / 33u; const int c = (int)(iu % 33u);
-    if (c < 32) { const float g = gxr[pv * 37 + c]; gx[pv * 32 + c] = g; gxv[pv * 33 + c] = g; }
-    else gxv[pv * 33 + 32] = gv1[pv] * v1[pv] * (1.f - v1[pv]);
-  }
+// backward of the two lines above in one sweep (round 5: was a row-scale backward launch + this kernel):
+//   t = gxr[:, c] + gxv1[:, c] * v1;  gx = t;  gxv[:, :32] = t;  gv1 = sum_c gxv1[:, c] * xr[:, c];  gxv[:, 32] = gv1 * v1 (1 - v1)
+__global__ void __launch_bounds__(256) visfc_post_bwd_kernel(const float* __restrict__ gxr, const float* __restrict__ gxv1, const float* __restrict__ xr,
+                                                             const float* __restrict__ v1, long PV, float* __restrict__ gx, float* __restrict__ gxv) {
+  const long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int c = threadIdx.x & 31;
+  if (r >= PV) return;
+  const float v = v1[r], g = gxv1[r * 32 + c];
+  const float t = gxr[r * 37 + c] + g * v;
+  gx[r * 32 + c] = t;
+  gxv[r * 33 + c] = t;
+  float acc = g * xr[r * 37 + c];
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 32);
+  if (c == 0) gxv[r * 33 + 32] = acc * v * (1.f - v);
 }
 // wgt2 = v2 / (sum_v v2 + 1e-8);  gin[:, 64] = mean_v wgt2   (ibrnet.py:352-355); v2 lives in xr[:, 32]
 __global__ void wgt2_kernel(const float* __restrict__ xr, long P, int V, float* __restrict__ wgt2, float* __restrict__ gin) {
@@ -178,11 +169,11 @@ struct Ws {
   // forward activations
   float *pe_in, *imf;
   float *dh1[4], *dh2[4], *dout[4];
-  float *vis, *hit, *pe_h, *d1, *dfeat, *n1, *nfs, *w0, *glob, *hb, *xin, *b1, *x, *xw, *v1h, *xv, *v1, *xr, *xv1, *f1, *wgt2;
+  float *vis, *hit, *pe_h, *d1, *dfeat, *n1, *nfs, *w0, *glob, *hb, *xin, *b1, *x, *v1h, *xv, *v1, *xr, *xv1, *f1, *wgt2;
   float *gin, *g1, *g2, *gp, *q, *k, *v, *o, *fo, *ln, *og1, *sigma, *r1, *r2, *logit, *blend, *colors;
   // gradients
-  float *gsigma, *gcol, *glogit, *gr2, *gr1, *gxr, *gog1, *gln, *gfo, *go, *gq, *gk, *gv, *ggp, *gg1, *ggin, *gwgt2, *gf1, *gxv1, *gv1,
-      *gx, *gxv, *gv1h, *gxw, *gb1, *ghb, *gxin, *gglob, *gw0, *gn1, *gdfeat, *gd1, *gpe_h, *gpe_in, *gdout[4], *gdh2[4], *gdh1[4];
+  float *gsigma, *gcol, *glogit, *gr2, *gr1, *gxr, *gog1, *gln, *gfo, *go, *gq, *gk, *gv, *ggp, *gg1, *ggin, *gwgt2, *gf1, *gxv1,
+      *gx, *gxv, *gv1h, *gb1, *ghb, *gxin, *gglob, *gw0, *gn1, *gdfeat, *gd1, *gpe_h, *gpe_in, *gdout[4], *gdh2[4], *gdh1[4];
 };
 
 static size_t plan(Ws& w, long P, int V, int dn, char* base) {
@@ -201,7 +192,7 @@ static size_t plan(Ws& w, long P, int V, int dn, char* base) {
   for (int m = 0; m < 4; ++m) { w.dh1[m] = take(PV * 32); w.dh2[m] = take(PV * 32); w.dout[m] = take(PV * 2); }
   w.vis = take(PV); w.hit = take(PV); w.pe_h = take(PV * 32); w.d1 = take(PV * 16); w.dfeat = take(PV * 35); w.n1 = take(PV * 8);
   w.nfs = take(PV); w.w0 = take(PV); w.glob = take(P * 140); w.hb = take(P * 64); w.xin = take(PV * 207); w.b1 = take(PV * 64); w.x = take(PV * 32);
-  w.xw = take(PV * 32); w.v1h = take(PV * 32); w.xv = take(PV * 33); w.v1 = take(PV); w.xr = take(PV * 37); w.xv1 = take(PV * 32);
+  w.v1h = take(PV * 32); w.xv = take(PV * 33); w.v1 = take(PV); w.xr = take(PV * 37); w.xv1 = take(PV * 32);
   w.f1 = take(PV * 32); w.wgt2 = take(PV);
   w.gin = take(P * 65); w.g1 = take(P * 64); w.g2 = take(P * 16); w.gp = take(P * 16); w.q = take(P * 16); w.k = take(P * 16);
   w.v = take(P * 16); w.o = take(P * 16); w.fo = take(P * 16); w.ln = take(P * 16); w.og1 = take(P * 16); w.sigma = take(P);
@@ -209,7 +200,7 @@ static size_t plan(Ws& w, long P, int V, int dn, char* base) {
   w.gsigma = take(P); w.gcol = take(P * 3); w.glogit = take(PV); w.gr2 = take(PV * 8); w.gr1 = take(PV * 16); w.gxr = take(PV * 37);
   w.gog1 = take(P * 16); w.gln = take(P * 16); w.gfo = take(P * 16); w.go = take(P * 16); w.gq = take(P * 16); w.gk = take(P * 16);
   w.gv = take(P * 16); w.ggp = take(P * 16); w.gg1 = take(P * 64); w.ggin = take(P * 65); w.gwgt2 = take(PV); w.gf1 = take(PV * 32);
-  w.gxv1 = take(PV * 32); w.gv1 = take(PV); w.gx = take(PV * 32); w.gxv = take(PV * 33); w.gv1h = take(PV * 32); w.gxw = take(PV * 32);
+  w.gxv1 = take(PV * 32); w.gx = take(PV * 32); w.gxv = take(PV * 33); w.gv1h = take(PV * 32);
   w.gb1 = take(PV * 64); w.ghb = take(P * 64); w.gxin = take(PV * 207); w.gglob = take(P * 140); w.gw0 = take(PV); w.gn1 = take(PV * 8);
   w.gdfeat = take(PV * 35); w.gd1 = take(PV * 16); w.gpe_h = take(PV * 32); w.gpe_in = take(PV * 34);
   for (int m = 0; m < 4; ++m) { w.gdout[m] = take(PV * 2); w.gdh2[m] = take(PV * 32); w.gdh1[m] = take(PV * 32); }
@@ -580,8 +571,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   const Lin vf_l[2] = {{w.x, 32, w.v1h, 32, w.gv1h, 32, R_VF_0_W, R_VF_0_B, 32, 32, ACT_ELU, 0, 0, wgt},                      // vis_fc
                        {w.v1h, 32, w.xv, 33, w.gxv, 33, R_VF_2_W, R_VF_2_B, 32, 33, ACT_ELU}};
   if (do_fwd) L(chain_fwd(c, vf_l, 2, PV));
-  if (do_fwd) hipLaunchKernelGGL(visfc_post_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.x, w.xv, PV, w.xr, w.v1);
-  if (do_fwd) hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV * 32)), dim3(256), 0, st, w.xv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32);
+  if (do_fwd) hipLaunchKernelGGL(visfc_post_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.x, w.xv, PV, w.xr, w.v1, w.xv1);
   const Lin v2_l[2] = {{w.xv1, 32, w.f1, 32, w.gf1, 32, R_V2_0_W, R_V2_0_B, 32, 32, ACT_ELU},                       // vis_fc2 -> xr[:, 32]
                        {w.f1, 32, w.xr + 32, 37, w.gxr + 32, 37, R_V2_2_W, R_V2_2_B, 32, 1, ACT_SIGMOID}};
   if (do_fwd) L(chain_fwd(c, v2_l, 2, PV));
@@ -649,8 +639,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   hipLaunchKernelGGL(wgt2_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, w.gwgt2, w.ggin, P, V, w.gxr);
   PGRF_TCHECK("train pooled geometry backward");
   L(chain_bwd(c, v2_l, 2, PV, w.gxv1, 32, 0));
-  hipLaunchKernelGGL(rowscale_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxv1, 32, 0, w.xr, 37, 0, w.v1, 1, 0.f, PV, 32, w.gxr, 37, 0, w.gv1);
-  hipLaunchKernelGGL(visfc_post_bwd_kernel, dim3(nblk(PV * 33)), dim3(256), 0, st, w.gxr, w.gv1, w.v1, PV, w.gx, w.gxv);
+  hipLaunchKernelGGL(visfc_post_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxr, w.gxv1, w.xr, w.v1, PV, w.gx, w.gxv);
   L(chain_bwd(c, vf_l, 2, PV, w.gx, 32, 1));                                             // gx += wgt * (delta W)
   PGRF_TCHECK("train visibility backward");
   L(chain_bwd(c, base_l, 2, PV, w.gxin + 140, 207, 0));                                  // d / d(per-view columns); delta of base_fc.0 left in gb1
