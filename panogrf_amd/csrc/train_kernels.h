@@ -855,6 +855,26 @@ __global__ void gather32_kernel(const float* __restrict__ map, long view_stride,
   }
   *reinterpret_cast<float4*>(out + pv * ldo + dc + q * 4) = s;
 }
+// rgb_feat = [rgb | gathered img_feats] + dir_feat -> xin[:, 140:175]  (ibrnet.py:325-327): the gather of the image features with the direction
+// feature added on its way out (round 5: was the gather into a [PV, 32] buffer + an elementwise launch that re-read it)
+__global__ void gather32_rgbfeat_kernel(const float* __restrict__ map, long view_stride, const int* __restrict__ to, const float* __restrict__ tw,
+                                        long PV, int V, const float* __restrict__ rgb, const float* __restrict__ dfeat, float* __restrict__ xin) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PV * 8) return;
+  const long pv = i / 8; const int q = (int)(i % 8);
+  const float* mb = map + (pv % V) * view_stride + q * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float4 m = *reinterpret_cast<const float4*>(mb + (size_t)to[pv * 4 + t] * 32);
+    const float w = tw[pv * 4 + t];
+    s.x += m.x * w; s.y += m.y * w; s.z += m.z * w; s.w += m.w * w;
+  }
+  const float* df = dfeat + pv * 35;
+  float* xo = xin + pv * 207 + 140;
+  xo[3 + q * 4] = s.x + df[3 + q * 4]; xo[4 + q * 4] = s.y + df[4 + q * 4]; xo[5 + q * 4] = s.z + df[5 + q * 4]; xo[6 + q * 4] = s.w + df[6 + q * 4];
+  if (q == 0) { xo[0] = rgb[pv * 3] + df[0]; xo[1] = rgb[pv * 3 + 1] + df[1]; xo[2] = rgb[pv * 3 + 2] + df[2]; }
+}
 // gmap[v][o_t][c] += w_t * g[pv, c]   (transpose of the gather: scatter-add with atomics)
 __global__ void gather32_bwd_kernel(float* __restrict__ gmap, long view_stride, const int* __restrict__ to, const float* __restrict__ tw,
                                     long PV, int V, const float* __restrict__ g, int ldg, int gc) {

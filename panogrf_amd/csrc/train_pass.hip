@@ -62,14 +62,6 @@ __global__ void rowscale_kernel(float* __restrict__ y, int ldy, int yc, const fl
     y[r * ldy + yc + c] = x[r * ldx + xc + c] * (s ? s[r * sstride] : cst);
   }
 }
-// rgb_feat = [rgb | img_feats] + dir_feat  (ibrnet.py:325-327) -> xin[:, 140:175]
-__global__ void rgbfeat_kernel(const float* __restrict__ rgb, const float* __restrict__ imf, const float* __restrict__ dfeat, long PV,
-                               float* __restrict__ xin) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < PV * 35; i += (long)gridDim.x * blockDim.x) {
-    const unsigned iu = (unsigned)i; const long pv = iu / 35u; const int c = (int)(iu % 35u);
-    xin[pv * 207 + 140 + c] = (c < 3 ? rgb[pv * 3 + c] : imf[pv * 32 + c - 3]) + dfeat[pv * 35 + c];
-  }
-}
 // x2 = x + x_res, v1 = sigmoid(xv[32])  (ibrnet.py:347-350); x2 -> xr[:, 0:32]; xv1 = x2 * v1 (vis_fc2's input) in the same sweep
 // (round 5: was this kernel + a row-scale launch).  32 lanes per row.
 __global__ void __launch_bounds__(256) visfc_post_kernel(const float* __restrict__ x, const float* __restrict__ xv, long PV, float* __restrict__ xr,
@@ -167,7 +159,7 @@ struct Ws {
   int *tap_rf_o, *tap_if_o;
   float *tap_rf_w, *tap_if_w, *rgb, *dd, *depth_v, *hw, *w1, *pos, *grep;
   // forward activations
-  float *pe_in, *imf;
+  float *pe_in;
   float *dh1[4], *dh2[4], *dout[4];
   float *vis, *hit, *pe_h, *d1, *dfeat, *n1, *nfs, *w0, *glob, *hb, *xin, *b1, *x, *v1h, *xv, *v1, *xr, *xv1, *f1, *wgt2;
   float *gin, *g1, *g2, *gp, *q, *k, *v, *o, *fo, *ln, *og1, *sigma, *r1, *r2, *logit, *blend, *colors;
@@ -188,7 +180,7 @@ static size_t plan(Ws& w, long P, int V, int dn, char* base) {
   w.tap_rf_w = take(PV * 4); w.tap_if_w = take(PV * 4);
   w.rgb = take(PV * 3); w.dd = take(PV * 4); w.depth_v = take(PV); w.hw = take(P * 2); w.w1 = take(PV); w.pos = take((long)dn * 16);
   w.grep = take((long)(kGradReplicas - 1) * kGradSlot * R_COUNT);
-  w.pe_in = take(PV * 34); w.imf = take(PV * 32);
+  w.pe_in = take(PV * 34);
   for (int m = 0; m < 4; ++m) { w.dh1[m] = take(PV * 32); w.dh2[m] = take(PV * 32); w.dout[m] = take(PV * 2); }
   w.vis = take(PV); w.hit = take(PV); w.pe_h = take(PV * 32); w.d1 = take(PV * 16); w.dfeat = take(PV * 35); w.n1 = take(PV * 8);
   w.nfs = take(PV); w.w0 = take(PV); w.glob = take(P * 140); w.hb = take(P * 64); w.xin = take(PV * 207); w.b1 = take(PV * 64); w.x = take(PV * 32);
@@ -529,7 +521,6 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   if (do_fwd) hipLaunchKernelGGL(posenc_table_kernel, dim3(nblk((long)dn * 16)), dim3(256), 0, st, w.pos, dn);
   const long rf_stride = (long)frame->hr * frame->wr * 32, if_stride = (long)frame->hf * frame->wf * 32;
   if (do_fwd) hipLaunchKernelGGL(gather32_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->ray_feats, rf_stride, w.tap_rf_o, w.tap_rf_w, PV, V, w.pe_in, 34, 0);
-  if (do_fwd) hipLaunchKernelGGL(gather32_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.imf, 32, 0);
   PGRF_TCHECK("train geometry");
 
   // ------------------------------------------------------------------ forward, every activation kept
@@ -550,7 +541,7 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   const Lin rd_l[2] = {{w.dd, 4, w.d1, 16, w.gd1, 16, R_RD_0_W, R_RD_0_B, 4, 16, ACT_ELU},                          // ray_dir_fc
                        {w.d1, 16, w.dfeat, 35, w.gdfeat, 35, R_RD_2_W, R_RD_2_B, 16, 35, ACT_ELU}};
   if (do_fwd) L(chain_fwd(c, rd_l, 2, PV));
-  if (do_fwd) hipLaunchKernelGGL(rgbfeat_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.rgb, w.imf, w.dfeat, PV, w.xin);
+  if (do_fwd) hipLaunchKernelGGL(gather32_rgbfeat_kernel, dim3(nblk(PV * 8)), dim3(256), 0, st, frame->img_feats, if_stride, w.tap_if_o, w.tap_if_w, PV, V, w.rgb, w.dfeat, w.xin);
   const Lin nf_l[2] = {{w.xin + 175, 207, w.n1, 8, w.gn1, 8, R_NF_0_W, R_NF_0_B, 32, 8, ACT_ELU},                   // neuray_fc -> weight0 (ibrnet.py:337-338)
                        {w.n1, 8, w.nfs, 1, w.gw0, 1, R_NF_2_W, R_NF_2_B, 8, 1, ACT_SIGMOID}};
   if (do_fwd) L(chain_fwd(c, nf_l, 2, PV));
