@@ -271,7 +271,7 @@ def train_bench(args, dev, rank, world, distributed):
     params = {k: torch.nn.Parameter(v.to(dev).clone()) for k, v in case['weights'].items()}
     img_feats = f['img_feats'].clone().requires_grad_(True)
     ray_feats = f['ray_feats'].clone().requires_grad_(True)
-    opt = torch.optim.Adam(list(params.values()), lr=1e-4)
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4, fused=True)      # (one fused kernel for the ~120 small tensors; the foreach form is 1.4 ms of host time per step)
     use_vis = case['cfg']['dist_decoder_cfg']['use_vis']
     target_img = f['imgs'][0].permute(1, 2, 0).reshape(-1, 3)
     g = torch.Generator().manual_seed(100 + rank)
@@ -349,7 +349,7 @@ def train_bench(args, dev, rank, world, distributed):
         fr = {k: v for k, v in f.items()}
         fr['img_feats'] = f['img_feats'].clone().requires_grad_(True)
         fr['ray_feats'] = f['ray_feats'].clone().requires_grad_(True)
-        eopt = torch.optim.Adam(list(pw.values()), lr=1e-4)
+        eopt = torch.optim.Adam(list(pw.values()), lr=1e-4, fused=True)
         qdr = case['frame']['que_depth_range'].to(dev)
 
         def estep(i):

@@ -10,7 +10,7 @@ case = bench.synthetic_case(H, W, V, dn, seed=0, fine=True)
 f = {k: v.to(dev) for k, v in case['frame'].items()}
 params = {k: torch.nn.Parameter(v.to(dev).clone()) for k, v in case['weights'].items()}
 img_feats = f['img_feats'].clone().requires_grad_(True); ray_feats = f['ray_feats'].clone().requires_grad_(True)
-opt = torch.optim.Adam(list(params.values()), lr=1e-4)
+opt = torch.optim.Adam(list(params.values()), lr=1e-4, fused=True)
 target_img = f['imgs'][0].permute(1, 2, 0).reshape(-1, 3)
 g = torch.Generator().manual_seed(100)
 N = 45
