@@ -70,7 +70,7 @@ class RenderLoss(Loss):
         polar = bool(c['use_polar_weighted_loss'])
         weights_gt = data_pr['polar_weights'] if polar else None          # 1,rn,1
 
-        def compute_loss(rgb_pr, rgb_gt):
+        def photometric(rgb_pr, rgb_gt):
             if polar:
                 loss = torch.sum((rgb_pr - rgb_gt) ** 2 * weights_gt, -1)
                 if c['use_ray_mask']:
@@ -81,17 +81,17 @@ class RenderLoss(Loss):
                 return torch.sum(loss * ray_mask, 1) / (torch.sum(ray_mask, 1) + 1e-7)
             return torch.mean(loss, 1)
 
-        results = {}
+        terms = []          # (loss key, predicted-colour key) in the reference's order
         if not c['fix_coarse'] and not one_mlp:
-            results['loss_rgb_nr'] = compute_loss(rgb_nr, rgb_gt)
+            terms.append(('loss_rgb_nr', 'pixel_colors_nr'))
             if c['use_dr_loss']:
-                results['loss_rgb_dr'] = compute_loss(data_pr['pixel_colors_dr'], rgb_gt)
+                terms.append(('loss_rgb_dr', 'pixel_colors_dr'))
         if c['use_hierarchical_sampling'] or c.get('diner_depth_guided_sampling'):
             if c['use_dr_fine_loss']:
-                results['loss_rgb_dr_fine'] = compute_loss(data_pr['pixel_colors_dr_fine'], rgb_gt)
+                terms.append(('loss_rgb_dr_fine', 'pixel_colors_dr_fine'))
             if c['use_nr_fine_loss']:
-                results['loss_rgb_nr_fine'] = compute_loss(data_pr['pixel_colors_nr_fine'], rgb_gt)
-        return results
+                terms.append(('loss_rgb_nr_fine', 'pixel_colors_nr_fine'))
+        return {name: photometric(rgb_nr if src == 'pixel_colors_nr' else data_pr[src], rgb_gt) for name, src in terms}
 
 
 class DepthLoss(Loss):
@@ -108,18 +108,16 @@ class DepthLoss(Loss):
             key = 'pixel_colors_nr_fine' if self.cfg.get('diner_depth_guided_sampling') else 'pixel_colors_nr'
             return {'loss_depth': torch.zeros([1], dtype=torch.float32, device=data_pr[key].device)}
         coords, depth_pr = data_pr['depth_coords'], data_pr['depth_mean']            # rfn,pn,2 / rfn,pn
-        depth_maps = data_gt['ref_imgs_info']['true_depth']                          # rfn,1,h,w
-        _, _, h, w = depth_maps.shape
-        depth_gt = _interpolate_feats(depth_maps, coords, h, w, padding_mode='border', align_corners=True)[..., 0]
+        true_depth = data_gt['ref_imgs_info']['true_depth']                          # [rfn, 1, h, w]
+        h, w = true_depth.shape[-2:]
+        depth_gt = _interpolate_feats(true_depth, coords, h, w, padding_mode='border', align_corners=True)[..., 0]
         depth_range = data_gt['ref_imgs_info']['depth_range']
         near, far = -1 / depth_range[:, 0:1], -1 / depth_range[:, 1:2]
 
-        def process(depth):
-            depth = -1 / torch.clamp(depth, min=1e-5)
-            return torch.clamp((depth - near) / (far - near), min=0, max=1.0)
-        depth_gt = process(depth_gt)
+        inv = -1 / torch.clamp(depth_gt, min=1e-5)                                    # normalised inverse depth in [0, 1]
+        depth_gt = torch.clamp((inv - near) / (far - near), min=0, max=1.0)
 
-        def compute_loss(pr):
+        def depth_term(pr):
             if self.cfg['depth_loss_type'] == 'l2':
                 loss = (depth_gt - pr) ** 2
             elif self.cfg['depth_loss_type'] == 'smooth_l1':
@@ -127,9 +125,9 @@ class DepthLoss(Loss):
             else:
                 raise ValueError(f"depth_loss_type {self.cfg['depth_loss_type']!r}")
             return torch.mean(loss, 1)
-        out = {'loss_depth': compute_loss(depth_pr)}
+        out = {'loss_depth': depth_term(depth_pr)}
         if 'depth_mean_fine' in data_pr:
-            out['loss_depth_fine'] = compute_loss(data_pr['depth_mean_fine'])
+            out['loss_depth_fine'] = depth_term(data_pr['depth_mean_fine'])
         return out
 
 
