@@ -278,14 +278,14 @@ def train_bench(args, dev, rank, world, distributed):
     n_batches = args.warmup + args.steps
     idxs = [torch.randperm(H * W, generator=g)[:rays].to(dev) for _ in range(n_batches)]
     us = [torch.rand(rays, dn, generator=g).to(dev) for _ in range(n_batches)]
+    # the batches (pixel coordinates and their ground-truth colours) are the data loader's product, prepared like the draws above
+    batches = [(torch.stack([(idx % W).float(), (idx // W).float()], -1), target_img[idx]) for idx in idxs]
     que_dr = [0.5, 15.0]
     common = (f['imgs'], img_feats, ray_feats, f['w2c'], f['ref_depth_range'], case['frame']['que_c2w'], case['frame']['que_depth_range'], params)
     flat_grads = None
 
     def step(i):
-        idx = idxs[i]
-        coords = torch.stack([(idx % W).float(), (idx // W).float()], -1)
-        tgt = target_img[idx]
+        coords, tgt = batches[i]
         depth = E.sample_coarse_depth(case['cfg']['min_depth'], case['cfg']['max_depth'], rays, dn, device=dev)
         oc = E.render_pass_autograd(*common, 'dist_decoder', 'agg_net', use_vis, coords, depth)
         fd = E.sample_fine_depth(depth, oc['hit_prob_nr'].detach(), que_dr, dn, u=us[i])
@@ -353,9 +353,7 @@ def train_bench(args, dev, rank, world, distributed):
         qdr = case['frame']['que_depth_range'].to(dev)
 
         def estep(i):
-            idx = idxs[i]
-            coords = torch.stack([(idx % W).float(), (idx // W).float()], -1)
-            tgt = target_img[idx]
+            coords, tgt = batches[i]
             depth = O.sample_coarse_depth(case['cfg']['min_depth'], case['cfg']['max_depth'], rays, dn).to(dev)
             oc = O.render_pass(pw, 'dist_decoder', 'agg_net', fr, coords, depth, {'use_vis': use_vis})
             fd = O.sample_fine_depth(depth, oc['hit_prob_nr'].detach(), qdr, dn, u=us[i])
