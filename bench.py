@@ -290,7 +290,7 @@ def train_bench(args, dev, rank, world, distributed):
         oc = E.render_pass_autograd(*common, 'dist_decoder', 'agg_net', use_vis, coords, depth)
         fd = E.sample_fine_depth(depth, oc['hit_prob_nr'].detach(), que_dr, dn, u=us[i])
         of = E.render_pass_autograd(*common, 'fine_dist_decoder', 'fine_agg_net', use_vis, coords, fd)
-        loss = ((of['pixel_colors_nr'] - tgt) ** 2).mean() + ((oc['pixel_colors_nr'] - tgt) ** 2).mean()
+        loss = torch.nn.functional.mse_loss(of['pixel_colors_nr'], tgt) + torch.nn.functional.mse_loss(oc['pixel_colors_nr'], tgt)
         opt.zero_grad(set_to_none=True)
         img_feats.grad = ray_feats.grad = None
         loss.backward()
@@ -359,7 +359,7 @@ def train_bench(args, dev, rank, world, distributed):
             fd = O.sample_fine_depth(depth, oc['hit_prob_nr'].detach(), qdr, dn, u=us[i])
             fd = torch.sort(fd, -1)[0]
             of = O.render_pass(pw, 'fine_dist_decoder', 'fine_agg_net', fr, coords, fd, {'use_vis': use_vis})
-            loss = ((of['pixel_colors_nr'] - tgt) ** 2).mean() + ((oc['pixel_colors_nr'] - tgt) ** 2).mean()
+            loss = torch.nn.functional.mse_loss(of['pixel_colors_nr'], tgt) + torch.nn.functional.mse_loss(oc['pixel_colors_nr'], tgt)
             eopt.zero_grad(set_to_none=True)
             loss.backward()
             eopt.step()
