@@ -1134,6 +1134,85 @@ __global__ void __launch_bounds__(256) stats_bwd_kernel(const float* __restrict_
   }
 }
 
+// The same with FOUR features per lane (round 5, late): 16 lanes per point (F <= 64: lane li holds columns 4 li .. 4 li + 3), four points per
+// wave, every row access one dword-aligned 16-byte load per lane; the last quad of a row is masked after the load and stored column by
+// column (the next column belongs to someone else).  A quarter of the memory instructions of the lane-per-feature form for the same bytes.
+template <int NS>
+__global__ void __launch_bounds__(256) stats_bwd4_kernel(const float* __restrict__ x, int ldx, int xc, int V, int F, long P,
+                                                         const float* __restrict__ stat, int lds, const float* __restrict__ g, int ldg,
+                                                         float* __restrict__ gx, int ldgx, int gxc, StatSet s0, StatSet s1) {
+  const int lane = threadIdx.x & 63, li = lane & 15, c0 = 4 * li;
+  const long p = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool pok = p < P;
+  const long pc = pok ? p : P - 1;
+  const bool on = c0 < F;                       // this lane has at least one live column
+  const int cc = on ? c0 : 0;
+  unsigned msk[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) msk[e] = (on && c0 + e < F) ? 0xffffffffu : 0u;
+  auto ld4 = [&](const float* q, float (&o)[4]) {
+    const F4U t = *reinterpret_cast<const F4U*>(q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __uint_as_float(__float_as_uint(t.v[e]) & msk[e]);
+  };
+  float xs[4][4], go[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (u < V) {
+      ld4(x + (pc * V + u) * ldx + xc + cc, xs[u]);
+      ld4(gx + (pc * V + u) * ldgx + gxc + cc, go[u]);
+    }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const StatSet& S = k == 0 ? s0 : s1;
+    float m[4], gm[4], gvar[4], ws[4];
+    ld4(stat + pc * lds + S.mc + cc, m);
+    ld4(g + pc * ldg + S.gmc + cc, gm);
+    ld4(g + pc * ldg + S.gvc + cc, gvar);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < V) ws[u] = S.w[pc * V + u];
+    float gmt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float Sw = 0.f;                           // sum_u w_u (x_u - m): zero only when the weights sum to one
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < V) Sw += ws[u] * (xs[u][e] - m[e]);
+      gmt[e] = gm[e] - 2.f * Sw * gvar[e];      // total gradient reaching the mean
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u < V) {
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xs[u][e] - m[e];
+          go[u][e] += ws[u] * gmt[e] + 2.f * ws[u] * d * gvar[e];
+          part += msk[e] ? xs[u][e] * gmt[e] + d * d * gvar[e] : 0.f;
+        }
+        if (S.gw) {
+#pragma unroll
+          for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 16);
+          if (li == 0 && pok) S.gw[p * V + u] += part;
+        }
+      }
+    }
+  }
+  if (pok && on) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < V) {
+        float* q = gx + (p * V + u) * ldgx + gxc + c0;
+        if (c0 + 4 <= F) { F4U o; o.v[0] = go[u][0]; o.v[1] = go[u][1]; o.v[2] = go[u][2]; o.v[3] = go[u][3]; *reinterpret_cast<F4U*>(q) = o; }
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c0 + e < F) q[e] = go[u][e];
+        }
+      }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // ray attention (ibrnet.py:7-27,52-102): 4 heads of dimension 4 over the dn samples of a ray, temperature 2; for ONE
 // source view the reference's mask makes every logit equal (uniform weights).  q, k, v, o: [P,16] with head h at columns 4h..

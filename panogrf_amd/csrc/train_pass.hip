@@ -625,6 +625,10 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   L(lin_bwd(c, w.gp, 16, w.v, 16, w.gv, 16, R_ATT_V_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(chain_bwd(c, geo_l, 2, P, w.ggin, 65, 0));
   (void)hipMemsetAsync(w.gwgt2, 0, PV * 4, st);
+  static const bool stats4 = [] { const char* e = getenv("PGRF_TRAIN_STATS4"); return !(e && e[0] == '0'); }();      // four features per lane (5.16 -> 5.10 ms per step); 0 = a lane per feature
+  if (stats4) hipLaunchKernelGGL(stats_bwd4_kernel<1>, dim3(nblk(P, 16)), dim3(256), 0, st, w.xr, 37, 0, V, 32, P, w.gin, 65, w.ggin, 65, w.gxr, 37, 0,
+                                 StatSet{w.wgt2, 0, 32, 0, 32, w.gwgt2}, StatSet{});
+  else
   hipLaunchKernelGGL(stats_bwd_kernel<1>, dim3(nblk(P, 4 * kStatPts)), dim3(256), 0, st, w.xr, 37, 0, V, 32, P, w.gin, 65, w.ggin, 65, w.gxr, 37, 0,
                      StatSet{w.wgt2, 0, 32, 0, 32, w.gwgt2}, StatSet{});
   hipLaunchKernelGGL(wgt2_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, w.gwgt2, w.ggin, P, V, w.gxr);
@@ -638,6 +642,9 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   L(chain_bwd(c, glob_l, 1, P, w.gglob, 140, 0));                                         // d glob = d hb W[:, 0:140]  (+ that block's dW, P rows)
   (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
   // both weightings of the per-view features (weight0 = sigmoid(neuray_fc) / V with a gradient, weight1 = 1 / V without) in one sweep
+  if (stats4) hipLaunchKernelGGL(stats_bwd4_kernel<2>, dim3(nblk(P, 16)), dim3(256), 0, st, w.xin, 207, 140, V, 35, P, w.glob, 140, w.gglob, 140, w.gxin, 207, 140,
+                                 StatSet{w.w0, 0, 35, 0, 35, w.gw0}, StatSet{w.w1, 70, 105, 70, 105, nullptr});
+  else
   hipLaunchKernelGGL(stats_bwd_kernel<2>, dim3(nblk(P, 4 * kStatPts)), dim3(256), 0, st, w.xin, 207, 140, V, 35, P, w.glob, 140, w.gglob, 140, w.gxin, 207, 140,
                      StatSet{w.w0, 0, 35, 0, 35, w.gw0}, StatSet{w.w1, 70, 105, 70, 105, nullptr});
   PGRF_TCHECK("train view statistics backward");
