@@ -1137,10 +1137,13 @@ __global__ void __launch_bounds__(256) stats_bwd_kernel(const float* __restrict_
 // The same with FOUR features per lane (round 5, late): 16 lanes per point (F <= 64: lane li holds columns 4 li .. 4 li + 3), four points per
 // wave, every row access one dword-aligned 16-byte load per lane; the last quad of a row is masked after the load and stored column by
 // column (the next column belongs to someone else).  A quarter of the memory instructions of the lane-per-feature form for the same bytes.
-template <int NS>
+// W2 (the pooled-geometry statistics, ibrnet.py:352-358): set 0's weights are wgt2 = v2 / (sum_v v2 + 1e-8) with v2 = x[:, w2x], and g[:, w2g]
+// carries d / d(mean_v wgt2): the gradient of v2 (was wgt2_bwd_kernel behind a zeroed gwgt2 buffer) is formed here from the per-view weight
+// gradients the wave has just reduced, and added to gx[:, w2x]; s0.gw is not written.
+template <int NS, bool W2 = false>
 __global__ void __launch_bounds__(256) stats_bwd4_kernel(const float* __restrict__ x, int ldx, int xc, int V, int F, long P,
                                                          const float* __restrict__ stat, int lds, const float* __restrict__ g, int ldg,
-                                                         float* __restrict__ gx, int ldgx, int gxc, StatSet s0, StatSet s1) {
+                                                         float* __restrict__ gx, int ldgx, int gxc, StatSet s0, StatSet s1, int w2x = 0, int w2g = 0) {
   const int lane = threadIdx.x & 63, li = lane & 15, c0 = 4 * li;
   const long p = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   const bool pok = p < P;
@@ -1156,6 +1159,7 @@ __global__ void __launch_bounds__(256) stats_bwd4_kernel(const float* __restrict
     for (int e = 0; e < 4; ++e) o[e] = __uint_as_float(__float_as_uint(t.v[e]) & msk[e]);
   };
   float xs[4][4], go[4][4];
+  float gw2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < 4; ++u)
     if (u < V) {
@@ -1191,13 +1195,27 @@ __global__ void __launch_bounds__(256) stats_bwd4_kernel(const float* __restrict
           go[u][e] += ws[u] * gmt[e] + 2.f * ws[u] * d * gvar[e];
           part += msk[e] ? xs[u][e] * gmt[e] + d * d * gvar[e] : 0.f;
         }
-        if (S.gw) {
+        if (S.gw || (W2 && k == 0)) {
 #pragma unroll
           for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 16);
-          if (li == 0 && pok) S.gw[p * V + u] += part;
+          if (W2 && k == 0) gw2[u] = part;
+          else if (li == 0 && pok) S.gw[p * V + u] += part;
         }
       }
     }
+  }
+  if (W2 && li == 0 && pok) {
+    float v2[4], S2 = 0.f, dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < V) { v2[u] = x[(p * V + u) * ldx + w2x]; S2 += v2[u]; }
+    const float den = S2 + 1e-8f, gmw = g[p * ldg + w2g] / (float)V;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < V) dot += (gw2[u] + gmw) * v2[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < V) gx[(p * V + u) * ldgx + w2x] += (gw2[u] + gmw) / den - dot / (den * den);
   }
   if (pok && on) {
 #pragma unroll

@@ -624,14 +624,15 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   L(lin_bwd(c, w.gp, 16, w.k, 16, w.gk, 16, R_ATT_K_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(lin_bwd(c, w.gp, 16, w.v, 16, w.gv, 16, R_ATT_V_W, -1, w.ggp, 16, 1, P, 16, 16, ACT_NONE));
   L(chain_bwd(c, geo_l, 2, P, w.ggin, 65, 0));
-  (void)hipMemsetAsync(w.gwgt2, 0, PV * 4, st);
   static const bool stats4 = [] { const char* e = getenv("PGRF_TRAIN_STATS4"); return !(e && e[0] == '0'); }();      // four features per lane (5.16 -> 5.10 ms per step); 0 = a lane per feature
-  if (stats4) hipLaunchKernelGGL(stats_bwd4_kernel<1>, dim3(nblk(P, 16)), dim3(256), 0, st, w.xr, 37, 0, V, 32, P, w.gin, 65, w.ggin, 65, w.gxr, 37, 0,
-                                 StatSet{w.wgt2, 0, 32, 0, 32, w.gwgt2}, StatSet{});
-  else
+  if (stats4) hipLaunchKernelGGL((stats_bwd4_kernel<1, true>), dim3(nblk(P, 16)), dim3(256), 0, st, w.xr, 37, 0, V, 32, P, w.gin, 65, w.ggin, 65, w.gxr, 37, 0,
+                                 StatSet{w.wgt2, 0, 32, 0, 32, nullptr}, StatSet{}, 32, 64);      // + the gradient of v2 = xr[:, 32] (was wgt2_bwd_kernel)
+  else {
+  (void)hipMemsetAsync(w.gwgt2, 0, PV * 4, st);
   hipLaunchKernelGGL(stats_bwd_kernel<1>, dim3(nblk(P, 4 * kStatPts)), dim3(256), 0, st, w.xr, 37, 0, V, 32, P, w.gin, 65, w.ggin, 65, w.gxr, 37, 0,
                      StatSet{w.wgt2, 0, 32, 0, 32, w.gwgt2}, StatSet{});
   hipLaunchKernelGGL(wgt2_bwd_kernel, dim3(nblk(P)), dim3(256), 0, st, w.xr, w.gwgt2, w.ggin, P, V, w.gxr);
+  }
   PGRF_TCHECK("train pooled geometry backward");
   L(chain_bwd(c, v2_l, 2, PV, w.gxv1, 32, 0));
   hipLaunchKernelGGL(visfc_post_bwd_kernel, dim3(nblk(PV, 8)), dim3(256), 0, st, w.gxr, w.gxv1, w.xr, w.v1, PV, w.gx, w.gxv);
