@@ -1064,7 +1064,7 @@ __global__ void stats_kernel(const float* __restrict__ x, int ldx, int xc, int V
 // sweep -- x is read and gx read-modified-written once, the two terms added in the order the two launches added them: 2 x 100 us -> 139 us;
 // (ii) PGRF_STAT_PTS points per wave, two in flight (measured per 2 048-ray training step, tools/ab_train_variants.sh: 1 point 5.95 ms,
 // 2 points 5.89, 4 points 6.07: the kernel is bound by the round trips of short rows at a 207-float stride, and wants waves, not long ones).
-struct StatSet { const float* w; int mc, vc, gmc, gvc; float* gw; };    // weights [PV], stat / g columns of (mean, var), gw [PV] or null
+struct StatSet { const float* w; int mc, vc, gmc, gvc; float* gw; float gws = 1.f; };    // weights [PV], stat / g columns of (mean, var), gw [PV] or null; gws: stats_bwd4_kernel WRITES gws * (weight gradient)
 #ifndef PGRF_STAT_PTS
 #define PGRF_STAT_PTS 2
 #endif
@@ -1199,7 +1199,7 @@ __global__ void __launch_bounds__(256) stats_bwd4_kernel(const float* __restrict
 #pragma unroll
           for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 16);
           if (W2 && k == 0) gw2[u] = part;
-          else if (li == 0 && pok) S.gw[p * V + u] += part;
+          else if (li == 0 && pok) S.gw[p * V + u] = part * S.gws;      // (written: this kernel is the buffer's only producer)
         }
       }
     }

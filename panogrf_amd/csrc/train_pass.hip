@@ -641,16 +641,17 @@ int pgrf_render_pass_backward_phase(const PgrfFrame* frame, const float* const* 
   L(chain_bwd(c, base_l, 2, PV, w.gxin + 140, 207, 0));                                  // d / d(per-view columns); delta of base_fc.0 left in gb1
   hipLaunchKernelGGL(reduce_views_kernel, dim3(nblk(P * 16)), dim3(256), 0, st, w.ghb, 64, 0, w.gb1, 64, 0, P, V, 64, 0);      // d hb = sum over the views
   L(chain_bwd(c, glob_l, 1, P, w.gglob, 140, 0));                                         // d glob = d hb W[:, 0:140]  (+ that block's dW, P rows)
-  (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
-  // both weightings of the per-view features (weight0 = sigmoid(neuray_fc) / V with a gradient, weight1 = 1 / V without) in one sweep
+  // both weightings of the per-view features (weight0 = sigmoid(neuray_fc) / V with a gradient, weight1 = 1 / V without) in one sweep;
+  // weight0 = sigmoid(neuray_fc) * wgt: the gradient enters the sigmoid output scaled by wgt
   if (stats4) hipLaunchKernelGGL(stats_bwd4_kernel<2>, dim3(nblk(P, 16)), dim3(256), 0, st, w.xin, 207, 140, V, 35, P, w.glob, 140, w.gglob, 140, w.gxin, 207, 140,
-                                 StatSet{w.w0, 0, 35, 0, 35, w.gw0}, StatSet{w.w1, 70, 105, 70, 105, nullptr});
-  else
+                                 StatSet{w.w0, 0, 35, 0, 35, w.gw0, wgt}, StatSet{w.w1, 70, 105, 70, 105, nullptr});      // gw0 written, scaled
+  else {
+  (void)hipMemsetAsync(w.gw0, 0, PV * 4, st);
   hipLaunchKernelGGL(stats_bwd_kernel<2>, dim3(nblk(P, 4 * kStatPts)), dim3(256), 0, st, w.xin, 207, 140, V, 35, P, w.glob, 140, w.gglob, 140, w.gxin, 207, 140,
                      StatSet{w.w0, 0, 35, 0, 35, w.gw0}, StatSet{w.w1, 70, 105, 70, 105, nullptr});
-  PGRF_TCHECK("train view statistics backward");
-  // weight0 = sigmoid(neuray_fc) * wgt: the gradient enters the sigmoid output scaled by wgt
   hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(PV)), dim3(256), 0, st, w.gw0, 1, 0, w.gw0, 1, 0, (const float*)nullptr, 0, wgt, PV, 1);
+  }
+  PGRF_TCHECK("train view statistics backward");
   L(chain_bwd(c, nf_l, 2, PV, w.gxin + 175, 207, 1));                                                               // += onto the neuray columns
   hipLaunchKernelGGL(slice_kernel, dim3(nblk(PV * 35)), dim3(256), 0, st, w.gdfeat, 35, 0, w.gxin, 207, 140, PV, 35, 0);
   if (g_img_feats) {      // (nothing of the pass reads the map gradient: beside the remaining chains on a side stream)
