@@ -336,7 +336,10 @@ def train_bench(args, dev, rank, world, distributed):
            'data': 'synthetic',
            'config': {'workload': f'training step: {rays} random rays per rank of a {H}x{W} ERP query, {V} source views, {dn} coarse + {dn} fine '
                                   f'samples; gradients to all per-ray weights and to img_feats / ray_feats; Adam; encoders outside',
-                      'rays_per_step_per_rank': rays, 'parallelism': f'data-parallel x{world}, gradient all-reduce'},
+                      'rays_per_step_per_rank': rays, 'parallelism': f'data-parallel x{world}, gradient all-reduce',
+                      # (what the timed step contains since round 5 -- records of rounds <= 4 under this metric name also prepared the
+                      #  batch and ran the foreach Adam and a 15-kernel loss inside the step, so their ms_per_step is not comparable)
+                      'batch_prep_in_step': False, 'optimizer': 'adam-fused', 'loss': 'mse_loss (coarse + fine)'},
            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
                         'traffic': None, 'kernel': 'whole step on the stream (2 staged forward passes with their activations kept, 2 reverse sweeps, sampler, loss, Adam)',
                         'kernel_ms': gpu_ms, 'flop_per_ray': 3 * flop_per_ray(V, dn, 2), 'rays_per_launch': rays,
@@ -624,7 +627,7 @@ def main():
         gf_view = gf / V
         wino = 3.375 if args.reg == 'unet2' else 1.0
         rl_build = {'bound': 'hbm', 'achieved': cv_bytes / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0, 'peak': 8000.0, 'unit': 'GB/s',
-                    'kernel': 'cost_volume_kernel', 'kernel_ms': build_ms, 'algorithmic_bytes_per_launch': cv_bytes, 'traffic': None}
+                    'kernel': 'cost_volume_pipe_kernel', 'kernel_ms': build_ms, 'algorithmic_bytes_per_launch': cv_bytes, 'traffic': None}
         rl_build['frac'] = rl_build['achieved'] / rl_build['peak']
         rl_reg = {'bound': 'mfma', 'achieved': gf_view / wino / (reg_ms * 1e-3) / 1e12 if reg_ms > 0 else 0.0, 'peak': PEAK_F32_MFMA_TFLOPS,
                   'unit': 'TFLOP/s', 'kernel': args.reg + ' forward (all its launches)', 'kernel_ms': reg_ms,

@@ -126,12 +126,17 @@ static int do_render_pass(const PgrfFrame* frame, const float* blob, int flags, 
     // Rays of a full panorama (or of whole row tiles of one) arrive row-major: visited in 2-D pixel tiles, the workgroups
     // resident on an XCD gather from a compact patch of the source maps instead of a 1-pixel-high strip.  Measured: +1.9 % for
     // 4 views of 1024x2048 (341.4 -> 335.0 ms; one query row's footprint in the maps is ~40 MB there, ten times an XCD's
-    // L2), +-0.3 % at 512x1024 x 2 views and at 2 views of 1024x2048, -0.5 % on a fine pass -> on by default from 2 Mpx of source
-    // maps (4 views of 512x1024; it was 8 Mpx until round 5).  PGRF_RAY_TILE="tw th" forces a tile, "0" turns it off.  Any other ray list keeps its order.
+    // L2), +-0.3 % at 512x1024 x 2 views and at 2 views of 1024x2048, -0.5 % on a fine pass -> on by default from 8 Mpx of source
+    // maps, and from 2 Mpx for four views (4 views of 512x1024).  PGRF_RAY_TILE="tw th" forces a tile, "0" turns it off.  Any other ray list keeps its order.
     int tw = 0, th = 0;
     const char* e = getenv("PGRF_RAY_TILE");
     if (e) { if (sscanf(e, "%d %d", &tw, &th) < 2) th = tw; }
-    else if ((size_t)frame->rfn * frame->H * frame->W >= ((size_t)2 << 20)) tw = th = 16;     // (round 5: 4 views of 512x1024 65.07 -> 64.65 ms)
+    else {
+      // gated on the cases that were measured: from 8 Mpx of source maps for any view count (round 4), from 2 Mpx for the four-view
+      // kernel (round 5: 4 views of 512x1024 65.07 -> 64.65 ms); 2 views of 1024x2048 (4 Mpx, +-0.3 %) keep the row-major order
+      const size_t px = (size_t)frame->rfn * frame->H * frame->W;
+      if (px >= ((size_t)8 << 20) || (frame->rfn >= 4 && px >= ((size_t)2 << 20))) tw = th = 16;
+    }
     if (tw > 0 && th > 0 && frame->W % tw == 0 && rn % (frame->W * th) == 0 && !frame->perspective) {
       a.order_w = frame->W; a.order_tw = tw; a.order_th = th;
     }

@@ -128,7 +128,12 @@ struct CvArgs {
 
 struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
 
+// The warp geometry (inv3, pixel_dir, warp_taps) is compiled with `fp contract(on)`: a * b + c is fused where it is WRITTEN as one
+// expression, by the front end, and nowhere else.  hipcc's default lets the back end fuse across statements, and what it fuses depends
+// on the code the function is inlined into -- the single-stage and the pipelined kernel then disagree by an ulp in a pixel coordinate
+// (1.5e-5 in a cost) for general poses.  With the pragma every instance computes the same bits.
 __device__ __forceinline__ void inv3(const float* m, float* o) {   // adjugate / determinant
+#pragma clang fp contract(on)
   const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
   const float A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
   const float det = a * A + b * Bc + c * Cc;
@@ -149,6 +154,7 @@ struct BatchPose {
 // Depends on the pixel only: computed once per wave and reused for every depth plane of the wave's chunk.
 template <bool GEN>
 __device__ __forceinline__ void pixel_dir(const CvArgs& a, int y, int x, float& ux, float& uy, float& uz) {
+#pragma clang fp contract(on)
   const float PI_F = 3.14159265358979323846f, HALF_PI_F = 1.57079632679489661923f, TWO_PI_F = 6.28318530717958647692f;
   const double PI_D = 3.14159265358979323846;
   const float fx = (float)x, fy = (float)y;
@@ -180,6 +186,7 @@ __device__ __forceinline__ void pixel_dir(const CvArgs& a, int y, int x, float& 
 template <bool GEN>
 __device__ __forceinline__ Taps warp_taps(const CvArgs& a, const BatchPose& bp, const float* __restrict__ Rs,
                                           const float* __restrict__ ts, float ux, float uy, float uz, float depth) {
+#pragma clang fp contract(on)
   const float PI_F = 3.14159265358979323846f, HALF_PI_F = 1.57079632679489661923f, TWO_PI_F = 6.28318530717958647692f;
   const float mx = depth * ux, my = depth * uy, mz = depth * uz;
   const float dx = mx - bp.tr[0], dy = my - bp.tr[1], dz = mz - bp.tr[2];
@@ -255,12 +262,28 @@ __device__ __forceinline__ Taps warp_taps(const CvArgs& a, const BatchPose& bp, 
 #ifndef PGRF_CV_WAVES
 #define PGRF_CV_WAVES 1          // minimum waves per SIMD the register allocation must allow (tuning knob)
 #endif
+#ifndef PGRF_CV_TILE_W_DEFAULT
+#define PGRF_CV_TILE_W_DEFAULT 16   // columns of a wave's pixel patch (64 = a 1-pixel-high strip; PGRF_CV_TILE_W overrides at run time;
+                                    // measured at 128x256x64, single-stage kernel: 64 -> 80.6, 32 -> 83-85, 16 -> 71-74, 8 -> 73-75 us)
+#endif
+#ifndef PGRF_CV_PIPE_DEFAULT
+#define PGRF_CV_PIPE_DEFAULT 2      // voxel groups in flight per wave of the pipelined instance (0 = single-stage kernel);
+                                    // 128x256x64, one view: 1 -> 64-66 us (4 waves per SIMD), 2 -> 64-65 (3), 4 -> 69-70 (2); two views
+                                    // per batch (streamed stores): 1 -> 54-55, 2 -> 52-55, 4 -> 55-56 us per view
+#endif
+#ifndef PGRF_CV_PIPE_ORDER
+#define PGRF_CV_PIPE_ORDER 0
+#endif
+#ifndef PGRF_CV_PIPE_DCH
+#define PGRF_CV_PIPE_DCH 4          // depth planes per wave of the pipelined instance (128x256x64, one view: 2 -> 72-76, 4 -> 64-65,
+                                    // 8 -> 72-73, 16 -> 75 us), halved while the launch has fewer than 2 048 waves
+#endif
 #ifndef PGRF_CV_MINITEMS
 #define PGRF_CV_MINITEMS 4096    // planes per wave are halved until the launch has this many waves (tuning knob;
                                  // measured at 128x256x64: 4096 -> 74 us, 8192 -> 85, 16384 -> 76, 32768 -> 82)
 #endif
 template <bool GEN, int NSRC, bool C32, bool ABS, bool DIVIDE>
-__global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const CvArgs a, int dch, int nchunk, int tiles_per_img) {
+__global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const CvArgs a, int dch, int nchunk, int tiles_per_img, int tws) {
   // A lane always moves 4 channels (16 B) of a voxel and C/4 consecutive lanes cover the voxel's contiguous C*4 bytes, so
   // every wave load instruction reads whole 128-byte lines and every wave store instruction writes 1 KiB of
   // consecutive addresses.  C32: 8 lanes per voxel, and a lane handles G = 2 voxels (8 apart) per inner iteration for
@@ -280,8 +303,20 @@ __global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const C
   const int chunk = __builtin_amdgcn_readfirstlane((int)(item % nchunk));
   const int tile = __builtin_amdgcn_readfirstlane((int)(item / nchunk));
   const int b = tile / tiles_per_img;
-  const int pix0 = (tile % tiles_per_img) * 64;
-  const int pix = min(pix0 + lane, hw - 1);
+  // The wave's 64 pixels: a (64 >> tws)-row x (1 << tws)-column patch of the reference image (tws = 6: 64 consecutive pixels in
+  // row-major order, any h * w).  A 2-D patch warps into a compact patch of the source map: the four taps of its 64 voxels touch
+  // ~80-100 distinct 128-byte texels instead of ~130-200 along a 1-pixel-high strip, so more of the gathers hit the L1 and fewer
+  // requests go to the L2.  Voxel `o` (the lane that owns its geometry) is pixel pix_of(o); a store instruction still covers >= 8
+  // consecutive pixels of one row (1 KiB of consecutive bytes at C = 32).
+  const int twm = (1 << tws) - 1;
+  int pix0;
+  {
+    const int t = tile % tiles_per_img;
+    if (tws == 6) pix0 = t * 64;
+    else { const int tiles_x = a.w >> tws; pix0 = (t / tiles_x) * (64 >> tws) * a.w + ((t % tiles_x) << tws); }
+  }
+  auto pix_of = [&](int o) { return pix0 + (o >> tws) * a.w + (o & twm); };
+  const int pix = min(pix_of(lane), hw - 1);
   float ux, uy, uz;
   pixel_dir<GEN>(a, pix / a.w, pix % a.w, ux, uy, uz);
   BatchPose bp;
@@ -302,7 +337,7 @@ __global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const C
     for (int it = 0; it < 4; ++it)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const int rpix = min(pix0 + (it * G + g) * vpg + sub, hw - 1);
+        const int rpix = min(pix_of((it * G + g) * vpg + sub), hw - 1);
         rvs[it][g] = *reinterpret_cast<const float4*>(fb + ((size_t)a.ref_idx * hw + rpix) * C + cg * 4);
       }
   }
@@ -349,7 +384,7 @@ __global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const C
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int opix = pix0 + (it * G + g) * vpg + sub;
+      const int opix = pix_of((it * G + g) * vpg + sub);
 #ifdef PGRF_CV_ABL_STORE    // timing experiment: only values that can never occur are stored
       if (opix < hw && acc[g].x == -12345.f)
 #else
@@ -393,7 +428,7 @@ __global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const C
       for (int it = 0; it < 4; ++it) stream_voxels(it, rvs[it], op);
     } else {
       for (int it = 0; it < nit; ++it) {
-        const int rpix = min(pix0 + it * vpg + sub, hw - 1);
+        const int rpix = min(pix_of(it * vpg + sub), hw - 1);
         float4 rv[G];
         rv[0] = *reinterpret_cast<const float4*>(fb + ((size_t)a.ref_idx * hw + rpix) * C + cg * 4);
         stream_voxels(it, rv, op);
@@ -404,9 +439,155 @@ __global__ void __launch_bounds__(256, PGRF_CV_WAVES) cost_volume_kernel(const C
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined instance of the same computation for the shipped case: m3d convention, C = 32, abs_diff, power-of-two divisor,
+// images that divide into whole 64-pixel patches, <= 2 source views per voxel.
+// The kernel above finishes one group of voxels (loads -> wait for all of them -> blend -> store) before it requests the next,
+// and gfx950 retires a wave's loads and stores in issue order on ONE counter: the loads of a group can only be seen complete once
+// the stores of the group before them are acknowledged, so a wave alternates between waiting for the read path and for the write
+// path and neither stays busy (r05: 63 % of the wave cycles parked in s_waitcnt at 46-49 % of 8 TB/s).  Here a wave keeps P groups
+// of 8 voxels in flight across group AND plane boundaries: while group j is blended and stored, the taps of groups j+1 .. j+P-1
+// are on their way and group j+P is requested; the warp geometry of plane d+1 is computed (VALU) at the start of plane d's
+// streaming, into the other half of a two-plane tap buffer, so the stream never drains at a plane boundary either.  Same
+// operations on the same values in the same order as cost_volume_kernel: bit-identical volumes (tests/test_gpu_cost_volume.py).
+template <int NSRC, int P, bool NT>
+__global__ void __launch_bounds__(256) cost_volume_pipe_kernel(const CvArgs a, int dch, int nchunk, int tiles_per_img, int tws, int order) {
+  constexpr int C = 32, NG = 8;                    // 8 lanes per voxel, 8 voxels per group (one wave instruction), 8 groups per plane
+  static_assert(NG % P == 0, "the stage index of a group must be static");
+  __shared__ __attribute__((aligned(16))) float lds_taps[4][2][NSRC][64][8];   // [wave][plane parity][source][voxel][4 offsets | 4 weights]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hw = a.h * a.w;
+  const long item = (long)blockIdx.x * 4 + wave;
+  const long nitems = (long)a.B * tiles_per_img * nchunk;
+  if (item >= nitems) return;
+  // order 0: a tile's depth chunks are consecutive work items (a workgroup = one patch at four depth ranges);
+  // order 1: a chunk's tiles are consecutive (a workgroup = four neighbouring patches at the same depths)
+  const long ntile_all = (long)a.B * tiles_per_img;
+  const int chunk = __builtin_amdgcn_readfirstlane((int)(order ? item / ntile_all : item % nchunk));
+  const int tile = __builtin_amdgcn_readfirstlane((int)(order ? item % ntile_all : item / nchunk));
+  const int b = tile / tiles_per_img;
+  const int twm = (1 << tws) - 1;
+  int pix0;
+  {
+    const int t = tile % tiles_per_img;
+    if (tws == 6) pix0 = t * 64;
+    else { const int tiles_x = a.w >> tws; pix0 = (t / tiles_x) * (64 >> tws) * a.w + ((t % tiles_x) << tws); }
+  }
+  auto pix_of = [&](int o) { return pix0 + (o >> tws) * a.w + (o & twm); };
+  const int pix = pix_of(lane);
+  float ux, uy, uz;
+  pixel_dir<false>(a, pix / a.w, pix % a.w, ux, uy, uz);
+  BatchPose bp;
+  {
+    const float* Rr = a.rots + ((size_t)b * a.S + a.ref_idx) * 9;
+    const float* tr = a.trans + ((size_t)b * a.S + a.ref_idx) * 3;
+    inv3(Rr, bp.Ri);
+    bp.tr[0] = tr[0]; bp.tr[1] = tr[1]; bp.tr[2] = tr[2];
+  }
+  const int sub = lane >> 3, cg = lane & 7;
+  const float* __restrict__ fb = a.feats + (size_t)b * a.S * hw * C;
+  const float rdiv = 1.f / a.div;
+  // group j = voxels j*8 .. j*8+7 of the patch; this lane moves channels cg*4 .. cg*4+3 of voxel j*8 + sub.  (sub < 8 <= patch
+  // width: the voxel's pixel is pix_of(j*8) + sub, a wave-uniform offset per group.)
+  float4 rvs[NG];
+  unsigned vo[NG];                                 // element offset of the lane's 16 bytes inside a plane
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int rpix = pix_of(j * 8) + sub;
+    vo[j] = (unsigned)rpix * C + cg * 4;
+    rvs[j] = *reinterpret_cast<const float4*>(fb + (size_t)a.ref_idx * hw * C + vo[j]);
+  }
+  struct Stage { float4 p[NSRC][4]; float4 tw[NSRC]; };
+  Stage st[P];
+  auto geometry = [&](float depth, int par) {
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      const float* Rs = a.rots + ((size_t)b * a.S + a.src_idx[s]) * 9;
+      const float* ts = a.trans + ((size_t)b * a.S + a.src_idx[s]) * 3;
+      const Taps t = warp_taps<false>(a, bp, Rs, ts, ux, uy, uz, depth);
+      float4* dst = reinterpret_cast<float4*>(&lds_taps[wave][par][s][lane][0]);
+      dst[0] = make_float4(__int_as_float(t.o00), __int_as_float(t.o01), __int_as_float(t.o10), __int_as_float(t.o11));
+      dst[1] = make_float4(t.w00, t.w01, t.w10, t.w11);
+    }
+  };
+  auto issue = [&](Stage& S, int par, int j) {
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      const float* sb = fb + (size_t)a.src_idx[s] * hw * C + cg * 4;
+      const float4* tpv = reinterpret_cast<const float4*>(&lds_taps[wave][par][s][j * 8 + sub][0]);
+      const float4 to = tpv[0];
+      S.tw[s] = tpv[1];
+      S.p[s][0] = *reinterpret_cast<const float4*>(sb + (unsigned)__float_as_int(to.x));
+      S.p[s][1] = *reinterpret_cast<const float4*>(sb + (unsigned)__float_as_int(to.y));
+      S.p[s][2] = *reinterpret_cast<const float4*>(sb + (unsigned)__float_as_int(to.z));
+      S.p[s][3] = *reinterpret_cast<const float4*>(sb + (unsigned)__float_as_int(to.w));
+    }
+  };
+  auto finish = [&](const Stage& S, int j, float* __restrict__ op) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+      const float4 tw = S.tw[s];
+      const float4 &p00 = S.p[s][0], &p01 = S.p[s][1], &p10 = S.p[s][2], &p11 = S.p[s][3];
+      float4 wv;       // ((p00 w00 + p01 w01) + p10 w10) + p11 w11 as the contraction cost_volume_kernel compiles to
+      wv.x = fmaf(p11.x, tw.w, fmaf(p10.x, tw.z, fmaf(p00.x, tw.x, p01.x * tw.y)));
+      wv.y = fmaf(p11.y, tw.w, fmaf(p10.y, tw.z, fmaf(p00.y, tw.x, p01.y * tw.y)));
+      wv.z = fmaf(p11.z, tw.w, fmaf(p10.z, tw.z, fmaf(p00.z, tw.x, p01.z * tw.y)));
+      wv.w = fmaf(p11.w, tw.w, fmaf(p10.w, tw.z, fmaf(p00.w, tw.x, p01.w * tw.y)));
+      const float4 rv = rvs[j];
+      acc.x += fabsf(wv.x - rv.x) * rdiv; acc.y += fabsf(wv.y - rv.y) * rdiv;
+      acc.z += fabsf(wv.z - rv.z) * rdiv; acc.w += fabsf(wv.w - rv.w) * rdiv;
+    }
+    if (NT) {
+      typedef float f32x4nt __attribute__((ext_vector_type(4)));
+      const f32x4nt vv = {acc.x, acc.y, acc.z, acc.w};
+      __builtin_nontemporal_store(vv, reinterpret_cast<f32x4nt*>(op + vo[j]));
+    } else {
+      *reinterpret_cast<float4*>(op + vo[j]) = acc;
+    }
+  };
+
+  const int d0 = chunk * dch, d1 = min(d0 + dch, a.D);
+  const float* __restrict__ dp = a.depth + (size_t)b * a.D * hw + pix;
+  geometry(dp[(size_t)d0 * hw], 0);
+  float depth_next = dp[(size_t)min(d0 + 1, d1 - 1) * hw];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < P; ++k) issue(st[k], 0, k);
+  for (int d = d0; d < d1; ++d) {
+    const int par = (d - d0) & 1;
+    // taps of plane d + 1 (the last plane of the chunk computes itself again: the P groups requested from it are never used)
+    const float depth_n2 = dp[(size_t)min(d + 2, d1 - 1) * hw];
+    geometry(depth_next, par ^ 1);
+    depth_next = depth_n2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* __restrict__ op = a.out + ((size_t)b * a.D + d) * hw * C;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      finish(st[j % P], j, op);
+      if (j + P < NG) issue(st[j % P], par, j + P);
+      else issue(st[j % P], par ^ 1, j + P - NG);
+    }
+    __builtin_amdgcn_wave_barrier();     // plane d + 2's tap stores (next iteration) must not pass this plane's tap loads
+  }
+}
+
 int launch_cost_volume(const CvArgs& a, void* stream) {
   const int hw = a.h * a.w;
-  const int tiles_per_img = (hw + 63) / 64;
+  // pixel patch of a wave: PGRF_CV_TILE_W columns x 64 / PGRF_CV_TILE_W rows where the image divides into such patches and a store
+  // instruction still covers whole patch rows (patch width >= voxels per store instruction); otherwise 64 consecutive pixels
+  const char* tw_e = getenv("PGRF_CV_TILE_W");        // read per launch (tests flip it inside one process)
+  const int tile_w_env = tw_e ? atoi(tw_e) : PGRF_CV_TILE_W_DEFAULT;
+  int tws = 6;
+  {
+    const int vpg = 64 / (a.C / 4 < 64 ? a.C / 4 : 64);      // voxels per wave instruction (C = 32 streams two such groups per iteration)
+    for (int s_ = 3; s_ < 6; ++s_)
+      if ((1 << s_) == tile_w_env && a.w % (1 << s_) == 0 && a.h % (64 >> s_) == 0 && (1 << s_) >= vpg) tws = s_;
+  }
+  const int tiles_per_img = tws == 6 ? (hw + 63) / 64 : hw / 64;
   // planes per wave: amortises the per-pixel prologue; keep >= ~32 waves per CU when the volume allows it
   int dch = 8;
   while (dch > 1 && (long)a.B * tiles_per_img * ((a.D + dch - 1) / dch) < PGRF_CV_MINITEMS) dch >>= 1;
@@ -416,8 +597,40 @@ int launch_cost_volume(const CvArgs& a, void* stream) {
   int ex = 0;
   const bool divide = std::frexp(a.div, &ex) != 0.5f;      // not a power of two: 1/div is not exact
   const bool c32 = (a.C == 32), abs_ = (a.cost_type == 0);
+  // the pipelined instance (PGRF_CV_PIPE=0: the single-stage kernel; = 1 / 2 / 4 / 8: groups in flight per wave)
+  {
+    const char* pe = getenv("PGRF_CV_PIPE");
+    const int pipe = pe ? atoi(pe) : PGRF_CV_PIPE_DEFAULT;
+    if (pipe > 0 && a.dataset == PGRF_DATASET_M3D && c32 && abs_ && !divide && a.n_src <= 2 && hw % 64 == 0) {
+      const char* oe = getenv("PGRF_CV_ORDER");
+      int order = oe ? atoi(oe) : PGRF_CV_PIPE_ORDER;
+      const char* de = getenv("PGRF_CV_DCH");
+      // Work-item order and planes per wave decide WHICH 8 KB pieces of the volume are written at the same time, and in the stage
+      // (caches full of the previous kernels' dirty lines) that moves the build by +-15 % in no monotone way
+      // (profiles/r06_cost_volume_stage_proxy.txt: tools/cv_stage_proxy.py, [1 GB read-modify-write, hypotheses, BUILD, CostRegNet] per step).
+      // Shipped: launches that stream their stores (volumes >= 128 MiB) take chunk-major order with 16 planes per wave, smaller ones
+      // tile-major order with 4 -- against the round-5 kernel in the same proxy (profiles/r06_cost_volume_stage_stores.txt): 128x256x64
+      // two views 72 -> 68 us per view, one view 95 -> 66, 64x128x64 two views 25.8 -> 20.4, one view 28 -> 25.
+      if (!oe) order = a.stream_stores ? 1 : 0;
+      int pd = de ? atoi(de) : (a.stream_stores ? 16 : PGRF_CV_PIPE_DCH);
+      if (pd < 1) pd = 1;
+      if (pd > a.D) pd = a.D;
+      if (!de) while (pd > 1 && (long)a.B * tiles_per_img * ((a.D + pd - 1) / pd) < 2048) pd >>= 1;
+      const int pn = (a.D + pd - 1) / pd;
+      const long pitems = (long)a.B * tiles_per_img * pn;
+      const unsigned pblocks = (unsigned)((pitems + 3) / 4);
+#define PGRF_CVP(N_, P_) do { \
+        if (a.stream_stores) hipLaunchKernelGGL((cost_volume_pipe_kernel<N_, P_, true>), dim3(pblocks), dim3(256), 0, (hipStream_t)stream, a, pd, pn, tiles_per_img, tws, order); \
+        else hipLaunchKernelGGL((cost_volume_pipe_kernel<N_, P_, false>), dim3(pblocks), dim3(256), 0, (hipStream_t)stream, a, pd, pn, tiles_per_img, tws, order); } while (0)
+      if (a.n_src == 1) { if (pipe >= 8) PGRF_CVP(1, 8); else if (pipe >= 4) PGRF_CVP(1, 4); else if (pipe >= 2) PGRF_CVP(1, 2); else PGRF_CVP(1, 1); }
+      else { if (pe && pipe >= 4) PGRF_CVP(2, 4); else if (pe && pipe >= 2) PGRF_CVP(2, 2); else PGRF_CVP(2, 1); }   // (two source views: 40 registers per group in flight -- one group unless asked)
+#undef PGRF_CVP
+      PGRF_CHECK_LAUNCH("cost_volume (pipelined)");
+      return PGRF_OK;
+    }
+  }
 #define PGRF_CV5(GEN_, N_, C32_, ABS_, DIV_) \
-  hipLaunchKernelGGL((cost_volume_kernel<GEN_, N_, C32_, ABS_, DIV_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dch, nchunk, tiles_per_img)
+  hipLaunchKernelGGL((cost_volume_kernel<GEN_, N_, C32_, ABS_, DIV_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dch, nchunk, tiles_per_img, tws)
   // the shipped convention gets every specialisation; the other conventions share the run-time-switched kernel
 #define PGRF_CV_M3D(N_) do { \
     if (c32 && abs_ && !divide) PGRF_CV5(false, N_, true, true, false); \
@@ -476,15 +689,17 @@ int pgrf_cost_volume_erp(const float* feats, const float* depth_volume, const fl
   a.feats = feats; a.depth = depth_volume; a.rots = rots; a.trans = trans; a.out = out;
   a.B = B; a.S = S; a.h = h; a.w = w; a.C = C; a.D = D; a.ref_idx = ref_idx; a.n_src = n_src; a.div = src_div;
   a.cost_type = cost_type; a.dataset = dataset;
-  // Non-temporal stores: the kernel alone 75-76 -> 62 us at 128x256x64 (4.6 TB/s), but ONE such volume (268 MB) then is not in the last-level
-  // cache when the regulariser's first convolution reads it right behind: cost-volume stage of bench.py 1.76-1.78 ms either way
-  // (profiles/r03_dead_ends.txt).  A BATCH of volumes larger than the 256 MB last-level cache does not stay resident whatever the stores do --
-  // from 384 MB on they stream by default (two views at 128x256x64, the product stage's batch: build 83 -> 73 us per view, stage 1.59 -> 1.58 ms
-  // with CostRegNet, 11.12 -> 11.01 ms with UNet2).  PGRF_CV_STREAM_STORES=0 / 1 forces either way.
+  // Non-temporal stores of the volume.  Round 3 measured them in a clean loop (kernel alone 75-76 -> 62 us at 128x256x64, stage unchanged:
+  // the regulariser's first convolution then fetches the 268 MB from HBM) and kept them for batches beyond the 256 MB last-level cache
+  // (>= 384 MB).  Round 6 re-measured IN CONTEXT -- every step [1 GB read-modify-write (what a render pass leaves in the caches),
+  // hypotheses, build, regulariser], tools/cv_stage_nt.py, profiles/r06_cost_volume_stage_stores.txt: with the caches full of other
+  // kernels' dirty lines a plain-store build must evict as it allocates, and ONE 268 MB volume builds in 88 us with plain stores, 66 us
+  // streamed, build + CostRegNet 834 -> 819 us (UNet2: equal); two 64x128x64 volumes (128 MiB) 23.7 -> 20.4 us, totals equal; one
+  // (64 MiB) 25.1 -> 26.3 us.  So volumes stream from 128 MiB on.  PGRF_CV_STREAM_STORES=0 / 1 forces either way.
   {
     const char* e = getenv("PGRF_CV_STREAM_STORES");
     const double out_bytes = (double)B * D * h * w * C * 4.0;
-    a.stream_stores = e ? (atoi(e) != 0) : (out_bytes >= 384.0 * 1048576.0);
+    a.stream_stores = e ? (atoi(e) != 0) : (out_bytes >= 128.0 * 1048576.0);
   }
   for (int i = 0; i < kMaxSrc; ++i) {
     a.src_idx[i] = i < n_src ? src_idx_host[i] : 0;

@@ -1153,10 +1153,18 @@ __global__ void __launch_bounds__(256) stats_bwd4_kernel(const float* __restrict
   unsigned msk[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) msk[e] = (on && c0 + e < F) ? 0xffffffffu : 0u;
+  // 16-byte row accesses only where all four columns exist: the lane that holds a ragged tail (F not a multiple of four) reads its
+  // live columns one by one, so nothing is touched past column F - 1 (the last row of a buffer has no padding behind it)
+  const bool full = on ? (c0 + 4 <= F) : (F >= 4);
   auto ld4 = [&](const float* q, float (&o)[4]) {
-    const F4U t = *reinterpret_cast<const F4U*>(q);
+    if (full) {
+      const F4U t = *reinterpret_cast<const F4U*>(q);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = __uint_as_float(__float_as_uint(t.v[e]) & msk[e]);
+      for (int e = 0; e < 4; ++e) o[e] = __uint_as_float(__float_as_uint(t.v[e]) & msk[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = msk[e] ? q[e] : 0.f;
+    }
   };
   float xs[4][4], go[4][4];
   float gw2[4] = {0.f, 0.f, 0.f, 0.f};

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "pgrf_internal.h"
 #include "pgrf_layout.h"
@@ -384,17 +385,48 @@ static bool chain_narrow(const Lin* l, int n) {
   return true;
 }
 static int chain_wpb() { static const int v = [] { const char* e = getenv("PGRF_TRAIN_CHAIN_WPB"); return (e && atoi(e) == 4) ? 4 : 8; }(); return v; }   // waves per chain workgroup (8: half the workgroups = half the weight stagings of a launch: 5.45 -> 5.39 ms per step; 4 = round 4)
-static dim3 chain_grid(long rows, size_t lds, int max_per_cu) {
+// Grid of a persistent chain launch = resident workgroups of THIS instance (a workgroup stages the chain's weights once and then walks
+// its tiles): the runtime's occupancy answer for the instance's registers and LDS, not a constant -- the __launch_bounds__ second
+// argument is waves per SIMD, so the eight-wave instances do not keep the four-wave ones' workgroups per CU (fwd<8,8> 166 VGPRs: one
+// workgroup per CU, bwd<4,8> 112 VGPRs: two).  PGRF_TRAIN_CHAIN_WGS=n forces n per CU; PGRF_TRAIN_CHAIN_GRID=legacy = the round-5
+// constants (max_per_cu counts four-wave workgroups).
+static dim3 chain_grid(const void* kernel, int threads, long rows, size_t lds, int max_per_cu) {
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   static const int per_cu_env = [] { const char* e = getenv("PGRF_TRAIN_CHAIN_WGS"); return e ? atoi(e) : 0; }();
-  const int wpb = chain_wpb();
-  if (wpb == 8) max_per_cu = (max_per_cu + 1) / 2;          // (max_per_cu counts four-wave workgroups: the register-bound occupancy)
-  int per_cu = (int)(160 * 1024 / (lds + 1024));
-  if (per_cu > max_per_cu) per_cu = max_per_cu;
+  static const bool legacy = [] { const char* e = getenv("PGRF_TRAIN_CHAIN_GRID"); return e && !strcmp(e, "legacy"); }();
+  const int wpb = threads / 64;
+  int per_cu;
+  if (legacy) {
+    if (wpb == 8) max_per_cu = (max_per_cu + 1) / 2;
+    per_cu = (int)(160 * 1024 / (lds + 1024));
+    if (per_cu > max_per_cu) per_cu = max_per_cu;
+  } else {
+    // cached per (instance, LDS bytes rounded up to 4 KB): a handful of distinct values per process
+    struct Key { const void* k; size_t l; int v; };
+    static std::mutex mu;
+    static std::vector<Key> cache;
+    const size_t lkey = (lds + 4095) / 4096;
+    per_cu = -1;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (const Key& e : cache) if (e.k == kernel && e.l == lkey) { per_cu = e.v; break; }
+    }
+    if (per_cu < 0) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lkey * 4096) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+      per_cu = n;
+      std::lock_guard<std::mutex> g(mu);
+      cache.push_back(Key{kernel, lkey, n});
+    }
+  }
   if (per_cu < 1) per_cu = 1;
   if (per_cu_env > 0) per_cu = per_cu_env;
   const long tiles = (rows + 32 * wpb - 1) / (32 * wpb), cap = (long)ncu * per_cu;
   return dim3((unsigned)(tiles < cap ? tiles : cap));
+}
+template <typename K>
+static dim3 chain_grid_of(K kernel, int threads, long rows, size_t lds, int max_per_cu) {
+  return chain_grid(reinterpret_cast<const void*>(kernel), threads, rows, lds, max_per_cu);
 }
 static int chain_fwd(const Ctx& c, const Lin* l, int n, long rows, const float* add = nullptr, int ldadd = 0, int addV = 1) {
   if (int rc = chain_check(l, n)) return rc;
@@ -408,10 +440,10 @@ static int chain_fwd(const Ctx& c, const Lin* l, int n, long rows, const float* 
   const size_t lds = chain_layout(a);
   if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
   if (chain_wpb() == 8) {
-    if (chain_narrow(l, n)) hipLaunchKernelGGL((chain_fwd_kernel<4, 8>), chain_grid(rows, lds, 6), dim3(512), lds, c.st, a);
-    else hipLaunchKernelGGL((chain_fwd_kernel<8, 8>), chain_grid(rows, lds, 3), dim3(512), lds, c.st, a);
-  } else if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_fwd_kernel<4>, chain_grid(rows, lds, 6), dim3(256), lds, c.st, a);
-  else hipLaunchKernelGGL(chain_fwd_kernel<8>, chain_grid(rows, lds, 3), dim3(256), lds, c.st, a);
+    if (chain_narrow(l, n)) hipLaunchKernelGGL((chain_fwd_kernel<4, 8>), chain_grid_of(chain_fwd_kernel<4, 8>, 512, rows, lds, 6), dim3(512), lds, c.st, a);
+    else hipLaunchKernelGGL((chain_fwd_kernel<8, 8>), chain_grid_of(chain_fwd_kernel<8, 8>, 512, rows, lds, 3), dim3(512), lds, c.st, a);
+  } else if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_fwd_kernel<4>, chain_grid_of(chain_fwd_kernel<4>, 256, rows, lds, 6), dim3(256), lds, c.st, a);
+  else hipLaunchKernelGGL(chain_fwd_kernel<8>, chain_grid_of(chain_fwd_kernel<8>, 256, rows, lds, 3), dim3(256), lds, c.st, a);
   PGRF_TCHECK("train chain forward");
   return PGRF_OK;
 }
@@ -428,10 +460,10 @@ static int chain_bwd(const Ctx& c, const Lin* l, int n, long rows, float* dX, in
   const size_t lds = chain_layout(a);
   if (lds > 65536) return set_error(PGRF_ERR_UNSUPPORTED, "train chain: %zu bytes of weights do not fit the LDS copy", lds);
   if (chain_wpb() == 8) {
-    if (chain_narrow(l, n)) hipLaunchKernelGGL((chain_bwd_kernel<4, 8>), chain_grid(rows, lds, 5), dim3(512), lds, c.st, a);
-    else hipLaunchKernelGGL((chain_bwd_kernel<8, 8>), chain_grid(rows, lds, 2), dim3(512), lds, c.st, a);
-  } else if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_bwd_kernel<4>, chain_grid(rows, lds, 5), dim3(256), lds, c.st, a);
-  else hipLaunchKernelGGL(chain_bwd_kernel<8>, chain_grid(rows, lds, 2), dim3(256), lds, c.st, a);
+    if (chain_narrow(l, n)) hipLaunchKernelGGL((chain_bwd_kernel<4, 8>), chain_grid_of(chain_bwd_kernel<4, 8>, 512, rows, lds, 5), dim3(512), lds, c.st, a);
+    else hipLaunchKernelGGL((chain_bwd_kernel<8, 8>), chain_grid_of(chain_bwd_kernel<8, 8>, 512, rows, lds, 2), dim3(512), lds, c.st, a);
+  } else if (chain_narrow(l, n)) hipLaunchKernelGGL(chain_bwd_kernel<4>, chain_grid_of(chain_bwd_kernel<4>, 256, rows, lds, 5), dim3(256), lds, c.st, a);
+  else hipLaunchKernelGGL(chain_bwd_kernel<8>, chain_grid_of(chain_bwd_kernel<8>, 256, rows, lds, 2), dim3(256), lds, c.st, a);
   c.fork();
   for (int k = n - 1; k >= 0; --k) L_dw(c, l[k].X, l[k].ldx, l[k].dY, l[k].lddy, l[k].rw, l[k].rb, rows, l[k].IN, l[k].OUT, l[k].wld, l[k].wcol, l[k].xscale);
   PGRF_TCHECK("train chain backward");

@@ -446,7 +446,8 @@ class RenderPassFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, coords, depth, img_feats, ray_feats, *raw):
-        imgs, w2c, ref_dr, que_c2w, que_dr, use_vis, precision, frame_kw = meta
+        imgs, w2c, ref_dr, que_c2w, que_dr, use_vis, precision, frame_kw = meta[:8]
+        grad_mode = meta[8] if len(meta) > 8 else True
         F_ = RenderPassFunction
         kw_t = [v for _, v in sorted(frame_kw.items()) if torch.is_tensor(v)]
         f_ts = [imgs, img_feats, ray_feats, w2c, ref_dr, que_c2w if torch.is_tensor(que_c2w) else None, que_dr] + kw_t
@@ -459,9 +460,10 @@ class RenderPassFunction(torch.autograd.Function):
         # rematerialising backward, ~9 KB less memory per (ray, sample, view) held): the staged forward's outputs ARE the pass's outputs
         # (equal to the fused kernel's to 2e-5, tests/test_gpu_train_backward.py), so the fused launch and the second forward are saved.
         rn = coords.shape[0]
-        # (only when some differentiable input needs a gradient: grad mode is always off inside Function.forward, so a caller under
-        # torch.no_grad() or with frozen inputs would otherwise pay the staged forward and its workspace for nothing)
-        keep = any(ctx.needs_input_grad[3:]) and os.environ.get('PANOGRF_TRAIN_KEEP_ACTS', '1') != '0' and precision in (None, 'f32') and rn > 0 and \
+        # (only when a backward can follow: needs_input_grad mirrors the inputs' requires_grad flags whatever the grad mode, and grad
+        # mode is always off inside Function.forward, so the CALLER's mode rides in `meta` -- a caller under torch.no_grad() or with
+        # frozen inputs would otherwise pay the staged forward and its workspace for nothing)
+        keep = grad_mode and any(ctx.needs_input_grad[3:]) and os.environ.get('PANOGRF_TRAIN_KEEP_ACTS', '1') != '0' and precision in (None, 'f32') and rn > 0 and \
             lib.pgrf_render_pass_backward_workspace_bytes(frame.rfn, rn, depth.shape[1]) <= int(float(os.environ.get('PANOGRF_TRAIN_KEEP_ACTS_MAX_GB', '16')) * 2 ** 30)
         ctx.ws = None
         if keep:
@@ -545,6 +547,7 @@ def render_pass_autograd(imgs, img_feats, ray_feats, w2c, ref_depth_range, que_c
                 continue
             raise PgrfError(f"module lacks parameter '{key}'")
         raw.append(named_params[key])
-    meta = (imgs.detach(), w2c.detach(), ref_depth_range.detach(), que_c2w, que_depth_range, bool(use_vis), precision, frame_kw)
+    meta = (imgs.detach(), w2c.detach(), ref_depth_range.detach(), que_c2w, que_depth_range, bool(use_vis), precision, frame_kw,
+            torch.is_grad_enabled())
     px, rd, hit, col, den = RenderPassFunction.apply(meta, coords, depth, img_feats, ray_feats, *raw)
     return {'pixel_colors_nr': px, 'render_depth': rd, 'hit_prob_nr': hit, 'colors_nr': col, 'density_nr': den}

@@ -87,3 +87,61 @@ def test_cost_volume_dataset_conventions_vs_reference(ds):
     # 8x16 maps of N(0,1) noise: one float ulp of an angle moves a tap weight by ~1e-6 of a unit-variance difference
     assert float((two.cpu() - g[f'{ds}.two']).abs().max()) < 2e-4
     assert float((mv.cpu() - g[f'{ds}.mv']).abs().max()) < 2e-4
+
+
+def _cv_env(**kw):
+    import os
+    keys = ('PGRF_CV_PIPE', 'PGRF_CV_TILE_W', 'PGRF_CV_DCH', 'PGRF_CV_ORDER', 'PGRF_CV_STREAM_STORES')
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ.pop(k, None)
+    for k, v in kw.items():
+        os.environ[k] = str(v)
+    return old
+
+
+def _cv_env_restore(old):
+    import os
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize('h,w,B,S', [(8, 16, 2, 2), (16, 24, 1, 2), (32, 64, 2, 2), (16, 32, 1, 4), (24, 40, 1, 2)])
+def test_cost_volume_pipelined_instance_is_bit_identical_to_the_single_stage_kernel(h, w, B, S):
+    """The pipelined kernel (groups of voxels in flight across group and plane boundaries, 2-D pixel patches, the geometry of plane
+    d + 1 computed while plane d streams) performs the single-stage kernel's operations on the same values: equal bits for every
+    patch width, pipeline depth, planes-per-wave split (incl. ragged last chunks), work-item order and store flavour; both equal
+    the oracle.  Poses are random rotations + translations; D = 13 leaves ragged chunks."""
+    from oracle import cost_volume_oracle as O
+    from panogrf_amd import cost_volume as CV
+    g = torch.Generator().manual_seed(h * 131 + w)
+    D, Cc = 13, 32
+    feats = torch.randn(B, S, h, w, Cc, generator=g)
+    dv = torch.sort(0.3 + 9.0 * torch.rand(B, D, h, w, generator=g), dim=1)[0]
+    q = torch.linalg.qr(torch.randn(B, S, 3, 3, generator=g))[0]
+    rots = q * torch.sign(torch.linalg.det(q)).view(B, S, 1, 1)
+    trans = 0.4 * torch.randn(B, S, 3, generator=g)
+
+    def run():
+        if S == 2:
+            return CV.calculate_cost_volume_erp(ARGS, feats.cuda(), None, trans.cuda(), rots.cuda(), depth_volume=dv.cuda())
+        return CV.calculate_cost_volume_erp_multiview(ARGS, feats.cuda(), None, trans.cuda(), rots.cuda(), depth_volume=dv.cuda(), curr_idx=1)
+    old = _cv_env(PGRF_CV_PIPE=0, PGRF_CV_TILE_W=64)
+    try:
+        base = run().cpu()
+        ref = O.cost_volume_erp(feats, dv, rots, trans) if S == 2 else O.cost_volume_erp_multiview(feats, dv, rots, trans, 1)
+        err = (base - ref).abs()       # (a voxel within an ulp of the wrap seam may pick the other edge texel: a handful at most)
+        assert float(err.mean()) < 2e-5 and float((err > 5e-3).float().mean()) < 1e-5
+        for pipe in (0, 1, 2, 4, 8):
+            for tw in (64, 32, 16, 8):
+                for dch, order, nt in ((1, 0, 0), (3, 1, 0), (4, 0, 1), (64, 1, 1)):
+                    _cv_env(PGRF_CV_PIPE=pipe, PGRF_CV_TILE_W=tw, PGRF_CV_DCH=dch, PGRF_CV_ORDER=order, PGRF_CV_STREAM_STORES=nt)
+                    got = run().cpu()
+                    assert torch.equal(got, base), (pipe, tw, dch, order, nt)
+        _cv_env()                # the shipped defaults
+        assert torch.equal(run().cpu(), base)
+    finally:
+        _cv_env_restore(old)
