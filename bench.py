@@ -14,6 +14,7 @@ import json
 import math
 import os
 import sys
+import subprocess
 import time
 
 import torch
@@ -400,6 +401,47 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def live_hbm_traffic(argv_shape, timeout_s=240):
+    """HBM-side bytes per render_pass launch of THIS configuration, measured now: two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters in their own runs, no
+    other trace domain beside them -- MI355X_MICROARCH.md, rocprofv3 section), two steps each.  FETCH_SIZE is doubled (gfx950 tallies
+    the 128-byte requests of wide coalesced reads at 64 B); both counters are KiB.  Returns (bytes, description) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which('rocprofv3')
+    if rp is None:
+        return None, 'rocprofv3 not on PATH'
+    vals = {}
+    env = dict(os.environ)
+    env['TMPDIR'] = '/tmp'
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out = tempfile.mkdtemp(prefix='pgrf_pmc_', dir='/tmp')
+        # the profiled program is python itself (no shell, env or launcher hop between rocprofv3 and the process that opens the GPU)
+        cmd = [rp, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__),
+               '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-end-to-end', '--pmc-child'] + argv_shape
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if 'render_pass' in row.get('Kernel_Name', '') and row.get('Counter_Name') == counter:
+                        tot += float(row['Counter_Value']); n += 1
+            if r.returncode != 0 or n == 0:
+                return None, f'rocprofv3 --pmc {counter} pass failed (rc {r.returncode}, {n} kernel rows)'
+            vals[counter] = (tot / n, n)
+        except subprocess.TimeoutExpired:
+            return None, f'rocprofv3 --pmc {counter} pass exceeded {timeout_s} s'
+        except Exception as ex:          # measurement garnish: never takes the bench line down
+            return None, f'rocprofv3 --pmc {counter} pass: {ex!r}'[:200]
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    b = (2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]) * 1024.0
+    return b, (f"measured by this run: two child passes of this command under rocprofv3 --kernel-trace --pmc (FETCH_SIZE {vals['FETCH_SIZE'][0]:.4e} KiB x 2 per the "
+               f"gfx950 note + WRITE_SIZE {vals['WRITE_SIZE'][0]:.4e} KiB, averages over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} render_pass launches)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -421,6 +463,9 @@ def main():
     ap.add_argument('--eager-baseline', action='store_true', help='also time the eager PyTorch-ROCm port on this GPU over the WHOLE frame (minutes); a bounded strip is timed by default')
     ap.add_argument('--train', action='store_true', help='time a coarse + fine TRAINING step of the per-ray networks (forward, backward, Adam) on --train-rays rays per rank')
     ap.add_argument('--train-rays', type=int, default=2048)
+    ap.add_argument('--no-live-pmc', action='store_true',
+                    help='do not spawn the two rocprofv3 --pmc passes that measure roofline.traffic of this configuration (the committed counter file is quoted instead)')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)      # (set by the parent on the profiled child runs: never spawns again)
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the process group and run every collective even with ONE rank (exercises the RCCL branch on a 1-GPU box)')
     args = ap.parse_args()
@@ -585,7 +630,13 @@ def main():
     # collected from inside the process): profiles/<round>_render_pass_pmc.txt, FETCH_SIZE doubled per the gfx950
     # note of MI355X_MICROARCH.md (wide coalesced reads are tallied at half), both counters in KiB.
     traffic, traffic_source = None, None
-    if (H, W, V, dn, world) == (512, 1024, 2, 64, 1) and not args.fine and args.precision == 'f32':
+    live_why = None
+    if rank == 0 and world == 1 and not distributed and not (args.no_live_pmc or args.pmc_child or args.with_cost_volume):
+        shape = ['--height', str(H), '--width', str(W), '--views', str(V), '--samples', str(dn), '--precision', args.precision] + (['--fine'] if args.fine else [])
+        traffic, traffic_source = live_hbm_traffic(shape)
+        if traffic is None:
+            live_why, traffic_source = traffic_source, None
+    if traffic is None and (H, W, V, dn, world) == (512, 1024, 2, 64, 1) and not args.fine and args.precision == 'f32':
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_render_pass_pmc.txt')))[-1:]:
             vals = {}
@@ -596,7 +647,8 @@ def main():
             if len(vals) == 2:
                 traffic = (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
                 traffic_source = ('profiles/' + os.path.basename(f) + ': (2 x FETCH_SIZE + WRITE_SIZE) KiB of a rocprofv3 --pmc pass of '
-                                  'this command, NOT measured by this run (tools/profile_round.sh regenerates it)')
+                                  'this command, NOT measured by this run (tools/profile_round.sh regenerates it)'
+                                  + (f'; live passes: {live_why}' if live_why else ''))
     res = {
         'metric': f'rendered rays/sec ({H}x{W} ERP, {dn} samples)', 'value': rays_per_s, 'unit': 'rays/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,

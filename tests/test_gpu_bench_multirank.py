@@ -183,3 +183,25 @@ print('cabi rccl allgather ok')
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2500:])
     assert 'cabi rccl allgather ok' in r.stdout
+
+
+def test_bench_line_measures_its_own_hbm_traffic():
+    """The plain one-GPU bench line carries `roofline.traffic` measured by the run itself: two child passes of the same command under
+    `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE, WRITE_SIZE), per render_pass launch.  A small frame keeps the three processes short;
+    the per-sample outputs alone (hit probability, colours, density: 20 bytes per sample + 28 per ray) bound the bytes from below."""
+    import shutil
+    if shutil.which('rocprofv3') is None:
+        pytest.skip('rocprofv3 not installed')
+    H, W, dn = 64, 128, 32
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--height', str(H), '--width', str(W),
+           '--samples', str(dn), '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    rl = d['roofline']
+    assert rl['traffic_source'] and rl['traffic_source'].startswith('measured by this run'), rl['traffic_source']
+    assert rl['traffic'] > H * W * dn * 20 and rl['traffic'] < 64e9
+    # and the switch that keeps the committed file's figure (or null off the headline configuration)
+    r2 = subprocess.run(cmd + ['--no-live-pmc'], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    d2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d2['roofline']['traffic'] is None
