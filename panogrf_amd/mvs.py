@@ -315,7 +315,11 @@ class CostVolumeInitNet(nn.Module):
     def __init__(self, cfg, d_net=None):
         super().__init__()
         self.cfg = dict(cfg)
-        for key in ('wo_stereo', 'uncert_tune', 'use_gt_depth_ray', 'use_empty_depth_ray', 'handle_distort'):
+        # wo_stereo swaps the MVS net for a mono-depth net (select_mononet, out of scope: SURVEY section 2); uncert_tune wraps it in the
+        # UncertWrapper training head (network/omni_mvsnet/uncert_wrapper.py); handle_distort gives ResUNetLight a fourth (sin phi)
+        # input channel (network/ops.py:251-266).  No shipped configuration sets them.  use_gt_depth_ray / use_empty_depth_ray
+        # (network/init_net.py:593-595,639-646) are mirrored in forward().
+        for key in ('wo_stereo', 'uncert_tune', 'handle_distort'):
             if self.cfg.get(key):
                 raise PgrfError(f"cfg['{key}'] is not implemented")
         if self.cfg.get('init_net_feature_type') == 'ERP+TP':
@@ -352,13 +356,18 @@ class CostVolumeInitNet(nn.Module):
                 ret = self.depth_net.estimate_depth_using_cost_volume(panos, rots, trans, c['mvs_min_depth'], c['mvs_max_depth'],
                                                                       mono=mono)
             depth = torch.clamp_min(ret['depth'], 0.0).permute(0, 3, 1, 2)
+        mvs_depth = depth
+        if c.get('use_gt_depth_ray'):            # init_net.py:593-595: the ray features are built from the ground-truth depth of the
+            depth = ref_imgs_info['depth']       # reference views, 'mvs_depth' stays the network's
         ref_feats = self.res_net(F.interpolate(ref_imgs_info['imgs'], (c['depth_height'], c['depth_width']), mode='bilinear'))
         # extract_depth_for_init_impl (init_net.py:112-124): normalised inverse depth in [0,1] of the RENDER depth range
         near_inv, far_inv = -1.0 / c['min_depth'], -1.0 / c['max_depth']
         d = (-1.0 / torch.clamp(depth, min=1e-5) - near_inv) / (far_inv - near_inv)
         d = F.interpolate(torch.clamp(d, min=0, max=1.0), scale_factor=0.25, mode='bilinear', align_corners=False)
         ray_feats = self.out_conv(torch.cat([ref_feats, self.depth_conv(d)], 1))
-        return {'mvs_depth': depth, 'ray_feats': ray_feats}
+        if c.get('use_empty_depth_ray'):         # init_net.py:639-646: a fresh N(0, 1) tensor per call in place of the features
+            ray_feats = nn.Parameter(torch.randn(ray_feats.shape, device=ray_feats.device, dtype=ray_feats.dtype))
+        return {'mvs_depth': mvs_depth, 'ray_feats': ray_feats}
 
 
 name2init_net = {'cost_volume': CostVolumeInitNet}

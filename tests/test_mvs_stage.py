@@ -96,6 +96,30 @@ def test_init_net_vs_reference_and_through_the_renderer():
     bare = CostVolumeInitNet(cfg).cuda().eval()
     with pytest.raises(PgrfError):
         bare(ref, src, False)
+    # use_gt_depth_ray (init_net.py:593-595): the ray features come from ref_imgs_info['depth'], 'mvs_depth' stays the network's --
+    # fed the network's own depth as "ground truth" the features must be the ones above, fed another depth they must move
+    gt = CostVolumeInitNet(dict(cfg, use_gt_depth_ray=True), d_net=MF.StubMono()).eval()
+    gt.load_state_dict(inet.state_dict())
+    gt = gt.cuda()
+    with torch.no_grad():
+        o1 = gt(dict(ref, depth=out['mvs_depth']), src, False)
+        o2 = gt(dict(ref, depth=out['mvs_depth'] * 0.5 + 0.3), src, False)
+    # (two module instances: MIOpen may pick different convolution algorithms for them, so equal to round-off, not to the bit)
+    close = lambda a, b: float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    assert close(o1['mvs_depth'], out['mvs_depth']) and close(o1['ray_feats'], out['ray_feats'])
+    assert close(o2['mvs_depth'], out['mvs_depth']) and float((o2['ray_feats'] - out['ray_feats']).abs().max()) > 1e-2
+    # use_empty_depth_ray (init_net.py:639-646): a fresh trainable N(0, 1) tensor per call in place of the features
+    emp = CostVolumeInitNet(dict(cfg, use_empty_depth_ray=True), d_net=MF.StubMono()).eval()
+    emp.load_state_dict(inet.state_dict())
+    emp = emp.cuda()
+    with torch.no_grad():
+        e1, e2 = emp(ref, src, False), emp(ref, src, False)
+    assert e1['ray_feats'].shape == out['ray_feats'].shape and e1['ray_feats'].requires_grad and e1['ray_feats'].is_cuda
+    assert abs(float(e1['ray_feats'].mean())) < 0.05 and abs(float(e1['ray_feats'].std()) - 1.0) < 0.05
+    assert not torch.equal(e1['ray_feats'], e2['ray_feats']) and close(e1['mvs_depth'], out['mvs_depth'])
+    for key in ('wo_stereo', 'uncert_tune', 'handle_distort'):
+        with pytest.raises((PgrfError, NotImplementedError)):
+            CostVolumeInitNet(dict(cfg, **{key: True}), d_net=MF.StubMono())
 
 
 @pytest.mark.gpu
