@@ -631,7 +631,9 @@ def main():
     # note of MI355X_MICROARCH.md (wide coalesced reads are tallied at half), both counters in KiB.
     traffic, traffic_source = None, None
     live_why = None
-    if rank == 0 and world == 1 and not distributed and not (args.no_live_pmc or args.pmc_child or args.with_cost_volume):
+    # (never from inside a profiled process: tools/profile_round.sh and the tools/pmc_*.sh scripts run this file under rocprofv3 themselves)
+    under_profiler = 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+    if rank == 0 and world == 1 and not distributed and not (args.no_live_pmc or args.pmc_child or args.with_cost_volume or under_profiler):
         shape = ['--height', str(H), '--width', str(W), '--views', str(V), '--samples', str(dn), '--precision', args.precision] + (['--fine'] if args.fine else [])
         traffic, traffic_source = live_hbm_traffic(shape)
         if traffic is None:

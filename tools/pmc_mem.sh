@@ -7,7 +7,7 @@ mkdir -p $OUT
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${@:2} > $OUT/pass$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc ${@:2} > $OUT/pass$i.log 2>&1
   tail -1 $OUT/pass$i.log | cut -c1-200
 done
 python3 - <<PY

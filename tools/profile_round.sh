@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 2000 $OUT/bench.json
 # 2. kernel trace + stats of the bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc > $OUT/bench_trace.log 2>&1
 cp $(find $OUT/bench_trace -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 # 3. PMC passes (counters only + kernel trace)
 i=0
@@ -19,11 +19,11 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
            "SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
            "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc > $OUT/pmc$i.log 2>&1
 done
 python3 - > $OUT/pmc_summary.txt <<PY
 import csv, glob, collections
-print('# rocprofv3 --pmc passes on: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline  (per-launch averages)')
+print('# rocprofv3 --pmc passes on: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc  (per-launch averages)')
 for d in sorted(glob.glob('$OUT/pmc*/')):
     for f in glob.glob(d + '**/*counter_collection.csv', recursive=True):
         agg = collections.defaultdict(lambda: [0.0, 0])
@@ -79,5 +79,9 @@ cp $(find $OUT/train_trace -name "*kernel_stats.csv" | head -1) $OUT/train_kerne
 { echo "# memory-side and SQ counters of cost_volume_kernel at 128x256x64, per-launch averages (tools/pmc_cmd.sh ... tools/time_cost_volume.py 128 256 costregnet)";
   bash $R/tools/pmc_cmd.sh ${TAG}cv cost_volume $R/tools/time_cost_volume.py 128 256 costregnet 2>&1 | grep "per-launch"; } > $OUT/cost_volume_pmc.txt
 PANOGRF_WINO=32 python3 $R/tools/time_cost_volume.py 128 256 2>&1 | grep -E "UNet2" | sed 's/^/first-generation Winograd kernel (PANOGRF_WINO=32): /' >> $OUT/cv_128x256.log
+# 11. round 6: the cost-volume build IN CONTEXT (caches polluted like a frame leaves them; build and build + regulariser per view, the
+#     round-5 kernel beside the shipped one, plain vs streamed stores)
+{ echo "# tools/cv_stage_nt.py on MI355X ($TAG): per step [1 GB read-modify-write, hypotheses, BUILD, regulariser]; median of 6 steps, two rounds; us per view";
+  python3 $R/tools/cv_stage_nt.py 2>&1 | grep -vE "amdgpu.ids"; } > $OUT/cost_volume_in_stage.txt
 rm -rf $OUT/pmc[0-9] $OUT/bench_trace $OUT/cv_trace $OUT/train_trace
 ls $OUT
