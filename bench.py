@@ -401,7 +401,7 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def live_hbm_traffic(argv_shape, timeout_s=240):
+def live_hbm_traffic(argv_shape, timeout_s=150):
     """HBM-side bytes per render_pass launch of THIS configuration, measured now: two child runs of this script under
     `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters in their own runs, no
     other trace domain beside them -- MI355X_MICROARCH.md, rocprofv3 section), two steps each.  FETCH_SIZE is doubled (gfx950 tallies

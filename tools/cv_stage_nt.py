@@ -36,7 +36,7 @@ for regname in ('costregnet', 'unet2'):
             torch.cuda.synchronize()
             b = sorted(a[0].elapsed_time(a[1]) * 1e3 / V for a in evs); t = sorted(a[0].elapsed_time(a[2]) * 1e3 / V for a in evs)
             return b[len(b) // 2], t[len(t) // 2]
-        for name, kw in [('old (r05)', dict(PGRF_CV_PIPE=0, PGRF_CV_TILE_W=64)), ('shipped', {}), ('shipped, plain stores', dict(PGRF_CV_STREAM_STORES=0)),
+        for name, kw in [('r05 kernel, r06 stores', dict(PGRF_CV_PIPE=0, PGRF_CV_TILE_W=64)), ('shipped', {}), ('shipped, plain stores', dict(PGRF_CV_STREAM_STORES=0)),
                          ('shipped, streamed stores', dict(PGRF_CV_STREAM_STORES=1))]:
             r = [measure(kw) for _ in range(2)]
             print(f'{regname:10s} {ch}x{cw} B={V} {name:26s} build ' + ' '.join(f'{x[0]:6.1f}' for x in r) + ' us   build + regulariser ' + ' '.join(f'{x[1]:7.1f}' for x in r) + ' us per view', flush=True)

@@ -44,8 +44,8 @@ python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --fine > $OUT/bench_c
 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --views 3 > $OUT/bench_views3.json 2>/dev/null
 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --views 4 > $OUT/bench_views4.json 2>/dev/null
 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --precision f16x3 > $OUT/bench_f16x3.json 2>/dev/null
-python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --with-cost-volume > $OUT/bench_config3.json 2>/dev/null
-python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --with-cost-volume --reg costregnet > $OUT/bench_config3_costregnet.json 2>/dev/null
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --with-cost-volume > $OUT/bench_config3.json 2>/dev/null
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --with-cost-volume --reg costregnet > $OUT/bench_config3_costregnet.json 2>/dev/null
 python3 $R/bench.py --steps 3 --warmup 1 --views 4 --height 1024 --width 2048 > $OUT/bench_config5_1gpu.json 2>/dev/null      # with the PSNR block
 # 6. per-frame 2-D encoders and the MVS stage (init net)
 python3 $R/tools/time_encoders.py 2>&1 | grep -E "ms|err" > $OUT/encoders_timing.txt

@@ -71,6 +71,8 @@ if b:
                    f'({traffic / (r["kernel_ms"] * 1e-3) / 1e12:.2f} TB/s); L2 hit rate TCC_HIT / (HIT + MISS) = {hit * 100:.1f} %; '
                    f'MFMA-pipe busy SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8: the counter sums the 8 XCDs) = '
                    f'{c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * max(c.get("GRBM_GUI_ACTIVE", 1), 1) / 8.0) * 100:.0f} %.')
+    if str(r.get('traffic_source', '')).startswith('measured by this run') and r.get('traffic'):
+        out.append(f'The line\'s own `roofline.traffic` (two child passes of the run under `rocprofv3 --pmc`, bench.py `live_hbm_traffic`): {r["traffic"] / 1e9:.2f} GB per launch.')
     e = b.get('torch_eager_gpu_baseline')
     if e:
         out.append(f'Eager PyTorch-ROCm port of the reference path on the same GPU (driver-run, bounded strip: {e.get("sample", "")}): '
@@ -126,6 +128,7 @@ if rows:
     out += rows
     out.append('')
 for name, title in [('costvolume_timings.txt', 'Cost-volume side (`tools/time_cost_volume.py`)'),
+                    ('cost_volume_in_stage.txt', 'Cost-volume build inside a polluted-cache stage loop (`tools/cv_stage_nt.py`: per step 1 GB read-modify-write, hypotheses, BUILD, regulariser)'),
                     ('costregnet_layer_trace_128x256.txt', 'CostRegNet per-layer kernel durations at 128x256x64'),
                     ('costreg_conv_pmc.txt', "SQ counters of CostRegNet's conv kernels (`tools/pmc_conv.sh`)"),
                     ('winograd_vs_direct_layers.txt', 'Winograd kernels per UNet2 layer shape (`tools/check_wino.py time`: second generation | first generation | direct kernel)'),
