@@ -301,6 +301,62 @@ class MVSDepthNet(nn.Module):
         return self._tail(vol, x_d3, ref_mu, H, W)
 
 
+# ------------------------------------------------------------------------------------------------ uncertainty head
+class _ResBN(nn.Module):
+    """ResidualBlock with its DEFAULT norm layer (BatchNorm2d, running statistics in eval) and wrap padding, dim_in == dim_out
+    (network/ops.py:61-118 as network/omni_mvsnet/uncert_wrapper.py:72-93 builds it: no norm_layer argument)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Sequential(nn.BatchNorm2d(c), nn.ReLU(True), ErpPad(1), nn.Conv2d(c, c, 3, 1, 0, bias=False),
+                                  nn.BatchNorm2d(c), nn.ReLU(True), ErpPad(1), nn.Conv2d(c, c, 3, 1, 0, bias=False))
+
+    def forward(self, x):
+        return self.conv(x) + x
+
+
+class _Up2(nn.Module):
+    """`Upscale` (models/common_blocks.py:245-255): bilinear x2, align_corners=False.  No parameters."""
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+
+
+class UncertWrapper(nn.Module):
+    """cfg['uncert_tune'] (network/omni_mvsnet/uncert_wrapper.py:45-150): the MVS depth net (`mvs_net`, frozen) plus a small head
+    that predicts a per-pixel variance of its depth from the regularised cost volume (64 depth planes as channels at 1/4 resolution)
+    and the normalised depth: `volume_conv2d`, `depth_conv`, `out_conv` (two bilinear x2 steps back to the depth resolution).
+    `estimate_depth_using_cost_volume` returns the depth net's dict + 'var' [B,1,H,W] and 'pred_final' = [depth, var]; like the
+    reference's wrapper it has no multi-view method.  `args` is the INIT NET's cfg: its min_depth / max_depth (the render range)
+    normalise the depth LINEARLY here (uncert_wrapper.py:32-44), not in inverse depth as the init net's own tail does."""
+
+    def __init__(self, args, model):
+        super().__init__()
+        self.cfg = dict(args)
+        self.mvs_net = model
+        head = lambda cin: nn.Sequential(erp_conv(cin, 32, 3), _ResBN(32), nn.Conv2d(32, 32, 1, 1, bias=False))
+        self.volume_conv2d = head(64)
+        self.depth_conv = head(1)
+        self.out_conv = nn.Sequential(erp_conv(64, 32, 3), _ResBN(32), _Up2(), erp_conv(32, 16, 3), _Up2(), nn.Conv2d(16, 1, 1, 1, bias=False))
+
+    def estimate_depth_using_cost_volume(self, panos, rots, trans, min_depth=2, max_depth=100, mono=None):
+        ret = self.mvs_net.estimate_depth_using_cost_volume(panos, rots, trans, min_depth, max_depth, mono=mono)
+        depth = ret['depth'].permute(0, 3, 1, 2)
+        cost_reg = ret['cost_reg'].permute(0, 3, 1, 2)
+        near, far = float(self.cfg['min_depth']), float(self.cfg['max_depth'])
+        d = torch.clamp((torch.clamp(depth, min=1e-5) - near) / (far - near), min=0, max=1.0)
+        d = F.interpolate(d, scale_factor=0.25, mode='bilinear', align_corners=False)
+        u = self.out_conv(torch.cat([self.volume_conv2d(cost_reg), self.depth_conv(d)], 1))
+        var = F.softplus(u, beta=20).pow(2) if self.cfg.get('new_uncert_tune') else F.elu(u) + 1.0 + 1e-10
+        ret['var'] = var
+        ret['pred_final'] = torch.cat([depth, var], 1)
+        return ret
+
+    def estimate_depth_using_cost_volume_v3_erp_multiview(self, *a, **k):
+        raise PgrfError("cfg['uncert_tune'] with seq_len > 3: the reference's UncertWrapper has no multi-view method either "
+                        "(network/omni_mvsnet/uncert_wrapper.py)")
+
+
 # ------------------------------------------------------------------------------------------------ init net
 def _feat_head(cin):
     """conv3x3 + ResidualBlock(IN, wrap) + conv1x1 (network/init_net.py:541-574, network/ops.py:12-30,61-118)."""
@@ -315,11 +371,10 @@ class CostVolumeInitNet(nn.Module):
     def __init__(self, cfg, d_net=None):
         super().__init__()
         self.cfg = dict(cfg)
-        # wo_stereo swaps the MVS net for a mono-depth net (select_mononet, out of scope: SURVEY section 2); uncert_tune wraps it in the
-        # UncertWrapper training head (network/omni_mvsnet/uncert_wrapper.py); handle_distort gives ResUNetLight a fourth (sin phi)
-        # input channel (network/ops.py:251-266).  No shipped configuration sets them.  use_gt_depth_ray / use_empty_depth_ray
-        # (network/init_net.py:593-595,639-646) are mirrored in forward().
-        for key in ('wo_stereo', 'uncert_tune', 'handle_distort'):
+        # wo_stereo swaps the MVS net for a mono-depth net (select_mononet, out of scope: SURVEY section 2); handle_distort gives
+        # ResUNetLight a fourth (sin phi) input channel (network/ops.py:251-266).  No shipped configuration sets them.  uncert_tune
+        # (UncertWrapper below), use_gt_depth_ray / use_empty_depth_ray (network/init_net.py:593-595,639-646) are mirrored.
+        for key in ('wo_stereo', 'handle_distort'):
             if self.cfg.get(key):
                 raise PgrfError(f"cfg['{key}'] is not implemented")
         if self.cfg.get('init_net_feature_type') == 'ERP+TP':
@@ -329,6 +384,8 @@ class CostVolumeInitNet(nn.Module):
         depth_args.setdefault('mono_height', depth_args['height'])
         depth_args.setdefault('mono_width', depth_args['width'])
         self.depth_net = MVSDepthNet(depth_args, d_net)
+        if self.cfg.get('uncert_tune'):          # init_net.py:491-497: the wrapper gets the INIT NET's args, not depth_args
+            self.depth_net = UncertWrapper(self.cfg, self.depth_net)
         self.res_net = ResUNetLight(self.cfg, 3, (2, 3, 6, 3), 32, inplanes=32, use_wrap_padding=True)
         self.depth_conv = _feat_head(1)
         self.out_conv = _feat_head(64)
@@ -356,6 +413,7 @@ class CostVolumeInitNet(nn.Module):
                 ret = self.depth_net.estimate_depth_using_cost_volume(panos, rots, trans, c['mvs_min_depth'], c['mvs_max_depth'],
                                                                       mono=mono)
             depth = torch.clamp_min(ret['depth'], 0.0).permute(0, 3, 1, 2)
+            var = ret['var'] if c.get('uncert_tune') else None
         mvs_depth = depth
         if c.get('use_gt_depth_ray'):            # init_net.py:593-595: the ray features are built from the ground-truth depth of the
             depth = ref_imgs_info['depth']       # reference views, 'mvs_depth' stays the network's
@@ -367,7 +425,10 @@ class CostVolumeInitNet(nn.Module):
         ray_feats = self.out_conv(torch.cat([ref_feats, self.depth_conv(d)], 1))
         if c.get('use_empty_depth_ray'):         # init_net.py:639-646: a fresh N(0, 1) tensor per call in place of the features
             ray_feats = nn.Parameter(torch.randn(ray_feats.shape, device=ray_feats.device, dtype=ray_feats.dtype))
-        return {'mvs_depth': mvs_depth, 'ray_feats': ray_feats}
+        out = {'mvs_depth': mvs_depth, 'ray_feats': ray_feats}
+        if var is not None:
+            out['mvs_uncert'] = var              # init_net.py:591-592
+        return out
 
 
 name2init_net = {'cost_volume': CostVolumeInitNet}

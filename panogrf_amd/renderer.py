@@ -615,6 +615,8 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         ref_imgs_info['ray_feats'] = ret['ray_feats']
         if 'mvs_depth' in ret:
             ref_imgs_info['mvs_depth'] = ret['mvs_depth']
+        if 'mvs_uncert' in ret:                  # cfg['uncert_tune'] (network/renderer.py:710-711)
+            ref_imgs_info['mvs_uncert'] = ret['mvs_uncert']
         return self.render(que_imgs_info, ref_imgs_info, is_train, is_perspec)
 
     def _init_net_reusing(self, ref, src, is_train):
@@ -622,7 +624,7 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         `_reuse_enabled`).  Entries this module writes itself (ray_feats, img_feats, mvs_depth) are not part of the key."""
         reuse = self._reuse_enabled(ref['imgs'], is_train)
         if reuse:
-            mine = ('ray_feats', 'img_feats', 'mvs_depth')
+            mine = ('ray_feats', 'img_feats', 'mvs_depth', 'mvs_uncert')
             named = [('ref.' + k, ref[k]) for k in sorted(ref) if k not in mine and not k.startswith('_pgrf')]
             named += [('src.' + k, src[k]) for k in sorted(src or {})]
             wver = self._weights_version((self.init_net,)) if isinstance(self.init_net, nn.Module) else None
@@ -648,7 +650,8 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         net = self.init_net
         B = ref['imgs'].shape[0]
         if not (self.cfg.get('hip_shard_views', True) and tdist.is_available() and tdist.is_initialized() and
-                tdist.get_world_size() > 1 and B > 1 and isinstance(net, CostVolumeInitNet) and src is not None and not is_train):
+                tdist.get_world_size() > 1 and B > 1 and isinstance(net, CostVolumeInitNet) and src is not None and not is_train and
+                not net.cfg.get('uncert_tune')):          # (the sharded / captured forms below return ray_feats and mvs_depth only)
             return self._run_init_net(ref, src, is_train)
         rank, world = tdist.get_rank(), tdist.get_world_size()
         mine = D.view_shard(rank, world, B)
@@ -680,7 +683,7 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         mv = int(net.cfg.get('seq_len', 3)) > 3 if isinstance(net, CostVolumeInitNet) else False
         ok = (isinstance(net, CostVolumeInitNet) and src is not None and (not mv or 'nn_ids' in ref) and
               ref['imgs'].is_cuda and not torch.is_grad_enabled() and self.cfg.get('hip_graph_init_net', True) and
-              not net.cfg.get('hip_check_nan'))
+              not net.cfg.get('hip_check_nan') and not net.cfg.get('uncert_tune'))
         if not ok:
             return net(ref, src, is_train)
         run = net

@@ -29,16 +29,14 @@ from make_cv_fixtures import poses  # noqa: E402
 from mvs_fixtures import seeded_state, StubMono, MVS_ARGS  # noqa: E402  (tests/mvs_fixtures.py)
 
 
-def main():
-    torch.set_num_threads(1)
-    R.setup()
+def build_pipeline(H=32, W=64):
+    """The reference's FullPipeline assembled from its own factory, the stand-in mono net in place of UniFuse, seeded weights.
+    -> (fp, args, [(key, shape)])   (shared with make_uncert_fixtures.py)"""
     torch.nn.Module.cuda = lambda self, *a, **k: self          # the reference moves new layers to the GPU at build time
     torch.Tensor.cuda = lambda self, *a, **k: self
     from models.test_models import initialize_cost_volume_network
     from network.omni_mvsnet.pipeline3_model import FullPipeline
-    import network.init_net as init_net
 
-    H, W = 32, 64
     args = dict(MVS_ARGS, height=H, width=W, mono_height=H, mono_width=W, depth_height=H, depth_width=W)
     torch.manual_seed(0)
     unet, unet3d, dec1, dec2 = initialize_cost_volume_network(args, layers=5, size=4, use_wrap_padding=True, use_v_input=False,
@@ -64,6 +62,15 @@ def main():
     sd = fp.state_dict()
     shapes = [(k, tuple(v.shape)) for k, v in sd.items()]
     fp.load_state_dict(seeded_state(shapes, 61))
+    return fp, args, shapes
+
+
+def main():
+    torch.set_num_threads(1)
+    R.setup()
+    H, W = 32, 64
+    fp, args, shapes = build_pipeline(H, W)
+    import network.init_net as init_net
 
     g = torch.Generator().manual_seed(5)
     B = 2

@@ -117,9 +117,60 @@ def test_init_net_vs_reference_and_through_the_renderer():
     assert e1['ray_feats'].shape == out['ray_feats'].shape and e1['ray_feats'].requires_grad and e1['ray_feats'].is_cuda
     assert abs(float(e1['ray_feats'].mean())) < 0.05 and abs(float(e1['ray_feats'].std()) - 1.0) < 0.05
     assert not torch.equal(e1['ray_feats'], e2['ray_feats']) and close(e1['mvs_depth'], out['mvs_depth'])
-    for key in ('wo_stereo', 'uncert_tune', 'handle_distort'):
+    for key in ('wo_stereo', 'handle_distort'):
         with pytest.raises((PgrfError, NotImplementedError)):
             CostVolumeInitNet(dict(cfg, **{key: True}), d_net=MF.StubMono())
+
+
+def test_uncert_tune_state_dict_keys_match_reference():
+    """CPU: cfg['uncert_tune'] wraps the depth net in UncertWrapper (network/init_net.py:491-497): the wrapper's own layers and the
+    wrapped net's (`depth_net.mvs_net.*`) carry the reference's names and shapes, BatchNorm running statistics included."""
+    from panogrf_amd.mvs import CostVolumeInitNet
+    fx = MF.load('uncert_fixtures')
+    cfg = dict(_args(), use_wrap_padding=True, seq_len=3, min_depth=0.5, max_depth=15.0, uncert_tune=True)
+    inet = CostVolumeInitNet(cfg, d_net=MF.StubMono())
+    sd = {k: tuple(v.shape) for k, v in inet.state_dict().items()}
+    head = {k[len('depth_net.'):]: v for k, v in sd.items() if k.startswith('depth_net.') and not k.startswith('depth_net.mvs_net.')}
+    assert head == dict(MF.key_shapes(fx['head']['keys'])) and len(head) == 43
+    assert {k[len('depth_net.mvs_net.'):]: v for k, v in sd.items() if k.startswith('depth_net.mvs_net.')} == dict(MF.key_shapes(fx['pipe']['keys']))
+    assert {k: v for k, v in sd.items() if not k.startswith('depth_net.')} == dict(MF.key_shapes(fx['init']['keys']))
+
+
+@pytest.mark.gpu
+def test_uncert_tune_vs_reference():
+    """UncertWrapper.estimate_depth_using_cost_volume (both variance activations) and the init net's 'mvs_uncert' against vectors
+    from the reference's own wrapper (tests/golden/make_uncert_fixtures.py)."""
+    from panogrf_amd.mvs import CostVolumeInitNet, MVSDepthNet, UncertWrapper
+    from panogrf_amd import PgrfError
+    fx = MF.load('uncert_fixtures')
+    shapes, head, ishapes = (MF.key_shapes(fx[g]['keys']) for g in ('pipe', 'head', 'init'))
+    cfg = dict(_args(), use_wrap_padding=True, seq_len=3, min_depth=0.5, max_depth=15.0, uncert_tune=True)
+    t = fx['in']
+    for tag, extra in (('elu', {}), ('softplus', {'new_uncert_tune': True})):
+        w = UncertWrapper(dict(cfg, **extra), MVSDepthNet(_args(), d_net=MF.StubMono())).eval()
+        w.load_state_dict({**MF.seeded_state(head, 131), **{'mvs_net.' + k: v for k, v in MF.seeded_state(shapes, 61).items()}})
+        w = w.cuda()
+        with torch.no_grad():
+            ret = w.estimate_depth_using_cost_volume(t['panos'].cuda(), t['rots'].cuda(), t['trans'].cuda(), 0.1, 10.0)
+        want = fx[tag]
+        assert max_abs(ret['depth'].cpu(), want['depth']) < 2e-4 * max(1.0, float(want['depth'].max()))
+        assert ret['var'].shape == want['var'].shape and float(ret['var'].min()) > 0.0
+        assert max_abs(ret['var'].cpu(), want['var']) < 5e-4 * max(1.0, float(want['var'].max())), tag
+        assert max_abs(ret['pred_final'].cpu(), want['pred_final']) < 5e-4 * max(1.0, float(want['pred_final'].abs().max()))
+        with pytest.raises(PgrfError):
+            w.estimate_depth_using_cost_volume_v3_erp_multiview(None, None, None, 0, 0.1, 10.0)
+    inet = CostVolumeInitNet(cfg, d_net=MF.StubMono()).eval()
+    inet.load_state_dict({**MF.seeded_state(ishapes, 91), **{'depth_net.' + k: v for k, v in MF.seeded_state(head, 131).items()},
+                          **{'depth_net.mvs_net.' + k: v for k, v in MF.seeded_state(shapes, 61).items()}})
+    inet = inet.cuda()
+    t = fx['init']
+    ref = {'imgs': t['ref_imgs'].cuda(), 'rots': t['ref_rots'].cuda(), 'trans': t['ref_trans'].cuda()}
+    src = {'imgs': t['src_imgs'].cuda(), 'rots': t['src_rots'].cuda(), 'trans': t['src_trans'].cuda()}
+    with torch.no_grad():
+        out = inet(ref, src, False)
+    assert max_abs(out['mvs_depth'].cpu(), t['mvs_depth']) < 2e-4 * max(1.0, float(t['mvs_depth'].max()))
+    assert max_abs(out['mvs_uncert'].cpu(), t['mvs_uncert']) < 5e-4 * max(1.0, float(t['mvs_uncert'].max()))
+    assert max_abs(out['ray_feats'].cpu(), t['ray_feats']) < 5e-4 * max(1.0, float(t['ray_feats'].abs().max()))
 
 
 @pytest.mark.gpu
