@@ -346,6 +346,19 @@ def train_bench(args, dev, rank, world, distributed):
                         'kernel_ms': gpu_ms, 'flop_per_ray': 3 * flop_per_ray(V, dn, 2), 'rays_per_launch': rays,
                         'note': 'algorithmic = 3 x forward FLOPs = what the step executes (PANOGRF_TRAIN_KEEP_ACTS=0: fused forward + rematerialising backward, 4 x)'},
            'loss_first_last': [float(losses[0].detach()), float(losses[-1].detach())]}
+    under_profiler = 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+    if rank == 0 and world == 1 and not distributed and not (args.no_live_pmc or args.pmc_child or under_profiler):
+        # the step is a chain of ~270 launches over materialised [rows, C] activations: beside the MFMA roof of its FLOPs, the HBM side --
+        # bytes per step from two child passes of this command under rocprofv3 --pmc, against the 8 TB/s peak
+        tb, tsrc = live_hbm_traffic(['--train', '--height', str(H), '--width', str(W), '--views', str(V), '--samples', str(dn),
+                                     '--train-rays', str(rays)], kernel=None, steps_total=3)
+        if tb is not None:
+            ach = tb / (gpu_ms * 1e-3) / 1e9
+            res['roofline_hbm'] = {'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': tb,
+                                   'traffic_source': tsrc, 'kernel_ms': gpu_ms,
+                                   'note': 'bytes per step (all kernels) / step time; FETCH_SIZE doubled as for wide coalesced reads (narrower accesses are uncalibrated on gfx950)'}
+        else:
+            res['roofline_hbm'] = {'error': tsrc}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the eager-autograd port on the same GPU: the oracle's torch ops (the reference's graph) under torch.autograd, same rays
         from oracle import render_oracle as O
@@ -401,11 +414,13 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def live_hbm_traffic(argv_shape, timeout_s=150):
+def live_hbm_traffic(argv_shape, timeout_s=150, kernel='render_pass', steps_total=None):
     """HBM-side bytes per render_pass launch of THIS configuration, measured now: two child runs of this script under
     `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters in their own runs, no
     other trace domain beside them -- MI355X_MICROARCH.md, rocprofv3 section), two steps each.  FETCH_SIZE is doubled (gfx950 tallies
-    the 128-byte requests of wide coalesced reads at 64 B); both counters are KiB.  Returns (bytes, description) or (None, why)."""
+    the 128-byte requests of wide coalesced reads at 64 B); both counters are KiB.  Returns (bytes, description) or (None, why).
+    kernel=None, steps_total=n: the counters are summed over EVERY kernel of the child process and divided by its n steps
+    (warm-up included) -- bytes per step of a multi-kernel step (bench.py --train)."""
     import csv
     import glob
     import shutil
@@ -426,11 +441,11 @@ def live_hbm_traffic(argv_shape, timeout_s=150):
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if 'render_pass' in row.get('Kernel_Name', '') and row.get('Counter_Name') == counter:
+                    if (kernel is None or kernel in row.get('Kernel_Name', '')) and row.get('Counter_Name') == counter:
                         tot += float(row['Counter_Value']); n += 1
             if r.returncode != 0 or n == 0:
                 return None, f'rocprofv3 --pmc {counter} pass failed (rc {r.returncode}, {n} kernel rows)'
-            vals[counter] = (tot / n, n)
+            vals[counter] = (tot / (n if steps_total is None else steps_total), n)
         except subprocess.TimeoutExpired:
             return None, f'rocprofv3 --pmc {counter} pass exceeded {timeout_s} s'
         except Exception as ex:          # measurement garnish: never takes the bench line down
@@ -438,8 +453,10 @@ def live_hbm_traffic(argv_shape, timeout_s=150):
         finally:
             shutil.rmtree(out, ignore_errors=True)
     b = (2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]) * 1024.0
+    what = (f"averages over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} {kernel} launches" if steps_total is None else
+            f"sums over all {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} kernel launches of the child's {steps_total} steps (warm-up and set-up kernels included), per step")
     return b, (f"measured by this run: two child passes of this command under rocprofv3 --kernel-trace --pmc (FETCH_SIZE {vals['FETCH_SIZE'][0]:.4e} KiB x 2 per the "
-               f"gfx950 note + WRITE_SIZE {vals['WRITE_SIZE'][0]:.4e} KiB, averages over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} render_pass launches)")
+               f"gfx950 note + WRITE_SIZE {vals['WRITE_SIZE'][0]:.4e} KiB, {what})")
 
 
 def main():

@@ -100,6 +100,10 @@ if bt:
                f'forward + backward + Adam of the per-ray networks: {bt["ms_per_step"]:.2f} ms per step = {bt["value"] / 1e3:.1f} k rays/s = {r["achieved"]:.1f} TFLOP/s '
                f'algorithmic (3 x the forward) = **{r["frac"] * 100:.1f} %** of the f32 MFMA peak'
                + (f'; eager-autograd port of the reference graph on the same GPU {eg["ms_per_step"]:.0f} ms per step -> {eg["speedup_hip_over_eager"]:.1f} x.' if 'ms_per_step' in eg else '.'))
+    rh = bt.get('roofline_hbm') or {}
+    if 'frac' in rh:
+        out.append(f'The step is bound by the HBM side of its materialised activations: {rh["traffic"] / 1e9:.2f} GB per step (all kernels; two child passes of the run '
+                   f'under `rocprofv3 --pmc`) = {rh["achieved"] / 1e3:.2f} TB/s = **{rh["frac"] * 100:.0f} %** of 8 TB/s (`roofline_hbm` on the same line).')
     out.append('')
 
 rows = []
